@@ -1,0 +1,217 @@
+"""Network spec of the hot path: the `net:` section of the reference's YAML -> dims and parameter table.
+
+Mirrors the constructor arguments of the reference's ``SpeechRecognizer``
+(lvsr/bricks/recognizer.py:176-204) and the Blocks parameter naming that is the checkpoint
+contract (libs/blocks/blocks/model.py:60-161; names verified by instantiating the reference, see
+oracle/theano_harness/gen_golden.py which asserts this table against the reference's own
+``Model(cost).get_parameter_dict()``).
+
+Pure Python + numpy on purpose: it is imported by the golden-vector generator that runs inside the
+scratch Theano environment, by the tests and by the product.
+"""
+from collections import OrderedDict
+import copy
+
+SUPPORTED_ACTIVATIONS = ("maxout2", "rectifier", "tanh", "identity")
+
+_DEFAULTS = dict(
+    input_dim=None,            # F; reference: input_dims={'recordings': F}
+    num_phonemes=None,         # V (number of labels incl. <eol>)
+    eos_label=None,
+    dims_bidir=None,           # [H]*n_layers
+    subsample=None,            # [1]*n_layers if None (recognizer.py:237-238)
+    dim_dec=None,              # D
+    dim_matcher=None,          # M; defaults to dim_dec (recognizer.py:224-225)
+    attention_type="content",  # 'content' | 'content_and_conv'
+    conv_n=None,               # c: filter half width
+    conv_num_filters=1,        # K
+    prior=None,                # dict(type=..., ...); None -> expanding 0/10000/0/0 (attention.py:74-77)
+    energy_normalizer="softmax",
+    post_merge_dims=None,      # [P] or None
+    post_merge_activation="tanh",  # reference default Tanh() (recognizer.py:206-207)
+    embed_outputs=True,
+    dim_output_embedding=None,
+    use_states_for_readout=True,
+    data_prepend_eos=True,
+    max_decoded_length_scale=1,
+)
+
+DEFAULT_PRIOR = dict(type="expanding", initial_begin=0, initial_end=10000, min_speed=0, max_speed=0)
+
+
+def normalize_net_config(cfg):
+    """Fill defaults and validate the subset of the reference's `net:` schema this path supports."""
+    out = copy.deepcopy(_DEFAULTS)
+    for k, v in cfg.items():
+        if k not in out:
+            raise ValueError("unknown net config key %r" % (k,))
+        out[k] = copy.deepcopy(v)
+    for k in ("input_dim", "num_phonemes", "dims_bidir", "dim_dec"):
+        if out[k] is None:
+            raise ValueError("net config key %r is required" % (k,))
+    out["dims_bidir"] = [int(d) for d in out["dims_bidir"]]
+    if out["subsample"] is None:
+        out["subsample"] = [1] * len(out["dims_bidir"])
+    out["subsample"] = [int(s) for s in out["subsample"]]
+    if len(out["subsample"]) != len(out["dims_bidir"]):
+        raise ValueError("subsample and dims_bidir must have the same length")
+    if out["eos_label"] is None:
+        out["eos_label"] = out["num_phonemes"] - 1
+    if out["dim_matcher"] is None:
+        out["dim_matcher"] = out["dim_dec"]
+    if out["attention_type"] not in ("content", "content_and_conv"):
+        # same error class as the reference (recognizer.py:275-277)
+        raise ValueError("Unknown attention type {}".format(out["attention_type"]))
+    if out["attention_type"] == "content_and_conv":
+        if out["conv_n"] is None:
+            raise ValueError("content_and_conv attention needs conv_n")
+        if out["prior"] is None:
+            out["prior"] = dict(DEFAULT_PRIOR)
+        out["prior"].setdefault("type", "expanding")
+    else:
+        out["prior"] = None
+    if out["energy_normalizer"] is None:
+        out["energy_normalizer"] = "softmax"
+    if out["energy_normalizer"] != "softmax":
+        raise NotImplementedError("energy_normalizer %r: only 'softmax' is built" % out["energy_normalizer"])
+    if out["post_merge_dims"] is not None:
+        if len(out["post_merge_dims"]) != 1:
+            raise NotImplementedError("only single-layer post_merge_dims is built")
+        if out["post_merge_activation"] not in SUPPORTED_ACTIVATIONS:
+            raise ValueError("post_merge_activation must be one of %s" % (SUPPORTED_ACTIVATIONS,))
+        if out["post_merge_activation"] == "maxout2" and out["post_merge_dims"][0] % 2:
+            raise ValueError("Maxout(2) needs an even post_merge dim")
+    return out
+
+
+class Dims(object):
+    """Symbol table of SURVEY.md: F,H[],E,D,M,K,c,V,P,pieces,fb (feedback dim)."""
+
+    def __init__(self, cfg):
+        cfg = normalize_net_config(cfg)
+        self.cfg = cfg
+        self.F = cfg["input_dim"]
+        self.Hs = list(cfg["dims_bidir"])
+        self.subsample = list(cfg["subsample"])
+        self.n_layers = len(self.Hs)
+        self.E = 2 * self.Hs[-1]
+        self.D = cfg["dim_dec"]
+        self.M = cfg["dim_matcher"]
+        self.V = cfg["num_phonemes"]
+        self.conv = cfg["attention_type"] == "content_and_conv"
+        self.K = cfg["conv_num_filters"] if self.conv else 0
+        self.c = cfg["conv_n"] if self.conv else 0
+        self.embed = bool(cfg["embed_outputs"])
+        if self.embed:
+            self.FB = self.D if cfg["dim_output_embedding"] is None else cfg["dim_output_embedding"]
+        else:
+            self.FB = self.V + 1          # OneOfNFeedback(num_phonemes + 1), recognizer.py:284
+        if cfg["post_merge_dims"]:
+            self.P = cfg["post_merge_dims"][0]
+            self.act = cfg["post_merge_activation"]
+            self.pieces = 2 if self.act == "maxout2" else 1
+            self.Pout = self.P // self.pieces
+        else:
+            self.P = self.V
+            self.act = "identity"
+            self.pieces = 1
+            self.Pout = self.V
+        self.post_merge = bool(cfg["post_merge_dims"])
+        self.use_states_for_readout = bool(cfg["use_states_for_readout"])
+
+    def layer_input_dim(self, i):
+        return self.F if i == 0 else 2 * self.Hs[i - 1]
+
+    def subsampled_length(self, T):
+        for s in self.subsample:
+            T = (T + s - 1) // s          # x[::s]
+        return T
+
+
+def parameter_shapes(cfg):
+    """name -> shape, names exactly as the reference's Model.get_parameter_dict()."""
+    d = Dims(cfg)
+    p = OrderedDict()
+    for i, H in enumerate(d.Hs):
+        I = d.layer_input_dim(i)
+        for direction in ("forward", "backward"):
+            base = "/recognizer/encoder/bidir%d/%s" % (i, direction)
+            p[base + "/fork/fork_inputs.W"] = (I, H)
+            p[base + "/fork/fork_inputs.b"] = (H,)
+            p[base + "/fork/fork_gate_inputs.W"] = (I, 2 * H)
+            p[base + "/fork/fork_gate_inputs.b"] = (2 * H,)
+            p[base + "/gatedrecurrent.state_to_state"] = (H, H)
+            p[base + "/gatedrecurrent.state_to_gates"] = (H, 2 * H)
+            p[base + "/gatedrecurrent.initial_state"] = (H,)
+    g = "/recognizer/generator"
+    att = g + "/att_trans/" + ("conv_att" if d.conv else "cont_att")
+    p[att + "/preprocess.W"] = (d.E, d.M)
+    p[att + "/preprocess.b"] = (d.M,)
+    p[att + "/state_trans/transform_states.W"] = (d.D, d.M)
+    p[att + "/energy_comp/linear.W"] = (d.M, 1)
+    if d.conv:
+        p[att + "/conv1d.filters"] = (d.K, 2 * d.c + 1)
+        p[att + "/handler.W"] = (d.K, d.M)
+    p[g + "/att_trans/distribute/fork_inputs.W"] = (d.E, d.D)
+    p[g + "/att_trans/distribute/fork_gate_inputs.W"] = (d.E, 2 * d.D)
+    p[g + "/att_trans/transition.state_to_state"] = (d.D, d.D)
+    p[g + "/att_trans/transition.state_to_gates"] = (d.D, 2 * d.D)
+    p[g + "/att_trans/transition.initial_state"] = (d.D,)
+    p[g + "/fork/fork_inputs.W"] = (d.FB, d.D)
+    p[g + "/fork/fork_inputs.b"] = (d.D,)
+    p[g + "/fork/fork_gate_inputs.W"] = (d.FB, 2 * d.D)
+    p[g + "/fork/fork_gate_inputs.b"] = (2 * d.D,)
+    if d.use_states_for_readout:
+        p[g + "/readout/merge/transform_states.W"] = (d.D, d.P)
+    p[g + "/readout/merge/transform_weighted_averages.W"] = (d.E, d.P)
+    if d.post_merge:
+        p[g + "/readout/post_merge/bias.b"] = (d.P,)
+        p[g + "/readout/post_merge/mlp/linear_0.W"] = (d.Pout, d.V)
+        p[g + "/readout/post_merge/mlp/linear_0.b"] = (d.V,)
+    else:
+        p[g + "/readout/bias.b"] = (d.V,)
+    if d.embed:
+        p[g + "/readout/lookupfeedback/lookuptable.W"] = (d.V + 1, d.FB)
+    return p
+
+
+def count_parameters(cfg):
+    n = 0
+    for shape in parameter_shapes(cfg).values():
+        k = 1
+        for s in shape:
+            k *= s
+        n += k
+    return n
+
+
+# ----------------------------------------------------------------------------------------------
+# Named configurations (BASELINE.json `configs`)
+# ----------------------------------------------------------------------------------------------
+def timit_tiny():
+    return dict(input_dim=40, num_phonemes=62, dims_bidir=[128], subsample=[1], dim_dec=128, dim_matcher=128,
+                attention_type="content", post_merge_dims=[128], post_merge_activation="maxout2",
+                embed_outputs=True, data_prepend_eos=False)
+
+
+def wsj_base(prior=None):
+    return dict(input_dim=40, num_phonemes=33, dims_bidir=[256] * 4, subsample=[1, 1, 2, 2], dim_dec=256,
+                dim_matcher=512, attention_type="content_and_conv", conv_n=100, conv_num_filters=10,
+                prior=prior if prior is not None else dict(DEFAULT_PRIOR),
+                post_merge_dims=[256], post_merge_activation="maxout2", embed_outputs=False,
+                data_prepend_eos=False)
+
+
+def wsj_deep():
+    return dict(input_dim=40, num_phonemes=33, dims_bidir=[512] * 6, subsample=[1, 1, 1, 1, 2, 2], dim_dec=512,
+                dim_matcher=512, attention_type="content_and_conv", conv_n=100, conv_num_filters=10,
+                prior=dict(DEFAULT_PRIOR), post_merge_dims=[512], post_merge_activation="maxout2",
+                embed_outputs=False, data_prepend_eos=False)
+
+
+WORKLOADS = {
+    # name: (net config factory, B, T, L)
+    "timit_tiny": (timit_tiny, 2, 200, 40),
+    "wsj_base": (wsj_base, 16, 800, 100),
+    "wsj_deep": (wsj_deep, 8, 1500, 190),
+}

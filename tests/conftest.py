@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "attention-lvcsr_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_path(name):
+    return os.path.join(GOLDEN, name + ".npz")
+
+
+def load_golden(name):
+    import json
+    import numpy
+    path = golden_path(name)
+    if not os.path.exists(path):
+        pytest.skip("golden fixture %s missing" % name)
+    z = numpy.load(path, allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return z, meta
+
+
+@pytest.fixture(scope="session")
+def gpu_device():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")

@@ -1,0 +1,142 @@
+"""Pin the CPU oracle (oracle/lvsr_oracle.py) against (a) the reference's own known-answer tests and
+(b) golden fixtures produced by running the reference itself (oracle/theano_harness/gen_golden.py)."""
+import itertools
+
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from conftest import load_golden
+from oracle import lvsr_oracle as O
+from lvsr_amd import synthetic
+
+SMALL_CASES = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean",
+               "tiny_content_embed", "tiny_content_relu", "small_conv", "small_conv_median",
+               "small_conv_expanding"]
+
+
+def test_conv1d_reference_golden():
+    # /root/reference/tests/test_conv1d.py:6-13
+    a = torch.tensor([[1.0, 2, 3], [1, 0, 1]])
+    b = torch.tensor([[2, 1], [1, 3.0]])
+    assert_allclose(O.conv1d_valid(a, b).numpy(), [[[5, 8], [5, 9]], [[1, 2], [3, 1]]])
+    assert_allclose(O.conv1d_full(a, b).numpy(), [[[2, 5, 8, 3], [1, 5, 9, 9]], [[2, 1, 2, 1], [1, 3, 1, 3]]])
+
+
+def test_smallest_reference_golden():
+    # /root/reference/libs/blocks/tests/test_search.py:65-69
+    a = numpy.array([[3, 6, 4], [1, 2, 7]])
+    ind, mins = O.smallest(a, 2)
+    assert numpy.all(numpy.array(ind) == numpy.array([[1, 1], [0, 1]]))
+    assert numpy.all(mins == [1, 2])
+
+
+def test_gru_one_step_reference_golden():
+    # /root/reference/libs/blocks/tests/bricks/test_recurrent.py:432-455 (gate activation Tanh there)
+    h0 = 0.1 * numpy.array([[1, 1, 0], [0, 1, 1]], dtype=numpy.float32)
+    x = 0.1 * numpy.array([[1, 2, 3], [4, 5, 6]], dtype=numpy.float32)
+    zi, ri = (h0 + x) / 2, -x
+    W = 2 * numpy.ones((3, 3), dtype=numpy.float32)
+    z = numpy.tanh(h0.dot(W) + zi)
+    r = numpy.tanh(h0.dot(W) + ri)
+    h1 = z * numpy.tanh((r * h0).dot(W) + x) + (1 - z) * h0
+    t = torch.tensor
+    got = O.gru_step(t(h0), t(x), t(numpy.hstack([zi, ri])), t(W), t(numpy.hstack([W, W])), gate_act=torch.tanh)
+    assert_allclose(h1, got.numpy(), rtol=1e-6)
+
+
+def test_gru_masked_sequence_and_bidirectional_reference_semantics():
+    # test_recurrent.py:457-495 (masked 24-step sequence) and :498-535 (backward = forward on reversed input/mask)
+    rng = numpy.random.RandomState(1)
+    W = rng.normal(0, 1, (3, 3)).astype(numpy.float32)
+    Wg = rng.normal(0, 1, (3, 6)).astype(numpy.float32)
+    x = 0.1 * numpy.asarray(list(itertools.permutations(range(4))), dtype=numpy.float32)
+    x = numpy.ones((24, 4, 3), dtype=numpy.float32) * x[..., None]
+    ri = 0.3 - x
+    zi = 2 * ri
+    mask = numpy.ones((24, 4), dtype=numpy.float32)
+    mask[12:24, 3] = 0
+    h = numpy.zeros((25, 4, 3), dtype=numpy.float32)
+    for i in range(1, 25):
+        z = numpy.tanh(h[i - 1].dot(Wg[:, :3]) + zi[i - 1])
+        r = numpy.tanh(h[i - 1].dot(Wg[:, 3:]) + ri[i - 1])
+        h[i] = numpy.tanh((r * h[i - 1]).dot(W) + x[i - 1])
+        h[i] = z * h[i] + (1 - z) * h[i - 1]
+        h[i] = mask[i - 1, :, None] * h[i] + (1 - mask[i - 1, :, None]) * h[i - 1]
+    t = torch.tensor
+    gi = numpy.concatenate([zi, ri], axis=2)
+    got = O.gru_sequence(t(x), t(gi), t(mask), t(W), t(Wg), torch.zeros(3), gate_act=torch.tanh)
+    assert_allclose(h[1:], got.numpy(), rtol=1e-4, atol=1e-6)
+    fwd_on_rev = O.gru_sequence(t(x[::-1].copy()), t(gi[::-1].copy()), t(mask[::-1].copy()), t(W), t(Wg),
+                                torch.zeros(3), gate_act=torch.tanh)
+    bwd = O.gru_sequence(t(x), t(gi), t(mask), t(W), t(Wg), torch.zeros(3), reverse=True, gate_act=torch.tanh)
+    assert_allclose(fwd_on_rev.numpy()[::-1], bwd.numpy(), rtol=1e-6)
+
+
+def _oracle_for(meta, dtype):
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"],
+                                 ragged=meta["ragged"])
+    return O.OracleRecognizer(meta["cfg"], params, dtype=dtype), batch
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_cost_alignment_gradients_vs_reference(case, dtype):
+    z, meta = load_golden(case)
+    orc, batch = _oracle_for(meta, dtype)
+    out, grads = orc.cost_and_grads(batch)
+    cm = out["cost_matrix"].detach().numpy()
+    assert_allclose(cm, z["cost_matrix"], rtol=2e-5, atol=2e-6)
+    assert abs(cm.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-5          # north_star: 1e-4 relative
+    w = out["weights"].detach().numpy()
+    assert_allclose(w, z["weights"], rtol=1e-4, atol=2e-6)
+    assert (w.argmax(axis=2) == z["weights_argmax"]).all()                      # bit-exact alignment indices
+    assert_allclose(out["encoded"].detach().numpy(), z["encoded"], rtol=1e-4, atol=2e-6)
+    if "energies" in z.files:
+        assert_allclose(out["energies"].detach().numpy(), z["energies"], rtol=1e-4, atol=5e-6)
+    for name in z["grad_names"]:
+        name = str(name)
+        ref = z["grad:" + name]
+        scale = max(1e-3, numpy.abs(ref).max())
+        assert_allclose(grads[name] / scale, ref / scale, rtol=0, atol=5e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_beam_search_vs_reference(case):
+    z, meta = load_golden(case)
+    if not meta.get("beam"):
+        pytest.skip("no beam fixture in this case")
+    orc, batch = _oracle_for(meta, torch.float32)
+    for bi, b in enumerate(meta["beam"]):
+        s = dict(b["settings"])
+        utt = s.pop("utt", 0)
+        bs = s.pop("beam_size")
+        tl = int(batch["recordings_mask"][:, utt].sum())
+        outs, costs = orc.beam_search(batch["recordings"][:tl, utt], bs, **s)
+        assert outs == b["outputs"], (case, bi)
+        assert_allclose(costs, b["costs"], rtol=1e-5, atol=1e-5)
+        key = "analyze%d_cost" % bi
+        if key in z.files and outs:
+            hyp = numpy.array(outs[0], dtype=numpy.int64)
+            c, w = orc.analyze(batch["recordings"][:tl, utt], hyp)
+            assert_allclose(c, z[key], rtol=1e-4, atol=1e-5)
+            assert_allclose(w, z["analyze%d_weights" % bi], rtol=1e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", ["timit_tiny"])
+def test_full_size_config_vs_reference(case):
+    z, meta = load_golden(case)
+    orc, batch = _oracle_for(meta, torch.float32)
+    out, grads = orc.cost_and_grads(batch)
+    cm = out["cost_matrix"].detach().numpy()
+    assert abs(cm.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-5
+    assert_allclose(cm, z["cost_matrix"], rtol=1e-4, atol=1e-5)
+    w = out["weights"].detach().numpy()
+    nb = z["weights_sub"].shape[1]
+    assert_allclose(w[:, :nb], z["weights_sub"], rtol=1e-3, atol=1e-6)
+    assert (w.argmax(axis=2) == z["weights_argmax"]).all()
+    for name, fp in zip(z["grad_names"], z["grad_fp"]):
+        got = synthetic.fingerprint(str(name), grads[str(name)])
+        assert_allclose(got, fp, rtol=2e-3, atol=2e-4 * max(1.0, fp[0]), err_msg=str(name))
