@@ -1,0 +1,209 @@
+// fp32 GEMM on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32 products, f32 accumulate).
+// Used for the dense, non-recurrent contractions of the path: encoder input forks (K1), attended
+// preprocess (K4), readout merge (K10) and all their weight/input gradients.
+//
+//   C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C + bias[N]
+//
+// 64x64x16 work-group tile, 4 waves, each wave a 32x32 sub-tile = 2x2 MFMA 16x16 tiles; operands
+// staged k-major in LDS so every MFMA operand read is a conflict-free row of 16 consecutive floats.
+// Optional deterministic split-K (partials in a caller-provided workspace, fixed-order reduction)
+// for the tall-skinny weight-gradient shapes (K = T*B rows).
+#include "common.h"
+
+#define BM 64
+#define BN 64
+#define BK 16
+#define LDS_LD (BM + 4)
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc, transA, transB;
+    float alpha, beta;
+    int ksplit;        // number of K splits (grid.z); >1 => write raw partials to `part`
+    int kchunk;        // K elements per split (multiple of BK)
+    float* part;       // (ksplit, M, N) workspace
+};
+
+__global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
+    __shared__ float As[BK][LDS_LD];
+    __shared__ float Bs[BK][LDS_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int kbeg = blockIdx.z * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int rowbase = (wave >> 1) * 32, colbase = (wave & 1) * 32;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        // ---- stage A tile (BM x BK) -> As[k][m]; thread mapping follows the contiguous memory dim
+        if (!g.transA) {            // A[m*lda + k]: k contiguous
+            const int kk = tid & 15, mm = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int m = m0 + mm + p * 16, k = k0 + kk;
+                As[kk][mm + p * 16] = (m < g.M && k < kend) ? g.A[(size_t)m * g.lda + k] : 0.f;
+            }
+        } else {                    // A[k*lda + m]: m contiguous
+            const int mm = tid & 63, kk = tid >> 6;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int m = m0 + mm, k = k0 + kk + p * 4;
+                As[kk + p * 4][mm] = (m < g.M && k < kend) ? g.A[(size_t)k * g.lda + m] : 0.f;
+            }
+        }
+        if (!g.transB) {            // B[k*ldb + n]: n contiguous
+            const int nn = tid & 63, kk = tid >> 6;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int n = n0 + nn, k = k0 + kk + p * 4;
+                Bs[kk + p * 4][nn] = (n < g.N && k < kend) ? g.B[(size_t)k * g.ldb + n] : 0.f;
+            }
+        } else {                    // B[n*ldb + k]: k contiguous
+            const int kk = tid & 15, nn = tid >> 4;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int n = n0 + nn + p * 16, k = k0 + kk;
+                Bs[kk][nn + p * 16] = (n < g.N && k < kend) ? g.B[(size_t)n * g.ldb + k] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK; ks += 4) {
+            const int kr = ks + (lane >> 4), li = lane & 15;
+            float a[2], b[2];
+            a[0] = As[kr][rowbase + li];
+            a[1] = As[kr][rowbase + 16 + li];
+            b[0] = Bs[kr][colbase + li];
+            b[1] = Bs[kr][colbase + 16 + li];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + rowbase + i * 16 + (lane >> 4) * 4 + r;
+                const int n = n0 + colbase + j * 16 + (lane & 15);
+                if (m < g.M && n < g.N) {
+                    if (g.ksplit > 1) {
+                        g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                    } else {
+                        float v = g.alpha * acc[i][j][r];
+                        if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
+                        if (g.bias) v += g.bias[n];
+                        g.C[(size_t)m * g.ldc + n] = v;
+                    }
+                }
+            }
+}
+
+__global__ __launch_bounds__(256) void lvsr_sgemm_splitk_reduce(GemmArgs g) {
+    const size_t total = (size_t)g.M * g.N;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / g.N), n = (int)(idx % g.N);
+        float s = 0.f;
+        for (int z = 0; z < g.ksplit; ++z) s += g.part[(size_t)z * total + idx];
+        float v = g.alpha * s;
+        if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
+        if (g.bias) v += g.bias[n];
+        g.C[(size_t)m * g.ldc + n] = v;
+    }
+}
+
+// column sums: out[n] = beta*out[n] + sum_m X[m*ldx + n]   (bias gradients)
+__global__ __launch_bounds__(256) void lvsr_colsum_kernel(const float* X, int M, int N, int ldx, float* out, float beta) {
+    __shared__ float red[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    float s = 0.f;
+    if (n < N)
+        for (int m = g; m < M; m += 4) s += X[(size_t)m * ldx + n];
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        const int c = threadIdx.x & 63;
+        float v = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        out[n] = (beta != 0.f ? beta * out[n] : 0.f) + v;
+    }
+}
+
+// out[c*rows + r] = in[r*cols + c]
+__global__ __launch_bounds__(256) void lvsr_transpose_kernel(const float* in, int rows, int cols, float* out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][j];
+    }
+}
+
+extern "C" {
+
+int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+               long long ws_bytes) {
+    LVSR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "lvsr_sgemm: negative dimension");
+    if (M == 0 || N == 0) return LVSR_OK;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB;
+    g.alpha = alpha; g.beta = beta; g.ksplit = 1; g.kchunk = ((K + BK - 1) / BK) * BK; g.part = nullptr;
+    if (g.kchunk == 0) g.kchunk = BK;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    // deterministic split-K when the output is too small to fill 256 CUs and K is long
+    if (ws && tiles < 128 && K >= 1024) {
+        int want = (512 + tiles - 1) / tiles;
+        int maxk = K / 256;
+        if (want > maxk) want = maxk;
+        long long need = (long long)want * M * N * 4;
+        while (want > 1 && need > ws_bytes) { --want; need = (long long)want * M * N * 4; }
+        if (want > 1) {
+            int chunk = (K + want - 1) / want;
+            chunk = ((chunk + BK - 1) / BK) * BK;
+            g.ksplit = (K + chunk - 1) / chunk;
+            g.kchunk = chunk;
+            g.part = ws;
+        }
+    }
+    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, g.ksplit);
+    hipLaunchKernelGGL(lvsr_sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    if (g.ksplit > 1) {
+        int nb = (int)(((size_t)M * N + 255) / 256);
+        if (nb > 2048) nb = 2048;
+        hipLaunchKernelGGL(lvsr_sgemm_splitk_reduce, dim3(nb), dim3(256), 0, (hipStream_t)stream, g);
+    }
+    return lvsr_check_launch("lvsr_sgemm");
+}
+
+int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta) {
+    if (N <= 0) return LVSR_OK;
+    hipLaunchKernelGGL(lvsr_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, M, N, ldx, out, beta);
+    return lvsr_check_launch("lvsr_colsum");
+}
+
+int lvsr_transpose(void* stream, const float* in, int rows, int cols, float* out) {
+    if (rows <= 0 || cols <= 0) return LVSR_OK;
+    hipLaunchKernelGGL(lvsr_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       in, rows, cols, out);
+    return lvsr_check_launch("lvsr_transpose");
+}
+
+}  // extern "C"

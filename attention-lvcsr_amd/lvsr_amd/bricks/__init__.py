@@ -1,0 +1,125 @@
+"""Host-side mirror of lvsr.bricks: Encoder (lvsr/bricks/__init__.py:54-83) driving the HIP kernels.
+
+`Encoder.apply(input_, mask)` keeps the reference signature and returns `(encoded, encoded_mask)`;
+`Encoder.backward(d_encoded)` is the BPTT counterpart the reference gets from theano.grad.
+All arithmetic happens in the C-ABI library (lvsr_sgemm / lvsr_bigru_fwd / lvsr_bigru_bwd / lvsr_colsum);
+torch is used for buffers and views only.
+"""
+import torch
+
+
+class Encoder(object):
+    def __init__(self, dims, store, lib, workspace, use_graph=True):
+        self.d = dims
+        self.store = store
+        self.lib = lib
+        self.ws = workspace
+        self.use_graph = use_graph
+        self._saved = None
+
+    def _names(self, i, direction):
+        base = "/recognizer/encoder/bidir%d/%s" % (i, direction)
+        return dict(Wi=base + "/fork/fork_inputs.W", bi=base + "/fork/fork_inputs.b",
+                    Wg=base + "/fork/fork_gate_inputs.W", bg=base + "/fork/fork_gate_inputs.b",
+                    Whh=base + "/gatedrecurrent.state_to_state", Whg=base + "/gatedrecurrent.state_to_gates",
+                    h0=base + "/gatedrecurrent.initial_state")
+
+    def apply(self, input_, mask=None, save_for_backward=True):
+        """input_ (T,B,F) fp32, mask (T,B) fp32 or None -> encoded (T',B,2H_last), encoded_mask (T',B)."""
+        d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
+        T, B = int(input_.shape[0]), int(input_.shape[1])
+        x = input_.contiguous()
+        m = None if mask is None else mask.contiguous()
+        saved = []
+        gemm_ws = ws.get("gemm_ws", (1 << 22,))
+        for i, (H, s) in enumerate(zip(d.Hs, d.subsample)):
+            I = d.layer_input_dim(i)
+            Ts = (T + s - 1) // s
+            xg = ws.get("enc%d.xg" % i, (T, B, 6 * H))
+            y = ws.get("enc%d.y" % i, (T, B, 2 * H))
+            ysub = y if s == 1 else ws.get("enc%d.ysub" % i, (Ts, B, 2 * H))
+            u = ws.get("enc%d.u" % i, (T, B, 2 * H))
+            r = ws.get("enc%d.r" % i, (T, B, 2 * H))
+            c = ws.get("enc%d.c" % i, (T, B, 2 * H))
+            rh = ws.get("enc%d.rh" % i, (T, B, 2 * H))
+            x2, xg2 = x.view(T * B, I), xg.view(T * B, 6 * H)
+            W = []
+            for di, direction in enumerate(("forward", "backward")):
+                n = self._names(i, direction)
+                lib.sgemm(x2, p[n["Wi"]], xg2[:, di * 3 * H: di * 3 * H + H], bias=p[n["bi"]])
+                lib.sgemm(x2, p[n["Wg"]], xg2[:, di * 3 * H + H: di * 3 * H + 3 * H], bias=p[n["bg"]])
+                W.append((p[n["Whh"]], p[n["Whg"]], p[n["h0"]]))
+            lib.bigru_fwd(xg, m, W[0], W[1], y, ysub, s, u, r, c, rh, T, B, H, self.use_graph)
+            saved.append(dict(x=x, mask=m, T=T, y=y, u=u, r=r, c=c, rh=rh))
+            x = ysub
+            if m is not None and s > 1:
+                mm = ws.get("enc%d.msub" % i, (Ts, B))
+                mm.copy_(m[::s])
+                m = mm
+            T = Ts
+        if m is None:
+            m = ws.get("enc.ones_mask", (T, B))
+            m.fill_(1.0)
+        if save_for_backward:
+            self._saved = saved
+        return x, m
+
+    def backward(self, d_encoded):
+        """d_encoded (T',B,2H_last): gradient wrt `encoded`.  Writes the encoder parameter gradients."""
+        d, p, g, lib, ws = self.d, self.store.p, self.store.g, self.lib, self.ws
+        assert self._saved is not None, "apply() must run first"
+        gemm_ws = ws.get("gemm_ws", (1 << 22,))
+        dy = d_encoded.contiguous()
+        B = int(dy.shape[1])
+        for i in reversed(range(d.n_layers)):
+            H, s, I = d.Hs[i], d.subsample[i], d.layer_input_dim(i)
+            sv = self._saved[i]
+            T = sv["T"]
+            dxg = ws.get("enc%d.dxg" % i, (T, B, 6 * H))
+            Bp = (B + 15) // 16 * 16
+            dh_ws = ws.get("enc%d.dh" % i, (4 * Bp * H,))
+            WT = []
+            for di, direction in enumerate(("forward", "backward")):
+                n = self._names(i, direction)
+                whhT = ws.get("enc%d.%d.WhhT" % (i, di), (H, H))
+                whgT = ws.get("enc%d.%d.WhgT" % (i, di), (2 * H, H))
+                lib.transpose(p[n["Whh"]], whhT)
+                lib.transpose(p[n["Whg"]], whgT)
+                WT.append((whhT, whgT, p[n["h0"]]))
+            nf, nb = self._names(i, "forward"), self._names(i, "backward")
+            lib.bigru_bwd(sv["mask"], sv["y"], sv["u"], sv["r"], sv["c"], WT[0], WT[1], dy, s, dxg, dh_ws,
+                          g[nf["h0"]], g[nb["h0"]], T, B, H, self.use_graph)
+            x2 = sv["x"].view(T * B, I)
+            dxg2 = dxg.view(T * B, 6 * H)
+            y2 = sv["y"].view(T * B, 2 * H)
+            rh2 = sv["rh"].view(T * B, 2 * H)
+            dx = None
+            if i > 0:
+                dx = ws.get("enc%d.dx" % i, (T, B, I))
+            for di, direction in enumerate(("forward", "backward")):
+                n = self._names(i, direction)
+                dc = dxg2[:, di * 3 * H: di * 3 * H + H]               # d pre-activation of the candidate
+                dg = dxg2[:, di * 3 * H + H: di * 3 * H + 3 * H]       # d pre-activation of [update|reset]
+                hcol = slice(di * H, (di + 1) * H)
+                lib.sgemm(rh2[:, hcol], dc, g[n["Whh"]], transA=True, ws=gemm_ws)
+                if T > 1:
+                    if di == 0:     # h_{t-1} = y[t-1]
+                        lib.sgemm(y2[: (T - 1) * B, hcol], dg[B:], g[n["Whg"]], transA=True, ws=gemm_ws)
+                    else:           # backward direction: previous state in scan order is y[t+1]
+                        lib.sgemm(y2[B:, hcol], dg[: (T - 1) * B], g[n["Whg"]], transA=True, ws=gemm_ws)
+                    beta = 1.0
+                else:
+                    beta = 0.0
+                # the first scan step starts from the (broadcast) initial state: rank-B update with lda = 0
+                first = dg[:B] if di == 0 else dg[(T - 1) * B:]
+                lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0)
+                lib.sgemm(x2, dc, g[n["Wi"]], transA=True, ws=gemm_ws)
+                lib.sgemm(x2, dg, g[n["Wg"]], transA=True, ws=gemm_ws)
+                lib.colsum(dc, g[n["bi"]])
+                lib.colsum(dg, g[n["bg"]])
+                if dx is not None:
+                    dx2 = dx.view(T * B, I)
+                    lib.sgemm(dc, p[n["Wi"]], dx2, transB=True, beta=(0.0 if di == 0 else 1.0))
+                    lib.sgemm(dg, p[n["Wg"]], dx2, transB=True, beta=1.0)
+            dy = dx
+        return None

@@ -1,0 +1,70 @@
+"""Parameter storage: one flat fp32 buffer for values and one for gradients, named views in the
+reference's Blocks naming.  A flat gradient buffer is what the data-parallel step
+all-reduces (one RCCL all-reduce per step) and what the optimiser kernel walks.
+"""
+from collections import OrderedDict
+
+import numpy
+import torch
+
+from .spec import parameter_shapes
+
+
+class Workspace(object):
+    """Shape-keyed buffer cache.  Pointers must stay stable across steps because the captured
+    hipGraphs of the recurrent loops bake them in."""
+
+    def __init__(self, device):
+        self.device = device
+        self._bufs = {}
+
+    def get(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(int(s) for s in shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(key[1], dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for t in self._bufs.values())
+
+
+class ParameterStore(object):
+    def __init__(self, cfg, device, values=None):
+        self.shapes = parameter_shapes(cfg)
+        self.device = torch.device(device)
+        offs, total = OrderedDict(), 0
+        for name, shape in self.shapes.items():
+            n = int(numpy.prod(shape))
+            offs[name] = (total, n)
+            total += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.offsets = offs
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.p = OrderedDict((k, self.flat[o:o + n].view(self.shapes[k])) for k, (o, n) in offs.items())
+        self.g = OrderedDict((k, self.grad[o:o + n].view(self.shapes[k])) for k, (o, n) in offs.items())
+        if values is not None:
+            self.set_values(values)
+
+    def num_parameters(self):
+        return sum(n for _, n in self.offsets.values())
+
+    def set_values(self, values):
+        missing = set(self.shapes) - set(values)
+        extra = set(values) - set(self.shapes)
+        if missing or extra:
+            raise ValueError("parameter names do not match: missing %s, unexpected %s" % (sorted(missing), sorted(extra)))
+        for k, v in values.items():
+            v = numpy.asarray(v, dtype=numpy.float32)
+            if tuple(v.shape) != tuple(self.shapes[k]):
+                raise ValueError("shape mismatch for %s: %s vs %s" % (k, v.shape, self.shapes[k]))
+            self.p[k].copy_(torch.from_numpy(numpy.ascontiguousarray(v)))
+
+    def get_values(self):
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.p.items())
+
+    def get_grads(self):
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.g.items())

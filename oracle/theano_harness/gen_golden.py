@@ -129,7 +129,11 @@ def run_case(name, cfg, B, T, L, ragged, param_seed, batch_seed, scale=1.0, stor
             b = bs.get("utt", 0)
             tl = int(batch["recordings_mask"][:, b].sum())
             x1 = batch["recordings"][:tl, b]
-            outs_, costs_ = rec.beam_search({"recordings": x1}, **kw)
+            try:
+                outs_, costs_ = rec.beam_search({"recordings": x1}, **kw)
+            except Exception as e:   # blocks.search.CandidateNotFoundError is part of the contract
+                beams.append(dict(settings=bs, outputs=None, costs=None, error=type(e).__name__))
+                continue
             beams.append(dict(settings=bs, outputs=[[int(t) for t in o] for o in outs_],
                               costs=[float(c_) for c_ in costs_]))
             if analyze and outs_:

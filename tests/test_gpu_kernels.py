@@ -1,0 +1,66 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): HIP library through the C-ABI vs the CPU oracle."""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from oracle import lvsr_oracle as O
+from lvsr_amd import spec, synthetic, native
+from lvsr_amd.params import ParameterStore, Workspace
+from lvsr_amd.bricks import Encoder
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("transA,transB", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (257, 130, 1033), (512, 768, 2048)])
+def test_sgemm(gpu_device, transA, transB, M, N, K):
+    lib = native.get()
+    rng = numpy.random.RandomState(0)
+    A = torch.tensor(rng.normal(size=(K, M) if transA else (M, K)), dtype=torch.float32, device=gpu_device)
+    B = torch.tensor(rng.normal(size=(N, K) if transB else (K, N)), dtype=torch.float32, device=gpu_device)
+    C0 = torch.tensor(rng.normal(size=(M, N)), dtype=torch.float32, device=gpu_device)
+    bias = torch.tensor(rng.normal(size=(N,)), dtype=torch.float32, device=gpu_device)
+    ws = torch.empty(1 << 22, device=gpu_device)
+    C = C0.clone()
+    lib.sgemm(A, B, C, transA=transA, transB=transB, alpha=0.5, beta=2.0, bias=bias, ws=ws)
+    ref = 0.5 * ((A.T if transA else A).double() @ (B.T if transB else B).double()) + 2.0 * C0.double() + bias.double()
+    assert_allclose(C.cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-4 * numpy.sqrt(K))
+
+
+def _enc_cfg(Hs, sub, F=40):
+    return dict(input_dim=F, num_phonemes=6, dims_bidir=Hs, subsample=sub, dim_dec=4, dim_matcher=7,
+                attention_type="content", post_merge_dims=None, embed_outputs=True)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask", [([3, 3], [1, 2], 3, 13, True), ([20], [3], 17, 7, True),
+                                                   ([64, 48], [2, 1], 16, 60, True), ([32], [1], 5, 40, False)])
+def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph):
+    lib = native.get()
+    cfg = _enc_cfg(Hs, sub)
+    params = synthetic.make_params(cfg, seed=3)
+    batch = synthetic.make_batch(cfg, B, T, 4, seed=5, ragged=True)
+    x = torch.tensor(batch["recordings"])
+    m = torch.tensor(batch["recordings_mask"]) if use_mask else None
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    enc_ref, mask_ref = orc.encode(x.double(), None if m is None else m.double())
+    rng = numpy.random.RandomState(0)
+    dy = torch.tensor(rng.normal(size=tuple(enc_ref.shape)), dtype=torch.float64)
+    (enc_ref * dy).sum().backward()
+    store = ParameterStore(cfg, gpu_device, params)
+    enc = Encoder(spec.Dims(cfg), store, lib, Workspace(gpu_device), use_graph=use_graph)
+    for rep in range(2):      # second pass replays the cached graphs
+        out, out_mask = enc.apply(x.to(gpu_device), None if m is None else m.to(gpu_device))
+        enc.backward(dy.float().to(gpu_device))
+        torch.cuda.synchronize()
+        assert_allclose(out.cpu().numpy(), enc_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
+        assert_allclose(out_mask.cpu().numpy(), mask_ref.numpy())
+        for name, g in store.g.items():
+            if "/encoder/" not in name:
+                continue
+            ref = orc.p[name].grad.numpy()
+            scale = max(1e-3, numpy.abs(ref).max())
+            assert_allclose(g.cpu().numpy() / scale, ref / scale, atol=1e-4, rtol=0, err_msg=name)
+    if use_graph:
+        assert lib._lvsr_graph_count() > 0, "hipGraph capture did not engage"
