@@ -39,39 +39,85 @@ __device__ __forceinline__ float wave_max(float v) {
 // "row-block matmul" used by every recurrent step kernel.
 //
 // A 256-thread work-group (4 waves) produces one 16x16 tile  out[r][c] = sum_k A(r,k) * W[k][c0+c]
-// for r in the work-group's 16-row (utterance) tile.  K is split over the 4 waves in MFMA-sized
-// chunks of 4 (wave w takes chunks w, w+4, ...), partial tiles are summed through LDS in a fixed
-// order (deterministic).  A(r,k) is a functor so elementwise pre-processing of the operand
-// (e.g. dh*u*(1-c^2) in BPTT) is fused into the load.  W is row-major (K, ldw).
-// Batch rows map to the MFMA M dimension: one step of the recurrence for 16 utterances is exactly
-// one 16-row MFMA tile, so nothing is padded at the reference batch size.
+// for its 16-row (utterance) tile; batch rows are the MFMA M dimension, so one recurrence step for
+// 16 utterances is exactly one 16-row tile.  A recurrent step is latency bound (a few thousand
+// dependent steps per layer), so the body is organised to have every operand load in flight at once:
+//   * K is split in 4 contiguous slices of Kw (one per wave); inside a wave MFMA lane (i, kk) owns
+//     Kw/4 CONSECUTIVE k values, so its A operand is NQ = Kw/16 float4 loads from one row;
+//   * the weight is pre-packed (lvsr_pack_b) in exactly that order: P[tile][wave][q][lane][4], one
+//     coalesced 1 KiB wave-load per q; the packed copy stays L2 resident across steps;
+//   * all 2*NQ float4 loads are issued before the first MFMA; two accumulators alternate so the
+//     40-cycle dependent MFMA latency never exceeds the 32-cycle issue interval.
+// The order in which k values meet inside the fmaf chain is a property of the packing only, so it is
+// identical for every launch (deterministic results).
 // ---------------------------------------------------------------------------------------------
-template <class AFn>
-__device__ __forceinline__ f32x4 rb_partial(f32x4 acc, AFn afn, const float* __restrict__ W, int ldw, int K,
-                                            int c0, int ncols) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = lane & 15, kk = lane >> 4;
-    const bool colok = (c0 + i) < ncols;
-    for (int k0 = wave * 4; k0 < K; k0 += 16) {
-        const int k = k0 + kk;
-        float a = 0.f, b = 0.f;
-        if (k < K) {
-            a = afn(i, k);
-            if (colok) b = W[(size_t)k * ldw + c0 + i];
-        }
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+__host__ __device__ __forceinline__ int lvsr_pack_kw(int K) { return ((K + 3) / 4 + 15) / 16 * 16; }
+
+struct RowSrc {            // A operand rows: row i at base + i*ld (ld = 0 broadcasts one row), valid rows < nrows
+    const float* base; long long ld; int nrows; int K; bool vec;
+    __device__ __forceinline__ float4 operator()(int i, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= nrows || k >= K) return v;
+        const float* p = base + (size_t)i * ld + k;
+        if (vec && k + 3 < K) return *(const float4*)p;
+        v.x = p[0];
+        if (k + 1 < K) v.y = p[1];
+        if (k + 2 < K) v.z = p[2];
+        if (k + 3 < K) v.w = p[3];
+        return v;
     }
-    return acc;
+};
+__device__ __forceinline__ RowSrc row_src(const float* base, long long ld, int nrows, int K) {
+    RowSrc s;
+    s.base = base; s.ld = ld; s.nrows = nrows; s.K = K;
+    s.vec = ((ld & 3) == 0) && ((K & 3) == 0) && ((((size_t)base) & 15) == 0);
+    return s;
 }
 
-// Sum the 4 per-wave partial tiles; afterwards thread tid owns element (row = tid>>4, col = tid&15).
-__device__ __forceinline__ float rb_reduce(f32x4 acc) {
+template <int N, class A4>
+__device__ __forceinline__ void rb_chunk(f32x4& acc0, f32x4& acc1, const A4& a4, const float4* __restrict__ p, int i,
+                                         int k0) {
+    float4 a[N], b[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        b[q] = p[q * 64];
+        a[q] = a4(i, k0 + 4 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].y, b[q].y, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].z, b[q].z, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].w, b[q].w, acc1, 0, 0, 0);
+    }
+}
+
+// Accumulate this wave's K-slice of tile `tile` of packed weight P (logical K x N) into acc0/acc1.
+// a4(i, k) returns A[i][k..k+3] (zero beyond K / beyond the valid rows).
+template <class A4>
+__device__ __forceinline__ void rb_mm(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K,
+                                      int tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int Kw = lvsr_pack_kw(K), NQ = Kw >> 4;
+    int k0 = wave * Kw + kk * (Kw >> 2);
+    const float4* p = (const float4*)P + ((size_t)(tile * 4 + wave) * NQ) * 64 + lane;
+    int q = 0;
+    for (; q + 8 <= NQ; q += 8, p += 8 * 64, k0 += 32) rb_chunk<8>(acc0, acc1, a4, p, i, k0);
+    if (q + 4 <= NQ) { rb_chunk<4>(acc0, acc1, a4, p, i, k0); q += 4; p += 4 * 64; k0 += 16; }
+    if (q + 2 <= NQ) { rb_chunk<2>(acc0, acc1, a4, p, i, k0); q += 2; p += 2 * 64; k0 += 8; }
+    if (q < NQ) rb_chunk<1>(acc0, acc1, a4, p, i, k0);
+}
+
+// Sum the per-wave partial tiles; afterwards thread tid owns element (row = tid>>4, col = tid&15).
+__device__ __forceinline__ float rb_reduce(f32x4 acc0, f32x4 acc1) {
     __shared__ float red[4][16][17];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();   // protect `red` against a previous use in the same kernel
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc0[r] + acc1[r];
     __syncthreads();
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
     return ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
 }
+#define F32X4_ZERO ((f32x4){0.f, 0.f, 0.f, 0.f})

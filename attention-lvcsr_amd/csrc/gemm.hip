@@ -9,6 +9,7 @@
 // Optional deterministic split-K (partials in a caller-provided workspace, fixed-order reduction)
 // for the tall-skinny weight-gradient shapes (K = T*B rows).
 #include "common.h"
+#include "lvsr_hip.h"
 
 #define BM 64
 #define BN 64
@@ -155,6 +156,21 @@ __global__ __launch_bounds__(256) void lvsr_transpose_kernel(const float* in, in
     }
 }
 
+// Pack a weight into the operand order of rb_mm (common.h): P[tile][wave][q][lane][r] with
+// k = wave*Kw + (lane>>4)*(Kw/4) + 4q + r, col = tile*16 + (lane&15); zero padded.
+__global__ __launch_bounds__(256) void lvsr_pack_b_kernel(const float* W, int ldw, int K, int N, int trans, float* P,
+                                                          int Kw, int NQ, long long total) {
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const int r = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+        const long long g = idx >> 8;
+        const int q = (int)(g % NQ), wave = (int)((g / NQ) & 3), tile = (int)(g / NQ / 4);
+        const int k = wave * Kw + (lane >> 4) * (Kw >> 2) + 4 * q + r, col = tile * 16 + (lane & 15);
+        float v = 0.f;
+        if (k < K && col < N) v = trans ? W[(size_t)col * ldw + k] : W[(size_t)k * ldw + col];
+        P[idx] = v;
+    }
+}
+
 extern "C" {
 
 int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
@@ -204,6 +220,22 @@ int lvsr_transpose(void* stream, const float* in, int rows, int cols, float* out
     hipLaunchKernelGGL(lvsr_transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                        in, rows, cols, out);
     return lvsr_check_launch("lvsr_transpose");
+}
+
+long long lvsr_pack_size(int K, int N) {
+    if (K <= 0 || N <= 0) return 0;
+    return (long long)((N + 15) / 16) * 16 * 4 * lvsr_pack_kw(K);
+}
+
+int lvsr_pack_b(void* stream, const float* W, int ldw, int K, int N, int trans, float* packed) {
+    LVSR_REQUIRE(K > 0 && N > 0 && W && packed, "lvsr_pack_b: bad arguments K=%d N=%d", K, N);
+    const int Kw = lvsr_pack_kw(K), NQ = Kw / 16;
+    const long long total = lvsr_pack_size(K, N);
+    int nb = (int)((total + 255) / 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(lvsr_pack_b_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N, trans, packed, Kw,
+                       NQ, total);
+    return lvsr_check_launch("lvsr_pack_b");
 }
 
 }  // extern "C"

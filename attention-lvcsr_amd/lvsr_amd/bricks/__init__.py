@@ -16,6 +16,7 @@ class Encoder(object):
         self.ws = workspace
         self.use_graph = use_graph
         self._saved = None
+        self._packs = {}
 
     def _names(self, i, direction):
         base = "/recognizer/encoder/bidir%d/%s" % (i, direction)
@@ -23,6 +24,25 @@ class Encoder(object):
                     Wg=base + "/fork/fork_gate_inputs.W", bg=base + "/fork/fork_gate_inputs.b",
                     Whh=base + "/gatedrecurrent.state_to_state", Whg=base + "/gatedrecurrent.state_to_gates",
                     h0=base + "/gatedrecurrent.initial_state")
+
+    def _packed(self, i):
+        """Packed (MFMA operand order) copies of the recurrent weights of layer i, refreshed when the
+        parameters changed (store.version)."""
+        ent = self._packs.get(i)
+        if ent is not None and ent["version"] == self.store.version:
+            return ent
+        H, p, lib, ws = self.d.Hs[i], self.store.p, self.lib, self.ws
+        ent = dict(version=self.store.version, Whh=[], Whg=[], WhhT=[], WhgT=[])
+        for di, direction in enumerate(("forward", "backward")):
+            n = self._names(i, direction)
+            for key, W, trans in (("Whh", p[n["Whh"]], False), ("Whg", p[n["Whg"]], False),
+                                  ("WhhT", p[n["Whh"]], True), ("WhgT", p[n["Whg"]], True)):
+                K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+                buf = ws.get("enc%d.%d.%s_p" % (i, di, key), (lib.pack_size(K, N),))
+                lib.pack_b(W, buf, trans=trans)
+                ent[key].append(buf)
+        self._packs[i] = ent
+        return ent
 
     def apply(self, input_, mask=None, save_for_backward=True):
         """input_ (T,B,F) fp32, mask (T,B) fp32 or None -> encoded (T',B,2H_last), encoded_mask (T',B)."""
@@ -43,13 +63,16 @@ class Encoder(object):
             c = ws.get("enc%d.c" % i, (T, B, 2 * H))
             rh = ws.get("enc%d.rh" % i, (T, B, 2 * H))
             x2, xg2 = x.view(T * B, I), xg.view(T * B, 6 * H)
-            W = []
+            pk = self._packed(i)
+            h0s = []
             for di, direction in enumerate(("forward", "backward")):
                 n = self._names(i, direction)
                 lib.sgemm(x2, p[n["Wi"]], xg2[:, di * 3 * H: di * 3 * H + H], bias=p[n["bi"]])
                 lib.sgemm(x2, p[n["Wg"]], xg2[:, di * 3 * H + H: di * 3 * H + 3 * H], bias=p[n["bg"]])
-                W.append((p[n["Whh"]], p[n["Whg"]], p[n["h0"]]))
-            lib.bigru_fwd(xg, m, W[0], W[1], y, ysub, s, u, r, c, rh, T, B, H, self.use_graph)
+                h0s.append(p[n["h0"]])
+            lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", y, self.use_graph, xg=xg, mask=m,
+                    Whh_p=[pk["Whh"][0], pk["Whh"][1]], Whg_p=[pk["Whg"][0], pk["Whg"][1]], h0=h0s, y=y,
+                    ysub=(ysub if s > 1 else None), u=u, r=r, c=c, rh=rh, sub=s, T=T, B=B, H=H)
             saved.append(dict(x=x, mask=m, T=T, y=y, u=u, r=r, c=c, rh=rh))
             x = ysub
             if m is not None and s > 1:
@@ -78,17 +101,12 @@ class Encoder(object):
             dxg = ws.get("enc%d.dxg" % i, (T, B, 6 * H))
             Bp = (B + 15) // 16 * 16
             dh_ws = ws.get("enc%d.dh" % i, (4 * Bp * H,))
-            WT = []
-            for di, direction in enumerate(("forward", "backward")):
-                n = self._names(i, direction)
-                whhT = ws.get("enc%d.%d.WhhT" % (i, di), (H, H))
-                whgT = ws.get("enc%d.%d.WhgT" % (i, di), (2 * H, H))
-                lib.transpose(p[n["Whh"]], whhT)
-                lib.transpose(p[n["Whg"]], whgT)
-                WT.append((whhT, whgT, p[n["h0"]]))
+            pk = self._packed(i)
             nf, nb = self._names(i, "forward"), self._names(i, "backward")
-            lib.bigru_bwd(sv["mask"], sv["y"], sv["u"], sv["r"], sv["c"], WT[0], WT[1], dy, s, dxg, dh_ws,
-                          g[nf["h0"]], g[nb["h0"]], T, B, H, self.use_graph)
+            lib.run("lvsr_bigru_bwd", "lvsr_bigru_bwd_args", dxg, self.use_graph, mask=sv["mask"], y=sv["y"],
+                    u=sv["u"], r=sv["r"], c=sv["c"], WhhT_p=[pk["WhhT"][0], pk["WhhT"][1]],
+                    WhgT_p=[pk["WhgT"][0], pk["WhgT"][1]], h0=[p[nf["h0"]], p[nb["h0"]]], dy=dy, dxg=dxg, dh_ws=dh_ws,
+                    dh0=[g[nf["h0"]], g[nb["h0"]]], sub=s, T=T, B=B, H=H)
             x2 = sv["x"].view(T * B, I)
             dxg2 = dxg.view(T * B, 6 * H)
             y2 = sv["y"].view(T * B, 2 * H)

@@ -1,53 +1,124 @@
 """ctypes binding of the C-ABI library (include/lvsr_hip.h) — the only way the Python host side reaches
 the HIP kernels.  No torch types cross the boundary: tensors are passed as raw device pointers + sizes,
-the stream as a `hipStream_t` handle (torch's current stream on the tensor's device).
+the stream as a `hipStream_t` handle.
+
+The binding is generated from the header itself (structs and prototypes are parsed from
+include/lvsr_hip.h), so the header is the single source of truth for the ABI.
 
 The library is mandatory: if `liblvsr_hip.so` is missing or a call fails this raises; there is no
 PyTorch/CPU fallback anywhere in the product path.
 """
 import ctypes
 import os
+import re
 
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "liblvsr_hip.so")
+HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "lvsr_hip.h")
 
-c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
-P = c_void_p
-
-# name -> (restype, argtypes).  Must list every symbol declared in include/lvsr_hip.h
-# (tests/test_abi.py parses the header and checks both directions).
-SIGNATURES = {
-    "lvsr_last_error": (ctypes.c_char_p, []),
-    "lvsr_abi_version": (c_int, []),
-    "lvsr_sgemm": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_float, P, c_int, P, c_int, c_float, P, c_int, P, P, c_ll]),
-    "lvsr_colsum": (c_int, [P, P, c_int, c_int, c_int, P, c_float]),
-    "lvsr_transpose": (c_int, [P, P, c_int, c_int, P]),
-    "lvsr_graph_clear": (None, []),
-    "lvsr_graph_count": (c_int, []),
-    "lvsr_bigru_fwd": (c_int, [P] + [P] * 8 + [P, P, c_int] + [P] * 4 + [c_int] * 4),
-    "lvsr_bigru_bwd": (c_int, [P] + [P] * 5 + [P] * 6 + [P, c_int, P, P, P, P] + [c_int] * 4),
-}
+_SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
+            "long long": ctypes.c_longlong, "char": ctypes.c_char}
 
 
 class NativeError(RuntimeError):
     pass
 
 
+def _strip_comments(src):
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    src = re.sub(r"^\s*#.*$", " ", src, flags=re.M)
+    return src
+
+
+def _ctype(base, nptr, structs):
+    base = base.replace("const", " ").replace("struct", " ")
+    base = " ".join(base.split())
+    if nptr:
+        if base == "char" and nptr == 1:
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    if base == "void":
+        return None
+    if base in _SCALARS:
+        return _SCALARS[base]
+    if base in structs:
+        return structs[base]
+    raise NativeError("unsupported C type %r in %s" % (base, HEADER))
+
+
+def parse_header(path=HEADER):
+    """-> (structs: name -> ctypes.Structure subclass, functions: name -> (restype, [argtypes], [argnames]))."""
+    src = _strip_comments(open(path).read())
+    structs = {}
+    for m in re.finditer(r"typedef\s+struct\s+(\w+)\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        name, body = m.group(3), m.group(2)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            dm = re.match(r"((?:const\s+)?(?:unsigned\s+)?(?:long\s+long|\w+))\s*(.*)$", decl, flags=re.S)
+            base, rest = dm.group(1), dm.group(2)
+            for d in rest.split(","):
+                d = d.strip()
+                nptr = d.count("*")
+                d = d.replace("*", "").strip()
+                am = re.match(r"(\w+)\s*\[(\d+)\]$", d)
+                ct = _ctype(base, nptr, structs)
+                if am:
+                    fields.append((am.group(1), ct * int(am.group(2))))
+                else:
+                    fields.append((d, ct))
+        structs[name] = type(name, (ctypes.Structure,), {"_fields_": fields})
+    src_nostruct = re.sub(r"typedef\s+struct\s+\w+\s*\{.*?\}\s*\w+\s*;", " ", src, flags=re.S)
+    src_nostruct = re.sub(r'extern\s+"C"\s*\{', " ", src_nostruct)
+    functions = {}
+    for m in re.finditer(r"([\w\s\*]+?)\b(lvsr_\w+)\s*\(([^;{}]*?)\)\s*;", src_nostruct, flags=re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        restype = _ctype(ret.replace("*", ""), ret.count("*"), structs)
+        argtypes, argnames = [], []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                nptr = a.count("*")
+                a = a.replace("*", " ")
+                toks = a.split()
+                argnames.append(toks[-1])
+                base = " ".join(toks[:-1])
+                if nptr and base.replace("const", "").strip() in structs:
+                    argtypes.append(ctypes.POINTER(structs[base.replace("const", "").strip()]))
+                else:
+                    argtypes.append(_ctype(base, nptr, structs))
+        functions[name] = (restype, argtypes, argnames)
+    return structs, functions
+
+
 def ptr(t):
-    """Raw pointer of a tensor (or None)."""
+    """Raw address of a tensor (0 for None)."""
     if t is None:
         return None
-    if not t.is_contiguous() and t.dim() > 0 and t.numel() > 0:
-        # strided views are passed with explicit leading dimensions by the callers; they must
-        # at least be dense in the last dimension.
+    if isinstance(t, int):
+        return ctypes.c_void_p(t)
+    if t.dim() > 0 and t.numel() > 0:
         assert t.stride(-1) == 1, "last dimension must be contiguous"
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _addr(v):
+    if v is None:
+        return None
+    if isinstance(v, int):
+        return v
+    if v.dim() > 0 and v.numel() > 0:
+        assert v.stride(-1) == 1, "last dimension must be contiguous"
+    return v.data_ptr()
+
+
 class Lib(object):
-    def __init__(self, path=DEFAULT_LIB, signatures=None):
+    def __init__(self, path=DEFAULT_LIB):
         if not os.path.exists(path):
             raise NativeError(
                 "HIP extension %s not found: build it with `python __graft_entry__.py` "
@@ -55,21 +126,42 @@ class Lib(object):
         self.path = path
         self._dll = ctypes.CDLL(path)
         self.is_emulator = os.path.basename(path) != os.path.basename(DEFAULT_LIB)
-        for name, (res, args) in (signatures or SIGNATURES).items():
+        self.structs, self.functions = parse_header()
+        for name, (res, args, _) in self.functions.items():
             try:
                 fn = getattr(self._dll, name)
             except AttributeError:
-                raise NativeError("symbol %s missing from %s" % (name, path))
+                raise NativeError("symbol %s (declared in include/lvsr_hip.h) missing from %s" % (name, path))
             fn.restype = res
             fn.argtypes = args
             setattr(self, "_" + name, fn)
 
+    # ---- plumbing -----------------------------------------------------------------------------
     def stream_for(self, t):
         if t.is_cuda:
             return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
         if not self.is_emulator:
             raise NativeError("CPU tensor passed to the HIP library; the hot path runs on cuda devices only")
         return ctypes.c_void_p(0)
+
+    def make(self, struct_name, **kw):
+        """Build an argument block; tensors become raw addresses, lists fill pointer arrays."""
+        cls = self.structs[struct_name]
+        s = cls()
+        known = dict(cls._fields_)
+        for k, v in kw.items():
+            if k not in known:
+                raise NativeError("%s has no field %s" % (struct_name, k))
+            ft = known[k]
+            if isinstance(v, (list, tuple)):
+                arr = getattr(s, k)
+                for i, e in enumerate(v):
+                    arr[i] = _addr(e) if ft._type_ is ctypes.c_void_p else e
+            elif ft is ctypes.c_void_p:
+                setattr(s, k, _addr(v))
+            else:
+                setattr(s, k, v)
+        return s
 
     def call(self, name, *args):
         rc = getattr(self, "_" + name)(*args)
@@ -103,18 +195,23 @@ class Lib(object):
     def transpose(self, x, out):
         self.call("lvsr_transpose", self.stream_for(out), ptr(x), x.shape[0], x.shape[1], ptr(out))
 
+    def pack_size(self, K, N):
+        return int(self._lvsr_pack_size(K, N))
 
-    def bigru_fwd(self, xg, mask, Wf, Wb, y, ysub, sub, u, r, c, rh, T, B, H, use_graph):
-        """Wf/Wb = (state_to_state, state_to_gates, initial_state) of the forward / backward direction."""
-        self.call("lvsr_bigru_fwd", self.stream_for(y), ptr(xg), ptr(mask), ptr(Wf[0]), ptr(Wf[1]), ptr(Wf[2]),
-                  ptr(Wb[0]), ptr(Wb[1]), ptr(Wb[2]), ptr(y), ptr(ysub), sub, ptr(u), ptr(r), ptr(c), ptr(rh),
-                  T, B, H, int(use_graph))
+    def pack_b(self, W, packed, trans=False):
+        """W (K,N) [or (N,K) with trans=True] -> packed operand copy for the step kernels."""
+        K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+        assert packed.numel() >= self.pack_size(K, N)
+        self.call("lvsr_pack_b", self.stream_for(packed), ptr(W), W.stride(0), K, N, int(trans), ptr(packed))
 
-    def bigru_bwd(self, mask, y, u, r, c, WTf, WTb, dy, sub, dxg, dh_ws, dh0_f, dh0_b, T, B, H, use_graph):
-        """WTf/WTb = (state_to_state^T, state_to_gates^T, initial_state)."""
-        self.call("lvsr_bigru_bwd", self.stream_for(dxg), ptr(mask), ptr(y), ptr(u), ptr(r), ptr(c), ptr(WTf[0]),
-                  ptr(WTf[1]), ptr(WTf[2]), ptr(WTb[0]), ptr(WTb[1]), ptr(WTb[2]), ptr(dy), sub, ptr(dxg), ptr(dh_ws),
-                  ptr(dh0_f), ptr(dh0_b), T, B, H, int(use_graph))
+    def run(self, fn, struct_name, ref_tensor, use_graph=None, **fields):
+        """Call an args-struct entry point: fn(stream, &args[, use_graph])."""
+        a = self.make(struct_name, **fields)
+        if use_graph is None:
+            self.call(fn, self.stream_for(ref_tensor), ctypes.byref(a))
+        else:
+            self.call(fn, self.stream_for(ref_tensor), ctypes.byref(a), int(use_graph))
+        return a
 
 
 _default = None

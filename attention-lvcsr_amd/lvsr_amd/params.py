@@ -42,6 +42,7 @@ class ParameterStore(object):
             offs[name] = (total, n)
             total += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
         self.offsets = offs
+        self.version = 0          # bumped whenever parameter values change (packed copies key on it)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.p = OrderedDict((k, self.flat[o:o + n].view(self.shapes[k])) for k, (o, n) in offs.items())
@@ -62,6 +63,7 @@ class ParameterStore(object):
             if tuple(v.shape) != tuple(self.shapes[k]):
                 raise ValueError("shape mismatch for %s: %s vs %s" % (k, v.shape, self.shapes[k]))
             self.p[k].copy_(torch.from_numpy(numpy.ascontiguousarray(v)))
+        self.version += 1
 
     def get_values(self):
         return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.p.items())

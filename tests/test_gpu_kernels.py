@@ -50,9 +50,13 @@ def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph
     (enc_ref * dy).sum().backward()
     store = ParameterStore(cfg, gpu_device, params)
     enc = Encoder(spec.Dims(cfg), store, lib, Workspace(gpu_device), use_graph=use_graph)
+    side = torch.cuda.Stream(gpu_device)     # hipGraph capture needs a non-null stream
+    xd, md, dyd = x.to(gpu_device), None if m is None else m.to(gpu_device), dy.float().to(gpu_device)
+    torch.cuda.synchronize()
     for rep in range(2):      # second pass replays the cached graphs
-        out, out_mask = enc.apply(x.to(gpu_device), None if m is None else m.to(gpu_device))
-        enc.backward(dy.float().to(gpu_device))
+        with torch.cuda.stream(side):
+            out, out_mask = enc.apply(xd, md)
+            enc.backward(dyd)
         torch.cuda.synchronize()
         assert_allclose(out.cpu().numpy(), enc_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
         assert_allclose(out_mask.cpu().numpy(), mask_ref.numpy())

@@ -114,6 +114,12 @@ def test_beam_search_vs_reference(case):
         utt = s.pop("utt", 0)
         bs = s.pop("beam_size")
         tl = int(batch["recordings_mask"][:, utt].sum())
+        if b.get("error"):
+            # the reference raised blocks.search.CandidateNotFoundError (search.py:379-380): part of the contract
+            assert b["error"] == "CandidateNotFoundError"
+            with pytest.raises(LookupError):
+                orc.beam_search(batch["recordings"][:tl, utt], bs, **s)
+            continue
         outs, costs = orc.beam_search(batch["recordings"][:tl, utt], bs, **s)
         assert outs == b["outputs"], (case, bi)
         assert_allclose(costs, b["costs"], rtol=1e-5, atol=1e-5)
