@@ -74,6 +74,18 @@ __device__ __forceinline__ RowSrc row_src(const float* base, long long ld, int n
     return s;
 }
 
+// guarded 4-element load: p[0..3] where only the first `nvalid` exist; vec = 16-B aligned fast path allowed
+__device__ __forceinline__ float4 ld4g(const float* p, int nvalid, bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nvalid <= 0) return v;
+    if (vec && nvalid >= 4) return *(const float4*)p;
+    v.x = p[0];
+    if (nvalid > 1) v.y = p[1];
+    if (nvalid > 2) v.z = p[2];
+    if (nvalid > 3) v.w = p[3];
+    return v;
+}
+
 template <int N, class A4>
 __device__ __forceinline__ void rb_chunk(f32x4& acc0, f32x4& acc1, const A4& a4, const float4* __restrict__ p, int i,
                                          int k0) {

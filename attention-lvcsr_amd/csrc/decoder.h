@@ -1,0 +1,69 @@
+// Shared definitions of the attention-decoder kernels (decoder_fwd.hip / decoder_bwd.hip).
+#pragma once
+#include "common.h"
+#include "graph_cache.h"
+#include "lvsr_hip.h"
+
+typedef lvsr_attdec_args AttDec;
+
+#define ATT_MAX_T 4096       // attended length held in LDS (alignment / energy rows)
+#define ATT_MAX_M 1024       // match dim held in LDS
+#define ATT_MAX_KM 8192      // conv_num_filters * match dim (handler matrix in LDS)
+#define ATT_MAX_FW 1024      // conv filter width 2c+1
+#define ATT_TB 16            // attended positions per work-group in the energy kernels (4 per wave)
+
+struct Win { int begin, end; };
+int attdec_check(const AttDec& a, const char* what);
+
+// Window of take_glimpses (lvsr/bricks/attention.py:123-161).  Content-only attention: whole sequence.
+__device__ __forceinline__ Win attdec_window(const AttDec& a, int i) {
+    Win w;
+    w.begin = 0; w.end = a.Tp;
+    if (a.K == 0) return w;
+    if (a.prior_type == 0) {
+        // int64 step * floatX constant -> float64 arithmetic on the f32-rounded speeds (:127-132,160-161)
+        const double step = (double)(a.step0 + i);
+        double bg = a.p0 + step * a.p2, en = a.p1 + step * a.p3;
+        bg = fmax(0.0, fmin((double)(a.Tp - 1), bg));
+        en = fmax(0.0, fmin((double)a.Tp, en));
+        w.begin = (int)floor(bg); w.end = (int)ceil(en);
+        return w;
+    }
+    const float before = (float)a.p0, after = (float)a.p1;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int b = 0; b < a.B; ++b) {
+        const float p = a.pos[(size_t)i * a.B + b];
+        mn = fminf(mn, floorf(p - before));
+        mx = fmaxf(mx, ceilf(p + after));
+    }
+    w.begin = (int)fmaxf(0.f, mn);
+    w.end = (int)fminf((float)a.Tp, mx);
+    if (w.end < w.begin) w.end = w.begin;
+    return w;
+}
+
+// attended_mask_cut * additional_mask for position t of utterance b (:148-168)
+__device__ __forceinline__ float attdec_mask(const AttDec& a, int i, int b, int t) {
+    float m = a.Am[(size_t)t * a.Am_ts + (size_t)b * a.Am_bs];
+    if (a.K > 0 && a.prior_type != 0) {
+        const float p = a.pos[(size_t)i * a.B + b];
+        const float lo = floorf(p - (float)a.p0), hi = ceilf(p + (float)a.p1);
+        m *= ((float)t > lo && (float)t < hi) ? 1.f : 0.f;
+    }
+    return m;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red /*[4]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red /*[4]*/) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}

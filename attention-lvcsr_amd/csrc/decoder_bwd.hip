@@ -1,0 +1,331 @@
+// Attention decoder, backward (K12 for K5-K9): reverse walk over the label steps, five kernels per step,
+// captured into one hipGraph like the forward.  Math (per step i, all names as in decoder_fwd.hip):
+//   GRU:   dsn = ym*ds; dpc = dsn*u*(1-c^2); dpu = dsn*(c-s)*u*(1-u); drh = dpc @ Whh^T; dpr = drh*s*r*(1-r)
+//          dwa = [dpc|dpu|dpr] @ [Wdi|Wdg]^T + dWA_readout
+//          ds' = dsn*(1-u) + (1-ym)*ds + drh*r + [dpu|dpr] @ Whg^T + dsW @ Ws^T + dS_readout
+//   att:   q[b,t] = dwa[b,:].A[t,b,:] + dalpha[b,t];  de = alpha*(q - sum_t alpha*q)      (masked softmax)
+//          dm[t,b,:] = de * w_e * (1 - tanh^2(match));  dPA += dm;  dsW = sum_t dm;  dcv = dm @ handler^T
+//          dalpha'[b,t'] = sum_k sum_d f[k,c+d] * dcv[b,k,t'+d]   (correlation, inside the step's window)
+// Window positions carry no gradient (disconnected_grad / floor, lvsr/bricks/attention.py:141-147).
+#include "decoder.h"
+
+typedef lvsr_attdec_bwd_args AttBwd;
+
+struct DecDpcSrc {    // A operand: ds * ym * u * (1 - c^2); ds rows ld=D, u,c rows ld=D
+    const float* ds; const float* u; const float* c; const float* mask;
+    int D, nrows; bool vec;
+    __device__ __forceinline__ float4 operator()(int i, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= nrows || k >= D) return v;
+        const float m = mask ? mask[i] : 1.f;
+        const size_t o = (size_t)i * D + k;
+        const float4 d4 = ld4g(ds + o, D - k, vec), u4 = ld4g(u + o, D - k, vec), c4 = ld4g(c + o, D - k, vec);
+        v.x = d4.x * m * u4.x * (1.f - c4.x * c4.x);
+        v.y = d4.y * m * u4.y * (1.f - c4.y * c4.y);
+        v.z = d4.z * m * u4.z * (1.f - c4.z * c4.z);
+        v.w = d4.w * m * u4.w * (1.f - c4.w * c4.w);
+        return v;
+    }
+};
+
+// B1: drh = dpc @ Whh^T; writes DXG[i] and dspart
+__global__ __launch_bounds__(256) void attbwd_gru_a_kernel(AttBwd g, int i) {
+    const AttDec& a = g.f;
+    const int D = a.D, B = a.B, tile = blockIdx.x, b0 = blockIdx.y * 16;
+    const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
+    const bool ok = b < B && j < D;
+    const size_t row = (size_t)i * B + b;
+    const float m = (ok && a.ymask) ? a.ymask[row] : 1.f;
+    const float uu = ok ? a.U[row * D + j] : 0.f, rr = ok ? a.R[row * D + j] : 0.f, cc = ok ? a.C[row * D + j] : 0.f;
+    const float sp = ok ? a.S[row * D + j] : 0.f;
+    const float dsv = ok ? g.ds[(size_t)b * D + j] : 0.f;
+    DecDpcSrc src;
+    src.ds = g.ds + (size_t)b0 * D; src.u = a.U + ((size_t)i * B + b0) * D; src.c = a.C + ((size_t)i * B + b0) * D;
+    src.mask = a.ymask ? a.ymask + (size_t)i * B + b0 : nullptr; src.D = D; src.nrows = B - b0;
+    src.vec = ((D & 3) == 0) && ((((size_t)src.ds | (size_t)src.u | (size_t)src.c) & 15) == 0);
+    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+    rb_mm(acc0, acc1, src, g.WhhT_p, D, tile);
+    const float drh = rb_reduce(acc0, acc1);
+    if (ok) {
+        const float dsn = m * dsv;
+        float* dx = g.DXG + row * 3 * D;
+        dx[j] = dsn * uu * (1.f - cc * cc);
+        dx[D + j] = dsn * (cc - sp) * uu * (1.f - uu);
+        dx[2 * D + j] = drh * sp * rr * (1.f - rr);
+        g.dspart[(size_t)b * D + j] = dsn * (1.f - uu) + (1.f - m) * dsv + drh * rr;
+    }
+}
+
+// B2: dwa = DXG[i] @ [Wdi|Wdg]^T + dWA_r (E tiles);  dsacc = dspart + [dpu|dpr] @ Whg^T (D tiles)
+__global__ __launch_bounds__(256) void attbwd_gru_b_kernel(AttBwd g, int i) {
+    const AttDec& a = g.f;
+    const int D = a.D, B = a.B, E = a.E;
+    const int ntE = (E + 15) / 16;
+    const int tileAll = blockIdx.x, b0 = blockIdx.y * 16;
+    const int b = b0 + (threadIdx.x >> 4);
+    const size_t row = (size_t)i * B + b;
+    const float* dx = g.DXG + ((size_t)i * B + b0) * 3 * D;
+    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+    if (tileAll < ntE) {
+        const int j = tileAll * 16 + (threadIdx.x & 15);
+        const bool ok = b < B && j < E;
+        const float add = (ok && g.dWA_r) ? g.dWA_r[row * E + j] : 0.f;
+        rb_mm(acc0, acc1, row_src(dx, 3 * D, B - b0, 3 * D), g.WdT_p, 3 * D, tileAll);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) g.DWA[row * E + j] = v + add;
+    } else {
+        const int tile = tileAll - ntE;
+        const int j = tile * 16 + (threadIdx.x & 15);
+        const bool ok = b < B && j < D;
+        const float part = ok ? g.dspart[(size_t)b * D + j] : 0.f;
+        rb_mm(acc0, acc1, row_src(dx + D, 3 * D, B - b0, 2 * D), g.WhgT_p, 2 * D, tile);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) g.dsacc[(size_t)b * D + j] = part + v;
+    }
+}
+
+// B3: q[b,t] = dwa[b,:] . A[t,b,:] + dalpha[b,t]   (0 outside the window); one wave per (b,t)
+__global__ __launch_bounds__(256) void attbwd_q_kernel(AttBwd g, int i) {
+    const AttDec& a = g.f;
+    const int b = blockIdx.y, t0 = blockIdx.x * ATT_TB, B = a.B, Tp = a.Tp, E = a.E;
+    const Win w = attdec_window(a, i);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* dwa = g.DWA + ((size_t)i * B + b) * E;
+    for (int tt = wave; tt < ATT_TB; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= Tp) break;
+        float q = 0.f;
+        if (t >= w.begin && t < w.end) {
+            const float* ar = a.A + (size_t)t * a.A_ts + (size_t)b * a.A_bs;
+            for (int e = lane; e < E; e += 64) q += dwa[e] * ar[e];
+            q = wave_sum(q);
+            if (a.K > 0) q += g.dalpha[(size_t)b * Tp + t];
+        }
+        if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
+    }
+}
+
+// B4: softmax backward + energy backward for 16 positions of one utterance.  Waves split the match
+// dimension (every LDS accumulator entry then has exactly one owner lane).
+__global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
+    __shared__ float Hs[ATT_MAX_KM];
+    __shared__ float Hacc[ATT_MAX_KM];
+    __shared__ float we[ATT_MAX_M];
+    __shared__ float sw[ATT_MAX_M];
+    __shared__ float swacc[ATT_MAX_M];
+    __shared__ float weacc[ATT_MAX_M];
+    __shared__ float cvs[ATT_TB * 64];
+    __shared__ float dcvw[4][ATT_TB * 64];
+    __shared__ float des[ATT_TB];
+    __shared__ float red[4];
+    const AttDec& a = g.f;
+    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATT_TB, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    const int nchunk = gridDim.x;
+    const Win w = attdec_window(a, i);
+    const float* al = a.W + ((size_t)(i + 1) * B + b) * Tp;       // alignment produced by step i
+    const float* qr = g.Q + (size_t)b * Tp;
+    float* dswp = g.dswp + ((size_t)b * nchunk + chunk) * M;
+    float* dcv = K > 0 ? g.DCV + ((size_t)i * B + b) * K * Tp : nullptr;
+    if (t0 >= w.end || t0 + ATT_TB <= w.begin) {                  // outside the window: no contribution
+        for (int m = threadIdx.x; m < M; m += 256) dswp[m] = 0.f;
+        for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
+            const int tt = x / K, k = x % K;
+            if (t0 + tt < Tp) dcv[(size_t)k * Tp + t0 + tt] = 0.f;
+        }
+        return;
+    }
+    float sd = 0.f;
+    for (int t = w.begin + threadIdx.x; t < w.end; t += 256) sd += al[t] * qr[t];
+    sd = block_sum(sd, red);
+    for (int x = threadIdx.x; x < K * M; x += 256) { Hs[x] = a.handler[x]; Hacc[x] = 0.f; }
+    for (int m = threadIdx.x; m < M; m += 256) {
+        we[m] = a.w_e[m];
+        sw[m] = a.sW[((size_t)i * B + b) * M + m];
+        swacc[m] = 0.f; weacc[m] = 0.f;
+    }
+    for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
+        const int tt = x / K, k = x % K, t = t0 + tt;
+        cvs[tt * 64 + k] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+    }
+    if (threadIdx.x < ATT_TB) {
+        const int t = t0 + threadIdx.x;
+        des[threadIdx.x] = (t >= w.begin && t < w.end) ? al[t] * (qr[t] - sd) : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int mbase = wave * 64 + lane;                            // owned m: mbase + 256*j, j < 4
+    for (int tt = 0; tt < ATT_TB; ++tt) {
+        const int t = t0 + tt;
+        const bool inside = t >= w.begin && t < w.end;             // block-uniform
+        float dm[4] = {0.f, 0.f, 0.f, 0.f};
+        if (inside) {
+            const float de = des[tt];
+            const float* pa = a.PA + (size_t)t * a.PA_ts + (size_t)b * a.PA_bs;
+            float* dpa = g.dPA + ((size_t)t * B + b) * M;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = mbase + 256 * j;
+                if (m < M) {
+                    float x = pa[m] + sw[m];
+                    for (int k = 0; k < K; ++k) x += cvs[tt * 64 + k] * Hs[k * M + m];
+                    const float th = tanhf(x);
+                    const float d = de * we[m] * (1.f - th * th);
+                    dm[j] = d;
+                    dpa[m] += d;
+                    swacc[m] += d;
+                    weacc[m] += de * th;
+                    for (int k = 0; k < K; ++k) Hacc[k * M + m] += cvs[tt * 64 + k] * d;
+                }
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = mbase + 256 * j;
+                if (m < M) p += dm[j] * Hs[k * M + m];
+            }
+            p = wave_sum(p);
+            if (lane == 0) dcvw[wave][tt * 64 + k] = p;
+        }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
+        const int tt = x / K, k = x % K;
+        if (t0 + tt < Tp)
+            dcv[(size_t)k * Tp + t0 + tt] = (dcvw[0][tt * 64 + k] + dcvw[1][tt * 64 + k]) + (dcvw[2][tt * 64 + k] + dcvw[3][tt * 64 + k]);
+    }
+    const size_t blk = (size_t)b * nchunk + chunk;
+    for (int m = threadIdx.x; m < M; m += 256) {
+        dswp[m] = swacc[m];
+        g.accWe[blk * M + m] += weacc[m];
+    }
+    for (int x = threadIdx.x; x < K * M; x += 256) g.accH[blk * K * M + x] += Hacc[x];
+}
+
+struct DswSrc {      // A operand of B5: dsW[b][m] = sum over chunks of the per-work-group partials
+    const float* dswp; float* store; int nchunk, M, nrows; bool vec;
+    __device__ __forceinline__ float4 operator()(int i, int k) const {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i >= nrows || k >= M) return v;
+        const float* p = dswp + (size_t)i * nchunk * M + k;
+        for (int c = 0; c < nchunk; ++c) {
+            const float4 x = ld4g(p + (size_t)c * M, M - k, vec);
+            v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+        }
+        if (store) {
+            float* s = store + (size_t)i * M + k;
+            s[0] = v.x;
+            if (k + 1 < M) s[1] = v.y;
+            if (k + 2 < M) s[2] = v.z;
+            if (k + 3 < M) s[3] = v.w;
+        }
+        return v;
+    }
+};
+
+// B5: new running gradients.  Blocks [0, nmm): ds = dsacc + dsW @ Ws^T + dS_r[i] (tile 0 also stores DSW[i]);
+// remaining blocks: dalpha = correlation of dcv with the filters inside the window.
+__global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
+    __shared__ float row[ATT_MAX_T];
+    __shared__ float fl[ATT_MAX_FW];
+    const AttDec& a = g.f;
+    const int D = a.D, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    const int rt = (B + 15) / 16, ntD = (D + 15) / 16, nmm = ntD * rt;
+    const int nchunk = (Tp + ATT_TB - 1) / ATT_TB;
+    int blk = blockIdx.x;
+    if (blk < nmm) {
+        const int tile = blk % ntD, b0 = (blk / ntD) * 16;
+        const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
+        const bool ok = b < B && j < D;
+        float base = ok ? g.dsacc[(size_t)b * D + j] : 0.f;
+        if (ok && g.dS_r) base += g.dS_r[((size_t)i * B + b) * D + j];
+        DswSrc src;
+        src.dswp = g.dswp + (size_t)b0 * nchunk * M;
+        src.store = tile == 0 ? g.DSW + ((size_t)i * B + b0) * M : nullptr;
+        src.nchunk = nchunk; src.M = M; src.nrows = B - b0;
+        src.vec = ((M & 3) == 0) && ((((size_t)src.dswp) & 15) == 0);
+        f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+        rb_mm(acc0, acc1, src, g.WsT_p, M, tile);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) g.ds[(size_t)b * D + j] = base + v;
+        return;
+    }
+    blk -= nmm;
+    const int nch = (Tp + 255) / 256;
+    const int ch = blk % nch, b = blk / nch;
+    const Win w = attdec_window(a, i);
+    const int t = ch * 256 + threadIdx.x;
+    const int FW = 2 * a.c + 1;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();
+        const float* dc = g.DCV + (((size_t)i * B + b) * K + k) * Tp;
+        for (int x = threadIdx.x; x < Tp; x += 256) row[x] = dc[x];       // zero outside the window by construction
+        for (int x = threadIdx.x; x < FW; x += 256) fl[x] = a.filters[(size_t)k * FW + x];
+        __syncthreads();
+        if (t < Tp && t >= w.begin && t < w.end) {
+            // cv[p] = sum_d f[c+d]*alpha[p-d]  =>  dalpha[t] = sum_d f[c+d]*dcv[t+d], t+d inside the window
+            const int dlo = max(-a.c, w.begin - t), dhi = min(a.c, w.end - 1 - t);
+            for (int d = dlo; d <= dhi; ++d) s += fl[a.c + d] * row[t + d];
+        }
+    }
+    if (t < Tp) g.dalpha[(size_t)b * Tp + t] = s;
+}
+
+// gradient wrt conv1d.filters: df[k][j] = sum_{i,b,t in win_i} dcv_i[b,k,t] * alpha_i[b, t-(j-c)]  (alpha index in win_i)
+__global__ __launch_bounds__(256) void attdec_filter_grad_kernel(AttDec a, const float* DCV, float* df) {
+    __shared__ float red[4];
+    const int j = blockIdx.x, k = blockIdx.y, FW = 2 * a.c + 1, d = j - a.c;
+    float s = 0.f;
+    for (int i = 0; i < a.L; ++i) {
+        const Win w = attdec_window(a, i);
+        const int n = w.end - w.begin;
+        for (int x = threadIdx.x; x < a.B * n; x += 256) {
+            const int b = x / n, t = w.begin + x % n, tp = t - d;
+            if (tp >= w.begin && tp < w.end)
+                s += DCV[(((size_t)i * a.B + b) * a.K + k) * a.Tp + t] * a.W[((size_t)i * a.B + b) * a.Tp + tp];
+        }
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) df[(size_t)k * FW + j] = s;
+}
+
+extern "C" {
+
+int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_graph) {
+    LVSR_REQUIRE(args != nullptr, "lvsr_attdec_bwd: null args");
+    AttBwd g;
+    memcpy(&g, args, sizeof(g));
+    const AttDec& a = g.f;
+    if (int rc = attdec_check(a, "lvsr_attdec_bwd")) return rc;
+    LVSR_REQUIRE((a.phases & 3) == 3, "lvsr_attdec_bwd: needs a full forward (phases = 3)");
+    LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd: contexts must be contiguous (Tp,B,*)");
+    hipStream_t s = (hipStream_t)stream;
+    const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;
+    const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, nch = (a.Tp + 255) / 256;
+    auto enqueue = [&]() {
+        for (int i = a.L - 1; i >= 0; --i) {
+            hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_q_kernel, dim3(nchunk, a.B), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_energy_kernel, dim3(nchunk, a.B), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.K > 0 ? a.B * nch : 0)), dim3(256), 0, s, g, i);
+        }
+    };
+    GraphKey key("attdec_bwd");
+    key.add(&g, sizeof(g));
+    return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_bwd");
+}
+
+int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters) {
+    LVSR_REQUIRE(f != nullptr && DCV && dfilters, "lvsr_attdec_filter_grad: null argument");
+    AttDec a;
+    memcpy(&a, f, sizeof(a));
+    if (int rc = attdec_check(a, "lvsr_attdec_filter_grad")) return rc;
+    if (a.K == 0) return LVSR_OK;
+    hipLaunchKernelGGL(attdec_filter_grad_kernel, dim3(2 * a.c + 1, a.K), dim3(256), 0, (hipStream_t)stream, a, DCV, dfilters);
+    return lvsr_check_launch("lvsr_attdec_filter_grad");
+}
+
+}  // extern "C"

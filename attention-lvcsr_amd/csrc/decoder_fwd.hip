@@ -1,0 +1,286 @@
+// Attention decoder, forward (K5-K9 of SURVEY.md §2.3): one decoder step = up to five small kernels
+// (pre: state projections + location convolution | energies | masked softmax + glimpse | GRU gates |
+// GRU candidate), the whole label loop captured into one hipGraph.  Same structure as encoder.hip:
+// every cross-unit dependency inside a step is a kernel boundary, every contraction with the batch as
+// the 16-row MFMA tile (rb_mm), everything else wave-parallel VALU work with shuffle reductions.
+//
+// Reference semantics (paths relative to the reference root):
+//   take_glimpses / compute_energies / compute_weights  lvsr/bricks/attention.py:98-213
+//   conv1d (true convolution, 'full' then [c:-c])        lvsr/expressions.py:28-54
+//   ShallowEnergyComputer (tanh -> linear, no bias)      libs/blocks/blocks/bricks/attention.py:417-447
+//   compute_weighted_averages                            libs/blocks/blocks/bricks/attention.py:236-256
+//   compute_states = Distribute + GatedRecurrent step    libs/blocks/blocks/bricks/attention.py:625-662,
+//                                                        libs/blocks/blocks/bricks/recurrent.py:608-620
+#include "decoder.h"
+
+// Window centre of one alignment row (lvsr/bricks/attention.py:133-144); sequential on purpose
+// (cumsum order decides where the median crossing lands).
+__device__ __forceinline__ float attdec_pos_of_row(const AttDec& a, const float* w) {
+    if (a.prior_type == 1) {
+        float p = 0.f;
+        for (int t = 0; t < a.Tp; ++t) p += w[t] * (float)t;
+        return p;
+    }
+    float c = 0.f;
+    bool prev = false;
+    for (int t = 0; t < a.Tp; ++t) {
+        c += w[t];
+        const bool ge = (c - 0.5f) >= 0.f;
+        if (t > 0 && ge && !prev) return (float)(t - 1);
+        prev = ge;
+    }
+    return 0.f;
+}
+
+__global__ __launch_bounds__(64) void attdec_pos_kernel(AttDec a, int slot) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < a.B) a.pos[(size_t)slot * a.B + b] = attdec_pos_of_row(a, a.W + ((size_t)slot * a.B + b) * a.Tp);
+}
+
+struct PreGrid { int rt, ntS, ntG, nmm, nch, nconv; };
+__host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
+    PreGrid g;
+    g.rt = (a.B + 15) / 16;
+    g.ntS = (a.phases & 1) ? (a.M + 15) / 16 : 0;
+    g.ntG = (a.phases & 2) ? (2 * a.D + 15) / 16 : 0;
+    g.nmm = (g.ntS + g.ntG) * g.rt;
+    g.nch = (a.Tp + 255) / 256;
+    g.nconv = ((a.phases & 1) && a.K > 0) ? a.B * a.K * g.nch : 0;
+    return g;
+}
+
+// pre: sW = s @ W_s (attention), sg = s @ W_hg (gate pre-activation, state part), cv = conv(alpha_prev)
+__global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
+    __shared__ float al[ATT_MAX_T];
+    __shared__ float fl[ATT_MAX_FW];
+    const PreGrid g = attdec_pre_grid(a);
+    const int D = a.D, B = a.B, Tp = a.Tp;
+    int blk = blockIdx.x;
+    if (blk < g.nmm) {
+        const int tileAll = blk % (g.ntS + g.ntG), b0 = (blk / (g.ntS + g.ntG)) * 16;
+        const float* Srow = a.S + ((size_t)i * B + b0) * D;
+        const int b = b0 + (threadIdx.x >> 4);
+        f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+        if (tileAll < g.ntS) {
+            rb_mm(acc0, acc1, row_src(Srow, D, B - b0, D), a.Ws_p, D, tileAll);
+            const float v = rb_reduce(acc0, acc1);
+            const int j = tileAll * 16 + (threadIdx.x & 15);
+            if (b < B && j < a.M) a.sW[((size_t)i * B + b) * a.M + j] = v;
+        } else {
+            const int tile = tileAll - g.ntS;
+            rb_mm(acc0, acc1, row_src(Srow, D, B - b0, D), a.Whg_p, D, tile);
+            const float v = rb_reduce(acc0, acc1);
+            const int j = tile * 16 + (threadIdx.x & 15);
+            if (b < B && j < 2 * D) a.sg[(size_t)b * 2 * D + j] = v;
+        }
+        return;
+    }
+    blk -= g.nmm;
+    const int ch = blk % g.nch, k = (blk / g.nch) % a.K, b = blk / (g.nch * a.K);
+    const Win w = attdec_window(a, i);
+    const float* wprev = a.W + ((size_t)i * B + b) * Tp;
+    for (int t = threadIdx.x; t < Tp; t += 256) al[t] = (t >= w.begin && t < w.end) ? wprev[t] : 0.f;
+    const int FW = 2 * a.c + 1;
+    for (int j = threadIdx.x; j < FW; j += 256) fl[j] = a.filters[(size_t)k * FW + j];
+    __syncthreads();
+    const int t = ch * 256 + threadIdx.x;
+    if (t < Tp) {
+        float s = 0.f;
+        if (t >= w.begin && t < w.end) {
+            // true convolution of the CUT alignment: out[t] = sum_d f[c+d] * al[t-d], t-d inside the window
+            const int dlo = max(-a.c, t - (w.end - 1)), dhi = min(a.c, t - w.begin);
+            for (int d = dlo; d <= dhi; ++d) s += fl[a.c + d] * al[t - d];
+        }
+        a.CV[(((size_t)i * B + b) * a.K + k) * Tp + t] = s;
+    }
+}
+
+// energies: e[b,t] = w_e . tanh(PA[t,b,:] + sW[b,:] + cv[b,:,t] @ handler); one wave per (b,t)
+__global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
+    __shared__ float Hs[ATT_MAX_KM];
+    __shared__ float we[ATT_MAX_M];
+    __shared__ float sw[ATT_MAX_M];
+    __shared__ float cvs[ATT_TB * 64];
+    const int b = blockIdx.y, t0 = blockIdx.x * ATT_TB, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    const Win w = attdec_window(a, i);
+    float* en = a.EN + ((size_t)i * B + b) * Tp;
+    if (t0 >= w.end || t0 + ATT_TB <= w.begin) {      // nothing of this block is inside the window: paste zeros
+        if (threadIdx.x < ATT_TB && t0 + threadIdx.x < Tp) en[t0 + threadIdx.x] = 0.f;
+        return;
+    }
+    for (int x = threadIdx.x; x < K * M; x += 256) Hs[x] = a.handler[x];
+    for (int m = threadIdx.x; m < M; m += 256) {
+        we[m] = a.w_e[m];
+        sw[m] = a.sW[((size_t)i * B + b) * M + m];
+    }
+    for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
+        const int tt = x / K, k = x % K, t = t0 + tt;
+        cvs[tt * 64 + k] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int tt = wave; tt < ATT_TB; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= Tp) break;
+        float e = 0.f;
+        if (t >= w.begin && t < w.end) {
+            const float* pa = a.PA + (size_t)t * a.PA_ts + (size_t)b * a.PA_bs;
+            for (int m = lane; m < M; m += 64) {
+                float x = pa[m] + sw[m];
+                for (int k = 0; k < K; ++k) x += cvs[tt * 64 + k] * Hs[k * M + m];
+                e += we[m] * tanhf(x);
+            }
+            e = wave_sum(e);
+        }
+        if (lane == 0) en[t] = e;
+    }
+}
+
+// masked softmax over the window + glimpse; grid (ceil(E/128), B).  Chunk 0 also writes the new alignment
+// row (pasted into zeros) and the next window centre.
+__global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
+    __shared__ float al[ATT_MAX_T];
+    __shared__ float red[4];
+    __shared__ float part[8][132];
+    const int b = blockIdx.y, chunk = blockIdx.x, B = a.B, Tp = a.Tp, E = a.E;
+    const Win w = attdec_window(a, i);
+    const float* en = a.EN + ((size_t)i * B + b) * Tp;
+    float mx = -3.0e38f;
+    for (int t = w.begin + threadIdx.x; t < w.end; t += 256) mx = fmaxf(mx, en[t]);
+    mx = block_max(mx, red);
+    float s = 0.f, anyone = 0.f;
+    for (int t = w.begin + threadIdx.x; t < w.end; t += 256) {
+        const float m = attdec_mask(a, i, b, t);
+        const float u = expf(en[t] - mx) * m;
+        al[t] = u;
+        s += u;
+        if (1.f - m == 0.f) anyone = 1.f;
+    }
+    s = block_sum(s, red);
+    anyone = block_max(anyone, red);
+    const float Z = s + (anyone > 0.f ? 0.f : 1.f);      // + all(1 - mask)  (lvsr/bricks/attention.py:210-212)
+    __syncthreads();
+    for (int t = threadIdx.x; t < Tp; t += 256) al[t] = (t >= w.begin && t < w.end) ? al[t] / Z : 0.f;
+    __syncthreads();
+    if (chunk == 0) {
+        float* wn = a.W + ((size_t)(i + 1) * B + b) * Tp;
+        for (int t = threadIdx.x; t < Tp; t += 256) wn[t] = al[t];
+        if (a.K > 0 && a.prior_type != 0 && threadIdx.x == 0) a.pos[(size_t)(i + 1) * B + b] = attdec_pos_of_row(a, al);
+    }
+    const int cg = threadIdx.x & 31, tg = threadIdx.x >> 5;
+    const int col = chunk * 128 + cg * 4;
+    const float* Ab = a.A + (size_t)b * a.A_bs + col;
+    const bool vec = ((a.A_ts & 3) == 0) && ((a.A_bs & 3) == 0) && ((((size_t)a.A) & 15) == 0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nvalid = E - col;
+    for (int t = w.begin + tg; t < w.end; t += 8) {
+        const float4 v = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
+        const float p = al[t];
+        acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
+    }
+    part[tg][cg * 4 + 0] = acc.x; part[tg][cg * 4 + 1] = acc.y; part[tg][cg * 4 + 2] = acc.z; part[tg][cg * 4 + 3] = acc.w;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c2 = chunk * 128 + threadIdx.x;
+        if (c2 < E) {
+            float r = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) r += part[g][threadIdx.x];
+            a.WA[((size_t)i * B + b) * E + c2] = r;
+        }
+    }
+}
+
+// GRU part 1: x_in = fork_x + wa @ W_di;  g = sigmoid(sg + fork_g + wa @ W_dg) -> u, r, rh = r*s
+__global__ __launch_bounds__(256) void attdec_gru1_kernel(AttDec a, int i) {
+    const int D = a.D, B = a.B, E = a.E;
+    const int ntX = (D + 15) / 16;
+    const int tileAll = blockIdx.x, b0 = blockIdx.y * 16;
+    const int b = b0 + (threadIdx.x >> 4);
+    const float* wa = a.WA + ((size_t)i * B + b0) * E;
+    const size_t row = (size_t)i * B + b;
+    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+    if (tileAll < ntX) {
+        const int j = tileAll * 16 + (threadIdx.x & 15);
+        const bool ok = b < B && j < D;
+        const float fx = ok ? a.xg[row * 3 * D + j] : 0.f;
+        rb_mm(acc0, acc1, row_src(wa, E, B - b0, E), a.Wdi_p, E, tileAll);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) a.xin[(size_t)b * D + j] = fx + v;
+    } else {
+        const int tile = tileAll - ntX;
+        const int j = tile * 16 + (threadIdx.x & 15);
+        const bool ok = b < B && j < 2 * D;
+        const float fg = ok ? a.xg[row * 3 * D + D + j] + a.sg[(size_t)b * 2 * D + j] : 0.f;
+        const float sp = (ok && j >= D) ? a.S[row * D + (j - D)] : 0.f;
+        rb_mm(acc0, acc1, row_src(wa, E, B - b0, E), a.Wdg_p, E, tile);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) {
+            const float g = sigmoidf_(v + fg);
+            if (j < D) a.U[row * D + j] = g;
+            else { a.R[row * D + (j - D)] = g; a.RH[row * D + (j - D)] = g * sp; }
+        }
+    }
+}
+
+// GRU part 2: candidate, state update, label-mask blend; writes state slot i+1
+__global__ __launch_bounds__(256) void attdec_gru2_kernel(AttDec a, int i) {
+    const int D = a.D, B = a.B;
+    const int tile = blockIdx.x, b0 = blockIdx.y * 16;
+    const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
+    const bool ok = b < B && j < D;
+    const size_t row = (size_t)i * B + b;
+    const float xin = ok ? a.xin[(size_t)b * D + j] : 0.f;
+    const float uu = ok ? a.U[row * D + j] : 0.f;
+    const float sp = ok ? a.S[row * D + j] : 0.f;
+    const float m = (ok && a.ymask) ? a.ymask[row] : 1.f;
+    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+    rb_mm(acc0, acc1, row_src(a.RH + ((size_t)i * B + b0) * D, D, B - b0, D), a.Whh_p, D, tile);
+    const float v = rb_reduce(acc0, acc1);
+    if (ok) {
+        const float cand = tanhf(v + xin);
+        float sn = cand * uu + sp * (1.f - uu);
+        sn = m * sn + (1.f - m) * sp;
+        a.C[row * D + j] = cand;
+        a.S[((size_t)(i + 1) * B + b) * D + j] = sn;
+    }
+}
+
+int attdec_check(const AttDec& a, const char* what) {
+    LVSR_REQUIRE(a.Tp > 0 && a.B > 0 && a.L > 0 && a.E > 0 && a.D > 0 && a.M > 0 && a.K >= 0, "%s: bad dims", what);
+    LVSR_REQUIRE(a.Tp <= ATT_MAX_T, "%s: attended length %d > %d", what, a.Tp, ATT_MAX_T);
+    LVSR_REQUIRE(a.M <= ATT_MAX_M && a.K * a.M <= ATT_MAX_KM && a.K <= 64, "%s: match dim / filters too large", what);
+    LVSR_REQUIRE(a.K == 0 || 2 * a.c + 1 <= ATT_MAX_FW, "%s: conv filter too wide", what);
+    LVSR_REQUIRE(a.prior_type >= 0 && a.prior_type <= 2, "%s: unknown prior type", what);
+    LVSR_REQUIRE(a.K == 0 || a.prior_type == 0 || a.pos != nullptr, "%s: window_around_* priors need pos", what);
+    return LVSR_OK;
+}
+
+extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int use_graph) {
+    LVSR_REQUIRE(args != nullptr, "lvsr_attdec_fwd: null args");
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    if (int rc = attdec_check(a, "lvsr_attdec_fwd")) return rc;
+    LVSR_REQUIRE((a.phases & 3) != 0, "lvsr_attdec_fwd: phases must select attention and/or GRU");
+    hipStream_t s = (hipStream_t)stream;
+    const PreGrid g = attdec_pre_grid(a);
+    auto enqueue = [&]() {
+        if ((a.phases & 1) && a.K > 0 && a.prior_type != 0)
+            hipLaunchKernelGGL(attdec_pos_kernel, dim3((a.B + 63) / 64), dim3(64), 0, s, a, 0);
+        for (int i = 0; i < a.L; ++i) {
+            if (g.nmm + g.nconv > 0)
+                hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm + g.nconv), dim3(256), 0, s, a, i);
+            if (a.phases & 1) {
+                hipLaunchKernelGGL(attdec_energy_kernel, dim3((a.Tp + ATT_TB - 1) / ATT_TB, a.B), dim3(256), 0, s, a, i);
+                hipLaunchKernelGGL(attdec_glimpse_kernel, dim3((a.E + 127) / 128, a.B), dim3(256), 0, s, a, i);
+            }
+            if (a.phases & 2) {
+                hipLaunchKernelGGL(attdec_gru1_kernel, dim3((a.D + 15) / 16 + (2 * a.D + 15) / 16, g.rt), dim3(256), 0, s, a, i);
+                hipLaunchKernelGGL(attdec_gru2_kernel, dim3((a.D + 15) / 16, g.rt), dim3(256), 0, s, a, i);
+            }
+        }
+    };
+    GraphKey key("attdec_fwd");
+    key.add(&a, sizeof(a));
+    return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd");
+}

@@ -1,0 +1,284 @@
+"""Host-side mirror of the attention sequence generator: Blocks `SequenceGenerator`
+(libs/blocks/blocks/bricks/sequence_generators.py:910-949) with `AttentionRecurrent` transition
+(libs/blocks/blocks/bricks/attention.py:479-772), the lvsr attention bricks (lvsr/bricks/attention.py:42-237),
+`Readout` + post-merge (sequence_generators.py:531-707, lvsr/bricks/recognizer.py:298-320) and
+`SoftmaxEmitter` (:751-800), as wired by `SpeechRecognizer.__init__` (lvsr/bricks/recognizer.py:250-343).
+
+`cost_matrix(outputs, mask, attended=, attended_mask=)` keeps the reference signature
+(sequence_generators.py:317-326); `backward()` is the counterpart of theano.grad through it.  All arithmetic
+is in the C-ABI library; torch only owns buffers/views.
+"""
+import math
+
+import numpy
+import torch
+
+ACT_KIND = {"identity": 0, "maxout2": 1, "rectifier": 2, "tanh": 3}
+PRIOR_KIND = {"expanding": 0, "window_around_mean": 1, "window_around_median": 2}
+ATT_TB = 16     # positions per work-group in the energy kernels (csrc/decoder.h)
+
+
+def _f32(x):
+    return float(numpy.float32(x))
+
+
+class SequenceGenerator(object):
+    def __init__(self, dims, store, lib, workspace, use_graph=True):
+        self.d = dims
+        self.store = store
+        self.lib = lib
+        self.ws = workspace
+        self.use_graph = use_graph
+        self._packs = None
+        self._saved = None
+        g = "/recognizer/generator"
+        att = g + "/att_trans/" + ("conv_att" if dims.conv else "cont_att")
+        self.n = dict(
+            Wpre=att + "/preprocess.W", bpre=att + "/preprocess.b", Ws=att + "/state_trans/transform_states.W",
+            we=att + "/energy_comp/linear.W", filters=att + "/conv1d.filters", handler=att + "/handler.W",
+            Wdi=g + "/att_trans/distribute/fork_inputs.W", Wdg=g + "/att_trans/distribute/fork_gate_inputs.W",
+            Whh=g + "/att_trans/transition.state_to_state", Whg=g + "/att_trans/transition.state_to_gates",
+            h0=g + "/att_trans/transition.initial_state",
+            Wfi=g + "/fork/fork_inputs.W", bfi=g + "/fork/fork_inputs.b",
+            Wfg=g + "/fork/fork_gate_inputs.W", bfg=g + "/fork/fork_gate_inputs.b",
+            Wms=g + "/readout/merge/transform_states.W", Wmw=g + "/readout/merge/transform_weighted_averages.W",
+            bpm=g + "/readout/post_merge/bias.b", Wout=g + "/readout/post_merge/mlp/linear_0.W",
+            bout=g + "/readout/post_merge/mlp/linear_0.b", bro=g + "/readout/bias.b",
+            table=g + "/readout/lookupfeedback/lookuptable.W")
+
+    # ---- packed operand copies ------------------------------------------------------------------
+    def _packed(self):
+        if self._packs is not None and self._packs["version"] == self.store.version:
+            return self._packs
+        p, lib, ws, n, d = self.store.p, self.lib, self.ws, self.n, self.d
+        ent = dict(version=self.store.version)
+
+        def pack(key, W, trans=False):
+            K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+            buf = ws.get("gen.%s_p" % key, (lib.pack_size(K, N),))
+            lib.pack_b(W, buf, trans=trans)
+            ent[key] = buf
+        pack("Ws", p[n["Ws"]]); pack("WsT", p[n["Ws"]], True)
+        pack("Whg", p[n["Whg"]]); pack("WhgT", p[n["Whg"]], True)
+        pack("Whh", p[n["Whh"]]); pack("WhhT", p[n["Whh"]], True)
+        pack("Wdi", p[n["Wdi"]]); pack("Wdg", p[n["Wdg"]])
+        wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
+        wd[:, : d.D].copy_(p[n["Wdi"]])
+        wd[:, d.D:].copy_(p[n["Wdg"]])
+        pack("WdT", wd, True)
+        self._packs = ent
+        return ent
+
+    def _prior(self):
+        pr = self.d.cfg["prior"]
+        if not self.d.conv:
+            return 0, (0.0, 0.0, 0.0, 0.0)
+        kind = PRIOR_KIND.get(pr.get("type", "expanding"))
+        if kind is None:
+            raise Exception("Unknown prior type: %s" % pr.get("type"))       # lvsr/bricks/attention.py:158-159
+        if kind == 0:
+            return 0, (float(pr["initial_begin"]), float(pr["initial_end"]), _f32(pr["min_speed"]), _f32(pr["max_speed"]))
+        return kind, (float(pr["before"]), float(pr["after"]), 0.0, 0.0)
+
+    # ---- argument block shared by training and generation ------------------------------------------
+    def _attdec_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast):
+        d, p, n = self.d, self.store.p, self.n
+        Tp = int(A.shape[0])
+        kind, pp = self._prior()
+        if broadcast:      # one utterance shared by every hypothesis (beam search)
+            strides = dict(A_ts=d.E, A_bs=0, PA_ts=d.M, PA_bs=0, Am_ts=1, Am_bs=0)
+        else:
+            strides = dict(A_ts=B * d.E, A_bs=d.E, PA_ts=B * d.M, PA_bs=d.M, Am_ts=B, Am_bs=1)
+        f = dict(Tp=Tp, B=B, L=L, E=d.E, D=d.D, M=d.M, K=d.K, c=d.c, prior_type=kind, step0=step0, phases=phases,
+                 p0=pp[0], p1=pp[1], p2=pp[2], p3=pp[3], A=A, PA=PA, Am=Am, Ws_p=pk["Ws"], w_e=p[n["we"]],
+                 filters=p[n["filters"]] if d.conv else None, handler=p[n["handler"]] if d.conv else None,
+                 Whg_p=pk["Whg"], Whh_p=pk["Whh"], Wdi_p=pk["Wdi"], Wdg_p=pk["Wdg"])
+        f.update(strides)
+        f.update(bufs)
+        return f
+
+    def _feedback_fork(self, labels_flat, nrows, xg, fb_buf=None):
+        """xg (nrows,3D) = fork(feedback(labels)): LookupFeedback / OneOfNFeedback then Fork of two Linear bricks
+        (sequence_generators.py:263-264, 839-842; lvsr/bricks/__init__.py:97-104)."""
+        d, p, n, lib = self.d, self.store.p, self.n, self.lib
+        st = lib.stream_for(xg)
+        if d.embed:
+            lib.call("lvsr_gather_rows", st, lib_ptr(p[n["table"]]), d.FB, lib_ptr(labels_flat), nrows, d.V + 1, d.FB,
+                     None, lib_ptr(fb_buf), d.FB)
+            lib.sgemm(fb_buf, p[n["Wfi"]], xg[:, : d.D], bias=p[n["bfi"]])
+            lib.sgemm(fb_buf, p[n["Wfg"]], xg[:, d.D:], bias=p[n["bfg"]])
+        else:
+            lib.call("lvsr_gather_rows", st, lib_ptr(p[n["Wfi"]]), d.D, lib_ptr(labels_flat), nrows, d.FB, d.D,
+                     lib_ptr(p[n["bfi"]]), lib_ptr(xg), 3 * d.D)
+            lib.call("lvsr_gather_rows", st, lib_ptr(p[n["Wfg"]]), 2 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
+                     lib_ptr(p[n["bfg"]]), lib_ptr(xg[:, d.D:]), 3 * d.D)
+
+    def preprocess(self, attended):
+        """attention.preprocess (lvsr/bricks/attention.py:228-230): PA = attended @ W + b."""
+        d, p, n = self.d, self.store.p, self.n
+        Tp, B = int(attended.shape[0]), int(attended.shape[1])
+        PA = self.ws.get("gen.PA", (Tp, B, d.M))
+        self.lib.sgemm(attended.view(Tp * B, d.E), p[n["Wpre"]], PA.view(Tp * B, d.M), bias=p[n["bpre"]])
+        return PA
+
+    def _readout(self, S2, WA2, nrows, tag):
+        """Readout.readout (sequence_generators.py:614-619) + post-merge (recognizer.py:298-320) -> logits."""
+        d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
+        R1 = ws.get("gen.R1" + tag, (nrows, d.P))
+        bias = p[n["bpm"]] if d.post_merge else p[n["bro"]]
+        lib.sgemm(WA2, p[n["Wmw"]], R1, bias=bias)
+        if d.use_states_for_readout:
+            lib.sgemm(S2, p[n["Wms"]], R1, beta=1.0)
+        if not d.post_merge:
+            return R1, None, R1
+        R2 = ws.get("gen.R2" + tag, (nrows, d.Pout))
+        lib.call("lvsr_act_fwd", lib.stream_for(R2), ACT_KIND[d.act], lib_ptr(R1), d.P, nrows, d.P, lib_ptr(R2), d.Pout)
+        logits = ws.get("gen.logits" + tag, (nrows, d.V))
+        lib.sgemm(R2, p[n["Wout"]], logits, bias=p[n["bout"]])
+        return R1, R2, logits
+
+    # ---- teacher-forced cost ---------------------------------------------------------------------
+    def cost_matrix(self, outputs, mask=None, attended=None, attended_mask=None, save_for_backward=True):
+        """outputs (L,B) int64 labels, mask (L,B) or None, attended (T',B,E), attended_mask (T',B) -> costs (L,B).
+        Also keeps `self.last` = dict(weights, energies, states, weighted_averages) (the auxiliary variables
+        `SpeechRecognizer.analyze` extracts, recognizer.py:452-494)."""
+        d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
+        L, B = int(outputs.shape[0]), int(outputs.shape[1])
+        Tp = int(attended.shape[0])
+        pk = self._packed()
+        A = attended.contiguous()
+        Am = attended_mask.contiguous()
+        labels = outputs.contiguous()
+        ym = None if mask is None else mask.contiguous()
+        PA = self.preprocess(A)
+        xg = ws.get("gen.xg", (L * B, 3 * d.D))
+        fb = ws.get("gen.fb", (L * B, d.FB)) if d.embed else None
+        self._feedback_fork(labels.view(-1), L * B, xg, fb)
+        S = ws.get("gen.S", (L + 1, B, d.D))
+        W = ws.get("gen.W", (L + 1, B, Tp))
+        S[0].copy_(p[n["h0"]].unsqueeze(0).expand(B, d.D))     # initial_state tiled (recurrent.py:622-624)
+        W[0].zero_()
+        if d.conv:
+            W[0, :, 0] = 1.0                                   # initial_glimpses (lvsr/bricks/attention.py:215-222)
+        Kc = max(d.K, 1)
+        bufs = dict(xg=xg, ymask=ym, S=S, W=W,
+                    pos=ws.get("gen.pos", (L + 1, B)) if (d.conv and self._prior()[0] != 0) else None,
+                    WA=ws.get("gen.WA", (L, B, d.E)), EN=ws.get("gen.EN", (L, B, Tp)), sW=ws.get("gen.sW", (L, B, d.M)),
+                    CV=ws.get("gen.CV", (L, B, Kc, Tp)) if d.conv else None,
+                    U=ws.get("gen.U", (L, B, d.D)), R=ws.get("gen.R", (L, B, d.D)), C=ws.get("gen.C", (L, B, d.D)),
+                    RH=ws.get("gen.RH", (L, B, d.D)), sg=ws.get("gen.sg", (B, 2 * d.D)), xin=ws.get("gen.xin", (B, d.D)))
+        fields = self._attdec_fields(pk, A, PA, Am, L, B, bufs, phases=3, step0=0, broadcast=False)
+        fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
+        WA = bufs["WA"]
+        S2, WA2 = S[:L].view(L * B, d.D), WA.view(L * B, d.E)
+        R1, R2, logits = self._readout(S2, WA2, L * B, "")
+        cost = ws.get("gen.cost", (L, B))
+        dlogits = ws.get("gen.dlogits", (L * B, d.V))
+        lib.call("lvsr_softmax_nll", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V,
+                 lib_ptr(cost), lib_ptr(dlogits), d.V, 1.0, None, 0)
+        self.last = dict(weights=W[1:], energies=bufs["EN"], states=S[:L], weighted_averages=WA)
+        if save_for_backward:
+            self._saved = dict(L=L, B=B, Tp=Tp, A=A, Am=Am, PA=PA, labels=labels, ym=ym, xg=xg, fb=fb, bufs=bufs,
+                               fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk)
+        return cost
+
+    def backward(self):
+        """Gradient of sum(cost_matrix) wrt every generator parameter (written to store.g) and wrt `attended`
+        (returned, (T',B,E))."""
+        d, p, g, n, lib, ws = self.d, self.store.p, self.store.g, self.n, self.lib, self.ws
+        sv = self._saved
+        assert sv is not None, "cost_matrix() must run first"
+        L, B, Tp = sv["L"], sv["B"], sv["Tp"]
+        bufs, pk = sv["bufs"], sv["pk"]
+        nrows = L * B
+        gws = ws.get("gemm_ws", (1 << 22,))
+        S2, WA2 = bufs["S"][:L].view(nrows, d.D), bufs["WA"].view(nrows, d.E)
+        dlogits, R1, R2 = sv["dlogits"], sv["R1"], sv["R2"]
+        # ---- readout backward
+        if d.post_merge:
+            lib.sgemm(R2, dlogits, g[n["Wout"]], transA=True, ws=gws)
+            lib.colsum(dlogits, g[n["bout"]])
+            dR2 = ws.get("gen.dR2", (nrows, d.Pout))
+            lib.sgemm(dlogits, p[n["Wout"]], dR2, transB=True)
+            dR1 = ws.get("gen.dR1", (nrows, d.P))
+            lib.call("lvsr_act_bwd", lib.stream_for(dR1), ACT_KIND[d.act], lib_ptr(R1), d.P, lib_ptr(dR2), d.Pout, nrows, d.P,
+                     lib_ptr(dR1), d.P)
+            lib.colsum(dR1, g[n["bpm"]])
+        else:
+            dR1 = dlogits
+            lib.colsum(dR1, g[n["bro"]])
+        lib.sgemm(WA2, dR1, g[n["Wmw"]], transA=True, ws=gws)
+        dWA_r = ws.get("gen.dWA_r", (nrows, d.E))
+        lib.sgemm(dR1, p[n["Wmw"]], dWA_r, transB=True)
+        dS_r = None
+        if d.use_states_for_readout:
+            lib.sgemm(S2, dR1, g[n["Wms"]], transA=True, ws=gws)
+            dS_r = ws.get("gen.dS_r", (nrows, d.D))
+            lib.sgemm(dR1, p[n["Wms"]], dS_r, transB=True)
+        # ---- recurrent part
+        nchunk = (Tp + ATT_TB - 1) // ATT_TB
+        Kc = max(d.K, 1)
+        DXG = ws.get("gen.DXG", (nrows, 3 * d.D))
+        DWA = ws.get("gen.DWA", (L, B, d.E))
+        DSW = ws.get("gen.DSW", (nrows, d.M))
+        DCV = ws.get("gen.DCV", (L, B, Kc, Tp)) if d.conv else None
+        dPA = ws.get("gen.dPA", (Tp, B, d.M), zero=True)
+        accH = ws.get("gen.accH", (B * nchunk, Kc * d.M), zero=True)
+        accWe = ws.get("gen.accWe", (B * nchunk, d.M), zero=True)
+        ds = ws.get("gen.ds", (B, d.D), zero=True)
+        dalpha = ws.get("gen.dalpha", (B, Tp), zero=True)
+        bw = lib.make("lvsr_attdec_bwd_args", WhhT_p=pk["WhhT"], WhgT_p=pk["WhgT"], WdT_p=pk["WdT"], WsT_p=pk["WsT"],
+                      dWA_r=dWA_r, dS_r=dS_r, DXG=DXG, DWA=DWA, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe,
+                      ds=ds, dalpha=dalpha, dspart=ws.get("gen.dspart", (B, d.D)), dsacc=ws.get("gen.dsacc", (B, d.D)),
+                      Q=ws.get("gen.Q", (B, Tp)), dswp=ws.get("gen.dswp", (B, nchunk, d.M)))
+        bw.f = lib.make("lvsr_attdec_args", **sv["fields"])
+        import ctypes
+        lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
+        # ---- weight gradients as batched GEMMs over all steps
+        dpc, dg = DXG[:, : d.D], DXG[:, d.D:]
+        RH2 = bufs["RH"].view(nrows, d.D)
+        lib.sgemm(RH2, dpc, g[n["Whh"]], transA=True, ws=gws)
+        lib.sgemm(S2, dg, g[n["Whg"]], transA=True, ws=gws)
+        lib.sgemm(WA2, dpc, g[n["Wdi"]], transA=True, ws=gws)
+        lib.sgemm(WA2, dg, g[n["Wdg"]], transA=True, ws=gws)
+        lib.sgemm(S2, DSW, g[n["Ws"]], transA=True, ws=gws)
+        lib.colsum(ds, g[n["h0"]])
+        lib.colsum(dpc, g[n["bfi"]])
+        lib.colsum(dg, g[n["bfg"]])
+        st = lib.stream_for(ds)
+        labels_flat = sv["labels"].view(-1)
+        if d.embed:
+            fb = sv["fb"]
+            lib.sgemm(fb, dpc, g[n["Wfi"]], transA=True, ws=gws)
+            lib.sgemm(fb, dg, g[n["Wfg"]], transA=True, ws=gws)
+            dfb = ws.get("gen.dfb", (nrows, d.FB))
+            lib.sgemm(dpc, p[n["Wfi"]], dfb, transB=True)
+            lib.sgemm(dg, p[n["Wfg"]], dfb, transB=True, beta=1.0)
+            lib.call("lvsr_scatter_add_rows", st, lib_ptr(dfb), d.FB, lib_ptr(labels_flat), nrows, d.V + 1, d.FB,
+                     lib_ptr(g[n["table"]]), d.FB, 0.0)
+        else:
+            lib.call("lvsr_scatter_add_rows", st, lib_ptr(dpc), 3 * d.D, lib_ptr(labels_flat), nrows, d.FB, d.D,
+                     lib_ptr(g[n["Wfi"]]), d.D, 0.0)
+            lib.call("lvsr_scatter_add_rows", st, lib_ptr(dg), 3 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
+                     lib_ptr(g[n["Wfg"]]), 2 * d.D, 0.0)
+        lib.colsum(accWe, g[n["we"]].view(-1))
+        if d.conv:
+            lib.colsum(accH, g[n["handler"]].view(-1))
+            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]))
+        # ---- attended: preprocess backward + glimpse backward
+        A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
+        lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws)
+        lib.colsum(dPA2, g[n["bpre"]])
+        dA = ws.get("gen.dA", (Tp, B, d.E))
+        lib.sgemm(dPA2, p[n["Wpre"]], dA.view(Tp * B, d.E), transB=True)
+        W = bufs["W"]
+        for b in range(B):
+            # dA[:, b, :] += alpha_b^T (T',L) @ dwa_b (L,E)
+            lib.sgemm(W[1:, b, :], DWA[:, b, :], dA[:, b, :], transA=True, beta=1.0, M=Tp, N=d.E, K=L,
+                      lda=B * Tp, ldb=B * d.E, ldc=B * d.E)
+        return dA
+
+
+def lib_ptr(t):
+    from ..native import ptr
+    return ptr(t)

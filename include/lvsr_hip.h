@@ -74,6 +74,100 @@ typedef struct lvsr_bigru_bwd_args {
 } lvsr_bigru_bwd_args;
 int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* a, int use_graph);
 
+/* ---- attention decoder (teacher forced or one generation step) ------------------------------------
+ * AttentionRecurrent.do_apply / take_glimpses / compute_states (libs/blocks/blocks/bricks/attention.py:
+ * 589-707), SequenceContentAndConvAttention (lvsr/bricks/attention.py:98-230: window prior, location
+ * convolution, energies, masked softmax, paste), content-only SequenceContentAttention
+ * (libs/blocks/blocks/bricks/attention.py:346-393; K = 0 here), compute_weighted_averages (:236-256),
+ * decoder GatedRecurrent step with Distribute'd glimpse (:625-662; recurrent.py:608-620).
+ * One call runs steps [0, L): step i reads state slot i (S, W) and writes slot i+1. */
+typedef struct lvsr_attdec_args {
+    int Tp, B, L, E, D, M, K, c;          /* K = conv_num_filters (0: content-only attention), c = conv_n */
+    int prior_type;                       /* 0 expanding, 1 window_around_mean, 2 window_around_median */
+    int step0;                            /* value of the reference's `step` state at slot 0 */
+    int phases;                           /* bit0: attention (glimpse) part, bit1: GRU part, of every step */
+    int pad0;
+    double p0, p1, p2, p3;                /* expanding: initial_begin, initial_end, f32(min_speed), f32(max_speed); window_around_*: before, after */
+    /* contexts; element (t,b,x) at base[t*ts + b*bs + x]; bs = 0 broadcasts one utterance (beam search) */
+    const float* A; const float* PA; const float* Am;
+    long long A_ts, A_bs, PA_ts, PA_bs, Am_ts, Am_bs;
+    /* attention parameters */
+    const float* Ws_p;                    /* packed state_trans/transform_states.W (K=D,N=M) */
+    const float* w_e;                     /* energy_comp/linear.W (M) */
+    const float* filters;                 /* conv1d.filters (K,2c+1) */
+    const float* handler;                 /* handler.W (K,M) */
+    /* decoder GRU parameters (packed) */
+    const float* Whg_p;                   /* transition.state_to_gates (K=D,N=2D) */
+    const float* Whh_p;                   /* transition.state_to_state (K=D,N=D) */
+    const float* Wdi_p;                   /* distribute/fork_inputs.W (K=E,N=D) */
+    const float* Wdg_p;                   /* distribute/fork_gate_inputs.W (K=E,N=2D) */
+    /* per-step inputs */
+    const float* xg;                      /* (L,B,3D) fork(feedback) incl. biases: [x_in | g_update | g_reset] */
+    const float* ymask;                   /* (L,B) or NULL */
+    /* state slots (slot 0 filled by the caller) */
+    float* S;                             /* (L+1,B,D) decoder states */
+    float* W;                             /* (L+1,B,Tp) alignments (weights) */
+    float* pos;                           /* (L+1,B) window centres derived from W (prior_type 1,2), else NULL */
+    /* per-step outputs */
+    float* WA;                            /* (L,B,E) weighted_averages */
+    float* EN;                            /* (L,B,Tp) energies */
+    /* saved for backward */
+    float* sW;                            /* (L,B,M) transformed states */
+    float* CV;                            /* (L,B,K,Tp) location-convolution features */
+    float* U; float* R; float* C; float* RH;   /* (L,B,D) */
+    /* scratch */
+    float* sg;                            /* (B,2D) state part of the gate pre-activations */
+    float* xin;                           /* (B,D) candidate input */
+} lvsr_attdec_args;
+int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
+
+/* Backward of lvsr_attdec_fwd (what theano.grad derives through the decoder scan,
+ * libs/blocks/blocks/algorithms/__init__.py:216-224).  Walks the steps in reverse; per-step tensors needed
+ * for the weight gradients (DXG, DWA, DSW, DCV) are left for batched GEMMs by the caller. */
+typedef struct lvsr_attdec_bwd_args {
+    lvsr_attdec_args f;                   /* the forward argument block (same buffers, contiguous contexts) */
+    const float* WhhT_p;                  /* packed state_to_state^T (K=D,N=D) */
+    const float* WhgT_p;                  /* packed state_to_gates^T (K=2D,N=D) */
+    const float* WdT_p;                   /* packed [distribute/fork_inputs.W | fork_gate_inputs.W]^T (K=3D,N=E) */
+    const float* WsT_p;                   /* packed transform_states.W^T (K=M,N=D) */
+    const float* dWA_r;                   /* (L,B,E) readout gradient wrt weighted_averages, or NULL */
+    const float* dS_r;                    /* (L,B,D) readout gradient wrt state slot i, or NULL */
+    float* DXG;                           /* (L,B,3D) out: gradient wrt [x_in | gate_in] pre-activations */
+    float* DWA;                           /* (L,B,E) out: total gradient wrt weighted_averages */
+    float* DSW;                           /* (L,B,M) out: gradient wrt transformed states */
+    float* DCV;                           /* (L,B,K,Tp) out: gradient wrt convolution features */
+    float* dPA;                           /* (Tp,B,M) in/out: accumulated gradient wrt preprocessed attended (caller zeroes) */
+    float* accH;                          /* (B*nchunk, K*M) in/out: per-work-group handler.W gradient partials (caller zeroes) */
+    float* accWe;                         /* (B*nchunk, M) in/out: per-work-group energy vector gradient partials (caller zeroes) */
+    float* ds;                            /* (B,D) in/out: running gradient wrt the state (caller zeroes; ends as grad wrt slot 0) */
+    float* dalpha;                        /* (B,Tp) in/out: running gradient wrt the alignment (caller zeroes) */
+    float* dspart; float* dsacc;          /* (B,D) scratch */
+    float* Q;                             /* (B,Tp) scratch */
+    float* dswp;                          /* (B,nchunk,M) scratch; nchunk = ceil(Tp/16) */
+} lvsr_attdec_bwd_args;
+int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
+/* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block */
+int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters);
+
+/* ---- feedback lookup, post-merge activation, softmax emitter ----------------------------------------
+ * LookupTable.apply (libs/blocks/blocks/bricks/lookup.py:48-68) / OneOfNFeedback (lvsr/bricks/__init__.py:
+ * 97-104); Maxout/Rectifier/Tanh (libs/blocks/blocks/bricks/simple.py:161-207); Softmax.log_probabilities,
+ * categorical_cross_entropy (:315-371); SoftmaxEmitter.cost/costs (sequence_generators.py:780-791). */
+/* out[r,:] = table[idx[r],:] + bias  (rows with idx outside [0,nrows) read as zero) */
+int lvsr_gather_rows(void* stream, const float* table, int ldt, const long long* idx, int n, int nrows, int width,
+                     const float* bias, float* out, int ldo);
+/* dst[v,:] = beta*dst[v,:] + sum_{r: idx[r]==v} src[r,:]  (deterministic) */
+int lvsr_scatter_add_rows(void* stream, const float* src, int lds, const long long* idx, int n, int nrows, int width,
+                          float* dst, int ldd, float beta);
+/* kind: 0 identity, 1 Maxout(2), 2 Rectifier, 3 Tanh; x (n,P) -> y (n,P or P/2) */
+int lvsr_act_fwd(void* stream, int kind, const float* x, int ldx, int n, int P, float* y, int ldy);
+int lvsr_act_bwd(void* stream, int kind, const float* x, int ldx, const float* dy, int lddy, int n, int P, float* dx,
+                 int lddx);
+/* per row: cost = -log_softmax(logits)[label]*mask; optional dlogits = (softmax-onehot)*mask*scale;
+ * optional neglogp = -log_softmax for every class (beam search `costs`) */
+int lvsr_softmax_nll(void* stream, const float* logits, int ld, const long long* labels, const float* mask, int n, int V,
+                     float* cost, float* dlogits, int ldd, float scale, float* neglogp, int ldn);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,41 @@
+"""Kernel-source logic checks on the CPU emulator: whole recognizer (encoder + attention decoder + readout)
+forward and backward against the pinned oracle and the reference's golden fixtures, at tiny sizes."""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from conftest import load_golden
+from emu import emu_lib
+from oracle import lvsr_oracle as O
+from lvsr_amd import synthetic
+from lvsr_amd.bricks.recognizer import SpeechRecognizer
+
+CASES = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_content_embed",
+         "tiny_content_relu"]
+
+
+def check_against(rec, cm, z, orc_out, orc_grads, tol=1.0):
+    w = rec.generator.last["weights"].cpu().numpy()
+    cmn = cm.cpu().numpy()
+    assert_allclose(cmn, orc_out["cost_matrix"].detach().numpy(), rtol=2e-4 * tol, atol=2e-5 * tol)
+    assert_allclose(w, orc_out["weights"].detach().numpy(), rtol=2e-4 * tol, atol=2e-6 * tol)
+    if z is not None:
+        assert abs(cmn.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-4          # north_star tolerance
+        assert (w.argmax(axis=2) == z["weights_argmax"]).all()                      # bit-exact alignment indices
+    got = rec.store.get_grads()
+    for name, ref in orc_grads.items():
+        scale = max(1e-3, numpy.abs(ref).max())
+        assert_allclose(got[name] / scale, ref / scale, rtol=0, atol=2e-4 * tol, err_msg=name)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_recognizer_cost_and_gradients_emulated(case):
+    z, meta = load_golden(case)
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float64)
+    out, grads = orc.cost_and_grads(batch)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=meta["cfg"])
+    cm = rec.cost_and_gradients(batch)
+    check_against(rec, cm, z, out, grads)
