@@ -10,7 +10,12 @@ typedef lvsr_attdec_args AttDec;
 #define ATT_MAX_M 1024       // match dim held in LDS
 #define ATT_MAX_KM 8192      // conv_num_filters * match dim (handler matrix in LDS)
 #define ATT_MAX_FW 1024      // conv filter width 2c+1
-#define ATT_TB 16            // attended positions per work-group in the energy kernels (4 per wave)
+#define ATT_TB 16            // attended positions per work-group in the q kernel (4 per wave)
+#define ATT_MS 32            // match-dim slice per work-group in the energy kernels
+#define ATT_TT 64            // attended positions per tile in the energy kernels (8 t-groups x 8)
+#define ATT_KMAX 16          // conv filters held in registers
+#define ATT_MAX_KT 16384     // conv_num_filters * attended length held in LDS (energy kernels)
+#define ATT_MAX_KF 8192      // conv_num_filters * filter width held in LDS
 
 struct Win { int begin, end; };
 int attdec_check(const AttDec& a, const char* what);

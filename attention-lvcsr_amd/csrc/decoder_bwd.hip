@@ -99,117 +99,128 @@ __global__ __launch_bounds__(256) void attbwd_q_kernel(AttBwd g, int i) {
             const float* ar = a.A + (size_t)t * a.A_ts + (size_t)b * a.A_bs;
             for (int e = lane; e < E; e += 64) q += dwa[e] * ar[e];
             q = wave_sum(q);
-            if (a.K > 0) q += g.dalpha[(size_t)b * Tp + t];
+            for (int k = 0; k < a.K; ++k) q += g.dalp[((size_t)b * a.K + k) * Tp + t];
         }
         if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
     }
 }
 
-// B4: softmax backward + energy backward for 16 positions of one utterance.  Waves split the match
-// dimension (every LDS accumulator entry then has exactly one owner lane).
+// B4: softmax backward + energy backward.  Grid (ceil(M/32), B, ceil(T'/64)), same decomposition as the forward
+// energy kernel.  Sums over positions (dsW, handler / energy-vector gradients) leave as per-tile partials, sums
+// over the match dimension (dcv) as per-slice partials; both are folded in a fixed order by their consumers.
 __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
-    __shared__ float Hs[ATT_MAX_KM];
-    __shared__ float Hacc[ATT_MAX_KM];
-    __shared__ float we[ATT_MAX_M];
-    __shared__ float sw[ATT_MAX_M];
-    __shared__ float swacc[ATT_MAX_M];
-    __shared__ float weacc[ATT_MAX_M];
-    __shared__ float cvs[ATT_TB * 64];
-    __shared__ float dcvw[4][ATT_TB * 64];
-    __shared__ float des[ATT_TB];
+    __shared__ float cvs[ATT_KMAX][ATT_TT];
+    __shared__ float des[ATT_TT];
+    __shared__ float dms[ATT_TT][ATT_MS + 1];
+    __shared__ float Hs[ATT_KMAX][ATT_MS + 1];
+    __shared__ float racc[8][ATT_KMAX + 2][ATT_MS + 1];
     __shared__ float red[4];
     const AttDec& a = g.f;
-    const int b = blockIdx.y, chunk = blockIdx.x, t0 = chunk * ATT_TB, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
-    const int nchunk = gridDim.x;
+    const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x, tile = blockIdx.z, ntile = gridDim.z;
+    const int B = a.B, Tp = a.Tp, M = a.M, K = a.K, t0 = tile * ATT_TT;
     const Win w = attdec_window(a, i);
-    const float* al = a.W + ((size_t)(i + 1) * B + b) * Tp;       // alignment produced by step i
-    const float* qr = g.Q + (size_t)b * Tp;
-    float* dswp = g.dswp + ((size_t)b * nchunk + chunk) * M;
-    float* dcv = K > 0 ? g.DCV + ((size_t)i * B + b) * K * Tp : nullptr;
-    if (t0 >= w.end || t0 + ATT_TB <= w.begin) {                  // outside the window: no contribution
-        for (int m = threadIdx.x; m < M; m += 256) dswp[m] = 0.f;
-        for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
-            const int tt = x / K, k = x % K;
-            if (t0 + tt < Tp) dcv[(size_t)k * Tp + t0 + tt] = 0.f;
-        }
+    const int ml = threadIdx.x & 31, tg = threadIdx.x >> 5, m = slice * ATT_MS + ml;
+    const bool mok = m < M;
+    const size_t bt = (size_t)b * ntile + tile;
+    if (t0 >= w.end || t0 + ATT_TT <= w.begin) {                   // tile outside the window: zero partial
+        if (tg == 0 && mok) g.dswp[bt * M + m] = 0.f;
         return;
     }
+    // independent loads first
+    float pav[8], dpv[8];
+    const float* pab = a.PA + (size_t)b * a.PA_bs + m;
+    float* dpab = g.dPA + (size_t)b * M + m;
+    const size_t dpa_ts = (size_t)B * M;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int t = t0 + tg + 8 * r;
+        const bool ok = t >= w.begin && t < w.end && mok;
+        pav[r] = ok ? pab[(size_t)t * a.PA_ts] : 0.f;
+        dpv[r] = ok ? dpab[(size_t)t * dpa_ts] : 0.f;
+    }
+    float Hk[ATT_KMAX], hacc[ATT_KMAX];
+#pragma unroll
+    for (int k = 0; k < ATT_KMAX; ++k) {
+        Hk[k] = (k < K && mok) ? a.handler[(size_t)k * M + m] : 0.f;
+        hacc[k] = 0.f;
+    }
+    const float we_m = mok ? a.w_e[m] : 0.f;
+    const float sw_m = mok ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
+    const float* al = a.W + ((size_t)(i + 1) * B + b) * Tp;       // alignment produced by step i
+    const float* qr = g.Q + (size_t)b * Tp;
     float sd = 0.f;
     for (int t = w.begin + threadIdx.x; t < w.end; t += 256) sd += al[t] * qr[t];
     sd = block_sum(sd, red);
-    for (int x = threadIdx.x; x < K * M; x += 256) { Hs[x] = a.handler[x]; Hacc[x] = 0.f; }
-    for (int m = threadIdx.x; m < M; m += 256) {
-        we[m] = a.w_e[m];
-        sw[m] = a.sW[((size_t)i * B + b) * M + m];
-        swacc[m] = 0.f; weacc[m] = 0.f;
-    }
-    for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
-        const int tt = x / K, k = x % K, t = t0 + tt;
-        cvs[tt * 64 + k] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
-    }
-    if (threadIdx.x < ATT_TB) {
+    if (threadIdx.x < ATT_TT) {
         const int t = t0 + threadIdx.x;
         des[threadIdx.x] = (t >= w.begin && t < w.end) ? al[t] * (qr[t] - sd) : 0.f;
     }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int mbase = wave * 64 + lane;                            // owned m: mbase + 256*j, j < 4
-    for (int tt = 0; tt < ATT_TB; ++tt) {
-        const int t = t0 + tt;
-        const bool inside = t >= w.begin && t < w.end;             // block-uniform
-        float dm[4] = {0.f, 0.f, 0.f, 0.f};
-        if (inside) {
-            const float de = des[tt];
-            const float* pa = a.PA + (size_t)t * a.PA_ts + (size_t)b * a.PA_bs;
-            float* dpa = g.dPA + ((size_t)t * B + b) * M;
+    for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
+        const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
+        cvs[k][tl] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+    }
+    if (tg == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = mbase + 256 * j;
-                if (m < M) {
-                    float x = pa[m] + sw[m];
-                    for (int k = 0; k < K; ++k) x += cvs[tt * 64 + k] * Hs[k * M + m];
-                    const float th = tanhf(x);
-                    const float d = de * we[m] * (1.f - th * th);
-                    dm[j] = d;
-                    dpa[m] += d;
-                    swacc[m] += d;
-                    weacc[m] += de * th;
-                    for (int k = 0; k < K; ++k) Hacc[k * M + m] += cvs[tt * 64 + k] * d;
-                }
-            }
+        for (int k = 0; k < ATT_KMAX; ++k) Hs[k][ml] = Hk[k];
+    }
+    __syncthreads();
+    float swacc = 0.f, weacc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int tl = tg + 8 * r, t = t0 + tl;
+        float d = 0.f;
+        if (t >= w.begin && t < w.end && mok) {
+            float x = pav[r] + sw_m;
+#pragma unroll
+            for (int k = 0; k < ATT_KMAX; ++k)
+                if (k < K) x += cvs[k][tl] * Hk[k];
+            const float th = tanhf(x);
+            const float de = des[tl];
+            d = de * we_m * (1.f - th * th);
+            dpab[(size_t)t * dpa_ts] = dpv[r] + d;
+            swacc += d;
+            weacc += de * th;
+#pragma unroll
+            for (int k = 0; k < ATT_KMAX; ++k)
+                if (k < K) hacc[k] += cvs[k][tl] * d;
         }
-        for (int k = 0; k < K; ++k) {
+        dms[tl][ml] = d;
+    }
+    racc[tg][0][ml] = swacc;
+    racc[tg][1][ml] = weacc;
+#pragma unroll
+    for (int k = 0; k < ATT_KMAX; ++k) racc[tg][2 + k][ml] = hacc[k];
+    __syncthreads();
+    float* dcvp = K > 0 ? g.dcvp + ((size_t)b * nslice + slice) * K * Tp : nullptr;
+    for (int x = threadIdx.x; x < ATT_TT * K; x += 256) {
+        const int tl = x / K, k = x % K, t = t0 + tl;
+        if (t >= w.begin && t < w.end) {
             float p = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = mbase + 256 * j;
-                if (m < M) p += dm[j] * Hs[k * M + m];
-            }
-            p = wave_sum(p);
-            if (lane == 0) dcvw[wave][tt * 64 + k] = p;
+            for (int j = 0; j < ATT_MS; ++j) p += dms[tl][j] * Hs[k][j];
+            dcvp[(size_t)k * Tp + t] = p;
         }
     }
-    __syncthreads();
-    for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
-        const int tt = x / K, k = x % K;
-        if (t0 + tt < Tp)
-            dcv[(size_t)k * Tp + t0 + tt] = (dcvw[0][tt * 64 + k] + dcvw[1][tt * 64 + k]) + (dcvw[2][tt * 64 + k] + dcvw[3][tt * 64 + k]);
+    for (int x = threadIdx.x; x < (2 + K) * ATT_MS; x += 256) {
+        const int v = x / ATT_MS, j = x % ATT_MS, mm = slice * ATT_MS + j;
+        if (mm < M) {
+            float r = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) r += racc[q][v][j];
+            if (v == 0) g.dswp[bt * M + mm] = r;
+            else if (v == 1) g.accWe[bt * M + mm] += r;
+            else g.accH[(bt * K + (v - 2)) * M + mm] += r;
+        }
     }
-    const size_t blk = (size_t)b * nchunk + chunk;
-    for (int m = threadIdx.x; m < M; m += 256) {
-        dswp[m] = swacc[m];
-        g.accWe[blk * M + m] += weacc[m];
-    }
-    for (int x = threadIdx.x; x < K * M; x += 256) g.accH[blk * K * M + x] += Hacc[x];
 }
 
-struct DswSrc {      // A operand of B5: dsW[b][m] = sum over chunks of the per-work-group partials
-    const float* dswp; float* store; int nchunk, M, nrows; bool vec;
+struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of the per-work-group partials
+    const float* dswp; float* store; int ntile, M, nrows; bool vec;
     __device__ __forceinline__ float4 operator()(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i >= nrows || k >= M) return v;
-        const float* p = dswp + (size_t)i * nchunk * M + k;
-        for (int c = 0; c < nchunk; ++c) {
+        const float* p = dswp + (size_t)i * ntile * M + k;
+        for (int c = 0; c < ntile; ++c) {
             const float4 x = ld4g(p + (size_t)c * M, M - k, vec);
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
@@ -225,14 +236,16 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over chunks of the per-
 };
 
 // B5: new running gradients.  Blocks [0, nmm): ds = dsacc + dsW @ Ws^T + dS_r[i] (tile 0 also stores DSW[i]);
-// remaining blocks: dalpha = correlation of dcv with the filters inside the window.
+// remaining blocks, one per (utterance b, filter k): fold the per-slice dcv partials of row k (stored as DCV[i]
+// for the filter gradient) and correlate with filter k inside the window:
+//   dalp[b,k,t] = sum_d f[k,c+d] * dcv[k,t+d];   the q kernel of the next (earlier) step adds the K rows up.
 __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
     __shared__ float row[ATT_MAX_T];
     __shared__ float fl[ATT_MAX_FW];
     const AttDec& a = g.f;
     const int D = a.D, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
     const int rt = (B + 15) / 16, ntD = (D + 15) / 16, nmm = ntD * rt;
-    const int nchunk = (Tp + ATT_TB - 1) / ATT_TB;
+    const int ntile = (Tp + ATT_TT - 1) / ATT_TT;
     int blk = blockIdx.x;
     if (blk < nmm) {
         const int tile = blk % ntD, b0 = (blk / ntD) * 16;
@@ -241,9 +254,9 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         float base = ok ? g.dsacc[(size_t)b * D + j] : 0.f;
         if (ok && g.dS_r) base += g.dS_r[((size_t)i * B + b) * D + j];
         DswSrc src;
-        src.dswp = g.dswp + (size_t)b0 * nchunk * M;
+        src.dswp = g.dswp + (size_t)b0 * ntile * M;
         src.store = tile == 0 ? g.DSW + ((size_t)i * B + b0) * M : nullptr;
-        src.nchunk = nchunk; src.M = M; src.nrows = B - b0;
+        src.ntile = ntile; src.M = M; src.nrows = B - b0;
         src.vec = ((M & 3) == 0) && ((((size_t)src.dswp) & 15) == 0);
         f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
         rb_mm(acc0, acc1, src, g.WsT_p, M, tile);
@@ -252,25 +265,29 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         return;
     }
     blk -= nmm;
-    const int nch = (Tp + 255) / 256;
-    const int ch = blk % nch, b = blk / nch;
+    const int k = blk % K, b = blk / K, nslice = (M + ATT_MS - 1) / ATT_MS;
     const Win w = attdec_window(a, i);
-    const int t = ch * 256 + threadIdx.x;
     const int FW = 2 * a.c + 1;
-    float s = 0.f;
-    for (int k = 0; k < K; ++k) {
-        __syncthreads();
-        const float* dc = g.DCV + (((size_t)i * B + b) * K + k) * Tp;
-        for (int x = threadIdx.x; x < Tp; x += 256) row[x] = dc[x];       // zero outside the window by construction
-        for (int x = threadIdx.x; x < FW; x += 256) fl[x] = a.filters[(size_t)k * FW + x];
-        __syncthreads();
-        if (t < Tp && t >= w.begin && t < w.end) {
-            // cv[p] = sum_d f[c+d]*alpha[p-d]  =>  dalpha[t] = sum_d f[c+d]*dcv[t+d], t+d inside the window
+    const float* pp = g.dcvp + ((size_t)b * nslice * K + k) * Tp;
+    float* dcv = g.DCV + (((size_t)i * B + b) * K + k) * Tp;
+    for (int t = threadIdx.x; t < Tp; t += 256) {
+        float s = 0.f;
+        if (t >= w.begin && t < w.end)
+            for (int sl = 0; sl < nslice; ++sl) s += pp[(size_t)sl * K * Tp + t];
+        row[t] = s;
+        dcv[t] = s;
+    }
+    for (int x = threadIdx.x; x < FW; x += 256) fl[x] = a.filters[(size_t)k * FW + x];
+    __syncthreads();
+    float* out = g.dalp + ((size_t)b * K + k) * Tp;
+    for (int t = threadIdx.x; t < Tp; t += 256) {
+        float s = 0.f;
+        if (t >= w.begin && t < w.end) {
             const int dlo = max(-a.c, w.begin - t), dhi = min(a.c, w.end - 1 - t);
             for (int d = dlo; d <= dhi; ++d) s += fl[a.c + d] * row[t + d];
         }
+        out[t] = s;
     }
-    if (t < Tp) g.dalpha[(size_t)b * Tp + t] = s;
 }
 
 // gradient wrt conv1d.filters: df[k][j] = sum_{i,b,t in win_i} dcv_i[b,k,t] * alpha_i[b, t-(j-c)]  (alpha index in win_i)
@@ -303,14 +320,14 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd: contexts must be contiguous (Tp,B,*)");
     hipStream_t s = (hipStream_t)stream;
     const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;
-    const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, nch = (a.Tp + 255) / 256;
+    const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, ntile = (a.Tp + ATT_TT - 1) / ATT_TT, nslice = (a.M + ATT_MS - 1) / ATT_MS;
     auto enqueue = [&]() {
         for (int i = a.L - 1; i >= 0; --i) {
             hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
             hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
             hipLaunchKernelGGL(attbwd_q_kernel, dim3(nchunk, a.B), dim3(256), 0, s, g, i);
-            hipLaunchKernelGGL(attbwd_energy_kernel, dim3(nchunk, a.B), dim3(256), 0, s, g, i);
-            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.K > 0 ? a.B * nch : 0)), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_energy_kernel, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + a.B * a.K), dim3(256), 0, s, g, i);
         }
     };
     GraphKey key("attdec_bwd");

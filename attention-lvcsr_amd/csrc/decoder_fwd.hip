@@ -95,44 +95,60 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
     }
 }
 
-// energies: e[b,t] = w_e . tanh(PA[t,b,:] + sW[b,:] + cv[b,:,t] @ handler); one wave per (b,t)
+// energies: e[b,t] = w_e . tanh(PA[t,b,:] + sW[b,:] + cv[b,:,t] @ handler).  Grid (ceil(M/32), B, ceil(T'/64)): a
+// work-group owns a 32-wide slice of the match dimension x 64 attended positions of one utterance; every thread
+// issues all of its loads (handler column, 8 PA values, conv features) before the first use, and ~4 work-groups
+// share a CU so their latencies overlap.  The slice's partial energies go to `ep`; the glimpse kernel folds the
+// slices in a fixed order.
 __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
-    __shared__ float Hs[ATT_MAX_KM];
-    __shared__ float we[ATT_MAX_M];
-    __shared__ float sw[ATT_MAX_M];
-    __shared__ float cvs[ATT_TB * 64];
-    const int b = blockIdx.y, t0 = blockIdx.x * ATT_TB, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    __shared__ float cvs[ATT_KMAX][ATT_TT];
+    __shared__ float cs[ATT_TT][ATT_MS + 1];
+    const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    const int t0 = blockIdx.z * ATT_TT;
     const Win w = attdec_window(a, i);
-    float* en = a.EN + ((size_t)i * B + b) * Tp;
-    if (t0 >= w.end || t0 + ATT_TB <= w.begin) {      // nothing of this block is inside the window: paste zeros
-        if (threadIdx.x < ATT_TB && t0 + threadIdx.x < Tp) en[t0 + threadIdx.x] = 0.f;
-        return;
+    if (t0 >= w.end || t0 + ATT_TT <= w.begin) return;             // tile outside the window: nothing to add
+    float* ep = a.ep + ((size_t)b * nslice + slice) * Tp;
+    const int ml = threadIdx.x & 31, tg = threadIdx.x >> 5, m = slice * ATT_MS + ml;
+    const bool mok = m < M;
+    float pav[8];
+    const float* pab = a.PA + (size_t)b * a.PA_bs + m;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int t = t0 + tg + 8 * r;
+        pav[r] = (t >= w.begin && t < w.end && mok) ? pab[(size_t)t * a.PA_ts] : 0.f;
     }
-    for (int x = threadIdx.x; x < K * M; x += 256) Hs[x] = a.handler[x];
-    for (int m = threadIdx.x; m < M; m += 256) {
-        we[m] = a.w_e[m];
-        sw[m] = a.sW[((size_t)i * B + b) * M + m];
-    }
-    for (int x = threadIdx.x; x < ATT_TB * K; x += 256) {
-        const int tt = x / K, k = x % K, t = t0 + tt;
-        cvs[tt * 64 + k] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+    float Hk[ATT_KMAX];
+#pragma unroll
+    for (int k = 0; k < ATT_KMAX; ++k) Hk[k] = (k < K && mok) ? a.handler[(size_t)k * M + m] : 0.f;
+    const float we_m = mok ? a.w_e[m] : 0.f;
+    const float sw_m = mok ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
+    for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
+        const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
+        cvs[k][tl] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int tt = wave; tt < ATT_TB; tt += 4) {
-        const int t = t0 + tt;
-        if (t >= Tp) break;
-        float e = 0.f;
-        if (t >= w.begin && t < w.end) {
-            const float* pa = a.PA + (size_t)t * a.PA_ts + (size_t)b * a.PA_bs;
-            for (int m = lane; m < M; m += 64) {
-                float x = pa[m] + sw[m];
-                for (int k = 0; k < K; ++k) x += cvs[tt * 64 + k] * Hs[k * M + m];
-                e += we[m] * tanhf(x);
-            }
-            e = wave_sum(e);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int tl = tg + 8 * r, t = t0 + tl;
+        float c = 0.f;
+        if (t >= w.begin && t < w.end && mok) {
+            float x = pav[r] + sw_m;
+#pragma unroll
+            for (int k = 0; k < ATT_KMAX; ++k)
+                if (k < K) x += cvs[k][tl] * Hk[k];
+            c = we_m * tanhf(x);
         }
-        if (lane == 0) en[t] = e;
+        cs[tl][ml] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < ATT_TT) {
+        const int t = t0 + threadIdx.x;
+        if (t >= w.begin && t < w.end) {
+            float e = 0.f;
+#pragma unroll
+            for (int j = 0; j < ATT_MS; ++j) e += cs[threadIdx.x][j];
+            ep[t] = e;
+        }
     }
 }
 
@@ -144,9 +160,19 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float part[8][132];
     const int b = blockIdx.y, chunk = blockIdx.x, B = a.B, Tp = a.Tp, E = a.E;
     const Win w = attdec_window(a, i);
-    const float* en = a.EN + ((size_t)i * B + b) * Tp;
+    __shared__ float en[ATT_MAX_T];
+    const int nslice = (a.M + ATT_MS - 1) / ATT_MS;
+    const float* ep = a.ep + (size_t)b * nslice * Tp;
     float mx = -3.0e38f;
-    for (int t = w.begin + threadIdx.x; t < w.end; t += 256) mx = fmaxf(mx, en[t]);
+    for (int t = threadIdx.x; t < Tp; t += 256) {
+        float e = 0.f;
+        if (t >= w.begin && t < w.end) {
+            for (int sl = 0; sl < nslice; ++sl) e += ep[(size_t)sl * Tp + t];
+            mx = fmaxf(mx, e);
+        }
+        en[t] = e;
+        if (chunk == 0) a.EN[((size_t)i * B + b) * Tp + t] = e;      // pasted into zeros
+    }
     mx = block_max(mx, red);
     float s = 0.f, anyone = 0.f;
     for (int t = w.begin + threadIdx.x; t < w.end; t += 256) {
@@ -249,7 +275,9 @@ __global__ __launch_bounds__(256) void attdec_gru2_kernel(AttDec a, int i) {
 int attdec_check(const AttDec& a, const char* what) {
     LVSR_REQUIRE(a.Tp > 0 && a.B > 0 && a.L > 0 && a.E > 0 && a.D > 0 && a.M > 0 && a.K >= 0, "%s: bad dims", what);
     LVSR_REQUIRE(a.Tp <= ATT_MAX_T, "%s: attended length %d > %d", what, a.Tp, ATT_MAX_T);
-    LVSR_REQUIRE(a.M <= ATT_MAX_M && a.K * a.M <= ATT_MAX_KM && a.K <= 64, "%s: match dim / filters too large", what);
+    LVSR_REQUIRE(a.M <= ATT_MAX_M && a.K <= ATT_KMAX && a.K * a.Tp <= ATT_MAX_KT && a.K * (2 * a.c + 1) <= ATT_MAX_KF,
+                 "%s: match dim / conv filters / attended length exceed the LDS budget (M<=%d, K<=%d, K*T'<=%d)", what,
+                 ATT_MAX_M, ATT_KMAX, ATT_MAX_KT);
     LVSR_REQUIRE(a.K == 0 || 2 * a.c + 1 <= ATT_MAX_FW, "%s: conv filter too wide", what);
     LVSR_REQUIRE(a.prior_type >= 0 && a.prior_type <= 2, "%s: unknown prior type", what);
     LVSR_REQUIRE(a.K == 0 || a.prior_type == 0 || a.pos != nullptr, "%s: window_around_* priors need pos", what);
@@ -271,7 +299,7 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
             if (g.nmm + g.nconv > 0)
                 hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm + g.nconv), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
-                hipLaunchKernelGGL(attdec_energy_kernel, dim3((a.Tp + ATT_TB - 1) / ATT_TB, a.B), dim3(256), 0, s, a, i);
+                hipLaunchKernelGGL(attdec_energy_kernel, dim3((a.M + ATT_MS - 1) / ATT_MS, a.B, (a.Tp + ATT_TT - 1) / ATT_TT), dim3(256), 0, s, a, i);
                 hipLaunchKernelGGL(attdec_glimpse_kernel, dim3((a.E + 127) / 128, a.B), dim3(256), 0, s, a, i);
             }
             if (a.phases & 2) {

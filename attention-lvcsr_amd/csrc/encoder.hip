@@ -223,10 +223,11 @@ int lvsr_bigru_fwd(void* stream, const lvsr_bigru_fwd_args* args, int use_graph)
     if (a.sub == 1) a.ysub = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int rt = (B + 15) / 16;
+    const int km = a.kernel_mask ? a.kernel_mask : 3;
     auto enqueue = [&]() {
         for (int n = 0; n < T; ++n) {
-            hipLaunchKernelGGL(enc_gates_kernel, dim3((2 * H + 15) / 16, rt, 2), dim3(256), 0, s, a, n);
-            hipLaunchKernelGGL(enc_cand_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, a, n);
+            if (km & 1) hipLaunchKernelGGL(enc_gates_kernel, dim3((2 * H + 15) / 16, rt, 2), dim3(256), 0, s, a, n);
+            if (km & 2) hipLaunchKernelGGL(enc_cand_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, a, n);
         }
     };
     GraphKey key("bigru_fwd");
@@ -245,11 +246,12 @@ int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* args, int use_graph)
     e.dh = e.a.dh_ws; e.dhpart = e.a.dh_ws + (size_t)2 * e.Bp * H;     // workspace: 4*Bp*H floats
     hipStream_t s = (hipStream_t)stream;
     const int rt = (B + 15) / 16;
+    const int km = e.a.kernel_mask ? e.a.kernel_mask : 3;
     auto enqueue = [&]() {
         hipLaunchKernelGGL(enc_bwd_init_kernel, dim3((e.Bp * H + 255) / 256, 1, 2), dim3(256), 0, s, e);
         for (int n = 0; n < T; ++n) {
-            hipLaunchKernelGGL(enc_bwd_a_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e, n);
-            hipLaunchKernelGGL(enc_bwd_b_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e, n);
+            if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e, n);
+            if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e, n);
         }
         hipLaunchKernelGGL(enc_bwd_h0_kernel, dim3((H + 255) / 256, 1, 2), dim3(256), 0, s, e);
     };

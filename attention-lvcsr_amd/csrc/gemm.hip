@@ -123,21 +123,42 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_splitk_reduce(GemmArgs g) {
     }
 }
 
-// column sums: out[n] = beta*out[n] + sum_m X[m*ldx + n]   (bias gradients)
-__global__ __launch_bounds__(256) void lvsr_colsum_kernel(const float* X, int M, int N, int ldx, float* out, float beta) {
+// column sums: out[n] = beta*out[n] + sum_m X[m*ldx + n]   (bias gradients, partial-sum folding)
+// grid (ceil(N/64), S): block (x, s) sums rows [s*rows_per, (s+1)*rows_per) of 64 columns; S > 1 writes
+// partials to the workspace and lvsr_colsum_finish folds them in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void lvsr_colsum_kernel(const float* X, int M, int N, int ldx, float* out, float beta,
+                                                          int rows_per, float* part) {
     __shared__ float red[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63);
     const int g = threadIdx.x >> 6;
-    float s = 0.f;
-    if (n < N)
-        for (int m = g; m < M; m += 4) s += X[(size_t)m * ldx + n];
-    red[g][threadIdx.x & 63] = s;
+    const int m0 = blockIdx.y * rows_per, m1 = min(M, m0 + rows_per);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        int m = m0 + g;
+        for (; m + 12 < m1; m += 16) {          // 4 independent loads in flight per thread
+            s0 += X[(size_t)m * ldx + n];
+            s1 += X[(size_t)(m + 4) * ldx + n];
+            s2 += X[(size_t)(m + 8) * ldx + n];
+            s3 += X[(size_t)(m + 12) * ldx + n];
+        }
+        for (; m < m1; m += 4) s0 += X[(size_t)m * ldx + n];
+    }
+    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && n < N) {
         const int c = threadIdx.x & 63;
-        float v = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
-        out[n] = (beta != 0.f ? beta * out[n] : 0.f) + v;
+        const float v = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+        if (part) part[(size_t)blockIdx.y * N + n] = v;
+        else out[n] = (beta != 0.f ? beta * out[n] : 0.f) + v;
     }
+}
+
+__global__ __launch_bounds__(256) void lvsr_colsum_finish(const float* part, int S, int N, float* out, float beta) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += part[(size_t)s * N + n];
+    out[n] = (beta != 0.f ? beta * out[n] : 0.f) + v;
 }
 
 // out[c*rows + r] = in[r*cols + c]
@@ -209,9 +230,22 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
     return lvsr_check_launch("lvsr_sgemm");
 }
 
-int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta) {
+int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,
+                long long ws_bytes) {
     if (N <= 0) return LVSR_OK;
-    hipLaunchKernelGGL(lvsr_colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, M, N, ldx, out, beta);
+    const int nx = (N + 63) / 64;
+    int S = 1;
+    if (ws && M >= 512) {
+        S = (M + 255) / 256;
+        const int want = (1024 + nx - 1) / nx;          // aim at ~1024 work-groups
+        if (S > want) S = want;
+        while (S > 1 && (long long)S * N * 4 > ws_bytes) --S;
+    }
+    const int rows_per = (M + S - 1) / S;
+    hipLaunchKernelGGL(lvsr_colsum_kernel, dim3(nx, S), dim3(256), 0, (hipStream_t)stream, X, M, N, ldx, out, beta, rows_per,
+                       S > 1 ? ws : nullptr);
+    if (S > 1)
+        hipLaunchKernelGGL(lvsr_colsum_finish, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, S, N, out, beta);
     return lvsr_check_launch("lvsr_colsum");
 }
 

@@ -1,0 +1,136 @@
+// Training step rules on the flat parameter / gradient buffers (K15 of SURVEY.md §2.3): one pass over
+// 5.2 M floats per rule group instead of Theano's per-variable update graph.
+//
+// Rule chain of the reference (lvsr/main.py:480-519):
+//   StepClipping(threshold)            libs/blocks/blocks/algorithms/__init__.py:610-643  (global L2 norm)
+//   Momentum(scale, momentum)          :431-461  = Scale then BasicMomentum
+//   AdaDelta(decay_rate, epsilon)      :464-515
+//   Restrict(VariableClipping(max_norm, axis=0), WEIGHT-role parameters)   :646-720, :864-893
+//   RemoveNotFinite(scaler)            :829-861  (per parameter tensor)
+// followed by parameter -= step (GradientDescent, :284-287 / :244-256).
+#include "common.h"
+#include "lvsr_hip.h"
+#include <string.h>
+
+typedef lvsr_opt_args Opt;
+
+__device__ __forceinline__ float blk_sum256(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// partial[b] = sum over the block's slice of (grad*grad_scale)^2   (fixed slices: deterministic)
+__global__ __launch_bounds__(256) void opt_sqnorm_kernel(Opt o) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < o.n; i += (long long)gridDim.x * 256) {
+        const float g = o.grad[i] * o.grad_scale;
+        s += g * g;
+    }
+    s = blk_sum256(s, red);
+    if (threadIdx.x == 0) o.scratch[2 + blockIdx.x] = s;
+}
+
+// scratch[0] = gradient norm, scratch[1] = StepClipping multiplier
+__global__ __launch_bounds__(256) void opt_norm_kernel(Opt o, int nparts) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += o.scratch[2 + i];
+    s = blk_sum256(s, red);
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(s);
+        o.scratch[0] = norm;
+        o.scratch[1] = (o.clip_threshold > 0.f && !(norm < o.clip_threshold)) ? o.clip_threshold / norm : 1.f;
+    }
+}
+
+// clipping multiplier, Scale, BasicMomentum, AdaDelta -> step
+__global__ __launch_bounds__(256) void opt_rules_kernel(Opt o) {
+    const float mult = o.scratch[1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < o.n; i += (long long)gridDim.x * 256) {
+        float s = o.grad[i] * o.grad_scale * mult;
+        if (o.use_momentum) {
+            s = o.learning_rate * s;
+            s = o.momentum * o.velocity[i] + s;
+            o.velocity[i] = s;
+        }
+        if (o.use_adadelta) {
+            const float ms = o.decay_rate * o.ms_step[i] + (1.f - o.decay_rate) * s * s;
+            const float dx = sqrtf(o.ms_dx[i] + o.epsilon) / sqrtf(ms + o.epsilon) * s;
+            o.ms_step[i] = ms;
+            o.ms_dx[i] = o.decay_rate * o.ms_dx[i] + (1.f - o.decay_rate) * dx * dx;
+            s = dx;
+        }
+        o.step[i] = s;
+    }
+}
+
+// VariableClipping(axis=0) on flagged (rows x cols) segments: one thread per column
+__global__ __launch_bounds__(256) void opt_maxnorm_kernel(Opt o) {
+    const long long* seg = o.segments + 4 * (long long)blockIdx.y;
+    const long long off = seg[0], rows = seg[1], cols = seg[2], flags = seg[3];
+    if (!(flags & 1)) return;
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= cols) return;
+    float s = 0.f;
+    for (long long r = 0; r < rows; ++r) {
+        const float v = o.param[off + r * cols + j] - o.step[off + r * cols + j];
+        s += v * v;
+    }
+    const float norm = sqrtf(s);
+    if (norm > o.max_norm) {
+        const float k = o.max_norm / norm;
+        for (long long r = 0; r < rows; ++r) {
+            const long long x = off + r * cols + j;
+            o.step[x] = o.param[x] - k * (o.param[x] - o.step[x]);
+        }
+    }
+}
+
+// RemoveNotFinite: segflag[s] = 1 when sum(step of segment s) is nan/inf
+__global__ __launch_bounds__(256) void opt_finite_kernel(Opt o) {
+    __shared__ float red[4];
+    const long long* seg = o.segments + 4 * (long long)blockIdx.x;
+    const long long off = seg[0], n = seg[1] * seg[2];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 256) s += o.step[off + i];
+    s = blk_sum256(s, red);
+    if (threadIdx.x == 0) o.segflag[blockIdx.x] = (s != s || s - s != 0.f) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void opt_apply_kernel(Opt o) {
+    const long long* seg = o.segments + 4 * (long long)blockIdx.y;
+    const long long off = seg[0], n = seg[1] * seg[2];
+    const int bad = o.remove_not_finite ? o.segflag[blockIdx.y] : 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float p = o.param[off + i];
+        const float s = bad ? (1.f - o.nonfinite_scaler) * p : o.step[off + i];
+        o.param[off + i] = p - s;
+    }
+}
+
+extern "C" int lvsr_opt_step(void* stream, const lvsr_opt_args* args) {
+    LVSR_REQUIRE(args != nullptr, "lvsr_opt_step: null args");
+    Opt o;
+    memcpy(&o, args, sizeof(o));
+    LVSR_REQUIRE(o.n > 0 && o.nseg > 0 && o.param && o.grad && o.step && o.segments && o.scratch && o.segflag,
+                 "lvsr_opt_step: missing buffers");
+    LVSR_REQUIRE(!o.use_momentum || o.velocity, "lvsr_opt_step: momentum needs a velocity buffer");
+    LVSR_REQUIRE(!o.use_adadelta || (o.ms_step && o.ms_dx), "lvsr_opt_step: AdaDelta needs its two accumulators");
+    hipStream_t s = (hipStream_t)stream;
+    const int nparts = 256;
+    int nb = (int)((o.n + 255) / 256);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(opt_sqnorm_kernel, dim3(nparts), dim3(256), 0, s, o);
+    hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(256), 0, s, o, nparts);
+    hipLaunchKernelGGL(opt_rules_kernel, dim3(nb), dim3(256), 0, s, o);
+    if (o.max_norm > 0.f)
+        hipLaunchKernelGGL(opt_maxnorm_kernel, dim3((o.max_cols + 255) / 256, o.nseg), dim3(256), 0, s, o);
+    if (o.remove_not_finite)
+        hipLaunchKernelGGL(opt_finite_kernel, dim3(o.nseg), dim3(256), 0, s, o);
+    hipLaunchKernelGGL(opt_apply_kernel, dim3(16, o.nseg), dim3(256), 0, s, o);
+    return lvsr_check_launch("lvsr_opt_step");
+}

@@ -133,8 +133,8 @@ class Encoder(object):
                 lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0)
                 lib.sgemm(x2, dc, g[n["Wi"]], transA=True, ws=gemm_ws)
                 lib.sgemm(x2, dg, g[n["Wg"]], transA=True, ws=gemm_ws)
-                lib.colsum(dc, g[n["bi"]])
-                lib.colsum(dg, g[n["bg"]])
+                lib.colsum(dc, g[n["bi"]], ws=gemm_ws)
+                lib.colsum(dg, g[n["bg"]], ws=gemm_ws)
                 if dx is not None:
                     dx2 = dx.view(T * B, I)
                     lib.sgemm(dc, p[n["Wi"]], dx2, transB=True, beta=(0.0 if di == 0 else 1.0))

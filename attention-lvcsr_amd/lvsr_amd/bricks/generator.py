@@ -15,7 +15,7 @@ import torch
 
 ACT_KIND = {"identity": 0, "maxout2": 1, "rectifier": 2, "tanh": 3}
 PRIOR_KIND = {"expanding": 0, "window_around_mean": 1, "window_around_median": 2}
-ATT_TB = 16     # positions per work-group in the energy kernels (csrc/decoder.h)
+ATT_MS = 32     # match-dim slice per work-group in the energy kernels (csrc/decoder.h)
 
 
 def _f32(x):
@@ -166,7 +166,8 @@ class SequenceGenerator(object):
                     WA=ws.get("gen.WA", (L, B, d.E)), EN=ws.get("gen.EN", (L, B, Tp)), sW=ws.get("gen.sW", (L, B, d.M)),
                     CV=ws.get("gen.CV", (L, B, Kc, Tp)) if d.conv else None,
                     U=ws.get("gen.U", (L, B, d.D)), R=ws.get("gen.R", (L, B, d.D)), C=ws.get("gen.C", (L, B, d.D)),
-                    RH=ws.get("gen.RH", (L, B, d.D)), sg=ws.get("gen.sg", (B, 2 * d.D)), xin=ws.get("gen.xin", (B, d.D)))
+                    RH=ws.get("gen.RH", (L, B, d.D)), sg=ws.get("gen.sg", (B, 2 * d.D)), xin=ws.get("gen.xin", (B, d.D)),
+                    ep=ws.get("gen.ep", (B, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
         fields = self._attdec_fields(pk, A, PA, Am, L, B, bufs, phases=3, step0=0, broadcast=False)
         fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
         WA = bufs["WA"]
@@ -197,16 +198,16 @@ class SequenceGenerator(object):
         # ---- readout backward
         if d.post_merge:
             lib.sgemm(R2, dlogits, g[n["Wout"]], transA=True, ws=gws)
-            lib.colsum(dlogits, g[n["bout"]])
+            lib.colsum(dlogits, g[n["bout"]], ws=gws)
             dR2 = ws.get("gen.dR2", (nrows, d.Pout))
             lib.sgemm(dlogits, p[n["Wout"]], dR2, transB=True)
             dR1 = ws.get("gen.dR1", (nrows, d.P))
             lib.call("lvsr_act_bwd", lib.stream_for(dR1), ACT_KIND[d.act], lib_ptr(R1), d.P, lib_ptr(dR2), d.Pout, nrows, d.P,
                      lib_ptr(dR1), d.P)
-            lib.colsum(dR1, g[n["bpm"]])
+            lib.colsum(dR1, g[n["bpm"]], ws=gws)
         else:
             dR1 = dlogits
-            lib.colsum(dR1, g[n["bro"]])
+            lib.colsum(dR1, g[n["bro"]], ws=gws)
         lib.sgemm(WA2, dR1, g[n["Wmw"]], transA=True, ws=gws)
         dWA_r = ws.get("gen.dWA_r", (nrows, d.E))
         lib.sgemm(dR1, p[n["Wmw"]], dWA_r, transB=True)
@@ -216,21 +217,24 @@ class SequenceGenerator(object):
             dS_r = ws.get("gen.dS_r", (nrows, d.D))
             lib.sgemm(dR1, p[n["Wms"]], dS_r, transB=True)
         # ---- recurrent part
-        nchunk = (Tp + ATT_TB - 1) // ATT_TB
+        nslice = (d.M + ATT_MS - 1) // ATT_MS
+        ntile = (Tp + 63) // 64
         Kc = max(d.K, 1)
         DXG = ws.get("gen.DXG", (nrows, 3 * d.D))
         DWA = ws.get("gen.DWA", (L, B, d.E))
         DSW = ws.get("gen.DSW", (nrows, d.M))
         DCV = ws.get("gen.DCV", (L, B, Kc, Tp)) if d.conv else None
         dPA = ws.get("gen.dPA", (Tp, B, d.M), zero=True)
-        accH = ws.get("gen.accH", (B * nchunk, Kc * d.M), zero=True)
-        accWe = ws.get("gen.accWe", (B * nchunk, d.M), zero=True)
+        accH = ws.get("gen.accH", (B * ntile, Kc * d.M), zero=True)
+        accWe = ws.get("gen.accWe", (B * ntile, d.M), zero=True)
         ds = ws.get("gen.ds", (B, d.D), zero=True)
-        dalpha = ws.get("gen.dalpha", (B, Tp), zero=True)
+        dalp = ws.get("gen.dalp", (B, Kc, Tp), zero=True)
         bw = lib.make("lvsr_attdec_bwd_args", WhhT_p=pk["WhhT"], WhgT_p=pk["WhgT"], WdT_p=pk["WdT"], WsT_p=pk["WsT"],
                       dWA_r=dWA_r, dS_r=dS_r, DXG=DXG, DWA=DWA, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe,
-                      ds=ds, dalpha=dalpha, dspart=ws.get("gen.dspart", (B, d.D)), dsacc=ws.get("gen.dsacc", (B, d.D)),
-                      Q=ws.get("gen.Q", (B, Tp)), dswp=ws.get("gen.dswp", (B, nchunk, d.M)))
+                      ds=ds, dalp=dalp, dspart=ws.get("gen.dspart", (B, d.D)), dsacc=ws.get("gen.dsacc", (B, d.D)),
+                      Q=ws.get("gen.Q", (B, Tp)),
+                      dcvp=ws.get("gen.dcvp", (B, nslice, Kc, Tp)) if d.conv else None,
+                      dswp=ws.get("gen.dswp", (B, ntile, d.M)))
         bw.f = lib.make("lvsr_attdec_args", **sv["fields"])
         import ctypes
         lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
@@ -242,9 +246,9 @@ class SequenceGenerator(object):
         lib.sgemm(WA2, dpc, g[n["Wdi"]], transA=True, ws=gws)
         lib.sgemm(WA2, dg, g[n["Wdg"]], transA=True, ws=gws)
         lib.sgemm(S2, DSW, g[n["Ws"]], transA=True, ws=gws)
-        lib.colsum(ds, g[n["h0"]])
-        lib.colsum(dpc, g[n["bfi"]])
-        lib.colsum(dg, g[n["bfg"]])
+        lib.colsum(ds, g[n["h0"]], ws=gws)
+        lib.colsum(dpc, g[n["bfi"]], ws=gws)
+        lib.colsum(dg, g[n["bfg"]], ws=gws)
         st = lib.stream_for(ds)
         labels_flat = sv["labels"].view(-1)
         if d.embed:
@@ -261,14 +265,14 @@ class SequenceGenerator(object):
                      lib_ptr(g[n["Wfi"]]), d.D, 0.0)
             lib.call("lvsr_scatter_add_rows", st, lib_ptr(dg), 3 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
                      lib_ptr(g[n["Wfg"]]), 2 * d.D, 0.0)
-        lib.colsum(accWe, g[n["we"]].view(-1))
+        lib.colsum(accWe, g[n["we"]].view(-1), ws=gws)
         if d.conv:
-            lib.colsum(accH, g[n["handler"]].view(-1))
+            lib.colsum(accH, g[n["handler"]].view(-1), ws=gws)
             lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]))
         # ---- attended: preprocess backward + glimpse backward
         A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
         lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws)
-        lib.colsum(dPA2, g[n["bpre"]])
+        lib.colsum(dPA2, g[n["bpre"]], ws=gws)
         dA = ws.get("gen.dA", (Tp, B, d.E))
         lib.sgemm(dPA2, p[n["Wpre"]], dA.view(Tp * B, d.E), transB=True)
         W = bufs["W"]

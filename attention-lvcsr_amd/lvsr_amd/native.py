@@ -187,10 +187,11 @@ class Lib(object):
         self.call("lvsr_sgemm", self.stream_for(C), int(transA), int(transB), M, N, K, alpha, ptr(A), lda, ptr(B), ldb,
                   beta, ptr(C), ldc, ptr(bias), ptr(ws), (ws.numel() * 4 if ws is not None else 0))
 
-    def colsum(self, X, out, beta=0.0, M=None, N=None, ldx=None):
+    def colsum(self, X, out, beta=0.0, M=None, N=None, ldx=None, ws=None):
         M = X.shape[0] if M is None else M
         N = X.shape[1] if N is None else N
-        self.call("lvsr_colsum", self.stream_for(out), ptr(X), M, N, X.stride(0) if ldx is None else ldx, ptr(out), beta)
+        self.call("lvsr_colsum", self.stream_for(out), ptr(X), M, N, X.stride(0) if ldx is None else ldx, ptr(out), beta,
+                  ptr(ws), (ws.numel() * 4 if ws is not None else 0))
 
     def transpose(self, x, out):
         self.call("lvsr_transpose", self.stream_for(out), ptr(x), x.shape[0], x.shape[1], ptr(out))

@@ -1,0 +1,79 @@
+"""Thin trainer around SpeechRecognizer: one data-parallel SGD step of the reference's recipe
+(lvsr/main.py:340-345 cost = cost_matrix.sum()/batch_size; :480-519 step rules; GradientDescent.process_batch,
+libs/blocks/blocks/algorithms/__init__.py:284-287).
+
+Data parallelism (new; the reference is single-device): every rank holds a full replica, processes its shard of
+the utterances (rank r takes utterances r::world), gradients of the summed cost are all-reduced (sum) in ONE
+RCCL collective over the flat gradient buffer, then divided by the GLOBAL batch size inside the fused optimiser
+kernel; all ranks apply identical updates.
+"""
+import ctypes
+
+import numpy
+import torch
+
+
+def _is_weight(name):
+    return name.endswith(".W") or name.endswith("state_to_state") or name.endswith("state_to_gates")
+
+
+class Trainer(object):
+    def __init__(self, recognizer, gradient_threshold=None, rules=("momentum",), scale=0.1, momentum=0.0,
+                 decay_rate=0.95, epsilon=1e-8, max_norm=0.0, max_norm_exclude_lookup=False, nonfinite_scaler=0.0,
+                 process_group=None, distributed=None):
+        self.rec = recognizer
+        st = recognizer.store
+        dev = st.device
+        self.conf = dict(clip_threshold=float(gradient_threshold or 0.0), use_momentum=int("momentum" in rules),
+                         use_adadelta=int("adadelta" in rules), learning_rate=float(scale), momentum=float(momentum),
+                         decay_rate=float(decay_rate), epsilon=float(epsilon), max_norm=float(max_norm or 0.0),
+                         remove_not_finite=1, nonfinite_scaler=float(nonfinite_scaler))
+        n = st.flat.numel()
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=dev)
+        self.velocity = z() if self.conf["use_momentum"] else None
+        self.ms_step = z() if self.conf["use_adadelta"] else None
+        self.ms_dx = z() if self.conf["use_adadelta"] else None
+        self.step_buf = z()
+        seg, max_cols = [], 1
+        for name, (off, cnt) in st.offsets.items():
+            shape = st.shapes[name]
+            rows, cols = (int(shape[0]), int(numpy.prod(shape[1:]))) if len(shape) >= 2 else (1, int(cnt))
+            flag = int(self.conf["max_norm"] > 0 and _is_weight(name) and len(shape) == 2
+                       and not (max_norm_exclude_lookup and "lookuptable" in name))
+            if flag:
+                max_cols = max(max_cols, cols)
+            seg.append([off, rows, cols, flag])
+        self.max_cols = max_cols
+        self.segments = torch.tensor(seg, dtype=torch.int64, device=dev)
+        self.segflag = torch.zeros(len(seg), dtype=torch.int32, device=dev)
+        self.scratch = torch.zeros(2 + 256, dtype=torch.float32, device=dev)
+        if distributed is None:
+            distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        self.distributed = distributed
+        self.group = process_group
+        self.world = torch.distributed.get_world_size(process_group) if distributed else 1
+        self.rank = torch.distributed.get_rank(process_group) if distributed else 0
+
+    def gradient_norm(self):
+        """L2 norm of the (scaled, all-reduced) gradient of the last step: the reference's `total_gradient_norm`."""
+        return float(self.scratch[0])
+
+    def apply_gradients(self, global_batch_size):
+        rec, st, lib = self.rec, self.rec.store, self.rec.lib
+        with rec._on_stream():
+            if self.distributed and self.world > 1:
+                # ONE collective per step over the flat gradient bucket (sum); RCCL when the tensors are on GPUs
+                torch.distributed.all_reduce(st.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            a = lib.make("lvsr_opt_args", param=st.flat, grad=st.grad, velocity=self.velocity, ms_step=self.ms_step,
+                         ms_dx=self.ms_dx, step=self.step_buf, segments=self.segments, segflag=self.segflag,
+                         scratch=self.scratch, n=st.flat.numel(), nseg=int(self.segments.shape[0]), max_cols=self.max_cols,
+                         grad_scale=1.0 / float(global_batch_size), **self.conf)
+            lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
+            st.version += 1
+
+    def train_step(self, batch, global_batch_size=None):
+        """batch = this rank's shard (reference layout).  Returns the local cost.sum() as a device tensor."""
+        B_local = int(batch["labels"].shape[1])
+        cm = self.rec.cost_and_gradients(batch)
+        self.apply_gradients(global_batch_size if global_batch_size is not None else B_local * self.world)
+        return cm

@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: encoder+attention+decoder TRAINING frames/sec on WSJ-shape synthetic fbank batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wsj_base|wsj_deep|timit_tiny]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = forward + backward of the whole recognizer on one minibatch already resident in HBM, the (RCCL) sum
+all-reduce of the flat gradient buffer when N > 1, and the fused optimiser step (clip -> scale -> AdaDelta ->
+max-norm -> remove-not-finite).  Weak scaling: every rank processes B utterances per step (global batch N*B,
+rank r takes utterances r::N of the seeded global batch).  value = real (unpadded) input frames of all ranks per
+second.  Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+for _p in (REPO, os.path.join(REPO, "attention-lvcsr_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy
+import torch
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+TRAIN_CONF = dict(gradient_threshold=100.0, rules=("momentum", "adadelta"), scale=0.1, momentum=0.0, decay_rate=0.95,
+                  epsilon=1e-8, max_norm=1.0)        # exp/wsj/configs/wsj_jan_new.yaml training/regularization sections
+
+
+def recurrent_kernel_probe(rec, dims, T, B):
+    """Average launch duration of the dominant kernel (enc_bwd_b_kernel: dh_prev = [dpu|dpr] @ Whg^T, layer 0 shapes)
+    measured with HIP events on the recognizer's own stream over T back-to-back launches (kernel_mask = 2)."""
+    lib, ws, enc = rec.lib, rec.ws, rec.encoder
+    H = dims.Hs[0]
+    pk = enc._packed(0)
+    p = rec.store.p
+    nf, nb = enc._names(0, "forward"), enc._names(0, "backward")
+    Bp = (B + 15) // 16 * 16
+    bufs = dict(y=ws.get("enc0.y", (T, B, 2 * H)), u=ws.get("enc0.u", (T, B, 2 * H)), r=ws.get("enc0.r", (T, B, 2 * H)),
+                c=ws.get("enc0.c", (T, B, 2 * H)), dy=ws.get("probe.dy", (T, B, 2 * H)), dxg=ws.get("enc0.dxg", (T, B, 6 * H)),
+                dh_ws=ws.get("enc0.dh", (4 * Bp * H,)))
+    fields = dict(mask=None, WhhT_p=[pk["WhhT"][0], pk["WhhT"][1]], WhgT_p=[pk["WhgT"][0], pk["WhgT"][1]],
+                  h0=[p[nf["h0"]], p[nb["h0"]]], dh0=[ws.get("probe.dh0a", (H,)), ws.get("probe.dh0b", (H,))],
+                  sub=1, T=T, B=B, H=H, kernel_mask=2, **bufs)
+    times = []
+    with torch.cuda.stream(rec.stream):
+        for it in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(rec.stream)
+            lib.run("lvsr_bigru_bwd", "lvsr_bigru_bwd_args", bufs["dxg"], True, **fields)
+            e1.record(rec.stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1) * 1e-3 / T)
+    avg = sorted(times[1:])[len(times[1:]) // 2]
+    flops = 2.0 * B * (2 * H) * H * 2            # both directions in one launch
+    return avg, flops
+
+
+def cpu_baseline(cfg, params, B, T, L):
+    """The CPU oracle (torch fp32 restatement of the reference's algorithm, oracle/lvsr_oracle.py) timed on this
+    box's host cores on ONE full minibatch of the same workload (forward + backward)."""
+    from oracle import lvsr_oracle as O
+    from lvsr_amd import synthetic
+    batch = synthetic.make_batch(cfg, B, T, L, seed=1234)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float32)
+    ncores = min(8, os.cpu_count() or 1)        # the per-step matrices are small: more threads only add overhead
+    torch.set_num_threads(ncores)
+    t0 = time.time()
+    orc.cost_and_grads(batch)
+    dt = time.time() - t0
+    return dict(value=B * T / dt, unit="frames/s", cores=ncores, kind="port",
+                sample="1 forward+backward of one %dx%d-frame minibatch (%s) = %.1f s of CPU work; torch-CPU fp32 "
+                       "restatement of the reference's Theano graph" % (B, T, "same synthetic batch shape", dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="wsj_base")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d bench.py --gpus %d ..."
+                         % (args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = world > 1
+    if dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from lvsr_amd import spec, synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    from lvsr_amd.training import Trainer
+
+    factory, B, T, L = spec.WORKLOADS[args.workload]
+    cfg = factory()
+    dims = spec.Dims(cfg)
+    params = synthetic.make_params(cfg, seed=10)
+    rec = SpeechRecognizer(device=dev, params=params, net_config=cfg, use_graph=not args.no_graph)
+    trainer = Trainer(rec, distributed=dist, **TRAIN_CONF)
+    nsteps = args.steps + args.warmup
+    # synthetic global batches, seeded identically on every rank; rank r keeps utterances r::world; staged in HBM
+    nstage = min(nsteps, 4)
+    staged = []
+    for s in range(nstage):
+        gb = synthetic.make_batch(cfg, B * world, T, L, seed=1234 + s)
+        sh = synthetic.shard_batch(gb, rank, world)
+        staged.append({k: torch.from_numpy(v).to(dev) for k, v in sh.items()})
+    frames_per_step = float(sum(float(b["recordings_mask"].sum()) for b in staged[:1])) * world  # all-ones masks: B*T per rank
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist:
+            torch.distributed.barrier()
+
+    costs = []
+    for s in range(args.warmup):
+        cm = trainer.train_step(staged[s % nstage], global_batch_size=B * world)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        cm = trainer.train_step(staged[(args.warmup + s) % nstage], global_batch_size=B * world)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t[0])
+    last_cost = float(cm.sum())
+    assert numpy.isfinite(last_cost), "training diverged in the benchmark"
+    ms = elapsed / args.steps * 1e3
+    value = frames_per_step * args.steps / elapsed
+
+    if rank == 0:
+        train_flop_per_frame = {"wsj_base": 22.730e6, "wsj_deep": 143.43e6, "timit_tiny": 1.382e6}[args.workload]
+        avg_launch, flops = recurrent_kernel_probe(rec, dims, T, B)
+        peak = 157.3                                                   # TFLOP/s fp32 MFMA (MI355X_MICROARCH.md)
+        roof = dict(bound="mfma", kernel="enc_bwd_b_kernel", achieved=flops / avg_launch / 1e12, peak=peak, unit="TFLOP/s",
+                    frac=flops / avg_launch / 1e12 / peak, traffic=None, launch_us=avg_launch * 1e6, flops_per_launch=flops,
+                    whole_step_tflops=value / world * train_flop_per_frame / 1e12,
+                    whole_step_frac=value / world * train_flop_per_frame / 1e12 / peak)
+        out = dict(metric="encoder+attention+decoder training frames/sec (whole node)", value=value, unit="frames/s",
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="%s: B=%d utterances x T=%d frames x F=%d fbank per GPU, L=%d labels; %s" % (
+                       args.workload, B, T, dims.F, L, "x".join(str(h) for h in dims.Hs) + " BiGRU subsample " +
+                       str(dims.subsample) + ", " + cfg["attention_type"] + " attention, %d-unit GRU decoder" % dims.D),
+                       global_batch=B * world, per_gpu_batch=B, frames_per_step=frames_per_step,
+                       parallelism="dp%d" % world, optimizer="clip100+adadelta+maxnorm1", hip_graph=not args.no_graph,
+                       final_cost_per_utterance=last_cost / B),
+                   roofline=roof)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, params, B, T, L)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if dist:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

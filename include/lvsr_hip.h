@@ -35,8 +35,9 @@ int lvsr_graph_count(void);
 int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                long long ws_bytes);
-/* out[n] = beta*out[n] + sum_m X[m*ldx+n]  (bias gradients) */
-int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta);
+/* out[n] = beta*out[n] + sum_m X[m*ldx+n]  (bias gradients); ws: optional workspace for the row-split partials */
+int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,
+                long long ws_bytes);
 int lvsr_transpose(void* stream, const float* in, int rows, int cols, float* out);
 
 /* Pack a (K x N) weight (row-major, leading dim ldw; trans=1: the logical weight is W^T of an (N x K)
@@ -58,6 +59,8 @@ typedef struct lvsr_bigru_fwd_args {
     float* ysub;            /* (ceil(T/sub),B,2H) = y[::sub] when sub>1, else NULL */
     float* u; float* r; float* c; float* rh;   /* (T,B,2H) saved gates / candidate / r*h_prev for BPTT */
     int sub, T, B, H;
+    int kernel_mask;        /* 0 or 3: both step kernels; 1 / 2: only the gates / candidate kernel (timing probes) */
+    int pad0;
 } lvsr_bigru_fwd_args;
 int lvsr_bigru_fwd(void* stream, const lvsr_bigru_fwd_args* a, int use_graph);
 
@@ -71,6 +74,8 @@ typedef struct lvsr_bigru_bwd_args {
     float* dh_ws;            /* workspace 4*Bp*H floats, Bp = B rounded up to 16 */
     float* dh0[2];           /* (H) out: gradient wrt initial_state */
     int sub, T, B, H;
+    int kernel_mask;         /* 0 or 3: both step kernels; 1 / 2: only kernel A / kernel B (timing probes) */
+    int pad0;
 } lvsr_bigru_bwd_args;
 int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* a, int use_graph);
 
@@ -118,6 +123,7 @@ typedef struct lvsr_attdec_args {
     /* scratch */
     float* sg;                            /* (B,2D) state part of the gate pre-activations */
     float* xin;                           /* (B,D) candidate input */
+    float* ep;                            /* (B,ceil(M/32),Tp) partial energies of the match-dim slices */
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
@@ -137,13 +143,14 @@ typedef struct lvsr_attdec_bwd_args {
     float* DSW;                           /* (L,B,M) out: gradient wrt transformed states */
     float* DCV;                           /* (L,B,K,Tp) out: gradient wrt convolution features */
     float* dPA;                           /* (Tp,B,M) in/out: accumulated gradient wrt preprocessed attended (caller zeroes) */
-    float* accH;                          /* (B*nchunk, K*M) in/out: per-work-group handler.W gradient partials (caller zeroes) */
-    float* accWe;                         /* (B*nchunk, M) in/out: per-work-group energy vector gradient partials (caller zeroes) */
+    float* accH;                          /* (B*ntile, K*M) in/out: per-work-group handler.W gradient partials (caller zeroes); ntile = ceil(Tp/64) */
+    float* accWe;                         /* (B*ntile, M) in/out: per-work-group energy vector gradient partials (caller zeroes) */
     float* ds;                            /* (B,D) in/out: running gradient wrt the state (caller zeroes; ends as grad wrt slot 0) */
-    float* dalpha;                        /* (B,Tp) in/out: running gradient wrt the alignment (caller zeroes) */
+    float* dalp;                          /* (B,K,Tp) in/out: running gradient wrt the alignment, one row per filter (caller zeroes) */
     float* dspart; float* dsacc;          /* (B,D) scratch */
     float* Q;                             /* (B,Tp) scratch */
-    float* dswp;                          /* (B,nchunk,M) scratch; nchunk = ceil(Tp/16) */
+    float* dcvp;                          /* (B,ceil(M/32),K,Tp) scratch: per-slice partials of DCV */
+    float* dswp;                          /* (B,ntile,M) scratch: per-tile partials of DSW */
 } lvsr_attdec_bwd_args;
 int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
 /* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block */
@@ -167,6 +174,24 @@ int lvsr_act_bwd(void* stream, int kind, const float* x, int ldx, const float* d
  * optional neglogp = -log_softmax for every class (beam search `costs`) */
 int lvsr_softmax_nll(void* stream, const float* logits, int ld, const long long* labels, const float* mask, int n, int V,
                      float* cost, float* dlogits, int ldd, float scale, float* neglogp, int ldn);
+
+/* ---- optimiser step on the flat buffers -----------------------------------------------------------
+ * StepClipping -> Momentum(scale) -> AdaDelta -> Restrict(VariableClipping(axis=0), WEIGHT params) ->
+ * RemoveNotFinite -> parameter -= step  (lvsr/main.py:480-519; libs/blocks/blocks/algorithms/__init__.py:
+ * 378-515, 610-720, 829-893).  `grad` holds d(sum cost); grad_scale = 1/batch_size (lvsr/main.py:340-345). */
+typedef struct lvsr_opt_args {
+    float* param; const float* grad;      /* flat (n) */
+    float* velocity; float* ms_step; float* ms_dx;   /* flat (n) rule state (NULL when the rule is off) */
+    float* step;                          /* flat (n) out: the applied step (before RemoveNotFinite) */
+    const long long* segments;            /* (nseg,4): offset, rows, cols, flags (bit0: max-norm applies) */
+    int* segflag;                         /* (nseg) scratch / out: 1 = step was not finite */
+    float* scratch;                       /* (2+256): [0] gradient norm, [1] clip multiplier, partial sums */
+    long long n;
+    int nseg, max_cols;
+    int use_momentum, use_adadelta, remove_not_finite, pad0;
+    float grad_scale, clip_threshold, learning_rate, momentum, decay_rate, epsilon, max_norm, nonfinite_scaler;
+} lvsr_opt_args;
+int lvsr_opt_step(void* stream, const lvsr_opt_args* a);
 
 #ifdef __cplusplus
 }

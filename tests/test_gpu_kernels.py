@@ -68,3 +68,63 @@ def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph
             assert_allclose(g.cpu().numpy() / scale, ref / scale, atol=1e-4, rtol=0, err_msg=name)
     if use_graph:
         assert lib._lvsr_graph_count() > 0, "hipGraph capture did not engage"
+
+
+# ---- whole recognizer on the GPU: cost matrix, alignments, all parameter gradients -------------------
+from conftest import load_golden                                   # noqa: E402
+from lvsr_amd.bricks.recognizer import SpeechRecognizer            # noqa: E402
+
+SMALL = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_content_embed",
+         "tiny_content_relu", "small_conv_median", "small_conv_expanding"]
+
+
+def _setup(meta):
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"],
+                                 ragged=meta["ragged"])
+    return params, batch
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("case", SMALL)
+def test_recognizer_vs_reference_golden(gpu_device, case, use_graph):
+    """HIP path vs the fixtures produced by the reference's own Theano graph (and the oracle for full tensors)."""
+    z, meta = load_golden(case)
+    params, batch = _setup(meta)
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"], use_graph=use_graph)
+    for rep in range(2):
+        cm = rec.cost_and_gradients(batch)
+        torch.cuda.synchronize()
+        cmn = cm.cpu().numpy()
+        assert_allclose(cmn, z["cost_matrix"], rtol=2e-4, atol=2e-5)
+        assert abs(cmn.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-4              # north_star: 1e-4 relative
+        w = rec.generator.last["weights"].cpu().numpy()
+        assert_allclose(w, z["weights"], rtol=2e-4, atol=2e-6)
+        assert (w.argmax(axis=2) == z["weights_argmax"]).all()                          # bit-exact alignment indices
+        assert_allclose(rec.encoded.cpu().numpy(), z["encoded"], rtol=1e-4, atol=2e-6)
+        got = rec.store.get_grads()
+        for name in z["grad_names"]:
+            ref = z["grad:" + str(name)]
+            scale = max(1e-3, numpy.abs(ref).max())
+            assert_allclose(got[str(name)] / scale, ref / scale, rtol=0, atol=2e-4, err_msg=str(name))
+
+
+@pytest.mark.parametrize("case", ["timit_tiny", "wsj_base"])
+def test_full_size_configs_vs_reference_golden(gpu_device, case):
+    """BASELINE.json configs[0] and configs[1] at full size against the reference's outputs (fingerprints)."""
+    z, meta = load_golden(case)
+    params, batch = _setup(meta)
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"])
+    cm = rec.cost_and_gradients(batch)
+    torch.cuda.synchronize()
+    cmn = cm.cpu().numpy()
+    assert abs(cmn.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-4
+    assert_allclose(cmn, z["cost_matrix"], rtol=1e-3, atol=1e-4)
+    w = rec.generator.last["weights"].cpu().numpy()
+    nb = z["weights_sub"].shape[1]
+    assert_allclose(w[:, :nb], z["weights_sub"], rtol=1e-3, atol=1e-6)
+    assert (w.argmax(axis=2) == z["weights_argmax"]).all()
+    got = rec.store.get_grads()
+    for name, fp in zip(z["grad_names"], z["grad_fp"]):
+        mine = synthetic.fingerprint(str(name), got[str(name)])
+        assert_allclose(mine, fp, rtol=2e-3, atol=2e-4 * max(1.0, fp[0]), err_msg=str(name))

@@ -1,0 +1,106 @@
+"""Optimiser: (a) pin oracle/optimizer_oracle.py to the reference's own known-answer tests
+(libs/blocks/tests/algorithms/test_algorithms.py), (b) the fused HIP step (emulated here, real on the GPU box)
+against that oracle on a recognizer-shaped parameter set."""
+from collections import OrderedDict
+
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from oracle import optimizer_oracle as OO
+from lvsr_amd import synthetic
+from lvsr_amd.bricks.recognizer import SpeechRecognizer
+from lvsr_amd.training import Trainer
+
+
+def test_momentum_known_answers():          # test_algorithms.py:96-104
+    a = numpy.array([3, 4], numpy.float32)
+    rule = OO.Momentum(0.1, 0.5)
+    for want in ([0.6, 0.8], [0.9, 1.2], [1.05, 1.4]):
+        assert_allclose(rule.compute_steps({"a": 2 * a})["a"], want, rtol=1e-6)
+
+
+def test_adadelta_known_answers():          # test_algorithms.py:111-119
+    a = numpy.array([3, 4], numpy.float32)
+    rule = OO.AdaDelta(decay_rate=0.5, epsilon=1e-7)
+    for want in ([0.00044721, 0.00044721], [0.0005164, 0.0005164], [0.00056904, 0.00056904]):
+        assert_allclose(rule.compute_steps({"a": 2 * a})["a"], want, rtol=1e-5)
+    with pytest.raises(ValueError):
+        OO.AdaDelta(-1.0)
+    with pytest.raises(ValueError):
+        OO.AdaDelta(2.0)
+
+
+def test_step_clipping_known_answers():     # test_algorithms.py:182-192, :255-260
+    g = OrderedDict([(0, numpy.float32(3.0)), (1, numpy.float32(4.0))])
+    c1 = OO.step_clipping(g, 4)
+    assert_allclose([c1[0], c1[1]], [12 / 5.0, 16 / 5.0], rtol=1e-6)
+    c2 = OO.step_clipping(g, 5)
+    assert_allclose([c2[0], c2[1]], [3.0, 4.0])
+    comp = OO.Momentum(0.1, 0.0).compute_steps(OO.step_clipping(g, 4))
+    assert_allclose([comp[0], comp[1]], [12 / 50.0, 16 / 50.0], rtol=1e-6)
+
+
+def test_variable_clipping_known_answers():     # test_algorithms.py:199-225
+    assert_allclose(OO.variable_clipping([1, 1], [3, 2], 5), [3, 2])
+    assert_allclose(OO.variable_clipping([-1, -1, -1], [[3, 9, 2]], 5), [[0.78885438, 3.47213595, 0.34164079]], rtol=1e-5)
+    got = OO.variable_clipping([[1, -1, 1, -1], [-1, 1, -1, 1]], [[1, 2, 3, 4], [5, 6, 7, 8]], 10, axis=1)
+    assert_allclose(got, [[1, 2, 3, 4], [3.54858826, 4.79049022, 5.06478435, 6.30668631]], rtol=1e-5)
+
+
+def test_remove_not_finite_known_answers():     # test_algorithms.py:312-324
+    assert_allclose(OO.remove_not_finite(1.0, numpy.nan, 0.1), 0.9)
+    assert_allclose(OO.remove_not_finite(2.0, numpy.inf, 0.1), 1.8)
+    assert_allclose(OO.remove_not_finite(3.0, 0.123, 0.1), 0.123)
+    assert_allclose(OO.remove_not_finite(1.0, numpy.nan), 0.0)
+
+
+CFG = dict(input_dim=5, num_phonemes=6, dims_bidir=[3, 3], subsample=[1, 2], dim_dec=4, dim_matcher=7,
+           attention_type="content_and_conv", conv_n=2, conv_num_filters=3, post_merge_dims=[8],
+           post_merge_activation="maxout2", embed_outputs=True, data_prepend_eos=False)
+RULES = dict(gradient_threshold=2.0, rules=("momentum", "adadelta"), scale=0.5, momentum=0.3, decay_rate=0.9,
+             epsilon=1e-6, max_norm=0.9)
+
+
+def run_fused_vs_oracle(device, lib, poison=False):
+    params = synthetic.make_params(CFG, seed=21)
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=CFG)
+    tr = Trainer(rec, distributed=False, **RULES)
+    orc = OO.TrainingRules(**RULES)
+    cur = OrderedDict((k, v.copy()) for k, v in params.items())
+    rng = numpy.random.RandomState(3)
+    for it in range(3):
+        grads = OrderedDict((k, rng.normal(0, 1.0, v.shape).astype(numpy.float32)) for k, v in cur.items())
+        if poison and it == 1:
+            grads["/recognizer/generator/readout/post_merge/bias.b"][2] = numpy.nan
+        for k, g in grads.items():
+            rec.store.g[k].copy_(torch.from_numpy(g))
+        tr.apply_gradients(global_batch_size=4)
+        if poison and it == 1:
+            # a NaN anywhere makes the global norm NaN -> every step is NaN -> RemoveNotFinite(0.0) zeroes every parameter
+            cur = OrderedDict((k, numpy.zeros_like(v)) for k, v in cur.items())
+            got = rec.store.get_values()
+            for k in cur:
+                assert_allclose(got[k], cur[k], err_msg=k)
+            return
+        cur = orc.step(cur, OrderedDict((k, g / numpy.float32(4)) for k, g in grads.items()))
+        got = rec.store.get_values()
+        for k in cur:
+            assert_allclose(got[k], cur[k], rtol=2e-5, atol=2e-6, err_msg="%s it %d" % (k, it))
+
+
+def test_fused_step_emulated():
+    from emu import emu_lib
+    run_fused_vs_oracle("cpu", emu_lib())
+
+
+def test_fused_step_nonfinite_emulated():
+    from emu import emu_lib
+    run_fused_vs_oracle("cpu", emu_lib(), poison=True)
+
+
+@pytest.mark.gpu
+def test_fused_step_gpu(gpu_device):
+    run_fused_vs_oracle(gpu_device, None)
+    run_fused_vs_oracle(gpu_device, None, poison=True)
