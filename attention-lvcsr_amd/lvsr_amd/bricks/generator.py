@@ -286,3 +286,84 @@ class SequenceGenerator(object):
 def lib_ptr(t):
     from ..native import ptr
     return ptr(t)
+
+
+# ---- generation mode (what BeamSearch drives: libs/blocks/blocks/search.py:97-142) -----------------------
+def _generation_methods():
+    def init_generation(self, attended, attended_mask):
+        """context_computer (search.py:97-104): keep the single utterance's contexts; every hypothesis of the
+        beam reads them with a zero batch stride (no tiling as in search.py:336-338)."""
+        d = self.d
+        Tp = int(attended.shape[0])
+        assert int(attended.shape[1]) == 1, "generation mode decodes one utterance at a time"
+        A = attended.contiguous()
+        PA = self.preprocess(A)
+        self._gen = dict(Tp=Tp, A=A.view(Tp, d.E), Am=attended_mask.contiguous().view(Tp), PA=PA.view(Tp, d.M))
+
+    def generation_initial_states(self, n=1):
+        """initial_state_computer (search.py:106-110): states = tiled initial_state (recurrent.py:622-624),
+        weights = initial glimpses (lvsr/bricks/attention.py:215-222), outputs = num_phonemes
+        (recognizer.py:286, sequence_generators.py:793-795), step = 0."""
+        d, p, n_ = self.d, self.store.p, self.n
+        Tp = self._gen["Tp"]
+        S = p[n_["h0"]].unsqueeze(0).expand(n, d.D).clone()
+        W = torch.zeros(n, Tp, dtype=torch.float32, device=S.device)
+        if d.conv:
+            W[:, 0] = 1.0
+        return dict(states=S, weights=W, step=0, outputs=numpy.full((n,), d.V, dtype=numpy.int64))
+
+    def _gen_run(self, S, W, step0, phases, outputs=None):
+        d, lib, ws, g = self.d, self.lib, self.ws, self._gen
+        n, Tp = int(S.shape[0]), g["Tp"]
+        pk = self._packed()
+        tag = ".n%d" % n
+        Sb = ws.get("gs.S" + tag, (2, n, d.D))
+        Wb = ws.get("gs.W" + tag, (2, n, Tp))
+        Sb[0].copy_(S)
+        Wb[0].copy_(W)
+        xg = None
+        if phases & 2:
+            xg = ws.get("gs.xg" + tag, (n, 3 * d.D))
+            y = ws.get("gs.y" + tag, (n,), torch.int64)
+            y.copy_(torch.as_tensor(outputs, dtype=torch.int64), non_blocking=False)
+            fb = ws.get("gs.fb" + tag, (n, d.FB)) if d.embed else None
+            self._feedback_fork(y, n, xg, fb)
+        Kc = max(d.K, 1)
+        bufs = dict(xg=xg, ymask=None, S=Sb, W=Wb,
+                    pos=ws.get("gs.pos" + tag, (2, n)) if (d.conv and self._prior()[0] != 0) else None,
+                    WA=ws.get("gs.WA" + tag, (1, n, d.E)), EN=ws.get("gs.EN" + tag, (1, n, Tp)),
+                    sW=ws.get("gs.sW" + tag, (1, n, d.M)), CV=ws.get("gs.CV" + tag, (1, n, Kc, Tp)) if d.conv else None,
+                    U=ws.get("gs.U" + tag, (1, n, d.D)), R=ws.get("gs.R" + tag, (1, n, d.D)),
+                    C=ws.get("gs.C" + tag, (1, n, d.D)), RH=ws.get("gs.RH" + tag, (1, n, d.D)),
+                    sg=ws.get("gs.sg" + tag, (n, 2 * d.D)), xin=ws.get("gs.xin" + tag, (n, d.D)),
+                    ep=ws.get("gs.ep" + tag, (n, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
+        fields = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, n, bufs, phases=phases, step0=int(step0), broadcast=True)
+        lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", Sb, False, **fields)
+        return bufs
+
+    def generation_logprobs(self, S, W, step0):
+        """logprobs_computer (search.py:126-134): take_glimpses -> readout -> -log_softmax; (n,V) device tensor."""
+        d, lib, ws = self.d, self.lib, self.ws
+        n = int(S.shape[0])
+        bufs = self._gen_run(S, W, step0, phases=1)
+        _, _, logits = self._readout(bufs["S"][0], bufs["WA"][0], n, ".gen%d" % n)
+        logits = self.fuse_language_model(logits, n) if self.language_model is not None else logits
+        nl = ws.get("gs.neglogp.n%d" % n, (n, d.V))
+        lib.call("lvsr_softmax_nll", lib.stream_for(nl), lib_ptr(logits), d.V, None, None, n, d.V, None, None, 0, 1.0,
+                 lib_ptr(nl), d.V)
+        return nl
+
+    def generation_next_states(self, S, W, step0, outputs):
+        """next_state_computer (search.py:112-124): take_glimpses AGAIN on the re-arranged hypotheses (the window
+        of the location prior depends on the batch it is computed for) + compute_states with the chosen outputs."""
+        bufs = self._gen_run(S, W, step0, phases=3, outputs=outputs)
+        return dict(states=bufs["S"][1], weights=bufs["W"][1], step=int(step0) + 1,
+                    weighted_averages=bufs["WA"][0], outputs=numpy.asarray(outputs))
+
+    return dict(init_generation=init_generation, generation_initial_states=generation_initial_states, _gen_run=_gen_run,
+                generation_logprobs=generation_logprobs, generation_next_states=generation_next_states)
+
+
+for _k, _v in _generation_methods().items():
+    setattr(SequenceGenerator, _k, _v)
+SequenceGenerator.language_model = None

@@ -113,3 +113,36 @@ class SpeechRecognizer(object):
         last = self.generator.last
         torch.cuda.synchronize() if self.device.type == "cuda" else None
         return [cm[:, 0].cpu().numpy(), last["weights"][:, 0, :].cpu().numpy(), last["energies"][:, 0, :].cpu().numpy()]
+
+    # ---- decoding (recognizer.py:496-533) ------------------------------------------------------------
+    def compute_contexts(self, recordings):
+        """Encoder at batch 1 with NO input mask (init_beam_search builds the graph with use_mask=False,
+        recognizer.py:506; Encoder.apply then returns an all-ones mask, lvsr/bricks/__init__.py:78)."""
+        x = numpy.asarray(recordings, dtype=numpy.float32)
+        if x.ndim == 2:
+            x = x[:, None, :]
+        xb = self._t(x, torch.float32, "recordings")
+        encoded, encoded_mask = self.encoder.apply(xb, None, save_for_backward=False)
+        self.generator.init_generation(encoded, encoded_mask)
+
+    def init_beam_search(self, beam_size):
+        from ..search import BeamSearch
+        if getattr(self, "_beam_search", None) is not None and self.beam_size == beam_size:
+            return
+        self.beam_size = beam_size
+        self._beam_search = BeamSearch(beam_size, self)
+
+    def beam_search(self, inputs, **kwargs):
+        """-> (outputs: list of label lists, costs: list of floats), best first."""
+        self.init_beam_search(self.beam_size)
+        inputs = dict(inputs)
+        rec = numpy.asarray(inputs.pop("recordings"), dtype=numpy.float32)
+        if inputs:
+            raise Exception("Unknown inputs passed to beam search: {}".format(inputs.keys()))     # recognizer.py:525-528
+        max_length = int(rec.shape[0] / self.max_decoded_length_scale)                             # :519-520
+        outputs, search_costs = self._beam_search.search(
+            {"recordings": rec[:, None, :]}, self.eos_label, max_length, ignore_first_eol=self.data_prepend_eos, **kwargs)
+        return [[int(t) for t in o] for o in outputs], [float(c) for c in search_costs]
+
+    def lm_initial_states(self, n):
+        return self.generator.language_model.initial_states(n)

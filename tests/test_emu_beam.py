@@ -1,0 +1,45 @@
+"""Beam search through the emulated HIP generation step vs the hypotheses the reference produced (golden fixtures)."""
+import numpy
+import pytest
+from numpy.testing import assert_allclose
+
+from conftest import load_golden
+from emu import emu_lib
+from lvsr_amd import synthetic
+from lvsr_amd.bricks.recognizer import SpeechRecognizer
+from lvsr_amd.search import CandidateNotFoundError
+
+CASES = ["tiny_conv_nowindow", "tiny_conv_median", "tiny_content_embed", "tiny_content_relu"]
+
+
+def run_beam_case(case, device, lib):
+    z, meta = load_golden(case)
+    if not meta.get("beam"):
+        pytest.skip("no beam fixture")
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=meta["cfg"])
+    for bi, b in enumerate(meta["beam"]):
+        s = dict(b["settings"])
+        utt = s.pop("utt", 0)
+        bs = s.pop("beam_size")
+        tl = int(batch["recordings_mask"][:, utt].sum())
+        x = batch["recordings"][:tl, utt]
+        rec.init_beam_search(bs)
+        if b.get("error"):
+            with pytest.raises(CandidateNotFoundError):
+                rec.beam_search({"recordings": x}, **s)
+            continue
+        outs, costs = rec.beam_search({"recordings": x}, **s)
+        assert outs == b["outputs"], (case, bi)                                  # bit-exact hypotheses
+        assert_allclose(costs, b["costs"], rtol=2e-5, atol=2e-5)
+        key = "analyze%d_cost" % bi
+        if key in z.files and outs:
+            c, w, _ = rec.analyze({"recordings": x}, numpy.array(outs[0]))
+            assert_allclose(c, z[key], rtol=2e-4, atol=2e-5)
+            assert_allclose(w, z["analyze%d_weights" % bi], rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_beam_search_emulated(case):
+    run_beam_case(case, "cpu", emu_lib())

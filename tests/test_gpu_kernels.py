@@ -128,3 +128,11 @@ def test_full_size_configs_vs_reference_golden(gpu_device, case):
     for name, fp in zip(z["grad_names"], z["grad_fp"]):
         mine = synthetic.fingerprint(str(name), got[str(name)])
         assert_allclose(mine, fp, rtol=2e-3, atol=2e-4 * max(1.0, fp[0]), err_msg=str(name))
+
+
+# ---- beam search on the GPU vs the hypotheses the reference produced --------------------------------
+@pytest.mark.parametrize("case", ["tiny_conv_nowindow", "tiny_conv_median", "tiny_content_embed", "tiny_content_relu",
+                                  "small_conv_median"])
+def test_beam_search_vs_reference_golden(gpu_device, case):
+    from test_emu_beam import run_beam_case
+    run_beam_case(case, gpu_device, None)
