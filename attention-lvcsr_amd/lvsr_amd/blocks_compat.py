@@ -1,0 +1,137 @@
+"""Stand-ins for the Blocks / lvsr classes that the reference's YAML configs name through
+`!!python/name:` / `!!python/object/apply:` tags (lvsr/configs/prototype_speech.yaml:2-29,
+exp/wsj/configs/wsj_jan_new.yaml:25-72).  They carry configuration only — the arithmetic is in the HIP library —
+except the initialisation schemes, which generate numpy arrays exactly as blocks/initialization.py does.
+"""
+import numpy
+
+
+# ---- brick markers (net section) ---------------------------------------------------------------------
+class _Marker(object):
+    def __init__(self, *args, **kwargs):
+        self.args, self.kwargs = args, kwargs
+
+    def __repr__(self):
+        return "%s(%s)" % (type(self).__name__, ", ".join(map(repr, self.args)))
+
+
+class GatedRecurrent(_Marker):          # blocks.bricks.recurrent.GatedRecurrent (recurrent.py:486-624)
+    pass
+
+
+class SimpleRecurrent(_Marker):         # not built: selecting it raises in spec.from_reference_kwargs
+    pass
+
+
+class LSTM(_Marker):
+    pass
+
+
+class Tanh(_Marker):
+    pass
+
+
+class Rectifier(_Marker):
+    pass
+
+
+class Identity(_Marker):
+    pass
+
+
+class Logistic(_Marker):
+    pass
+
+
+class Maxout(_Marker):                  # blocks.bricks.Maxout(num_pieces) (simple.py:134-181)
+    def __init__(self, num_pieces=2, **kwargs):
+        _Marker.__init__(self, num_pieces, **kwargs)
+        self.num_pieces = num_pieces
+
+
+class SpeechBottom(_Marker):            # lvsr.bricks.recognizer.SpeechBottom (recognizer.py:105-157)
+    pass
+
+
+class LookupBottom(_Marker):
+    pass
+
+
+class H5PYAudioDataset(_Marker):        # lvsr.datasets.h5py.H5PYAudioDataset — data layer is out of scope
+    pass
+
+
+# ---- initialisation schemes (libs/blocks/blocks/initialization.py:80-209) --------------------------------
+class NdarrayInitialization(object):
+    def generate(self, rng, shape):
+        raise NotImplementedError
+
+
+class Constant(NdarrayInitialization):
+    """initialization.py:50-77"""
+    def __init__(self, constant=0.0):
+        self._constant = numpy.asarray(constant)
+
+    def generate(self, rng, shape):
+        dest = numpy.empty(shape, dtype=numpy.float32)
+        dest[...] = self._constant
+        return dest
+
+
+class IsotropicGaussian(NdarrayInitialization):
+    """initialization.py:80-103"""
+    def __init__(self, std=1, mean=0):
+        self._mean, self._std = mean, std
+
+    def generate(self, rng, shape):
+        return rng.normal(self._mean, self._std, size=shape).astype(numpy.float32)
+
+
+class Uniform(NdarrayInitialization):
+    """initialization.py:105-139"""
+    def __init__(self, mean=0., width=None, std=None):
+        if (width is not None) == (std is not None):
+            raise ValueError("must specify width or std, but not both")
+        self._mean = mean
+        self._width = width if width is not None else numpy.sqrt(12) * std
+
+    def generate(self, rng, shape):
+        w = self._width / 2
+        return rng.uniform(self._mean - w, self._mean + w, size=shape).astype(numpy.float32)
+
+
+class Orthogonal(NdarrayInitialization):
+    """initialization.py:163-209: QR of a Gaussian matrix, signs fixed by the diagonal of R."""
+    def __init__(self, scale=1):
+        self.scale = scale
+
+    def generate(self, rng, shape):
+        if len(shape) != 2:
+            raise ValueError
+        if shape[0] == shape[1]:
+            M = rng.randn(*shape).astype(numpy.float32)
+            Q, R = numpy.linalg.qr(M)
+            Q = Q * numpy.sign(numpy.diag(R))
+            return (Q * self.scale).astype(numpy.float32)
+        M1 = rng.randn(shape[0], shape[0]).astype(numpy.float32)
+        M2 = rng.randn(shape[1], shape[1]).astype(numpy.float32)
+        Q1, R1 = numpy.linalg.qr(M1)
+        Q2, R2 = numpy.linalg.qr(M2)
+        Q1 = Q1 * numpy.sign(numpy.diag(R1))
+        Q2 = Q2 * numpy.sign(numpy.diag(R2))
+        n_min = min(shape[0], shape[1])
+        return (numpy.dot(Q1[:, :n_min], Q2[:n_min, :]) * self.scale).astype(numpy.float32)
+
+
+# python path (as written in the reference's YAML tags) -> class
+REGISTRY = {
+    "blocks.bricks.recurrent.GatedRecurrent": GatedRecurrent,
+    "blocks.bricks.recurrent.SimpleRecurrent": SimpleRecurrent,
+    "blocks.bricks.recurrent.LSTM": LSTM,
+    "blocks.bricks.Tanh": Tanh, "blocks.bricks.Rectifier": Rectifier, "blocks.bricks.Identity": Identity,
+    "blocks.bricks.Logistic": Logistic, "blocks.bricks.Maxout": Maxout,
+    "lvsr.bricks.recognizer.SpeechBottom": SpeechBottom, "lvsr.bricks.recognizer.LookupBottom": LookupBottom,
+    "lvsr.datasets.h5py.H5PYAudioDataset": H5PYAudioDataset,
+    "blocks.initialization.Constant": Constant, "blocks.initialization.IsotropicGaussian": IsotropicGaussian,
+    "blocks.initialization.Uniform": Uniform, "blocks.initialization.Orthogonal": Orthogonal,
+}

@@ -70,6 +70,52 @@ class SpeechRecognizer(object):
     def set_parameter_values(self, values):
         self.store.set_values(values)
 
+    def load_params(self, path):
+        """recognizer.py:408-412: load a Blocks checkpoint (tar with `_parameters`) or an .npz by parameter name."""
+        from ..checkpoint import load_parameters
+        self.store.set_values(load_parameters(path))
+
+    def save_params(self, path):
+        from ..checkpoint import save_parameters
+        save_parameters(path, self.store.get_values())
+
+    def initialize(self, initialization, seed=1):
+        """Apply the reference's `initialization:` config section (lvsr/main.py:225-232): brick paths mapped to
+        {weights_init, biases_init, rec_weights_init, initial_states_init}, applied shallow-to-deep; recurrent weights
+        follow GatedRecurrent._initialize (libs/blocks/blocks/bricks/recurrent.py:567-580: state_to_gates =
+        hstack[init, init]).  The RNG stream is numpy.random.RandomState(seed) per parameter name — it does NOT
+        reproduce Blocks' per-brick seeding (parity tests always load explicit parameter values)."""
+        import zlib
+        chosen = {}
+        for path in sorted(initialization, key=lambda s: s.count("/")):
+            for name in self.store.shapes:
+                if name.startswith(path.rstrip("/") + "/") or name == path:
+                    chosen.setdefault(name, {}).update(initialization[path])
+        values = {}
+        for name, shape in self.store.shapes.items():
+            conf = chosen.get(name, {})
+            rng = numpy.random.RandomState((zlib.crc32(name.encode()) + seed) % (2 ** 31))
+            leaf = name.rsplit("/", 1)[-1]
+            rec = conf.get("rec_weights_init", conf.get("weights_init"))
+            if leaf.endswith("state_to_state") and rec is not None:
+                v = rec.generate(rng, shape)
+            elif leaf.endswith("state_to_gates") and rec is not None:
+                H = shape[0]
+                v = numpy.hstack([rec.generate(rng, (H, H)), rec.generate(rng, (H, H))])
+            elif leaf.endswith("initial_state"):
+                init = conf.get("initial_states_init")
+                v = init.generate(rng, shape) if init is not None else numpy.zeros(shape, numpy.float32)
+            elif leaf.endswith(".b"):
+                init = conf.get("biases_init")
+                v = init.generate(rng, shape) if init is not None else numpy.zeros(shape, numpy.float32)
+            else:
+                init = conf.get("weights_init")
+                if init is None:
+                    raise ValueError("no weights_init configured for %s" % name)
+                v = init.generate(rng, shape)
+            values[name] = numpy.asarray(v, numpy.float32)
+        self.store.set_values(values)
+
     # ---- training cost (recognizer.py:375-390) -------------------------------------------------------
     def cost(self, recordings=None, inputs_mask=None, labels=None, labels_mask=None, save_for_backward=True, **kw):
         """-> cost matrix (L,B) on the device.  `recordings` (T,B,F), `inputs_mask` (T,B) or None,
