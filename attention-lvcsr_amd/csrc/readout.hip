@@ -101,6 +101,40 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(const float* logits, i
     }
 }
 
+// ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104); one wave per hypothesis:
+//   x = [logsoftmax](am_beta * am) + lm_weight * [logsoftmax](-lm_add)  [-> logsoftmax]
+__device__ __forceinline__ float row_lse(const float* x, int V, float scale, int lane) {
+    float mx = -3.0e38f;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, scale * x[v]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(scale * x[v] - mx);
+    s = wave_sum(s);
+    return mx + logf(s);
+}
+__global__ __launch_bounds__(256) void shallow_fusion_kernel(const float* am, int ld, const float* lm_add, int n, int V,
+                                                             float am_beta, float lm_weight, int norm_am, int norm_lm,
+                                                             int norm_tot, float out_scale, float* out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const float* a = am + (size_t)r * ld;
+    const float* l = lm_add + (size_t)r * V;
+    float* o = out + (size_t)r * V;
+    const float lse_a = norm_am ? row_lse(a, V, am_beta, lane) : 0.f;
+    const float lse_l = norm_lm ? row_lse(l, V, -1.f, lane) : 0.f;
+    float lse_t = 0.f;
+    if (norm_tot) {
+        float mx = -3.0e38f;
+        for (int v = lane; v < V; v += 64) mx = fmaxf(mx, (am_beta * a[v] - lse_a) + lm_weight * (-l[v] - lse_l));
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int v = lane; v < V; v += 64) s += expf(((am_beta * a[v] - lse_a) + lm_weight * (-l[v] - lse_l)) - mx);
+        s = wave_sum(s);
+        lse_t = mx + logf(s);
+    }
+    for (int v = lane; v < V; v += 64) o[v] = out_scale * (((am_beta * a[v] - lse_a) + lm_weight * (-l[v] - lse_l)) - lse_t);
+}
+
 extern "C" {
 
 int lvsr_gather_rows(void* stream, const float* table, int ldt, const long long* idx, int n, int nrows, int width,
@@ -146,6 +180,14 @@ int lvsr_softmax_nll(void* stream, const float* logits, int ld, const long long*
     hipLaunchKernelGGL(softmax_nll_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, mask, n, V,
                        cost, dlogits, ldd, scale, neglogp, ldn);
     return lvsr_check_launch("lvsr_softmax_nll");
+}
+
+int lvsr_shallow_fusion(void* stream, const float* am, int ld, const float* lm_add, int n, int V, float am_beta,
+                        float lm_weight, int norm_am, int norm_lm, int norm_tot, float out_scale, float* out) {
+    if (n <= 0 || V <= 0) return LVSR_OK;
+    hipLaunchKernelGGL(shallow_fusion_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, am, ld, lm_add, n, V,
+                       am_beta, lm_weight, norm_am, norm_lm, norm_tot, out_scale, out);
+    return lvsr_check_launch("lvsr_shallow_fusion");
 }
 
 }  // extern "C"

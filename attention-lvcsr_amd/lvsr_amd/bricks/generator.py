@@ -310,7 +310,10 @@ def _generation_methods():
         W = torch.zeros(n, Tp, dtype=torch.float32, device=S.device)
         if d.conv:
             W[:, 0] = 1.0
-        return dict(states=S, weights=W, step=0, outputs=numpy.full((n,), d.V, dtype=numpy.int64))
+        # initial outputs: SoftmaxEmitter(initial_output=num_phonemes) (recognizer.py:286); with a language model the
+        # emitter is LMEmitter whose initial_outputs are zeros (language_models.py:172-175)
+        first = 0 if self.language_model is not None else d.V
+        return dict(states=S, weights=W, step=0, outputs=numpy.full((n,), first, dtype=numpy.int64))
 
     def _gen_run(self, S, W, step0, phases, outputs=None):
         d, lib, ws, g = self.d, self.lib, self.ws, self._gen
@@ -347,8 +350,15 @@ def _generation_methods():
         n = int(S.shape[0])
         bufs = self._gen_run(S, W, step0, phases=1)
         _, _, logits = self._readout(bufs["S"][0], bufs["WA"][0], n, ".gen%d" % n)
-        logits = self.fuse_language_model(logits, n) if self.language_model is not None else logits
         nl = ws.get("gs.neglogp.n%d" % n, (n, d.V))
+        lm = self.language_model
+        if lm is not None:
+            # ShallowFusionReadout + LMEmitter: the fused readout IS the log-probability; costs = -readout
+            add = ws.get("gs.lm_add.n%d" % n, (n, d.V))
+            add.copy_(lm.device_add)
+            lib.call("lvsr_shallow_fusion", lib.stream_for(nl), lib_ptr(logits), d.V, lib_ptr(add), n, d.V, lm.am_beta,
+                     lm.lm_weight, int(lm.norm[0]), int(lm.norm[1]), int(lm.norm[2]), -1.0, lib_ptr(nl))
+            return nl
         lib.call("lvsr_softmax_nll", lib.stream_for(nl), lib_ptr(logits), d.V, None, None, n, d.V, None, None, 0, 1.0,
                  lib_ptr(nl), d.V)
         return nl

@@ -190,5 +190,12 @@ class SpeechRecognizer(object):
             {"recordings": rec[:, None, :]}, self.eos_label, max_length, ignore_first_eol=self.data_prepend_eos, **kwargs)
         return [[int(t) for t in o] for o in outputs], [float(c) for c in search_costs]
 
+    def set_language_model(self, language_model):
+        """Attach (or detach with None) an `lvsr_amd.lm.FSTLanguageModel` for shallow-fusion decoding — the `lm:`
+        sub-section of the reference's net config (recognizer.py:322-343)."""
+        if language_model is not None and language_model.out_dim != self.d.V:
+            raise ValueError("language model covers %d characters, the recognizer %d" % (language_model.out_dim, self.d.V))
+        self.generator.language_model = language_model
+
     def lm_initial_states(self, n):
         return self.generator.language_model.initial_states(n)

@@ -69,7 +69,7 @@ class BeamSearch(object):
                 raise ValueError("Unknown stopping criterion {}".format(stop_on))
             with rec._on_stream():
                 if lm_states is not None:
-                    gen.language_model.stage(lm_states)
+                    gen.language_model.stage(lm_states, dev)
                 nl = gen.generation_logprobs(S, W, step)
             logprobs = nl.cpu().numpy().astype(numpy.float32)
             assert numpy.isfinite(logprobs).all()

@@ -193,6 +193,29 @@ typedef struct lvsr_opt_args {
 } lvsr_opt_args;
 int lvsr_opt_step(void* stream, const lvsr_opt_args* a);
 
+/* ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104):
+ * out = [logsoftmax](am_beta*am) + lm_weight*[logsoftmax](-lm_add) [-> logsoftmax]; with an LM the emitter is
+ * LMEmitter (costs = -readout, language_models.py:147-184): out_scale = -1 yields the beam-search costs directly. */
+int lvsr_shallow_fusion(void* stream, const float* am, int ld, const float* lm_add, int n, int V, float am_beta,
+                        float lm_weight, int norm_am, int norm_lm, int norm_tot, float out_scale, float* out);
+
+/* ---- mel-filterbank front end ------------------------------------------------------------------------
+ * The reference runs Kaldi offline (exp/wsj/write_hdf_dataset.sh:94-104: compute-fbank-feats --use-energy=true
+ * --num-mel-bins=40 | add-deltas, then global CMVN); Kaldi's source is not part of the reference tree, so these
+ * entry points follow Kaldi's documented defaults and their parity is UNPINNED (oracle/fbank_oracle.py). */
+typedef struct lvsr_fbank_cfg {
+    int frame_length, frame_shift;        /* samples (400, 160 at 16 kHz) */
+    int num_mel, use_energy, remove_dc, pad0;
+    float preemph, pad1;
+} lvsr_fbank_cfg;
+int lvsr_fbank_num_frames(long long nsamp, const lvsr_fbank_cfg* cfg);
+/* wav: int16 PCM; window (frame_length); melw (num_mel,256) dense filter weights; twiddle (2,512) cos|sin table;
+ * out (nframes, num_mel + use_energy), energy first */
+int lvsr_fbank(void* stream, const short* wav, long long nsamp, const lvsr_fbank_cfg* cfg, const float* window,
+               const float* melw, const float* twiddle, float* out);
+/* feats (T,dim) -> out (T,3*dim) = [static | delta | delta-delta], optionally (x-mean)*istd with (3*dim) stats */
+int lvsr_add_deltas_cmvn(void* stream, const float* feats, int T, int dim, const float* mean, const float* istd, float* out);
+
 #ifdef __cplusplus
 }
 #endif

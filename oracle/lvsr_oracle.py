@@ -313,13 +313,18 @@ class OracleRecognizer(object):
         A, Am, PA = ctx
         return A.expand(-1, n, -1), Am.expand(-1, n), PA.expand(-1, n, -1)
 
-    def logprobs(self, ctx, st):
-        """logprobs_computer: take_glimpses + readout + costs=-log_softmax (search.py:126-134)."""
+    def logprobs(self, ctx, st, lm=None, lm_vecs=None):
+        """logprobs_computer: take_glimpses + readout + costs=-log_softmax (search.py:126-134).  With a language model:
+        ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104) and LMEmitter.costs = -readout (:166-168)."""
         with torch.no_grad():
             n = st["states"].shape[0]
             A, Am, PA = self._tile(ctx, n)
             wa, alpha, en = self.take_glimpses(A, PA, Am, st["states"], st["weights"], int(st["step"][0]) if n else 0)
             r = self.readout(st["states"], wa)
+            if lm is not None:
+                from oracle import lm_oracle as LO
+                add = numpy.stack([lm["dense"].costs(v, lm["remap"], lm["no_transition_cost"]) for v in lm_vecs])
+                return -LO.shallow_fusion(r.numpy(), add, lm["weight"], lm.get("am_beta", 1.0), *lm.get("norms", (True, False, False)))
             return (-torch.log_softmax(r, dim=-1)).numpy()
 
     def next_states(self, ctx, st, outputs):
@@ -335,7 +340,7 @@ class OracleRecognizer(object):
 
     # -- beam search: libs/blocks/blocks/search.py:244-407 as driven by recognizer.py:513-533 ----
     def beam_search(self, x, beam_size, char_discount=0, round_to_inf=1e9, stop_on="patience",
-                    validate_solution_function=None):
+                    validate_solution_function=None, lm=None):
         x = numpy.asarray(x)
         max_length = int(x.shape[0] / self.cfg["max_decoded_length_scale"])
         ignore_first_eol = self.cfg["data_prepend_eos"]
@@ -343,6 +348,10 @@ class OracleRecognizer(object):
         ctx = self.contexts(x)
         Tp = ctx[0].shape[0]
         states = self.initial_states(1, Tp)
+        lm_vecs = None
+        if lm is not None:
+            states["outputs"] = numpy.zeros((1,), numpy.int64)      # LMEmitter.initial_outputs (language_models.py:172-175)
+            lm_vecs = [lm["dense"].initial()]
         all_outputs = states["outputs"][None, :]
         all_costs = numpy.zeros_like(all_outputs, dtype=numpy.float32)
         done = []
@@ -372,7 +381,7 @@ class OracleRecognizer(object):
                         break
             else:
                 raise ValueError("Unknown stopping criterion {}".format(stop_on))
-            logprobs = self.logprobs(ctx, states).astype(numpy.float32)
+            logprobs = self.logprobs(ctx, states, lm, lm_vecs).astype(numpy.float32)
             assert numpy.isfinite(logprobs).all()
             next_costs = all_costs[-1, :, None] + logprobs
             (indexes, outputs), chosen = smallest(next_costs, beam_size)
@@ -380,6 +389,8 @@ class OracleRecognizer(object):
             all_outputs = numpy.take(all_outputs, indexes, axis=1)
             all_costs = numpy.take(all_costs, indexes, axis=1)
             states = self.next_states(ctx, states, outputs)
+            if lm is not None:
+                lm_vecs = [lm["dense"].step(lm_vecs[j], lm["remap"][int(o)]) for j, o in zip(indexes, outputs)]
             all_outputs = numpy.vstack([all_outputs, outputs[None, :]])
             all_costs = numpy.vstack([all_costs, chosen[None, :]])
             mask = outputs != eol
@@ -390,6 +401,8 @@ class OracleRecognizer(object):
                 if validate_solution_function is None or validate_solution_function(x, all_outputs[:, idx]):
                     done.append((all_outputs[:, idx], all_costs[:, idx]))
             unfinished = numpy.where(mask == 1)[0]
+            if lm is not None:
+                lm_vecs = [lm_vecs[j] for j in unfinished]
             states = {k: take(v, unfinished) for k, v in states.items()}
             all_outputs = numpy.take(all_outputs, unfinished, axis=1)
             all_costs = numpy.take(all_costs, unfinished, axis=1)
