@@ -54,8 +54,12 @@ __device__ __forceinline__ float wave_max(float v) {
 __host__ __device__ __forceinline__ int lvsr_pack_kw(int K) { return ((K + 3) / 4 + 15) / 16 * 16; }
 
 struct RowSrc {            // A operand rows: row i at base + i*ld (ld = 0 broadcasts one row), valid rows < nrows
-    const float* base; long long ld; int nrows; int K; bool vec;
-    __device__ __forceinline__ float4 operator()(int i, int k) const {
+    const float* base; long long ld; int nrows; int K; bool vec; bool fast;
+    // FAST (uniform, decided once per kernel): 16-B aligned rows and no K padding -> one unguarded float4 load; rows
+    // beyond nrows re-read the last valid row (their results are discarded by the epilogue).
+    template <bool FAST>
+    __device__ __forceinline__ float4 get(int i, int k) const {
+        if (FAST) return *(const float4*)(base + (size_t)min(i, nrows - 1) * ld + k);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i >= nrows || k >= K) return v;
         const float* p = base + (size_t)i * ld + k;
@@ -67,10 +71,12 @@ struct RowSrc {            // A operand rows: row i at base + i*ld (ld = 0 broad
         return v;
     }
 };
+__device__ __forceinline__ bool rb_no_kpad(int K) { return K == 4 * lvsr_pack_kw(K); }
 __device__ __forceinline__ RowSrc row_src(const float* base, long long ld, int nrows, int K) {
     RowSrc s;
     s.base = base; s.ld = ld; s.nrows = nrows; s.K = K;
     s.vec = ((ld & 3) == 0) && ((K & 3) == 0) && ((((size_t)base) & 15) == 0);
+    s.fast = s.vec && nrows > 0 && rb_no_kpad(K);
     return s;
 }
 
@@ -86,15 +92,18 @@ __device__ __forceinline__ float4 ld4g(const float* p, int nvalid, bool vec) {
     return v;
 }
 
-template <int N, class A4>
+template <int N, bool FAST, class A4>
 __device__ __forceinline__ void rb_chunk(f32x4& acc0, f32x4& acc1, const A4& a4, const float4* __restrict__ p, int i,
                                          int k0) {
     float4 a[N], b[N];
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         b[q] = p[q * 64];
-        a[q] = a4(i, k0 + 4 * q);
+        a[q] = a4.template get<FAST>(i, k0 + 4 * q);
     }
+    // keep every load above the first MFMA: the scheduler otherwise interleaves load / wait / 4 MFMAs and exposes the
+    // memory latency once per q instead of once per chunk
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < N; ++q) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q].x, b[q].x, acc0, 0, 0, 0);
@@ -105,20 +114,26 @@ __device__ __forceinline__ void rb_chunk(f32x4& acc0, f32x4& acc1, const A4& a4,
 }
 
 // Accumulate this wave's K-slice of tile `tile` of packed weight P (logical K x N) into acc0/acc1.
-// a4(i, k) returns A[i][k..k+3] (zero beyond K / beyond the valid rows).
-template <class A4>
-__device__ __forceinline__ void rb_mm(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K,
-                                      int tile) {
+// a4.get<FAST>(i, k) returns A[i][k..k+3] (zero beyond K / beyond the valid rows on the guarded path).
+template <bool FAST, class A4>
+__device__ __forceinline__ void rb_mm_impl(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K,
+                                           int tile) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
     const int Kw = lvsr_pack_kw(K), NQ = Kw >> 4;
     int k0 = wave * Kw + kk * (Kw >> 2);
     const float4* p = (const float4*)P + ((size_t)(tile * 4 + wave) * NQ) * 64 + lane;
     int q = 0;
-    for (; q + 8 <= NQ; q += 8, p += 8 * 64, k0 += 32) rb_chunk<8>(acc0, acc1, a4, p, i, k0);
-    if (q + 4 <= NQ) { rb_chunk<4>(acc0, acc1, a4, p, i, k0); q += 4; p += 4 * 64; k0 += 16; }
-    if (q + 2 <= NQ) { rb_chunk<2>(acc0, acc1, a4, p, i, k0); q += 2; p += 2 * 64; k0 += 8; }
-    if (q < NQ) rb_chunk<1>(acc0, acc1, a4, p, i, k0);
+    for (; q + 8 <= NQ; q += 8, p += 8 * 64, k0 += 32) rb_chunk<8, FAST>(acc0, acc1, a4, p, i, k0);
+    if (q + 4 <= NQ) { rb_chunk<4, FAST>(acc0, acc1, a4, p, i, k0); q += 4; p += 4 * 64; k0 += 16; }
+    if (q + 2 <= NQ) { rb_chunk<2, FAST>(acc0, acc1, a4, p, i, k0); q += 2; p += 2 * 64; k0 += 8; }
+    if (q < NQ) rb_chunk<1, FAST>(acc0, acc1, a4, p, i, k0);
+}
+template <class A4>
+__device__ __forceinline__ void rb_mm(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K,
+                                      int tile) {
+    if (a4.fast) rb_mm_impl<true>(acc0, acc1, a4, P, K, tile);
+    else rb_mm_impl<false>(acc0, acc1, a4, P, K, tile);
 }
 
 // Sum the per-wave partial tiles; afterwards thread tid owns element (row = tid>>4, col = tid&15).

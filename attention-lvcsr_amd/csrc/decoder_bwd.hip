@@ -13,13 +13,17 @@ typedef lvsr_attdec_bwd_args AttBwd;
 
 struct DecDpcSrc {    // A operand: ds * ym * u * (1 - c^2); ds rows ld=D, u,c rows ld=D
     const float* ds; const float* u; const float* c; const float* mask;
-    int D, nrows; bool vec;
-    __device__ __forceinline__ float4 operator()(int i, int k) const {
+    int D, nrows; bool vec, fast;
+    template <bool FAST>
+    __device__ __forceinline__ float4 get(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i >= nrows || k >= D) return v;
+        if (FAST) i = min(i, nrows - 1);
+        else if (i >= nrows || k >= D) return v;
         const float m = mask ? mask[i] : 1.f;
         const size_t o = (size_t)i * D + k;
-        const float4 d4 = ld4g(ds + o, D - k, vec), u4 = ld4g(u + o, D - k, vec), c4 = ld4g(c + o, D - k, vec);
+        const float4 d4 = FAST ? *(const float4*)(ds + o) : ld4g(ds + o, D - k, vec);
+        const float4 u4 = FAST ? *(const float4*)(u + o) : ld4g(u + o, D - k, vec);
+        const float4 c4 = FAST ? *(const float4*)(c + o) : ld4g(c + o, D - k, vec);
         v.x = d4.x * m * u4.x * (1.f - c4.x * c4.x);
         v.y = d4.y * m * u4.y * (1.f - c4.y * c4.y);
         v.z = d4.z * m * u4.z * (1.f - c4.z * c4.z);
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(256) void attbwd_gru_a_kernel(AttBwd g, int i) {
     src.ds = g.ds + (size_t)b0 * D; src.u = a.U + ((size_t)i * B + b0) * D; src.c = a.C + ((size_t)i * B + b0) * D;
     src.mask = a.ymask ? a.ymask + (size_t)i * B + b0 : nullptr; src.D = D; src.nrows = B - b0;
     src.vec = ((D & 3) == 0) && ((((size_t)src.ds | (size_t)src.u | (size_t)src.c) & 15) == 0);
+    src.fast = src.vec && src.nrows > 0 && rb_no_kpad(D);
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
     rb_mm(acc0, acc1, src, g.WhhT_p, D, tile);
     const float drh = rb_reduce(acc0, acc1);
@@ -215,8 +220,9 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
 }
 
 struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of the per-work-group partials
-    const float* dswp; float* store; int ntile, M, nrows; bool vec;
-    __device__ __forceinline__ float4 operator()(int i, int k) const {
+    const float* dswp; float* store; int ntile, M, nrows; bool vec, fast;
+    template <bool FAST>
+    __device__ __forceinline__ float4 get(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i >= nrows || k >= M) return v;
         const float* p = dswp + (size_t)i * ntile * M + k;
@@ -258,6 +264,7 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         src.store = tile == 0 ? g.DSW + ((size_t)i * B + b0) * M : nullptr;
         src.ntile = ntile; src.M = M; src.nrows = B - b0;
         src.vec = ((M & 3) == 0) && ((((size_t)src.dswp) & 15) == 0);
+        src.fast = false;
         f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
         rb_mm(acc0, acc1, src, g.WsT_p, M, tile);
         const float v = rb_reduce(acc0, acc1);

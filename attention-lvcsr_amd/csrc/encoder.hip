@@ -31,18 +31,27 @@ struct HPrev {   // h_{t-1} rows of one direction
     __device__ __forceinline__ float at(int b, int k) const { return base[(size_t)b * ld + k]; }
 };
 
-__device__ __forceinline__ void enc_step_geometry(const EncFwd& a, int n, int dir, int& t, HPrev& hp) {
+__device__ __forceinline__ void enc_step_geometry(const EncFwd& a, const float* h0_d, int n, int dir, int& t, HPrev& hp) {
     t = dir == 0 ? n : a.T - 1 - n;
     const int tp = dir == 0 ? t - 1 : t + 1;
-    if (n == 0) { hp.base = a.h0[dir]; hp.ld = 0; }
+    if (n == 0) { hp.base = h0_d; hp.ld = 0; }
     else { hp.base = a.y + (size_t)tp * a.B * 2 * a.H + dir * a.H; hp.ld = 2 * a.H; }
 }
 
 // gates: g = sigmoid(h_prev @ W_hg + g_in[t]); u = g[:, :H], r = g[:, H:]; rh = r * h_prev
-__global__ __launch_bounds__(256) void enc_gates_kernel(EncFwd a, int n) {
-    const int dir = blockIdx.z, H = a.H, tile = blockIdx.x, b0 = blockIdx.y * 16;
+template <bool FAST>
+__global__ __launch_bounds__(256) void enc_gates_kernel(const float* xg, const float* mask, const float* Whh0, const float* Whh1, const float* Whg0, const float* Whg1, const float* h00, const float* h01, float* y, float* ysub, float* u, float* r, float* c, float* rh, int sub, int T, int B, int H, int n) {
+    // individual kernel arguments (not a by-value struct): the compiler then fetches all of them with one s_load burst in
+    // the entry block instead of one dependent scalar load per first use (5 serialized round trips = ~0.6 us per launch)
+    EncFwd a;
+    a.xg = xg; a.mask = mask; a.y = y; a.ysub = ysub; a.u = u; a.r = r; a.c = c; a.rh = rh; a.sub = sub; a.T = T; a.B = B; a.H = H;
+    const int dir = blockIdx.z;
+    const float* Whh_d = dir ? Whh1 : Whh0;
+    const float* Whg_d = dir ? Whg1 : Whg0;
+    const float* h0_d = dir ? h01 : h00;
+    const int tile = blockIdx.x, b0 = blockIdx.y * 16;
     int t; HPrev hp;
-    enc_step_geometry(a, n, dir, t, hp);
+    enc_step_geometry(a, h0_d, n, dir, t, hp);
     const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
     const bool ok = b < a.B && j < 2 * H;
     const size_t row = (size_t)t * a.B + b;
@@ -50,7 +59,7 @@ __global__ __launch_bounds__(256) void enc_gates_kernel(EncFwd a, int n) {
     const float gin = ok ? a.xg[row * 6 * H + dir * 3 * H + H + j] : 0.f;
     const float hpj = (ok && j >= H) ? hp.at(b, j - H) : 0.f;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm(acc0, acc1, row_src(hp.base + (size_t)b0 * hp.ld, hp.ld, a.B - b0, H), a.Whg_p[dir], H, tile);
+    rb_mm_impl<FAST>(acc0, acc1, row_src(hp.base + (size_t)b0 * hp.ld, hp.ld, a.B - b0, H), Whg_d, H, tile);
     const float v = rb_reduce(acc0, acc1);
     if (ok) {
         const float g = sigmoidf_(v + gin);
@@ -65,10 +74,19 @@ __global__ __launch_bounds__(256) void enc_gates_kernel(EncFwd a, int n) {
 }
 
 // candidate + state update + mask blend; writes y[t] (and the subsampled copy)
-__global__ __launch_bounds__(256) void enc_cand_kernel(EncFwd a, int n) {
-    const int dir = blockIdx.z, H = a.H, tile = blockIdx.x, b0 = blockIdx.y * 16;
+template <bool FAST>
+__global__ __launch_bounds__(256) void enc_cand_kernel(const float* xg, const float* mask, const float* Whh0, const float* Whh1, const float* Whg0, const float* Whg1, const float* h00, const float* h01, float* y, float* ysub, float* u, float* r, float* c, float* rh, int sub, int T, int B, int H, int n) {
+    // individual kernel arguments (not a by-value struct): the compiler then fetches all of them with one s_load burst in
+    // the entry block instead of one dependent scalar load per first use (5 serialized round trips = ~0.6 us per launch)
+    EncFwd a;
+    a.xg = xg; a.mask = mask; a.y = y; a.ysub = ysub; a.u = u; a.r = r; a.c = c; a.rh = rh; a.sub = sub; a.T = T; a.B = B; a.H = H;
+    const int dir = blockIdx.z;
+    const float* Whh_d = dir ? Whh1 : Whh0;
+    const float* Whg_d = dir ? Whg1 : Whg0;
+    const float* h0_d = dir ? h01 : h00;
+    const int tile = blockIdx.x, b0 = blockIdx.y * 16;
     int t; HPrev hp;
-    enc_step_geometry(a, n, dir, t, hp);
+    enc_step_geometry(a, h0_d, n, dir, t, hp);
     const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
     const bool ok = b < a.B && j < H;
     const size_t row = (size_t)t * a.B + b;
@@ -76,9 +94,9 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(EncFwd a, int n) {
     const float uu = ok ? a.u[row * 2 * H + dir * H + j] : 0.f;
     const float hprev = ok ? hp.at(b, j) : 0.f;
     const float m = (ok && a.mask) ? a.mask[row] : 1.f;
-    const float* rh = a.rh + ((size_t)t * a.B + b0) * 2 * H + dir * H;
+    const float* rh_t = a.rh + ((size_t)t * a.B + b0) * 2 * H + dir * H;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm(acc0, acc1, row_src(rh, 2 * H, a.B - b0, H), a.Whh_p[dir], H, tile);
+    rb_mm_impl<FAST>(acc0, acc1, row_src(rh_t, 2 * H, a.B - b0, H), Whh_d, H, tile);
     const float v = rb_reduce(acc0, acc1);
     if (ok) {
         const float cand = tanhf(v + xin);
@@ -93,16 +111,18 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(EncFwd a, int n) {
 // ---------------------------------------------------------------------------------------------
 // BPTT.  Per step (fwd direction walks t = T-1..0, bwd direction t = 0..T-1):
 //   dhn = m*dh; dc = dhn*u; du = dhn*(c-h_prev); dpre_c = dc*(1-c^2)
-//   drh = dpre_c @ Whh^T                                   (kernel A)
+//   drh = dpre_c @ Whh^T   and   vu = dpre_u @ Whg[:, :H]^T   (kernel A: two independent tile sets, both K = H)
 //   dr = drh*h_prev; dpre_u = du*u*(1-u); dpre_r = dr*r*(1-r)
-//   dh_prev = dhn*(1-u) + (1-m)*dh + drh*r + [dpre_u|dpre_r] @ Whg^T + dy[t_prev]   (kernel B)
+//   dh_prev = dhn*(1-u) + (1-m)*dh + drh*r + vu + dpre_r @ Whg[:, H:]^T + dy[t_prev]   (kernel B, K = H)
 //   dxg[t] = [dpre_c | dpre_u | dpre_r]
 // ---------------------------------------------------------------------------------------------
 struct EncBwd {
     EncBwd0 a;
     float* dh;       // (2,Bp,H) running dL/dh_t   (Bp = B rounded up to 16)
-    float* dhpart;   // (2,Bp,H)
+    float* dhpart;   // (2,Bp,H) elementwise part of dh_prev
+    float* vu;       // (2,Bp,H) dpre_u @ Whg_u^T (independent of drh, computed next to kernel A)
     int Bp;
+    long long rofs;  // offset of the reset block inside WhgT_p
 };
 
 __device__ __forceinline__ float enc_dy_at(const EncBwd0& a, int t, int b, int dir, int j) {
@@ -120,59 +140,85 @@ __global__ __launch_bounds__(256) void enc_bwd_init_kernel(EncBwd e) {
     e.dh[((size_t)dir * e.Bp + b) * a.H + j] = b < a.B ? enc_dy_at(a, t, b, dir, j) : 0.f;
 }
 
-__device__ __forceinline__ void enc_bwd_geometry(const EncBwd0& a, int n, int dir, int& t, int& tp, HPrev& hp) {
+__device__ __forceinline__ void enc_bwd_geometry(const EncBwd0& a, const float* h0_d, int n, int dir, int& t, int& tp, HPrev& hp) {
     t = dir == 0 ? a.T - 1 - n : n;
     tp = dir == 0 ? t - 1 : t + 1;
-    if (tp < 0 || tp >= a.T) { hp.base = a.h0[dir]; hp.ld = 0; }
+    if (tp < 0 || tp >= a.T) { hp.base = h0_d; hp.ld = 0; }
     else { hp.base = a.y + (size_t)tp * a.B * 2 * a.H + dir * a.H; hp.ld = 2 * a.H; }
 }
 
-struct DpcSrc {    // A operand of kernel A: dh * m * u * (1 - c^2), rows b0.. of step t
+struct DpcSrc {    // A operand of kernel A: dpre_c = dh*m*u*(1-c^2)  (hp == nullptr)  or  dpre_u = dh*m*(c-h_prev)*u*(1-u)
     const float* dh; const float* u; const float* c; const float* mask;   // dh rows ld=H; u,c rows ld=2H; mask[b]
-    int H, nrows; bool vec;
-    __device__ __forceinline__ float4 operator()(int i, int k) const {
+    const float* hp; long long hp_ld;                                     // h_prev rows (ld 2H, or 0 for the initial state)
+    int H, nrows; bool vec, fast;
+    template <bool FAST>
+    __device__ __forceinline__ float4 get(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i >= nrows || k >= H) return v;
+        if (FAST) i = min(i, nrows - 1);
+        else if (i >= nrows || k >= H) return v;
         const float m = mask ? mask[i] : 1.f;
         const float* pd = dh + (size_t)i * H + k;
         const float* pu = u + (size_t)i * 2 * H + k;
         const float* pc = c + (size_t)i * 2 * H + k;
-        if (vec) {
-            const float4 d4 = *(const float4*)pd, u4 = *(const float4*)pu, c4 = *(const float4*)pc;
-            v.x = d4.x * m * u4.x * (1.f - c4.x * c4.x);
-            v.y = d4.y * m * u4.y * (1.f - c4.y * c4.y);
-            v.z = d4.z * m * u4.z * (1.f - c4.z * c4.z);
-            v.w = d4.w * m * u4.w * (1.f - c4.w * c4.w);
+        const float4 d4 = FAST ? *(const float4*)pd : ld4g(pd, H - k, vec);
+        const float4 u4 = FAST ? *(const float4*)pu : ld4g(pu, H - k, vec);
+        const float4 c4 = FAST ? *(const float4*)pc : ld4g(pc, H - k, vec);
+        if (hp) {
+            const float* ph = hp + (size_t)i * hp_ld + k;
+            const float4 h4 = FAST ? *(const float4*)ph : ld4g(ph, H - k, vec);
+            v.x = d4.x * m * (c4.x - h4.x) * u4.x * (1.f - u4.x);
+            v.y = d4.y * m * (c4.y - h4.y) * u4.y * (1.f - u4.y);
+            v.z = d4.z * m * (c4.z - h4.z) * u4.z * (1.f - u4.z);
+            v.w = d4.w * m * (c4.w - h4.w) * u4.w * (1.f - u4.w);
             return v;
         }
-        v.x = pd[0] * m * pu[0] * (1.f - pc[0] * pc[0]);
-        if (k + 1 < H) v.y = pd[1] * m * pu[1] * (1.f - pc[1] * pc[1]);
-        if (k + 2 < H) v.z = pd[2] * m * pu[2] * (1.f - pc[2] * pc[2]);
-        if (k + 3 < H) v.w = pd[3] * m * pu[3] * (1.f - pc[3] * pc[3]);
+        v.x = d4.x * m * u4.x * (1.f - c4.x * c4.x);
+        v.y = d4.y * m * u4.y * (1.f - c4.y * c4.y);
+        v.z = d4.z * m * u4.z * (1.f - c4.z * c4.z);
+        v.w = d4.w * m * u4.w * (1.f - c4.w * c4.w);
         return v;
     }
 };
 
-__global__ __launch_bounds__(256) void enc_bwd_a_kernel(EncBwd e, int n) {
+template <bool FAST>
+__global__ __launch_bounds__(256) void enc_bwd_a_kernel(const float* mask, const float* y, const float* u, const float* r, const float* c, const float* WhhT0, const float* WhhT1, const float* WhgT0, const float* WhgT1, const float* h00, const float* h01, const float* dy, float* dxg, float* dh, float* dhpart, float* vu, long long rofs, int sub, int T, int B, int H, int Bp, int n) {
+    EncBwd e;                    // flat kernel arguments, see enc_gates_kernel
+    e.a.mask = mask; e.a.y = y; e.a.u = u; e.a.r = r; e.a.c = c; e.a.dy = dy; e.a.dxg = dxg; e.a.sub = sub; e.a.T = T; e.a.B = B; e.a.H = H;
+    e.dh = dh; e.dhpart = dhpart; e.vu = vu; e.Bp = Bp; e.rofs = rofs;
+    const int dir = blockIdx.z;
+    const float* WhhT_d = dir ? WhhT1 : WhhT0;
+    const float* WhgT_d = dir ? WhgT1 : WhgT0;
+    const float* h0_d = dir ? h01 : h00;
     const EncBwd0& a = e.a;
-    const int dir = blockIdx.z, H = a.H, tile = blockIdx.x, b0 = blockIdx.y * 16;
+    const int b0 = blockIdx.y * 16, nt = (H + 15) / 16;
+    const bool vu_path = (int)blockIdx.x >= nt;                    // second tile set: vu = dpre_u @ Whg_u^T
+    const int tile = vu_path ? blockIdx.x - nt : blockIdx.x;
     int t, tp; HPrev hp;
-    enc_bwd_geometry(a, n, dir, t, tp, hp);
-    const float* dh = e.dh + (size_t)dir * e.Bp * H;
+    enc_bwd_geometry(a, h0_d, n, dir, t, tp, hp);
+    const float* dh_d = e.dh + (size_t)dir * e.Bp * H;
     const size_t trow = (size_t)t * a.B;
     const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
     const bool ok = b < a.B && j < H;
+    DpcSrc src;
+    src.dh = dh_d + (size_t)b0 * H; src.u = a.u + (trow + b0) * 2 * H + dir * H; src.c = a.c + (trow + b0) * 2 * H + dir * H;
+    src.mask = a.mask ? a.mask + trow + b0 : nullptr; src.H = H; src.nrows = a.B - b0;
+    src.hp = nullptr; src.hp_ld = hp.ld;
+    src.vec = ((H & 3) == 0) && ((((size_t)src.dh | (size_t)src.u | (size_t)src.c | (size_t)hp.base) & 15) == 0);
+    src.fast = src.vec && src.nrows > 0 && rb_no_kpad(H);
+    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+    if (vu_path) {
+        src.hp = hp.base + (size_t)b0 * hp.ld;
+        rb_mm_impl<FAST>(acc0, acc1, src, WhgT_d, H, tile);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) e.vu[((size_t)dir * e.Bp + b) * H + j] = v;
+        return;
+    }
     const size_t o = (trow + b) * 2 * H + dir * H + j;
     const float m = (ok && a.mask) ? a.mask[trow + b] : 1.f;
     const float uu = ok ? a.u[o] : 0.f, rr = ok ? a.r[o] : 0.f, cc = ok ? a.c[o] : 0.f;
     const float hprev = ok ? hp.at(b, j) : 0.f;
-    const float dhv = ok ? dh[(size_t)b * H + j] : 0.f;
-    DpcSrc src;
-    src.dh = dh + (size_t)b0 * H; src.u = a.u + (trow + b0) * 2 * H + dir * H; src.c = a.c + (trow + b0) * 2 * H + dir * H;
-    src.mask = a.mask ? a.mask + trow + b0 : nullptr; src.H = H; src.nrows = a.B - b0;
-    src.vec = ((H & 3) == 0) && ((((size_t)src.dh | (size_t)src.u | (size_t)src.c) & 15) == 0);
-    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm(acc0, acc1, src, a.WhhT_p[dir], H, tile);
+    const float dhv = ok ? dh_d[(size_t)b * H + j] : 0.f;
+    rb_mm_impl<FAST>(acc0, acc1, src, WhhT_d, H, tile);
     const float drh = rb_reduce(acc0, acc1);
     if (ok) {
         const float dhn = m * dhv;
@@ -185,18 +231,26 @@ __global__ __launch_bounds__(256) void enc_bwd_a_kernel(EncBwd e, int n) {
     }
 }
 
-__global__ __launch_bounds__(256) void enc_bwd_b_kernel(EncBwd e, int n) {
+template <bool FAST>
+__global__ __launch_bounds__(256) void enc_bwd_b_kernel(const float* mask, const float* y, const float* u, const float* r, const float* c, const float* WhhT0, const float* WhhT1, const float* WhgT0, const float* WhgT1, const float* h00, const float* h01, const float* dy, float* dxg, float* dh, float* dhpart, float* vu, long long rofs, int sub, int T, int B, int H, int Bp, int n) {
+    EncBwd e;                    // flat kernel arguments, see enc_gates_kernel
+    e.a.mask = mask; e.a.y = y; e.a.u = u; e.a.r = r; e.a.c = c; e.a.dy = dy; e.a.dxg = dxg; e.a.sub = sub; e.a.T = T; e.a.B = B; e.a.H = H;
+    e.dh = dh; e.dhpart = dhpart; e.vu = vu; e.Bp = Bp; e.rofs = rofs;
+    const int dir = blockIdx.z;
+    const float* WhhT_d = dir ? WhhT1 : WhhT0;
+    const float* WhgT_d = dir ? WhgT1 : WhgT0;
+    const float* h0_d = dir ? h01 : h00;
     const EncBwd0& a = e.a;
-    const int dir = blockIdx.z, H = a.H, tile = blockIdx.x, b0 = blockIdx.y * 16;
+    const int tile = blockIdx.x, b0 = blockIdx.y * 16;
     int t, tp; HPrev hp;
-    enc_bwd_geometry(a, n, dir, t, tp, hp);
+    enc_bwd_geometry(a, h0_d, n, dir, t, tp, hp);
     const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
     const bool ok = b < a.B && j < H;
     const size_t o = ((size_t)dir * e.Bp + b) * H + j;
-    const float part = ok ? e.dhpart[o] + enc_dy_at(a, tp, b, dir, j) : 0.f;
-    const float* dg = a.dxg + ((size_t)t * a.B + b0) * 6 * H + dir * 3 * H + H;
+    const float part = ok ? e.dhpart[o] + e.vu[o] + enc_dy_at(a, tp, b, dir, j) : 0.f;
+    const float* dpr = a.dxg + ((size_t)t * a.B + b0) * 6 * H + dir * 3 * H + 2 * H;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm(acc0, acc1, row_src(dg, 6 * H, a.B - b0, 2 * H), a.WhgT_p[dir], 2 * H, tile);
+    rb_mm_impl<FAST>(acc0, acc1, row_src(dpr, 6 * H, a.B - b0, H), WhgT_d + e.rofs, H, tile);
     const float v = rb_reduce(acc0, acc1);
     if (ok) e.dh[o] = part + v;
 }
@@ -212,6 +266,9 @@ __global__ __launch_bounds__(256) void enc_bwd_h0_kernel(EncBwd e) {
     a.dh0[dir][j] = s;
 }
 
+int lvsr_bigru_fwd_persistent(hipStream_t s, const lvsr_bigru_fwd_args& a, int use_graph);
+int lvsr_bigru_bwd_persistent(hipStream_t s, const lvsr_bigru_bwd_args& a, int use_graph);
+
 extern "C" {
 
 int lvsr_bigru_fwd(void* stream, const lvsr_bigru_fwd_args* args, int use_graph) {
@@ -220,14 +277,22 @@ int lvsr_bigru_fwd(void* stream, const lvsr_bigru_fwd_args* args, int use_graph)
     const int T = a.T, B = a.B, H = a.H;
     LVSR_REQUIRE(T > 0 && B > 0 && H > 0 && a.sub >= 1, "lvsr_bigru_fwd: bad dims T=%d B=%d H=%d sub=%d", T, B, H, a.sub);
     LVSR_REQUIRE(a.sub == 1 || a.ysub != nullptr, "lvsr_bigru_fwd: subsample>1 needs ysub");
+    if (a.persistent) return lvsr_bigru_fwd_persistent((hipStream_t)stream, a, use_graph);
     if (a.sub == 1) a.ysub = nullptr;
     hipStream_t s = (hipStream_t)stream;
     const int rt = (B + 15) / 16;
     const int km = a.kernel_mask ? a.kernel_mask : 3;
+    // unguarded operand loads: no K padding in either contraction and 16-B aligned rows
+    const bool fast = (H % 64 == 0) && ((((size_t)a.y | (size_t)a.rh | (size_t)a.h0[0] | (size_t)a.h0[1]) & 15) == 0);
     auto enqueue = [&]() {
         for (int n = 0; n < T; ++n) {
-            if (km & 1) hipLaunchKernelGGL(enc_gates_kernel, dim3((2 * H + 15) / 16, rt, 2), dim3(256), 0, s, a, n);
-            if (km & 2) hipLaunchKernelGGL(enc_cand_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, a, n);
+            if (fast) {
+                if (km & 1) hipLaunchKernelGGL(enc_gates_kernel<true>, dim3((2 * H + 15) / 16, rt, 2), dim3(256), 0, s, a.xg, a.mask, a.Whh_p[0], a.Whh_p[1], a.Whg_p[0], a.Whg_p[1], a.h0[0], a.h0[1], a.y, a.ysub, a.u, a.r, a.c, a.rh, a.sub, a.T, a.B, a.H, n);
+                if (km & 2) hipLaunchKernelGGL(enc_cand_kernel<true>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, a.xg, a.mask, a.Whh_p[0], a.Whh_p[1], a.Whg_p[0], a.Whg_p[1], a.h0[0], a.h0[1], a.y, a.ysub, a.u, a.r, a.c, a.rh, a.sub, a.T, a.B, a.H, n);
+            } else {
+                if (km & 1) hipLaunchKernelGGL(enc_gates_kernel<false>, dim3((2 * H + 15) / 16, rt, 2), dim3(256), 0, s, a.xg, a.mask, a.Whh_p[0], a.Whh_p[1], a.Whg_p[0], a.Whg_p[1], a.h0[0], a.h0[1], a.y, a.ysub, a.u, a.r, a.c, a.rh, a.sub, a.T, a.B, a.H, n);
+                if (km & 2) hipLaunchKernelGGL(enc_cand_kernel<false>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, a.xg, a.mask, a.Whh_p[0], a.Whh_p[1], a.Whg_p[0], a.Whg_p[1], a.h0[0], a.h0[1], a.y, a.ysub, a.u, a.r, a.c, a.rh, a.sub, a.T, a.B, a.H, n);
+            }
         }
     };
     GraphKey key("bigru_fwd");
@@ -242,16 +307,24 @@ int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* args, int use_graph)
     e.a = *args;
     const int T = e.a.T, B = e.a.B, H = e.a.H;
     LVSR_REQUIRE(T > 0 && B > 0 && H > 0 && e.a.sub >= 1, "lvsr_bigru_bwd: bad dims");
+    if (e.a.persistent) return lvsr_bigru_bwd_persistent((hipStream_t)stream, e.a, use_graph);
     e.Bp = ((B + 15) / 16) * 16;
-    e.dh = e.a.dh_ws; e.dhpart = e.a.dh_ws + (size_t)2 * e.Bp * H;     // workspace: 4*Bp*H floats
+    e.dh = e.a.dh_ws; e.dhpart = e.a.dh_ws + (size_t)2 * e.Bp * H; e.vu = e.a.dh_ws + (size_t)4 * e.Bp * H;   // 6*Bp*H floats
+    e.rofs = (long long)((H + 15) / 16) * 16 * 4 * lvsr_pack_kw(H);       // = lvsr_pack_size(H, H)
     hipStream_t s = (hipStream_t)stream;
     const int rt = (B + 15) / 16;
     const int km = e.a.kernel_mask ? e.a.kernel_mask : 3;
+    const bool fast = (H % 64 == 0) && ((((size_t)e.a.u | (size_t)e.a.c | (size_t)e.a.dxg | (size_t)e.dh) & 15) == 0);
     auto enqueue = [&]() {
         hipLaunchKernelGGL(enc_bwd_init_kernel, dim3((e.Bp * H + 255) / 256, 1, 2), dim3(256), 0, s, e);
         for (int n = 0; n < T; ++n) {
-            if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e, n);
-            if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e, n);
+            if (fast) {
+                if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel<true>, dim3(2 * ((H + 15) / 16), rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+                if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel<true>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+            } else {
+                if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel<false>, dim3(2 * ((H + 15) / 16), rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+                if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel<false>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+            }
         }
         hipLaunchKernelGGL(enc_bwd_h0_kernel, dim3((H + 255) / 256, 1, 2), dim3(256), 0, s, e);
     };

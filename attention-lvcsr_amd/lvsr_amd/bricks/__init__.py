@@ -9,7 +9,8 @@ import torch
 
 
 class Encoder(object):
-    def __init__(self, dims, store, lib, workspace, use_graph=True):
+    def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=False):
+        self.use_persistent = bool(use_persistent) and not lib.is_emulator      # needs co-resident work-groups
         self.d = dims
         self.store = store
         self.lib = lib
@@ -35,14 +36,36 @@ class Encoder(object):
         ent = dict(version=self.store.version, Whh=[], Whg=[], WhhT=[], WhgT=[])
         for di, direction in enumerate(("forward", "backward")):
             n = self._names(i, direction)
-            for key, W, trans in (("Whh", p[n["Whh"]], False), ("Whg", p[n["Whg"]], False),
-                                  ("WhhT", p[n["Whh"]], True), ("WhgT", p[n["Whg"]], True)):
+            for key, W, trans in (("Whh", p[n["Whh"]], False), ("Whg", p[n["Whg"]], False), ("WhhT", p[n["Whh"]], True)):
                 K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
                 buf = ws.get("enc%d.%d.%s_p" % (i, di, key), (lib.pack_size(K, N),))
                 lib.pack_b(W, buf, trans=trans)
                 ent[key].append(buf)
+            # state_to_gates^T as two (K=H,N=H) blocks: update rows, then reset rows
+            sz = lib.pack_size(H, H)
+            buf = ws.get("enc%d.%d.WhgT_p" % (i, di), (2 * sz,))
+            Wg = p[n["Whg"]]
+            lib.pack_b(Wg[:, :H], buf[:sz], trans=True)
+            lib.pack_b(Wg[:, H:], buf[sz:], trans=True)
+            ent["WhgT"].append(buf)
         self._packs[i] = ent
         return ent
+
+    def _sync_ws(self, i, B, H):
+        """Scratch of the persistent cluster kernel (granule planes + abort word), or None when the layer runs as
+        per-step kernels (emulator, or a cluster that does not fit the chip)."""
+        if not self.use_persistent:
+            return None
+        nbytes = int(self.lib._lvsr_bigru_persist_ws_bytes(int(B), int(H)))
+        if nbytes <= 0:
+            return None
+        return self.ws.get("enc%d.sync" % i, ((nbytes + 3) // 4,), torch.int32)
+
+    def check_persistent(self):
+        """After a synchronisation point: raise if a persistent kernel gave up waiting for its cluster."""
+        for k, t in self.ws._bufs.items():
+            if k[0].startswith("enc") and k[0].endswith(".sync") and int(t[0]) != 0:
+                raise RuntimeError("persistent BiGRU kernel aborted (a work-group of the cluster was not scheduled)")
 
     def apply(self, input_, mask=None, save_for_backward=True):
         """input_ (T,B,F) fp32, mask (T,B) fp32 or None -> encoded (T',B,2H_last), encoded_mask (T',B)."""
@@ -64,15 +87,21 @@ class Encoder(object):
             rh = ws.get("enc%d.rh" % i, (T, B, 2 * H))
             x2, xg2 = x.view(T * B, I), xg.view(T * B, 6 * H)
             pk = self._packed(i)
+            sync = self._sync_ws(i, B, H)
             h0s = []
             for di, direction in enumerate(("forward", "backward")):
                 n = self._names(i, direction)
                 lib.sgemm(x2, p[n["Wi"]], xg2[:, di * 3 * H: di * 3 * H + H], bias=p[n["bi"]])
                 lib.sgemm(x2, p[n["Wg"]], xg2[:, di * 3 * H + H: di * 3 * H + 3 * H], bias=p[n["bg"]])
                 h0s.append(p[n["h0"]])
-            lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", y, self.use_graph, xg=xg, mask=m,
-                    Whh_p=[pk["Whh"][0], pk["Whh"][1]], Whg_p=[pk["Whg"][0], pk["Whg"][1]], h0=h0s, y=y,
-                    ysub=(ysub if s > 1 else None), u=u, r=r, c=c, rh=rh, sub=s, T=T, B=B, H=H)
+            if sync is not None:      # persistent cluster kernel: reads the plain weights and shards them into LDS itself
+                nf, nb = self._names(i, "forward"), self._names(i, "backward")
+                Whh, Whg = [p[nf["Whh"]], p[nb["Whh"]]], [p[nf["Whg"]], p[nb["Whg"]]]
+            else:
+                Whh, Whg = [pk["Whh"][0], pk["Whh"][1]], [pk["Whg"][0], pk["Whg"][1]]
+            lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", y, self.use_graph, xg=xg, mask=m, Whh_p=Whh, Whg_p=Whg, h0=h0s,
+                    y=y, ysub=(ysub if s > 1 else None), u=u, r=r, c=c, rh=rh, sub=s, T=T, B=B, H=H,
+                    persistent=int(sync is not None), sync_ws=sync)
             saved.append(dict(x=x, mask=m, T=T, y=y, u=u, r=r, c=c, rh=rh))
             x = ysub
             if m is not None and s > 1:
@@ -100,13 +129,18 @@ class Encoder(object):
             T = sv["T"]
             dxg = ws.get("enc%d.dxg" % i, (T, B, 6 * H))
             Bp = (B + 15) // 16 * 16
-            dh_ws = ws.get("enc%d.dh" % i, (4 * Bp * H,))
+            dh_ws = ws.get("enc%d.dh" % i, (6 * Bp * H,))
             pk = self._packed(i)
             nf, nb = self._names(i, "forward"), self._names(i, "backward")
+            sync = self._sync_ws(i, B, H)
+            if sync is not None:
+                WhhT, WhgT = [p[nf["Whh"]], p[nb["Whh"]]], [p[nf["Whg"]], p[nb["Whg"]]]
+            else:
+                WhhT, WhgT = [pk["WhhT"][0], pk["WhhT"][1]], [pk["WhgT"][0], pk["WhgT"][1]]
             lib.run("lvsr_bigru_bwd", "lvsr_bigru_bwd_args", dxg, self.use_graph, mask=sv["mask"], y=sv["y"],
-                    u=sv["u"], r=sv["r"], c=sv["c"], WhhT_p=[pk["WhhT"][0], pk["WhhT"][1]],
-                    WhgT_p=[pk["WhgT"][0], pk["WhgT"][1]], h0=[p[nf["h0"]], p[nb["h0"]]], dy=dy, dxg=dxg, dh_ws=dh_ws,
-                    dh0=[g[nf["h0"]], g[nb["h0"]]], sub=s, T=T, B=B, H=H)
+                    u=sv["u"], r=sv["r"], c=sv["c"], WhhT_p=WhhT, WhgT_p=WhgT, h0=[p[nf["h0"]], p[nb["h0"]]], dy=dy,
+                    dxg=dxg, dh_ws=dh_ws, dh0=[g[nf["h0"]], g[nb["h0"]]], sub=s, T=T, B=B, H=H,
+                    persistent=int(sync is not None), sync_ws=sync)
             x2 = sv["x"].view(T * B, I)
             dxg2 = dxg.view(T * B, 6 * H)
             y2 = sv["y"].view(T * B, 2 * H)

@@ -19,7 +19,8 @@ from .generator import SequenceGenerator
 
 
 class SpeechRecognizer(object):
-    def __init__(self, device="cuda:0", params=None, lib=None, use_graph=True, net_config=None, **net_kwargs):
+    def __init__(self, device="cuda:0", params=None, lib=None, use_graph=True, use_persistent=False, net_config=None,
+                 **net_kwargs):
         """`net_kwargs` = the reference's constructor keywords (recognizer.py:176-204), or pass an
         already-normalised `net_config` (lvsr_amd.spec).  `params` = dict name -> ndarray (Blocks names)."""
         from .. import native
@@ -36,7 +37,7 @@ class SpeechRecognizer(object):
         self.store = ParameterStore(cfg, self.device, params)
         self.ws = Workspace(self.device)
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
-        self.encoder = Encoder(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph)
+        self.encoder = Encoder(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph, use_persistent=use_persistent)
         self.generator = SequenceGenerator(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph)
         # hipGraph capture cannot run on the legacy null stream: the hot path owns a side stream
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None

@@ -60,24 +60,33 @@ typedef struct lvsr_bigru_fwd_args {
     float* u; float* r; float* c; float* rh;   /* (T,B,2H) saved gates / candidate / r*h_prev for BPTT */
     int sub, T, B, H;
     int kernel_mask;        /* 0 or 3: both step kernels; 1 / 2: only the gates / candidate kernel (timing probes) */
-    int pad0;
+    int persistent;         /* 1: one persistent launch for the whole time loop (needs sync_ws), 0: two kernels per step */
+    void* sync_ws;          /* lvsr_bigru_persist_ws_bytes(B,H) bytes of device scratch for the persistent mode */
 } lvsr_bigru_fwd_args;
 int lvsr_bigru_fwd(void* stream, const lvsr_bigru_fwd_args* a, int use_graph);
 
 typedef struct lvsr_bigru_bwd_args {
     const float* mask; const float* y; const float* u; const float* r; const float* c;
     const float* WhhT_p[2];  /* packed state_to_state^T (K=H,N=H) */
-    const float* WhgT_p[2];  /* packed state_to_gates^T (K=2H,N=H) */
+    const float* WhgT_p[2];  /* step kernels: packed [update rows | reset rows] of state_to_gates^T, each (K=H,N=H), reset block at
+                                offset lvsr_pack_size(H,H); persistent mode: the plain (H,2H) weight */
     const float* h0[2];
     const float* dy;         /* (ceil(T/sub),B,2H) gradient wrt the (subsampled) layer output */
     float* dxg;              /* (T,B,6H) out: gradient wrt xg */
-    float* dh_ws;            /* workspace 4*Bp*H floats, Bp = B rounded up to 16 */
+    float* dh_ws;            /* workspace 6*Bp*H floats, Bp = B rounded up to 16 */
     float* dh0[2];           /* (H) out: gradient wrt initial_state */
     int sub, T, B, H;
     int kernel_mask;         /* 0 or 3: both step kernels; 1 / 2: only kernel A / kernel B (timing probes) */
-    int pad0;
+    int persistent;          /* as in lvsr_bigru_fwd_args */
+    void* sync_ws;
 } lvsr_bigru_bwd_args;
 int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* a, int use_graph);
+/* Persistent mode: the layer's recurrent weights are sharded by hidden unit over a cluster of work-groups (one per CU,
+ * 16 units each) that keep their shard in LDS for the whole sequence and exchange h / r*h (forward) or dh / d(r*h)
+ * (backward) once per phase through 8-byte {epoch,value} granules.  Returns 0 when (B,H) cannot run persistently
+ * (cluster does not fit the chip): use the step kernels then.  After the stream has drained, the first int of sync_ws
+ * is non-zero if a work-group gave up waiting (results invalid). */
+long long lvsr_bigru_persist_ws_bytes(int B, int H);
 
 /* ---- attention decoder (teacher forced or one generation step) ------------------------------------
  * AttentionRecurrent.do_apply / take_glimpses / compute_states (libs/blocks/blocks/bricks/attention.py:

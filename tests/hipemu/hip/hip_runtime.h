@@ -211,6 +211,25 @@ inline int __shfl_down(int v, unsigned d, int width = 64) {
     return (int)hipemu::shfl_generic<long long, long long>(v, src);
 }
 
+// ---- agent-scope atomics / wave votes used by the persistent kernels (compile support only: the emulator runs
+// work-groups one after another, so kernels that wait for OTHER work-groups must not be launched on it) ----
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename T, typename V> inline void hipemu_atomic_store(T* p, V v) { *p = (T)v; }
+template <typename T> inline T hipemu_atomic_load(const T* p) { return *p; }
+#define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)
+#define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p)
+inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); }
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline int __all(int pred) {
+    int l = hipemu::lane_id();
+    int acc = 1;
+    for (int src = 0; src < hipemu::wave_size_here(); ++src) acc &= (hipemu::shfl_generic<long long, long long>(pred ? 1 : 0, src) != 0);
+    (void)l;
+    return acc;
+}
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+
 typedef float hipemu_f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_16x16x4_f32: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D: col=l&15, row=(l>>4)*4+reg;
 // result = k-ordered fmaf chain (cdna_hip_programming.md §3).

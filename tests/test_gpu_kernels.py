@@ -33,10 +33,11 @@ def _enc_cfg(Hs, sub, F=40):
                 attention_type="content", post_merge_dims=None, embed_outputs=True)
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("use_graph,persistent", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("Hs,sub,B,T,use_mask", [([3, 3], [1, 2], 3, 13, True), ([20], [3], 17, 7, True),
-                                                   ([64, 48], [2, 1], 16, 60, True), ([32], [1], 5, 40, False)])
-def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph):
+                                                   ([64, 48], [2, 1], 16, 60, True), ([32], [1], 5, 40, False),
+                                                   ([130], [1], 33, 21, True)])
+def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph, persistent):
     lib = native.get()
     cfg = _enc_cfg(Hs, sub)
     params = synthetic.make_params(cfg, seed=3)
@@ -49,7 +50,7 @@ def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph
     dy = torch.tensor(rng.normal(size=tuple(enc_ref.shape)), dtype=torch.float64)
     (enc_ref * dy).sum().backward()
     store = ParameterStore(cfg, gpu_device, params)
-    enc = Encoder(spec.Dims(cfg), store, lib, Workspace(gpu_device), use_graph=use_graph)
+    enc = Encoder(spec.Dims(cfg), store, lib, Workspace(gpu_device), use_graph=use_graph, use_persistent=persistent)
     side = torch.cuda.Stream(gpu_device)     # hipGraph capture needs a non-null stream
     xd, md, dyd = x.to(gpu_device), None if m is None else m.to(gpu_device), dy.float().to(gpu_device)
     torch.cuda.synchronize()
@@ -58,6 +59,7 @@ def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph
             out, out_mask = enc.apply(xd, md)
             enc.backward(dyd)
         torch.cuda.synchronize()
+        enc.check_persistent()
         assert_allclose(out.cpu().numpy(), enc_ref.detach().numpy(), rtol=1e-4, atol=1e-5)
         assert_allclose(out_mask.cpu().numpy(), mask_ref.numpy())
         for name, g in store.g.items():
@@ -68,6 +70,8 @@ def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph
             assert_allclose(g.cpu().numpy() / scale, ref / scale, atol=1e-4, rtol=0, err_msg=name)
     if use_graph:
         assert lib._lvsr_graph_count() > 0, "hipGraph capture did not engage"
+    if persistent:
+        assert any(k[0].endswith(".sync") for k in enc.ws._bufs), "persistent mode did not engage"
 
 
 # ---- whole recognizer on the GPU: cost matrix, alignments, all parameter gradients -------------------

@@ -17,8 +17,8 @@ for (Hs, sub, T, B, F) in [([256], [1], 800, 16, 512), ([512], [1], 800, 8, 1024
     x = torch.randn(T, B, F, device=dev)
     dy = torch.randn(T, B, 2 * Hs[-1], device=dev)
     stream = torch.cuda.Stream()
-    for use_graph in (False, True):
-        enc = Encoder(spec.Dims(cfg), store, lib, Workspace(dev), use_graph=use_graph)
+    for use_graph, persistent in ((True, False), (False, True), (True, True)):
+        enc = Encoder(spec.Dims(cfg), store, lib, Workspace(dev), use_graph=use_graph, use_persistent=persistent)
         with torch.cuda.stream(stream):
             for it in range(3):
                 t0 = time.time()
@@ -29,6 +29,6 @@ for (Hs, sub, T, B, F) in [([256], [1], 800, 16, 512), ([512], [1], 800, 8, 1024
                 enc.backward(dy)
                 e2.record()
                 torch.cuda.synchronize()
-                print("H=%d B=%d T=%d graph=%d it=%d fwd %.3f ms (%.2f us/step) bwd %.3f ms (%.2f us/step) host %.1f ms" % (
-                    Hs[0], B, T, use_graph, it, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T,
+                print("H=%d B=%d T=%d graph=%d persistent=%d it=%d fwd %.3f ms (%.2f us/step) bwd %.3f ms (%.2f us/step) host %.1f ms" % (
+                    Hs[0], B, T, use_graph, persistent, it, e0.elapsed_time(e1), e0.elapsed_time(e1) * 1e3 / T,
                     e1.elapsed_time(e2), e1.elapsed_time(e2) * 1e3 / T, (time.time() - t0) * 1e3), flush=True)
