@@ -102,8 +102,20 @@ __global__ __launch_bounds__(256) void attbwd_q_kernel(AttBwd g, int i) {
         float q = 0.f;
         if (t >= w.begin && t < w.end) {
             const float* ar = a.A + (size_t)t * a.A_ts + (size_t)b * a.A_bs;
-            for (int e = lane; e < E; e += 64) q += dwa[e] * ar[e];
-            q = wave_sum(q);
+            const bool vec = ((E & 3) == 0) && ((((size_t)ar | (size_t)dwa) & 15) == 0);
+            float q1 = 0.f;
+            int e = lane * 4;
+            for (; e + 256 < E; e += 512) {             // two independent 16-B loads per lane in flight
+                const float4 x0 = ld4g(ar + e, E - e, vec), y0 = ld4g(dwa + e, E - e, vec);
+                const float4 x1 = ld4g(ar + e + 256, E - e - 256, vec), y1 = ld4g(dwa + e + 256, E - e - 256, vec);
+                q += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
+                q1 += x1.x * y1.x + x1.y * y1.y + x1.z * y1.z + x1.w * y1.w;
+            }
+            for (; e < E; e += 256) {
+                const float4 x0 = ld4g(ar + e, E - e, vec), y0 = ld4g(dwa + e, E - e, vec);
+                q += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
+            }
+            q = wave_sum(q + q1);
             for (int k = 0; k < a.K; ++k) q += g.dalp[((size_t)b * a.K + k) * Tp + t];
         }
         if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
@@ -279,8 +291,18 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
     float* dcv = g.DCV + (((size_t)i * B + b) * K + k) * Tp;
     for (int t = threadIdx.x; t < Tp; t += 256) {
         float s = 0.f;
-        if (t >= w.begin && t < w.end)
-            for (int sl = 0; sl < nslice; ++sl) s += pp[(size_t)sl * K * Tp + t];
+        if (t >= w.begin && t < w.end) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int sl = 0;
+            for (; sl + 3 < nslice; sl += 4) {
+                s0 += pp[(size_t)sl * K * Tp + t];
+                s1 += pp[(size_t)(sl + 1) * K * Tp + t];
+                s2 += pp[(size_t)(sl + 2) * K * Tp + t];
+                s3 += pp[(size_t)(sl + 3) * K * Tp + t];
+            }
+            for (; sl < nslice; ++sl) s0 += pp[(size_t)sl * K * Tp + t];
+            s = (s0 + s1) + (s2 + s3);
+        }
         row[t] = s;
         dcv[t] = s;
     }
@@ -291,7 +313,16 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         float s = 0.f;
         if (t >= w.begin && t < w.end) {
             const int dlo = max(-a.c, w.begin - t), dhi = min(a.c, w.end - 1 - t);
-            for (int d = dlo; d <= dhi; ++d) s += fl[a.c + d] * row[t + d];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int d = dlo;
+            for (; d + 3 <= dhi; d += 4) {
+                s0 += fl[a.c + d] * row[t + d];
+                s1 += fl[a.c + d + 1] * row[t + d + 1];
+                s2 += fl[a.c + d + 2] * row[t + d + 2];
+                s3 += fl[a.c + d + 3] * row[t + d + 3];
+            }
+            for (; d <= dhi; ++d) s0 += fl[a.c + d] * row[t + d];
+            s = (s0 + s1) + (s2 + s3);
         }
         out[t] = s;
     }
@@ -305,6 +336,7 @@ __global__ __launch_bounds__(256) void attdec_filter_grad_kernel(AttDec a, const
     for (int i = 0; i < a.L; ++i) {
         const Win w = attdec_window(a, i);
         const int n = w.end - w.begin;
+#pragma unroll 4
         for (int x = threadIdx.x; x < a.B * n; x += 256) {
             const int b = x / n, t = w.begin + x % n, tp = t - d;
             if (tp >= w.begin && tp < w.end)

@@ -89,7 +89,17 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
         if (t >= w.begin && t < w.end) {
             // true convolution of the CUT alignment: out[t] = sum_d f[c+d] * al[t-d], t-d inside the window
             const int dlo = max(-a.c, t - (w.end - 1)), dhi = min(a.c, t - w.begin);
-            for (int d = dlo; d <= dhi; ++d) s += fl[a.c + d] * al[t - d];
+            // 4 independent accumulators: the loop is LDS-latency bound when every FMA waits for the previous one
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+            int d = dlo;
+            for (; d + 3 <= dhi; d += 4) {
+                s0 += fl[a.c + d] * al[t - d];
+                s1 += fl[a.c + d + 1] * al[t - d - 1];
+                s2 += fl[a.c + d + 2] * al[t - d - 2];
+                s3 += fl[a.c + d + 3] * al[t - d - 3];
+            }
+            for (; d <= dhi; ++d) s0 += fl[a.c + d] * al[t - d];
+            s = (s0 + s1) + (s2 + s3);
         }
         a.CV[(((size_t)i * B + b) * a.K + k) * Tp + t] = s;
     }
@@ -167,7 +177,16 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     for (int t = threadIdx.x; t < Tp; t += 256) {
         float e = 0.f;
         if (t >= w.begin && t < w.end) {
-            for (int sl = 0; sl < nslice; ++sl) e += ep[(size_t)sl * Tp + t];
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+            int sl = 0;
+            for (; sl + 3 < nslice; sl += 4) {          // independent loads in flight
+                e0 += ep[(size_t)sl * Tp + t];
+                e1 += ep[(size_t)(sl + 1) * Tp + t];
+                e2 += ep[(size_t)(sl + 2) * Tp + t];
+                e3 += ep[(size_t)(sl + 3) * Tp + t];
+            }
+            for (; sl < nslice; ++sl) e0 += ep[(size_t)sl * Tp + t];
+            e = (e0 + e1) + (e2 + e3);
             mx = fmaxf(mx, e);
         }
         en[t] = e;
@@ -199,10 +218,22 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     const bool vec = ((a.A_ts & 3) == 0) && ((a.A_bs & 3) == 0) && ((((size_t)a.A) & 15) == 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int nvalid = E - col;
-    for (int t = w.begin + tg; t < w.end; t += 8) {
-        const float4 v = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
-        const float p = al[t];
-        acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
+    {
+        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int t = w.begin + tg;
+        for (; t + 8 < w.end; t += 16) {               // two independent 16-B loads in flight per thread
+            const float4 v0 = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
+            const float4 v1 = ld4g(Ab + (size_t)(t + 8) * a.A_ts, nvalid, vec);
+            const float p0 = al[t], p1 = al[t + 8];
+            acc.x += p0 * v0.x; acc.y += p0 * v0.y; acc.z += p0 * v0.z; acc.w += p0 * v0.w;
+            acc2.x += p1 * v1.x; acc2.y += p1 * v1.y; acc2.z += p1 * v1.z; acc2.w += p1 * v1.w;
+        }
+        for (; t < w.end; t += 8) {
+            const float4 v = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
+            const float p = al[t];
+            acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
+        }
+        acc.x += acc2.x; acc.y += acc2.y; acc.z += acc2.z; acc.w += acc2.w;
     }
     part[tg][cg * 4 + 0] = acc.x; part[tg][cg * 4 + 1] = acc.y; part[tg][cg * 4 + 2] = acc.z; part[tg][cg * 4 + 3] = acc.w;
     __syncthreads();

@@ -119,8 +119,11 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const float* xg, const fl
 struct EncBwd {
     EncBwd0 a;
     float* dh;       // (2,Bp,H) running dL/dh_t   (Bp = B rounded up to 16)
-    float* dhpart;   // (2,Bp,H) elementwise part of dh_prev
+    float* dhpart;   // (2,Bp,H) elementwise part of dh_prev (+ drh*r)
     float* vu;       // (2,Bp,H) dpre_u @ Whg_u^T (independent of drh, computed next to kernel A)
+    float* dpc;      // (2,Bp,H) dpre_c of the CURRENT step, prepared by the previous step's kernel B (or the init kernel)
+    float* dpu;      // (2,Bp,H) dpre_u of the current step
+    float* base;     // (2,Bp,H) dhn*(1-u) + (1-m)*dh of the current step
     int Bp;
     long long rofs;  // offset of the reset block inside WhgT_p
 };
@@ -130,6 +133,28 @@ __device__ __forceinline__ float enc_dy_at(const EncBwd0& a, int t, int b, int d
     return a.dy[((size_t)(t / a.sub) * a.B + b) * 2 * a.H + dir * a.H + j];
 }
 
+// Everything of step t that depends on dh_t elementwise only: dpre_c, dpre_u (also the dxg outputs) and the elementwise
+// part of dh_{t-1}.  Called by the init kernel for the first step and by kernel B's epilogue for the following one, so that
+// kernel A's contraction operands are plain (B,H) rows.
+__device__ __forceinline__ void enc_bwd_prepare(const EncBwd& e, const float* h0_d, int dir, int t, int b, int j, float dhv) {
+    const EncBwd0& a = e.a;
+    const int H = a.H, tp = dir == 0 ? t - 1 : t + 1;
+    const size_t o = ((size_t)t * a.B + b) * 2 * H + dir * H + j;
+    const float uu = a.u[o], cc = a.c[o];
+    const float hprev = (tp < 0 || tp >= a.T) ? h0_d[j] : a.y[((size_t)tp * a.B + b) * 2 * H + dir * H + j];
+    const float m = a.mask ? a.mask[(size_t)t * a.B + b] : 1.f;
+    const float dhn = m * dhv;
+    const float dpc = dhn * uu * (1.f - cc * cc);
+    const float dpu = dhn * (cc - hprev) * uu * (1.f - uu);
+    const size_t q = ((size_t)dir * e.Bp + b) * H + j;
+    e.dpc[q] = dpc;
+    e.dpu[q] = dpu;
+    e.base[q] = dhn * (1.f - uu) + (1.f - m) * dhv;
+    float* dx = a.dxg + ((size_t)t * a.B + b) * 6 * H + dir * 3 * H;
+    dx[j] = dpc;
+    dx[H + j] = dpu;
+}
+
 __global__ __launch_bounds__(256) void enc_bwd_init_kernel(EncBwd e) {
     const EncBwd0& a = e.a;
     const int dir = blockIdx.z;
@@ -137,7 +162,14 @@ __global__ __launch_bounds__(256) void enc_bwd_init_kernel(EncBwd e) {
     if (idx >= e.Bp * a.H) return;
     const int b = idx / a.H, j = idx % a.H;
     const int t = dir == 0 ? a.T - 1 : 0;
-    e.dh[((size_t)dir * e.Bp + b) * a.H + j] = b < a.B ? enc_dy_at(a, t, b, dir, j) : 0.f;
+    const size_t q = ((size_t)dir * e.Bp + b) * a.H + j;
+    if (b < a.B) {
+        const float dhv = enc_dy_at(a, t, b, dir, j);
+        e.dh[q] = dhv;
+        enc_bwd_prepare(e, a.h0[dir], dir, t, b, j, dhv);
+    } else {
+        e.dh[q] = 0.f; e.dpc[q] = 0.f; e.dpu[q] = 0.f; e.base[q] = 0.f;
+    }
 }
 
 __device__ __forceinline__ void enc_bwd_geometry(const EncBwd0& a, const float* h0_d, int n, int dir, int& t, int& tp, HPrev& hp) {
@@ -147,95 +179,50 @@ __device__ __forceinline__ void enc_bwd_geometry(const EncBwd0& a, const float* 
     else { hp.base = a.y + (size_t)tp * a.B * 2 * a.H + dir * a.H; hp.ld = 2 * a.H; }
 }
 
-struct DpcSrc {    // A operand of kernel A: dpre_c = dh*m*u*(1-c^2)  (hp == nullptr)  or  dpre_u = dh*m*(c-h_prev)*u*(1-u)
-    const float* dh; const float* u; const float* c; const float* mask;   // dh rows ld=H; u,c rows ld=2H; mask[b]
-    const float* hp; long long hp_ld;                                     // h_prev rows (ld 2H, or 0 for the initial state)
-    int H, nrows; bool vec, fast;
-    template <bool FAST>
-    __device__ __forceinline__ float4 get(int i, int k) const {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (FAST) i = min(i, nrows - 1);
-        else if (i >= nrows || k >= H) return v;
-        const float m = mask ? mask[i] : 1.f;
-        const float* pd = dh + (size_t)i * H + k;
-        const float* pu = u + (size_t)i * 2 * H + k;
-        const float* pc = c + (size_t)i * 2 * H + k;
-        const float4 d4 = FAST ? *(const float4*)pd : ld4g(pd, H - k, vec);
-        const float4 u4 = FAST ? *(const float4*)pu : ld4g(pu, H - k, vec);
-        const float4 c4 = FAST ? *(const float4*)pc : ld4g(pc, H - k, vec);
-        if (hp) {
-            const float* ph = hp + (size_t)i * hp_ld + k;
-            const float4 h4 = FAST ? *(const float4*)ph : ld4g(ph, H - k, vec);
-            v.x = d4.x * m * (c4.x - h4.x) * u4.x * (1.f - u4.x);
-            v.y = d4.y * m * (c4.y - h4.y) * u4.y * (1.f - u4.y);
-            v.z = d4.z * m * (c4.z - h4.z) * u4.z * (1.f - u4.z);
-            v.w = d4.w * m * (c4.w - h4.w) * u4.w * (1.f - u4.w);
-            return v;
-        }
-        v.x = d4.x * m * u4.x * (1.f - c4.x * c4.x);
-        v.y = d4.y * m * u4.y * (1.f - c4.y * c4.y);
-        v.z = d4.z * m * u4.z * (1.f - c4.z * c4.z);
-        v.w = d4.w * m * u4.w * (1.f - c4.w * c4.w);
-        return v;
-    }
-};
-
+// kernel A: tiles [0,nt): drh = dpre_c @ Whh^T, dpre_r, dhpart;  tiles [nt,2nt): vu = dpre_u @ Whg[:, :H]^T
 template <bool FAST>
-__global__ __launch_bounds__(256) void enc_bwd_a_kernel(const float* mask, const float* y, const float* u, const float* r, const float* c, const float* WhhT0, const float* WhhT1, const float* WhgT0, const float* WhgT1, const float* h00, const float* h01, const float* dy, float* dxg, float* dh, float* dhpart, float* vu, long long rofs, int sub, int T, int B, int H, int Bp, int n) {
+__global__ __launch_bounds__(256) void enc_bwd_a_kernel(const float* mask, const float* y, const float* u, const float* r, const float* c, const float* WhhT0, const float* WhhT1, const float* WhgT0, const float* WhgT1, const float* h00, const float* h01, const float* dy, float* dxg, float* dh, float* dhpart, float* vu, float* dpc, float* dpu, float* base, long long rofs, int sub, int T, int B, int H, int Bp, int n) {
     EncBwd e;                    // flat kernel arguments, see enc_gates_kernel
     e.a.mask = mask; e.a.y = y; e.a.u = u; e.a.r = r; e.a.c = c; e.a.dy = dy; e.a.dxg = dxg; e.a.sub = sub; e.a.T = T; e.a.B = B; e.a.H = H;
-    e.dh = dh; e.dhpart = dhpart; e.vu = vu; e.Bp = Bp; e.rofs = rofs;
+    e.dh = dh; e.dhpart = dhpart; e.vu = vu; e.dpc = dpc; e.dpu = dpu; e.base = base; e.Bp = Bp; e.rofs = rofs;
     const int dir = blockIdx.z;
     const float* WhhT_d = dir ? WhhT1 : WhhT0;
     const float* WhgT_d = dir ? WhgT1 : WhgT0;
     const float* h0_d = dir ? h01 : h00;
     const EncBwd0& a = e.a;
     const int b0 = blockIdx.y * 16, nt = (H + 15) / 16;
-    const bool vu_path = (int)blockIdx.x >= nt;                    // second tile set: vu = dpre_u @ Whg_u^T
+    const bool vu_path = (int)blockIdx.x >= nt;
     const int tile = vu_path ? blockIdx.x - nt : blockIdx.x;
     int t, tp; HPrev hp;
     enc_bwd_geometry(a, h0_d, n, dir, t, tp, hp);
-    const float* dh_d = e.dh + (size_t)dir * e.Bp * H;
-    const size_t trow = (size_t)t * a.B;
     const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
     const bool ok = b < a.B && j < H;
-    DpcSrc src;
-    src.dh = dh_d + (size_t)b0 * H; src.u = a.u + (trow + b0) * 2 * H + dir * H; src.c = a.c + (trow + b0) * 2 * H + dir * H;
-    src.mask = a.mask ? a.mask + trow + b0 : nullptr; src.H = H; src.nrows = a.B - b0;
-    src.hp = nullptr; src.hp_ld = hp.ld;
-    src.vec = ((H & 3) == 0) && ((((size_t)src.dh | (size_t)src.u | (size_t)src.c | (size_t)hp.base) & 15) == 0);
-    src.fast = src.vec && src.nrows > 0 && rb_no_kpad(H);
+    const size_t q = ((size_t)dir * e.Bp + b) * H + j;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
     if (vu_path) {
-        src.hp = hp.base + (size_t)b0 * hp.ld;
-        rb_mm_impl<FAST>(acc0, acc1, src, WhgT_d, H, tile);
+        rb_mm_impl<FAST>(acc0, acc1, row_src(e.dpu + ((size_t)dir * e.Bp + b0) * H, H, a.B - b0, H), WhgT_d, H, tile);
         const float v = rb_reduce(acc0, acc1);
-        if (ok) e.vu[((size_t)dir * e.Bp + b) * H + j] = v;
+        if (ok) e.vu[q] = v;
         return;
     }
-    const size_t o = (trow + b) * 2 * H + dir * H + j;
-    const float m = (ok && a.mask) ? a.mask[trow + b] : 1.f;
-    const float uu = ok ? a.u[o] : 0.f, rr = ok ? a.r[o] : 0.f, cc = ok ? a.c[o] : 0.f;
+    const size_t o = ((size_t)t * a.B + b) * 2 * H + dir * H + j;
+    const float rr = ok ? a.r[o] : 0.f;
     const float hprev = ok ? hp.at(b, j) : 0.f;
-    const float dhv = ok ? dh_d[(size_t)b * H + j] : 0.f;
-    rb_mm_impl<FAST>(acc0, acc1, src, WhhT_d, H, tile);
+    const float bs = ok ? e.base[q] : 0.f;
+    rb_mm_impl<FAST>(acc0, acc1, row_src(e.dpc + ((size_t)dir * e.Bp + b0) * H, H, a.B - b0, H), WhhT_d, H, tile);
     const float drh = rb_reduce(acc0, acc1);
     if (ok) {
-        const float dhn = m * dhv;
-        const float dpc = dhn * uu * (1.f - cc * cc);
-        const float dpu = dhn * (cc - hprev) * uu * (1.f - uu);
-        const float dpr = drh * hprev * rr * (1.f - rr);
-        float* dx = a.dxg + (trow + b) * 6 * H + dir * 3 * H;
-        dx[j] = dpc; dx[H + j] = dpu; dx[2 * H + j] = dpr;
-        e.dhpart[((size_t)dir * e.Bp + b) * H + j] = dhn * (1.f - uu) + (1.f - m) * dhv + drh * rr;
+        a.dxg[((size_t)t * a.B + b) * 6 * H + dir * 3 * H + 2 * H + j] = drh * hprev * rr * (1.f - rr);
+        e.dhpart[q] = bs + drh * rr;
     }
 }
 
+// kernel B: dh_prev = dhpart + vu + dpre_r @ Whg[:, H:]^T + dy[t_prev]; then prepares the next step's elementwise terms
 template <bool FAST>
-__global__ __launch_bounds__(256) void enc_bwd_b_kernel(const float* mask, const float* y, const float* u, const float* r, const float* c, const float* WhhT0, const float* WhhT1, const float* WhgT0, const float* WhgT1, const float* h00, const float* h01, const float* dy, float* dxg, float* dh, float* dhpart, float* vu, long long rofs, int sub, int T, int B, int H, int Bp, int n) {
+__global__ __launch_bounds__(256) void enc_bwd_b_kernel(const float* mask, const float* y, const float* u, const float* r, const float* c, const float* WhhT0, const float* WhhT1, const float* WhgT0, const float* WhgT1, const float* h00, const float* h01, const float* dy, float* dxg, float* dh, float* dhpart, float* vu, float* dpc, float* dpu, float* base, long long rofs, int sub, int T, int B, int H, int Bp, int n) {
     EncBwd e;                    // flat kernel arguments, see enc_gates_kernel
     e.a.mask = mask; e.a.y = y; e.a.u = u; e.a.r = r; e.a.c = c; e.a.dy = dy; e.a.dxg = dxg; e.a.sub = sub; e.a.T = T; e.a.B = B; e.a.H = H;
-    e.dh = dh; e.dhpart = dhpart; e.vu = vu; e.Bp = Bp; e.rofs = rofs;
+    e.dh = dh; e.dhpart = dhpart; e.vu = vu; e.dpc = dpc; e.dpu = dpu; e.base = base; e.Bp = Bp; e.rofs = rofs;
     const int dir = blockIdx.z;
     const float* WhhT_d = dir ? WhhT1 : WhhT0;
     const float* WhgT_d = dir ? WhgT1 : WhgT0;
@@ -246,13 +233,17 @@ __global__ __launch_bounds__(256) void enc_bwd_b_kernel(const float* mask, const
     enc_bwd_geometry(a, h0_d, n, dir, t, tp, hp);
     const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
     const bool ok = b < a.B && j < H;
-    const size_t o = ((size_t)dir * e.Bp + b) * H + j;
-    const float part = ok ? e.dhpart[o] + e.vu[o] + enc_dy_at(a, tp, b, dir, j) : 0.f;
+    const size_t q = ((size_t)dir * e.Bp + b) * H + j;
+    const float part = ok ? e.dhpart[q] + e.vu[q] + enc_dy_at(a, tp, b, dir, j) : 0.f;
     const float* dpr = a.dxg + ((size_t)t * a.B + b0) * 6 * H + dir * 3 * H + 2 * H;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
     rb_mm_impl<FAST>(acc0, acc1, row_src(dpr, 6 * H, a.B - b0, H), WhgT_d + e.rofs, H, tile);
     const float v = rb_reduce(acc0, acc1);
-    if (ok) e.dh[o] = part + v;
+    if (ok) {
+        const float dhp = part + v;
+        e.dh[q] = dhp;
+        if (tp >= 0 && tp < a.T) enc_bwd_prepare(e, h0_d, dir, tp, b, j, dhp);
+    }
 }
 
 // d initial_state[dir][j] = sum_b dh[dir][b][j]
@@ -309,21 +300,25 @@ int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* args, int use_graph)
     LVSR_REQUIRE(T > 0 && B > 0 && H > 0 && e.a.sub >= 1, "lvsr_bigru_bwd: bad dims");
     if (e.a.persistent) return lvsr_bigru_bwd_persistent((hipStream_t)stream, e.a, use_graph);
     e.Bp = ((B + 15) / 16) * 16;
-    e.dh = e.a.dh_ws; e.dhpart = e.a.dh_ws + (size_t)2 * e.Bp * H; e.vu = e.a.dh_ws + (size_t)4 * e.Bp * H;   // 6*Bp*H floats
+    {
+        const size_t plane = (size_t)2 * e.Bp * H;                         // workspace: 12*Bp*H floats
+        e.dh = e.a.dh_ws; e.dhpart = e.dh + plane; e.vu = e.dh + 2 * plane; e.dpc = e.dh + 3 * plane; e.dpu = e.dh + 4 * plane;
+        e.base = e.dh + 5 * plane;
+    }
     e.rofs = (long long)((H + 15) / 16) * 16 * 4 * lvsr_pack_kw(H);       // = lvsr_pack_size(H, H)
     hipStream_t s = (hipStream_t)stream;
     const int rt = (B + 15) / 16;
     const int km = e.a.kernel_mask ? e.a.kernel_mask : 3;
-    const bool fast = (H % 64 == 0) && ((((size_t)e.a.u | (size_t)e.a.c | (size_t)e.a.dxg | (size_t)e.dh) & 15) == 0);
+    const bool fast = (H % 64 == 0) && ((((size_t)e.a.dxg | (size_t)e.dh) & 15) == 0);
     auto enqueue = [&]() {
         hipLaunchKernelGGL(enc_bwd_init_kernel, dim3((e.Bp * H + 255) / 256, 1, 2), dim3(256), 0, s, e);
         for (int n = 0; n < T; ++n) {
             if (fast) {
-                if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel<true>, dim3(2 * ((H + 15) / 16), rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
-                if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel<true>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+                if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel<true>, dim3(2 * ((H + 15) / 16), rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.dpc, e.dpu, e.base, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+                if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel<true>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.dpc, e.dpu, e.base, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
             } else {
-                if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel<false>, dim3(2 * ((H + 15) / 16), rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
-                if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel<false>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+                if (km & 1) hipLaunchKernelGGL(enc_bwd_a_kernel<false>, dim3(2 * ((H + 15) / 16), rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.dpc, e.dpu, e.base, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
+                if (km & 2) hipLaunchKernelGGL(enc_bwd_b_kernel<false>, dim3((H + 15) / 16, rt, 2), dim3(256), 0, s, e.a.mask, e.a.y, e.a.u, e.a.r, e.a.c, e.a.WhhT_p[0], e.a.WhhT_p[1], e.a.WhgT_p[0], e.a.WhgT_p[1], e.a.h0[0], e.a.h0[1], e.a.dy, e.a.dxg, e.dh, e.dhpart, e.vu, e.dpc, e.dpu, e.base, e.rofs, e.a.sub, e.a.T, e.a.B, e.a.H, e.Bp, n);
             }
         }
         hipLaunchKernelGGL(enc_bwd_h0_kernel, dim3((H + 255) / 256, 1, 2), dim3(256), 0, s, e);

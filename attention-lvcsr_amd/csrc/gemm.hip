@@ -110,6 +110,120 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
             }
 }
 
+// ---- 128x128x16 tile, v_mfma_f32_32x32x2_f32, register-prefetch double buffering ------------------------------------
+// Used when the output is at least one full tile: 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32 blocks (64 accumulator
+// registers).  Operands are staged k-major in LDS ([k][m], [k][n]) so each MFMA operand read is a conflict-free row of
+// 32 consecutive floats; the next k-tile is fetched from global memory into registers (float4 along the contiguous
+// dimension) while the current one is consumed.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define GM 128
+#define GN 128
+#define GK 16
+#define GLD (GM + 4)
+
+// one 128x16 (or 16x128) operand tile: 512 float4 units, 2 per thread.  CONTIG_K: element (x,k) at p[x*ld + k].
+template <bool CONTIG_K>
+__device__ __forceinline__ void gemm_tile_load(const float* __restrict__ p, int ld, int x0, int X, int k0, int kend, bool vec,
+                                               float4 (&r)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int u = threadIdx.x + h * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CONTIG_K) {
+            const int x = x0 + (u & 127), k = k0 + (u >> 7) * 4;
+            if (x < X && k < kend) v = ld4g(p + (size_t)x * ld + k, kend - k, vec);
+        } else {
+            const int k = k0 + (u >> 5), x = x0 + (u & 31) * 4;
+            if (k < kend && x < X) v = ld4g(p + (size_t)k * ld + x, X - x, vec);
+        }
+        r[h] = v;
+    }
+}
+template <bool CONTIG_K>
+__device__ __forceinline__ void gemm_tile_store(float (*S)[GLD], const float4 (&r)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int u = threadIdx.x + h * 256;
+        if (CONTIG_K) {
+            const int x = u & 127, k = (u >> 7) * 4;
+            S[k + 0][x] = r[h].x; S[k + 1][x] = r[h].y; S[k + 2][x] = r[h].z; S[k + 3][x] = r[h].w;
+        } else {
+            const int k = u >> 5, x = (u & 31) * 4;
+            *(float4*)&S[k][x] = r[h];
+        }
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const bool vecA = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[2], rb[2];
+    // A: not transposed -> (m,k) at A[m*lda+k] (contiguous k); transposed -> A[k*lda+m] (contiguous m)
+    gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
+    gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+    gemm_tile_store<!TA>(As[0], ra);
+    gemm_tile_store<TB>(Bs[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        const bool more = k0 + GK < kend;
+        if (more) {
+            gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
+            gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
+        }
+#pragma unroll
+        for (int ks = 0; ks < GK; ks += 2) {
+            const int kr = ks + (lane >> 5), li = lane & 31;
+            const float a0 = As[cur][kr][wm + li], a1 = As[cur][kr][wm + 32 + li];
+            const float b0 = Bs[cur][kr][wn + li], b1 = Bs[cur][kr][wn + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            gemm_tile_store<!TA>(As[cur ^ 1], ra);
+            gemm_tile_store<TB>(Bs[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn + j * 32 + (lane & 31);
+                if (m < g.M && n < g.N) {
+                    if (g.ksplit > 1) {
+                        g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                    } else {
+                        float v = g.alpha * acc[i][j][r];
+                        if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
+                        if (g.bias) v += g.bias[n];
+                        g.C[(size_t)m * g.ldc + n] = v;
+                    }
+                }
+            }
+}
+
 __global__ __launch_bounds__(256) void lvsr_sgemm_splitk_reduce(GemmArgs g) {
     const size_t total = (size_t)g.M * g.N;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
@@ -202,9 +316,12 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
     GemmArgs g;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB;
-    g.alpha = alpha; g.beta = beta; g.ksplit = 1; g.kchunk = ((K + BK - 1) / BK) * BK; g.part = nullptr;
-    if (g.kchunk == 0) g.kchunk = BK;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    g.alpha = alpha; g.beta = beta; g.ksplit = 1; g.kchunk = 0; g.part = nullptr;
+    const bool big = M >= 96 && N >= 96;                      // at least ~one 128x128 tile of real work
+    const int tm = big ? GM : BM, tn = big ? GN : BN, tk = big ? GK : BK;
+    const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+    g.kchunk = ((K + tk - 1) / tk) * tk;
+    if (g.kchunk == 0) g.kchunk = tk;
     // deterministic split-K when the output is too small to fill 256 CUs and K is long
     if (ws && tiles < 128 && K >= 1024) {
         int want = (512 + tiles - 1) / tiles;
@@ -214,18 +331,29 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
         while (want > 1 && need > ws_bytes) { --want; need = (long long)want * M * N * 4; }
         if (want > 1) {
             int chunk = (K + want - 1) / want;
-            chunk = ((chunk + BK - 1) / BK) * BK;
+            chunk = ((chunk + tk - 1) / tk) * tk;
             g.ksplit = (K + chunk - 1) / chunk;
             g.kchunk = chunk;
             g.part = ws;
         }
     }
-    dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, g.ksplit);
-    hipLaunchKernelGGL(lvsr_sgemm_kernel, grid, dim3(256), 0, (hipStream_t)stream, g);
+    dim3 grid((N + tn - 1) / tn, (M + tm - 1) / tm, g.ksplit);
+    hipStream_t st = (hipStream_t)stream;
+    if (!big) {
+        hipLaunchKernelGGL(lvsr_sgemm_kernel, grid, dim3(256), 0, st, g);
+    } else if (!transA && !transB) {
+        hipLaunchKernelGGL((lvsr_sgemm128_kernel<false, false>), grid, dim3(256), 0, st, g);
+    } else if (transA && !transB) {
+        hipLaunchKernelGGL((lvsr_sgemm128_kernel<true, false>), grid, dim3(256), 0, st, g);
+    } else if (!transA && transB) {
+        hipLaunchKernelGGL((lvsr_sgemm128_kernel<false, true>), grid, dim3(256), 0, st, g);
+    } else {
+        hipLaunchKernelGGL((lvsr_sgemm128_kernel<true, true>), grid, dim3(256), 0, st, g);
+    }
     if (g.ksplit > 1) {
         int nb = (int)(((size_t)M * N + 255) / 256);
         if (nb > 2048) nb = 2048;
-        hipLaunchKernelGGL(lvsr_sgemm_splitk_reduce, dim3(nb), dim3(256), 0, (hipStream_t)stream, g);
+        hipLaunchKernelGGL(lvsr_sgemm_splitk_reduce, dim3(nb), dim3(256), 0, st, g);
     }
     return lvsr_check_launch("lvsr_sgemm");
 }

@@ -129,7 +129,7 @@ class Encoder(object):
             T = sv["T"]
             dxg = ws.get("enc%d.dxg" % i, (T, B, 6 * H))
             Bp = (B + 15) // 16 * 16
-            dh_ws = ws.get("enc%d.dh" % i, (6 * Bp * H,))
+            dh_ws = ws.get("enc%d.dh" % i, (12 * Bp * H,))
             pk = self._packed(i)
             nf, nb = self._names(i, "forward"), self._names(i, "backward")
             sync = self._sync_ws(i, B, H)

@@ -45,7 +45,7 @@ def recurrent_kernel_probe(rec, dims, T, B):
     Bp = (B + 15) // 16 * 16
     bufs = dict(y=ws.get("enc0.y", (T, B, 2 * H)), u=ws.get("enc0.u", (T, B, 2 * H)), r=ws.get("enc0.r", (T, B, 2 * H)),
                 c=ws.get("enc0.c", (T, B, 2 * H)), dy=ws.get("probe.dy", (T, B, 2 * H)), dxg=ws.get("enc0.dxg", (T, B, 6 * H)),
-                dh_ws=ws.get("enc0.dh", (6 * Bp * H,)))
+                dh_ws=ws.get("enc0.dh", (12 * Bp * H,)))
     fields = dict(mask=None, WhhT_p=[pk["WhhT"][0], pk["WhhT"][1]], WhgT_p=[pk["WhgT"][0], pk["WhgT"][1]],
                   h0=[p[nf["h0"]], p[nb["h0"]]], dh0=[ws.get("probe.dh0a", (H,)), ws.get("probe.dh0b", (H,))],
                   sub=1, T=T, B=B, H=H, kernel_mask=2, **bufs)

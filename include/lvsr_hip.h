@@ -73,7 +73,7 @@ typedef struct lvsr_bigru_bwd_args {
     const float* h0[2];
     const float* dy;         /* (ceil(T/sub),B,2H) gradient wrt the (subsampled) layer output */
     float* dxg;              /* (T,B,6H) out: gradient wrt xg */
-    float* dh_ws;            /* workspace 6*Bp*H floats, Bp = B rounded up to 16 */
+    float* dh_ws;            /* workspace 12*Bp*H floats, Bp = B rounded up to 16 */
     float* dh0[2];           /* (H) out: gradient wrt initial_state */
     int sub, T, B, H;
     int kernel_mask;         /* 0 or 3: both step kernels; 1 / 2: only kernel A / kernel B (timing probes) */

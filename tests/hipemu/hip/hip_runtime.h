@@ -251,6 +251,26 @@ inline hipemu_f32x4 hipemu_mfma_f32_16x16x4f32(float a, float b, hipemu_f32x4 c,
     return d;
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 hipemu_mfma_f32_16x16x4f32
+typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x2_f32: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31], D: col=l&31, row=(reg&3)+8*(reg>>2)+4*(l>>5)
+inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 c, int, int, int) {
+    hipemu::State& s = hipemu::st();
+    int base = hipemu::wave_id() * 64;
+    int l = hipemu::lane_id();
+    s.xa[s.cur] = a; s.xb[s.cur] = b;
+    hipemu::wave_barrier();
+    hipemu_f32x16 d = c;
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) acc = std::fmaf(s.xa[base + row + 32 * k], s.xb[base + col + 32 * k], acc);
+        d[r] = acc;
+    }
+    hipemu::wave_barrier();
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

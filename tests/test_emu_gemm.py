@@ -8,7 +8,7 @@ from emu import emu_lib
 
 
 @pytest.mark.parametrize("transA,transB", [(False, False), (True, False), (False, True), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (65, 130, 33)])
+@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (65, 130, 33), (130, 141, 37), (96, 128, 16)])
 def test_sgemm_layouts(transA, transB, M, N, K):
     lib = emu_lib()
     rng = numpy.random.RandomState(0)
@@ -31,6 +31,19 @@ def test_sgemm_strided_and_splitk():
     Bm = torch.tensor(rng.normal(size=(K, 40)), dtype=torch.float32)[:, 3:3 + N]
     C = torch.zeros(M, 64)[:, :N]
     ws = torch.empty(8 * M * N)
+    lib.sgemm(A, Bm, C, transA=True, ws=ws)
+    assert_allclose(C.numpy(), (A.double().T @ Bm.double()).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_sgemm128_strided_and_splitk():
+    lib = emu_lib()
+    rng = numpy.random.RandomState(2)
+    M, N, K = 100, 132, 1060
+    big = torch.tensor(rng.normal(size=(K, 120)), dtype=torch.float32)
+    A = big[:, 8:8 + M]            # (K, M) view, row stride 120 -> transA, 16-B aligned base
+    Bm = torch.tensor(rng.normal(size=(K, 140)), dtype=torch.float32)[:, 3:3 + N]      # unaligned base -> scalar path
+    C = torch.zeros(M, 200)[:, :N]
+    ws = torch.empty(6 * M * N)
     lib.sgemm(A, Bm, C, transA=True, ws=ws)
     assert_allclose(C.numpy(), (A.double().T @ Bm.double()).numpy(), rtol=1e-4, atol=1e-4)
 

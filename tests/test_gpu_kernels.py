@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("transA,transB", [(False, False), (True, False), (False, True), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (257, 130, 1033), (512, 768, 2048)])
+@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (257, 130, 1033), (512, 768, 2048), (12800, 768, 512), (768, 512, 12800)])
 def test_sgemm(gpu_device, transA, transB, M, N, K):
     lib = native.get()
     rng = numpy.random.RandomState(0)

@@ -22,7 +22,7 @@ p = store.p
 nf, nb = enc._names(0, "forward"), enc._names(0, "backward")
 z = lambda *s: torch.randn(*s, device=dev) * 0.1
 bufs = dict(xg=z(T, B, 6 * H), y=z(T, B, 2 * H), u=torch.rand(T, B, 2 * H, device=dev), r=torch.rand(T, B, 2 * H, device=dev),
-            c=z(T, B, 2 * H), rh=z(T, B, 2 * H), dy=z(T, B, 2 * H), dxg=z(T, B, 6 * H), dh_ws=z(6 * 16 * H))
+            c=z(T, B, 2 * H), rh=z(T, B, 2 * H), dy=z(T, B, 2 * H), dxg=z(T, B, 6 * H), dh_ws=z(12 * 16 * H))
 stream = torch.cuda.Stream()
 def timeit(fn):
     ts = []
