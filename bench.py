@@ -35,8 +35,10 @@ TRAIN_CONF = dict(gradient_threshold=100.0, rules=("momentum", "adadelta"), scal
 
 
 def recurrent_kernel_probe(rec, dims, T, B):
-    """Average launch duration of the dominant kernel (enc_bwd_b_kernel: dh_prev = [dpu|dpr] @ Whg^T, layer 0 shapes)
-    measured with HIP events on the recognizer's own stream over T back-to-back launches (kernel_mask = 2)."""
+    """Average launch duration of the dominant kernel (enc_bwd_b_kernel: dh_prev = ... + dpre_r @ Whg[:, H:]^T, both
+    directions of one layer per launch) measured with HIP events on the recognizer's own stream over T back-to-back
+    graph-replayed launches (kernel_mask = 2; the figure therefore includes the dependent-launch boundary, which IS the
+    cost of this latency-bound kernel)."""
     lib, ws, enc = rec.lib, rec.ws, rec.encoder
     H = dims.Hs[0]
     pk = enc._packed(0)
@@ -59,7 +61,7 @@ def recurrent_kernel_probe(rec, dims, T, B):
             e1.synchronize()
             times.append(e0.elapsed_time(e1) * 1e-3 / T)
     avg = sorted(times[1:])[len(times[1:]) // 2]
-    flops = 2.0 * B * (2 * H) * H * 2            # both directions in one launch
+    flops = 2.0 * B * H * H * 2                  # (B,H) x (H,H) per direction, both directions in one launch
     return avg, flops
 
 
@@ -155,8 +157,11 @@ def main():
         train_flop_per_frame = {"wsj_base": 22.730e6, "wsj_deep": 143.43e6, "timit_tiny": 1.382e6}[args.workload]
         avg_launch, flops = recurrent_kernel_probe(rec, dims, T, B)
         peak = 157.3                                                   # TFLOP/s fp32 MFMA (MI355X_MICROARCH.md)
+        # HBM-side bytes per launch of this kernel from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB, uncorrected;
+        # profiles/r01_pmc_small_eager_step.md, H=256 B=16): 599 + 189 KiB vs 0.56 MB algorithmic (weights 512 KiB + rows)
+        traffic = (599.0 + 189.1) * 1024 if (dims.Hs[0] == 256 and B == 16) else None
         roof = dict(bound="mfma", kernel="enc_bwd_b_kernel", achieved=flops / avg_launch / 1e12, peak=peak, unit="TFLOP/s",
-                    frac=flops / avg_launch / 1e12 / peak, traffic=None, launch_us=avg_launch * 1e6, flops_per_launch=flops,
+                    frac=flops / avg_launch / 1e12 / peak, traffic=traffic, launch_us=avg_launch * 1e6, flops_per_launch=flops,
                     whole_step_tflops=value / world * train_flop_per_frame / 1e12,
                     whole_step_frac=value / world * train_flop_per_frame / 1e12 / peak)
         out = dict(metric="encoder+attention+decoder training frames/sec (whole node)", value=value, unit="frames/s",

@@ -14,6 +14,7 @@ busy = sum(e - s for _, s, e in step)
 print("last step: %d kernels, wall %.2f ms, sum of kernel durations %.2f ms" % (len(step), span / 1e6, busy / 1e6))
 groups = collections.OrderedDict()
 def grp(n):
+    n = n[5:] if n.startswith("void ") else n
     for k in ("enc_gates", "enc_cand", "enc_bwd_a", "enc_bwd_b", "lvsr_sgemm", "lvsr_colsum", "attdec", "attbwd", "opt_", "lvsr_pack"):
         if n.startswith(k):
             return k
