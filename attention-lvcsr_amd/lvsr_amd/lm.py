@@ -143,6 +143,19 @@ class FSTLanguageModel(object):
         self.norm = (bool(normalize_am_weights), bool(normalize_lm_weights), bool(normalize_tot_weights))
         self.out_dim = len(self.remap_table)
         self.device_add = None
+        # The walk is a pure function of the state set and of the weights RELATIVE to their minimum (costs are differences
+        # of log-sums, so a common offset cancels; transitions carry the offset through).  Hypotheses of a beam share LM
+        # states all the time, so memoising on that key removes almost all of the Python dict walking.
+        self._cost_cache = {}
+        self._trans_cache = {}
+
+    @staticmethod
+    def _key(sd):
+        if not sd:
+            return (), 0.0
+        items = sorted(sd.items())
+        base = min(w for _, w in items)
+        return tuple((s, round(w - base, 10)) for s, w in items), base
 
     # FSTCostsOp.perform, lvsr/ops.py:206-225
     def costs(self, states, weights):
@@ -150,13 +163,17 @@ class FSTLanguageModel(object):
         for st, wt in zip(states, weights):
             sd = dict(zip(st.tolist(), wt.tolist()))
             sd.pop(NOT_STATE, None)
-            c = numpy.ones(self.out_dim, dtype=numpy.float32) * self.no_transition_cost
-            if sd:
-                total = self.fst.combine_weights(*sd.values())
-                for nn_ch, fst_ch in self.remap_table.items():
-                    nxt = self.fst.expand(self.fst.transition(sd, fst_ch))
-                    if nxt:
-                        c[nn_ch] = self.fst.combine_weights(*nxt.values()) - total
+            key, _ = self._key(sd)
+            c = self._cost_cache.get(key)
+            if c is None:
+                c = numpy.ones(self.out_dim, dtype=numpy.float32) * self.no_transition_cost
+                if sd:
+                    total = self.fst.combine_weights(*sd.values())
+                    for nn_ch, fst_ch in self.remap_table.items():
+                        nxt = self.fst.expand(self.fst.transition(sd, fst_ch))
+                        if nxt:
+                            c[nn_ch] = self.fst.combine_weights(*nxt.values()) - total
+                self._cost_cache[key] = c
             out.append(c)
         return numpy.array(out, dtype=numpy.float32).reshape(len(states), self.out_dim)
 
@@ -173,9 +190,16 @@ class FSTLanguageModel(object):
         for st, wt, ch in zip(lm_states["states"], lm_states["weights"], outputs):
             sd = dict(zip(st.tolist(), wt.tolist()))
             sd.pop(NOT_STATE, None)
-            nxt = self.fst.expand(self.fst.transition(sd, self.remap_table[int(ch)]))
-            ns.append(_pad(nxt.keys(), NOT_STATE))
-            nw.append(_pad(nxt.values(), 0))
+            key, base = self._key(sd)
+            ck = (key, int(ch))
+            hit = self._trans_cache.get(ck)
+            if hit is None:
+                rel = {s_: w_ - base for s_, w_ in sd.items()}
+                nxt = self.fst.expand(self.fst.transition(rel, self.remap_table[int(ch)]))
+                hit = (list(nxt.keys()), list(nxt.values()))
+                self._trans_cache[ck] = hit
+            ns.append(_pad(hit[0], NOT_STATE))
+            nw.append(_pad([w_ + base for w_ in hit[1]], 0))
         states = numpy.array(ns, dtype=numpy.int64).reshape(len(outputs), MAX_STATES)
         weights = numpy.array(nw, dtype=numpy.float64).reshape(len(outputs), MAX_STATES)
         return dict(states=states, weights=weights, add=self.costs(states, weights))

@@ -1,0 +1,95 @@
+"""Size-independent properties at BASELINE.json's full WSJ-base size on the MI355X (the oracle is too slow there):
+batch independence of utterances, hipGraph == eager, persistent == step kernels, shard gradients add up (the
+data-parallel invariant), cost at near-zero weights = N_labels * ln V."""
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from lvsr_amd import spec, synthetic
+from lvsr_amd.bricks.recognizer import SpeechRecognizer
+
+pytestmark = pytest.mark.gpu
+
+B, T, L = 16, 800, 100
+
+
+@pytest.fixture(scope="module")
+def setup(gpu_device):
+    cfg = spec.wsj_base()
+    params = synthetic.make_params(cfg, seed=10)
+    batch = synthetic.make_batch(cfg, B, T, L, seed=77, ragged=True)
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    cm = rec.cost_and_gradients(batch)
+    torch.cuda.synchronize()
+    return dict(cfg=cfg, params=params, batch=batch, rec=rec, cm=cm.cpu().numpy().copy(),
+                w=rec.generator.last["weights"].cpu().numpy().copy(), grads=rec.store.get_grads())
+
+
+def test_utterances_are_independent_at_full_size(gpu_device, setup):
+    """Every utterance decoded alone (B=1, its own lengths) gives the same costs / alignments as inside the ragged batch."""
+    s = setup
+    solo = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"])
+    for b in (0, 5, 15):
+        one = {k: numpy.ascontiguousarray(v[:, b:b + 1]) for k, v in s["batch"].items()}
+        cm = solo.cost(recordings=one["recordings"], inputs_mask=one["recordings_mask"], labels=one["labels"],
+                       labels_mask=one["labels_mask"], save_for_backward=False).cpu().numpy()
+        assert_allclose(cm[:, 0], s["cm"][:, b], rtol=2e-5, atol=2e-5)
+        w = solo.generator.last["weights"].cpu().numpy()[:, 0]
+        assert (w.argmax(axis=1) == s["w"][:, b].argmax(axis=1)).all()
+
+
+def test_graph_replay_equals_eager_bitwise(gpu_device, setup):
+    s = setup
+    eager = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_graph=False)
+    cm = eager.cost_and_gradients(s["batch"]).cpu().numpy()
+    assert (cm == s["cm"]).all()
+    g = eager.store.get_grads()
+    for k in g:
+        assert (g[k] == s["grads"][k]).all(), k
+    again = s["rec"].cost_and_gradients(s["batch"]).cpu().numpy()          # replay of the cached graphs: deterministic
+    assert (again == s["cm"]).all()
+
+
+def test_persistent_cluster_kernels_agree_with_step_kernels(gpu_device, setup):
+    s = setup
+    per = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_persistent=True)
+    cm = per.cost_and_gradients(s["batch"]).cpu().numpy()
+    torch.cuda.synchronize()
+    per.encoder.check_persistent()
+    assert abs(cm.sum() - s["cm"].sum()) / abs(s["cm"].sum()) < 1e-5
+    assert_allclose(cm, s["cm"], rtol=1e-3, atol=1e-3)
+    g = per.store.get_grads()
+    for k in g:
+        scale = max(1e-3, numpy.abs(s["grads"][k]).max())
+        assert numpy.abs(g[k] - s["grads"][k]).max() / scale < 2e-3, k
+
+
+def test_shard_gradients_add_up_to_the_batch_gradient(gpu_device, setup):
+    """The data-parallel invariant behind the single all-reduce: grad(sum over all utterances) = sum over shards r::N."""
+    s = setup
+    rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"])
+    total, cost = None, 0.0
+    for r in range(4):
+        shard = synthetic.shard_batch(s["batch"], r, 4)
+        cost += float(rec.cost_and_gradients(shard).sum())
+        g = rec.store.grad.clone()
+        total = g if total is None else total + g
+    assert abs(cost - s["cm"].sum()) / abs(s["cm"].sum()) < 1e-5
+    ref = setup["rec"].store.grad
+    setup["rec"].cost_and_gradients(s["batch"])
+    torch.cuda.synchronize()
+    denom = float(ref.abs().max())
+    assert float((total - ref).abs().max()) / denom < 1e-4
+
+
+def test_cost_at_near_zero_weights_is_n_labels_ln_v(gpu_device):
+    """Free sanity check the survey recorded for the reference (5594.415 = 1600*ln 33 at near-zero init)."""
+    cfg = spec.wsj_base()
+    params = synthetic.make_params(cfg, seed=1, scale=1e-4)
+    params = {k: (v if not k.endswith(".b") and not k.endswith("initial_state") else numpy.zeros_like(v)) for k, v in params.items()}
+    batch = synthetic.make_batch(cfg, B, T, L, seed=1234)
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    cm = rec.cost(recordings=batch["recordings"], inputs_mask=batch["recordings_mask"], labels=batch["labels"],
+                  labels_mask=batch["labels_mask"], save_for_backward=False)
+    assert abs(float(cm.sum()) - B * L * numpy.log(33.0)) / (B * L * numpy.log(33.0)) < 1e-4
