@@ -1,0 +1,52 @@
+"""Decode driver: what `lvsr.main.search` reports per utterance (lvsr/main.py:705-864) — beam search, negative
+log-likelihood of the ground truth and of the best hypothesis through `analyze`, character/word error counts — around
+`SpeechRecognizer.beam_search`.  Dataset access is the caller's business: utterances come in as
+(recordings (T,F) ndarray, groundtruth label list) pairs."""
+import numpy
+
+from .error_rate import edit_distance, weights_std, monotonicity_penalty
+from .search import CandidateNotFoundError
+
+
+def search(recognizer, utterances, beam_size=10, char_discount=0.0, round_to_inf=1e9, stop_on="patience", to_words=None,
+           report=None):
+    """-> dict(per_utterance=[...], cer=, wer=, nll_groundtruth=, nll_recognized=).  `to_words(labels) -> list[str]` turns a
+    label sequence into words for WER (the reference decodes characters with its character map, lvsr/main.py:788-800)."""
+    recognizer.init_beam_search(beam_size)
+    rows, tot_err, tot_len, tot_werr, tot_wlen = [], 0, 0, 0, 0
+    for number, (recordings, groundtruth) in enumerate(utterances):
+        groundtruth = [int(t) for t in groundtruth]
+        inputs = {"recordings": recordings}
+        row = dict(number=number, groundtruth=groundtruth)
+        try:
+            outputs, search_costs = recognizer.beam_search(inputs, char_discount=char_discount, round_to_inf=round_to_inf,
+                                                           stop_on=stop_on)
+            recognized = outputs[0]
+            row.update(recognized=recognized, search_cost=search_costs[0])
+        except CandidateNotFoundError:                                       # lvsr/main.py:808-813
+            recognized = []
+            row.update(recognized=[], search_cost=float("nan"), error="CandidateNotFoundError")
+        gt_cost, gt_weights, _ = recognizer.analyze(inputs, numpy.asarray(groundtruth))
+        row.update(groundtruth_cost=float(gt_cost.sum()),
+                   weights_std=float(weights_std(gt_weights[:, None, :])),
+                   monotonicity_penalty=float(monotonicity_penalty(gt_weights[:, None, :])))
+        if recognized:
+            rec_cost, _, _ = recognizer.analyze(inputs, numpy.asarray(groundtruth), numpy.asarray(recognized))
+            row["recognized_cost"] = float(rec_cost.sum())
+        err = int(edit_distance(groundtruth, recognized))
+        row.update(char_errors=err, cer=err / float(len(groundtruth)))
+        tot_err += err
+        tot_len += len(groundtruth)
+        if to_words is not None:
+            gw, rw = to_words(groundtruth), to_words(recognized)
+            werr = int(edit_distance(gw, rw))
+            row.update(word_errors=werr, wer=werr / float(max(1, len(gw))))
+            tot_werr += werr
+            tot_wlen += len(gw)
+        rows.append(row)
+        if report is not None:
+            report(row)
+    out = dict(per_utterance=rows, cer=tot_err / float(max(1, tot_len)))
+    if to_words is not None:
+        out["wer"] = tot_werr / float(max(1, tot_wlen))
+    return out
