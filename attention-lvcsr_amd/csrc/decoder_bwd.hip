@@ -328,23 +328,39 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
     }
 }
 
-// gradient wrt conv1d.filters: df[k][j] = sum_{i,b,t in win_i} dcv_i[b,k,t] * alpha_i[b, t-(j-c)]  (alpha index in win_i)
-__global__ __launch_bounds__(256) void attdec_filter_grad_kernel(AttDec a, const float* DCV, float* df) {
-    __shared__ float red[4];
-    const int j = blockIdx.x, k = blockIdx.y, FW = 2 * a.c + 1, d = j - a.c;
-    float s = 0.f;
-    for (int i = 0; i < a.L; ++i) {
-        const Win w = attdec_window(a, i);
-        const int n = w.end - w.begin;
-#pragma unroll 4
-        for (int x = threadIdx.x; x < a.B * n; x += 256) {
-            const int b = x / n, t = w.begin + x % n, tp = t - d;
-            if (tp >= w.begin && tp < w.end)
-                s += DCV[(((size_t)i * a.B + b) * a.K + k) * a.Tp + t] * a.W[((size_t)i * a.B + b) * a.Tp + tp];
-        }
+// gradient wrt conv1d.filters: df[k][j] = sum_{i,b,t in win_i} dcv_i[b,k,t] * alpha_i[b, t-(j-c)]  (alpha index in win_i).
+// Block (chunk of R rows (i,b), filter k): the R rows of dcv and alpha are staged in LDS once, thread j owns lag j and
+// walks them; per-chunk partials are folded by lvsr_colsum in a fixed order.
+#define FG_LDS 8192
+__global__ __launch_bounds__(256) void attdec_filter_grad_kernel(AttDec a, const float* DCV, float* part, int R) {
+    __shared__ float X[FG_LDS];
+    __shared__ float Wr[FG_LDS];
+    __shared__ int wb[16], we[16];
+    const int chunk = blockIdx.x, k = blockIdx.y, FW = 2 * a.c + 1, Tp = a.Tp, nrow = a.L * a.B;
+    const int r0 = chunk * R, nr = min(R, nrow - r0);
+    if (threadIdx.x < nr) {
+        const Win w = attdec_window(a, (r0 + threadIdx.x) / a.B);
+        wb[threadIdx.x] = w.begin; we[threadIdx.x] = w.end;
     }
-    s = block_sum(s, red);
-    if (threadIdx.x == 0) df[(size_t)k * FW + j] = s;
+    for (int x = threadIdx.x; x < nr * Tp; x += 256) {
+        const int r = x / Tp, t = x % Tp, row = r0 + r;          // row = i*B + b
+        X[x] = DCV[((size_t)row * a.K + k) * Tp + t];
+        Wr[x] = a.W[(size_t)row * Tp + t];                        // alignment slot i = alpha_{i-1}
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < FW; j += 256) {
+        const int d = j - a.c;
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = 0; r < nr; ++r) {
+            const int lo = max(wb[r], wb[r] + d), hi = min(we[r], we[r] + d);     // t and t-d inside [begin,end)
+            const float* xr = X + r * Tp;
+            const float* ar = Wr + r * Tp - d;
+            int t = lo;
+            for (; t + 1 < hi; t += 2) { s0 += xr[t] * ar[t]; s1 += xr[t + 1] * ar[t + 1]; }
+            if (t < hi) s0 += xr[t] * ar[t];
+        }
+        part[((size_t)chunk * a.K + k) * FW + j] = s0 + s1;
+    }
 }
 
 extern "C" {
@@ -374,14 +390,23 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_bwd");
 }
 
-int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters) {
+int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters, float* ws,
+                            long long ws_bytes) {
     LVSR_REQUIRE(f != nullptr && DCV && dfilters, "lvsr_attdec_filter_grad: null argument");
     AttDec a;
     memcpy(&a, f, sizeof(a));
     if (int rc = attdec_check(a, "lvsr_attdec_filter_grad")) return rc;
     if (a.K == 0) return LVSR_OK;
-    hipLaunchKernelGGL(attdec_filter_grad_kernel, dim3(2 * a.c + 1, a.K), dim3(256), 0, (hipStream_t)stream, a, DCV, dfilters);
-    return lvsr_check_launch("lvsr_attdec_filter_grad");
+    int R = FG_LDS / a.Tp;
+    if (R > 16) R = 16;
+    if (R < 1) R = 1;
+    LVSR_REQUIRE(a.Tp <= FG_LDS, "lvsr_attdec_filter_grad: attended length %d > %d", a.Tp, FG_LDS);
+    const int nrow = a.L * a.B, nchunk = (nrow + R - 1) / R, FW = 2 * a.c + 1;
+    const long long need = (long long)nchunk * a.K * FW * 4;
+    LVSR_REQUIRE(ws && ws_bytes >= need, "lvsr_attdec_filter_grad: workspace of %lld bytes needed", need);
+    hipLaunchKernelGGL(attdec_filter_grad_kernel, dim3(nchunk, a.K), dim3(256), 0, (hipStream_t)stream, a, DCV, ws, R);
+    if (int rc = lvsr_check_launch("lvsr_attdec_filter_grad")) return rc;
+    return lvsr_colsum(stream, ws, nchunk, a.K * FW, a.K * FW, dfilters, 0.f, nullptr, 0);
 }
 
 }  // extern "C"

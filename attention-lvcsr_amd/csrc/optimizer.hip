@@ -50,6 +50,8 @@ __global__ __launch_bounds__(256) void opt_norm_kernel(Opt o, int nparts) {
 // clipping multiplier, Scale, BasicMomentum, AdaDelta -> step
 __global__ __launch_bounds__(256) void opt_rules_kernel(Opt o) {
     const float mult = o.scratch[1];
+    if (blockIdx.x == 0)
+        for (int sgi = threadIdx.x; sgi < o.nseg; sgi += 256) o.segflag[sgi] = 0;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < o.n; i += (long long)gridDim.x * 256) {
         float s = o.grad[i] * o.grad_scale * mult;
         if (o.use_momentum) {
@@ -68,37 +70,46 @@ __global__ __launch_bounds__(256) void opt_rules_kernel(Opt o) {
     }
 }
 
-// VariableClipping(axis=0) on flagged (rows x cols) segments: one thread per column
+// VariableClipping(axis=0) on flagged (rows x cols) segments.  Block (x, seg): 64 columns x 4 row groups; the column
+// norms of (param - step) are folded through LDS in a fixed order, then the same threads rescale their rows.
 __global__ __launch_bounds__(256) void opt_maxnorm_kernel(Opt o) {
+    __shared__ float red[4][64];
     const long long* seg = o.segments + 4 * (long long)blockIdx.y;
     const long long off = seg[0], rows = seg[1], cols = seg[2], flags = seg[3];
     if (!(flags & 1)) return;
-    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (j >= cols) return;
+    const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
+    if ((long long)blockIdx.x * 64 >= cols) return;
+    const int g = threadIdx.x >> 6;
     float s = 0.f;
-    for (long long r = 0; r < rows; ++r) {
-        const float v = o.param[off + r * cols + j] - o.step[off + r * cols + j];
-        s += v * v;
-    }
-    const float norm = sqrtf(s);
-    if (norm > o.max_norm) {
+    if (j < cols)
+        for (long long r = g; r < rows; r += 4) {
+            const float v = o.param[off + r * cols + j] - o.step[off + r * cols + j];
+            s += v * v;
+        }
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    const float norm = sqrtf(((red[0][c] + red[1][c]) + red[2][c]) + red[3][c]);
+    if (j < cols && norm > o.max_norm) {
         const float k = o.max_norm / norm;
-        for (long long r = 0; r < rows; ++r) {
+        for (long long r = g; r < rows; r += 4) {
             const long long x = off + r * cols + j;
             o.step[x] = o.param[x] - k * (o.param[x] - o.step[x]);
         }
     }
 }
 
-// RemoveNotFinite: segflag[s] = 1 when sum(step of segment s) is nan/inf
+// RemoveNotFinite: segflag[s] = 1 when sum(step of segment s) is nan/inf.  A non-finite sum needs a non-finite element
+// or an overflow; either way some partial sum of the segment is non-finite, so blocks (x, seg) test their slice and raise
+// the flag (idempotent store, no ordering needed); the flags are cleared by the rules kernel of the same step.
 __global__ __launch_bounds__(256) void opt_finite_kernel(Opt o) {
     __shared__ float red[4];
-    const long long* seg = o.segments + 4 * (long long)blockIdx.x;
+    const long long* seg = o.segments + 4 * (long long)blockIdx.y;
     const long long off = seg[0], n = seg[1] * seg[2];
     float s = 0.f;
-    for (long long i = threadIdx.x; i < n; i += 256) s += o.step[off + i];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += o.step[off + i];
     s = blk_sum256(s, red);
-    if (threadIdx.x == 0) o.segflag[blockIdx.x] = (s != s || s - s != 0.f) ? 1 : 0;
+    if (threadIdx.x == 0 && (s != s || s - s != 0.f)) o.segflag[blockIdx.y] = 1;
 }
 
 __global__ __launch_bounds__(256) void opt_apply_kernel(Opt o) {
@@ -128,9 +139,9 @@ extern "C" int lvsr_opt_step(void* stream, const lvsr_opt_args* args) {
     hipLaunchKernelGGL(opt_norm_kernel, dim3(1), dim3(256), 0, s, o, nparts);
     hipLaunchKernelGGL(opt_rules_kernel, dim3(nb), dim3(256), 0, s, o);
     if (o.max_norm > 0.f)
-        hipLaunchKernelGGL(opt_maxnorm_kernel, dim3((o.max_cols + 255) / 256, o.nseg), dim3(256), 0, s, o);
+        hipLaunchKernelGGL(opt_maxnorm_kernel, dim3((o.max_cols + 63) / 64, o.nseg), dim3(256), 0, s, o);
     if (o.remove_not_finite)
-        hipLaunchKernelGGL(opt_finite_kernel, dim3(o.nseg), dim3(256), 0, s, o);
+        hipLaunchKernelGGL(opt_finite_kernel, dim3(16, o.nseg), dim3(256), 0, s, o);
     hipLaunchKernelGGL(opt_apply_kernel, dim3(16, o.nseg), dim3(256), 0, s, o);
     return lvsr_check_launch("lvsr_opt_step");
 }

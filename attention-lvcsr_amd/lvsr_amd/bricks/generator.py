@@ -268,7 +268,8 @@ class SequenceGenerator(object):
         lib.colsum(accWe, g[n["we"]].view(-1), ws=gws)
         if d.conv:
             lib.colsum(accH, g[n["handler"]].view(-1), ws=gws)
-            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]))
+            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]), lib_ptr(gws),
+                     gws.numel() * 4)
         # ---- attended: preprocess backward + glimpse backward
         A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
         lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws)

@@ -162,8 +162,10 @@ typedef struct lvsr_attdec_bwd_args {
     float* dswp;                          /* (B,ntile,M) scratch: per-tile partials of DSW */
 } lvsr_attdec_bwd_args;
 int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
-/* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block */
-int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters);
+/* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block; ws: scratch of at least
+ * ceil(L*B / min(16, 8192/Tp)) * K * (2c+1) floats */
+int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters, float* ws,
+                            long long ws_bytes);
 
 /* ---- feedback lookup, post-merge activation, softmax emitter ----------------------------------------
  * LookupTable.apply (libs/blocks/blocks/bricks/lookup.py:48-68) / OneOfNFeedback (lvsr/bricks/__init__.py:
