@@ -129,6 +129,28 @@ __device__ __forceinline__ void rb_mm_impl(f32x4& acc0, f32x4& acc1, const A4& a
     if (q + 2 <= NQ) { rb_chunk<2, FAST>(acc0, acc1, a4, p, i, k0); q += 2; p += 2 * 64; k0 += 8; }
     if (q < NQ) rb_chunk<1, FAST>(acc0, acc1, a4, p, i, k0);
 }
+// Compile-time K (= 64*NQ, no padding): one straight-line chunk, no dispatch on the chunk count.
+template <int NQ, class A4>
+__device__ __forceinline__ void rb_mm_fixed(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int tile) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int k0 = wave * (16 * NQ) + kk * (4 * NQ);
+    const float4* p = (const float4*)P + ((size_t)(tile * 4 + wave) * NQ) * 64 + lane;
+    rb_chunk<NQ, true>(acc0, acc1, a4, p, i, k0);
+}
+// FAST kernels call this: H = 256 / 512 take the fixed-size path, other multiples of 64 the generic unguarded one.
+template <class A4>
+__device__ __forceinline__ void rb_mm_fast(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K, int tile) {
+    if (K == 256) rb_mm_fixed<4>(acc0, acc1, a4, P, tile);
+    else if (K == 512) rb_mm_fixed<8>(acc0, acc1, a4, P, tile);
+    else rb_mm_impl<true>(acc0, acc1, a4, P, K, tile);
+}
+template <bool FAST, class A4>
+__device__ __forceinline__ void rb_mm_sel(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K, int tile) {
+    if (FAST) rb_mm_fast(acc0, acc1, a4, P, K, tile);
+    else rb_mm_impl<false>(acc0, acc1, a4, P, K, tile);
+}
+
 template <class A4>
 __device__ __forceinline__ void rb_mm(f32x4& acc0, f32x4& acc1, const A4& a4, const float* __restrict__ P, int K,
                                       int tile) {
@@ -146,5 +168,15 @@ __device__ __forceinline__ float rb_reduce(f32x4 acc0, f32x4 acc1) {
     __syncthreads();
     const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
     return ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
+}
+// same, for kernels that fold exactly one tile (no earlier use of `red` to protect): one barrier instead of two
+__device__ __forceinline__ float rb_reduce_once(f32x4 acc0, f32x4 acc1) {
+    __shared__ float red1[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red1[wave][(lane >> 4) * 4 + r][lane & 15] = acc0[r] + acc1[r];
+    __syncthreads();
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    return ((red1[0][row][col] + red1[1][row][col]) + red1[2][row][col]) + red1[3][row][col];
 }
 #define F32X4_ZERO ((f32x4){0.f, 0.f, 0.f, 0.f})

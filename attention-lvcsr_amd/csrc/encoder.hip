@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void enc_gates_kernel(const float* xg, const f
     const float gin = ok ? a.xg[row * 6 * H + dir * 3 * H + H + j] : 0.f;
     const float hpj = (ok && j >= H) ? hp.at(b, j - H) : 0.f;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm_impl<FAST>(acc0, acc1, row_src(hp.base + (size_t)b0 * hp.ld, hp.ld, a.B - b0, H), Whg_d, H, tile);
-    const float v = rb_reduce(acc0, acc1);
+    rb_mm_sel<FAST>(acc0, acc1, row_src(hp.base + (size_t)b0 * hp.ld, hp.ld, a.B - b0, H), Whg_d, H, tile);
+    const float v = rb_reduce_once(acc0, acc1);
     if (ok) {
         const float g = sigmoidf_(v + gin);
         if (j < H) {
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void enc_cand_kernel(const float* xg, const fl
     const float m = (ok && a.mask) ? a.mask[row] : 1.f;
     const float* rh_t = a.rh + ((size_t)t * a.B + b0) * 2 * H + dir * H;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm_impl<FAST>(acc0, acc1, row_src(rh_t, 2 * H, a.B - b0, H), Whh_d, H, tile);
-    const float v = rb_reduce(acc0, acc1);
+    rb_mm_sel<FAST>(acc0, acc1, row_src(rh_t, 2 * H, a.B - b0, H), Whh_d, H, tile);
+    const float v = rb_reduce_once(acc0, acc1);
     if (ok) {
         const float cand = tanhf(v + xin);
         float hn = cand * uu + hprev * (1.f - uu);
@@ -135,21 +135,29 @@ __device__ __forceinline__ float enc_dy_at(const EncBwd0& a, int t, int b, int d
 
 // Everything of step t that depends on dh_t elementwise only: dpre_c, dpre_u (also the dxg outputs) and the elementwise
 // part of dh_{t-1}.  Called by the init kernel for the first step and by kernel B's epilogue for the following one, so that
-// kernel A's contraction operands are plain (B,H) rows.
-__device__ __forceinline__ void enc_bwd_prepare(const EncBwd& e, const float* h0_d, int dir, int t, int b, int j, float dhv) {
+// kernel A's contraction operands are plain (B,H) rows.  The saved activations it needs do not depend on the recurrence:
+// kernel B fetches them (EncPrep) before its contraction.
+struct EncPrep { float uu, cc, hprev, m; };
+__device__ __forceinline__ EncPrep enc_bwd_prefetch(const EncBwd& e, const float* h0_d, int dir, int t, int b, int j) {
     const EncBwd0& a = e.a;
     const int H = a.H, tp = dir == 0 ? t - 1 : t + 1;
     const size_t o = ((size_t)t * a.B + b) * 2 * H + dir * H + j;
-    const float uu = a.u[o], cc = a.c[o];
-    const float hprev = (tp < 0 || tp >= a.T) ? h0_d[j] : a.y[((size_t)tp * a.B + b) * 2 * H + dir * H + j];
-    const float m = a.mask ? a.mask[(size_t)t * a.B + b] : 1.f;
-    const float dhn = m * dhv;
-    const float dpc = dhn * uu * (1.f - cc * cc);
-    const float dpu = dhn * (cc - hprev) * uu * (1.f - uu);
+    EncPrep p;
+    p.uu = a.u[o]; p.cc = a.c[o];
+    p.hprev = (tp < 0 || tp >= a.T) ? h0_d[j] : a.y[((size_t)tp * a.B + b) * 2 * H + dir * H + j];
+    p.m = a.mask ? a.mask[(size_t)t * a.B + b] : 1.f;
+    return p;
+}
+__device__ __forceinline__ void enc_bwd_prepare(const EncBwd& e, const EncPrep& p, int dir, int t, int b, int j, float dhv) {
+    const EncBwd0& a = e.a;
+    const int H = a.H;
+    const float dhn = p.m * dhv;
+    const float dpc = dhn * p.uu * (1.f - p.cc * p.cc);
+    const float dpu = dhn * (p.cc - p.hprev) * p.uu * (1.f - p.uu);
     const size_t q = ((size_t)dir * e.Bp + b) * H + j;
     e.dpc[q] = dpc;
     e.dpu[q] = dpu;
-    e.base[q] = dhn * (1.f - uu) + (1.f - m) * dhv;
+    e.base[q] = dhn * (1.f - p.uu) + (1.f - p.m) * dhv;
     float* dx = a.dxg + ((size_t)t * a.B + b) * 6 * H + dir * 3 * H;
     dx[j] = dpc;
     dx[H + j] = dpu;
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(256) void enc_bwd_init_kernel(EncBwd e) {
     if (b < a.B) {
         const float dhv = enc_dy_at(a, t, b, dir, j);
         e.dh[q] = dhv;
-        enc_bwd_prepare(e, a.h0[dir], dir, t, b, j, dhv);
+        enc_bwd_prepare(e, enc_bwd_prefetch(e, a.h0[dir], dir, t, b, j), dir, t, b, j, dhv);
     } else {
         e.dh[q] = 0.f; e.dpc[q] = 0.f; e.dpu[q] = 0.f; e.base[q] = 0.f;
     }
@@ -200,8 +208,8 @@ __global__ __launch_bounds__(256) void enc_bwd_a_kernel(const float* mask, const
     const size_t q = ((size_t)dir * e.Bp + b) * H + j;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
     if (vu_path) {
-        rb_mm_impl<FAST>(acc0, acc1, row_src(e.dpu + ((size_t)dir * e.Bp + b0) * H, H, a.B - b0, H), WhgT_d, H, tile);
-        const float v = rb_reduce(acc0, acc1);
+        rb_mm_sel<FAST>(acc0, acc1, row_src(e.dpu + ((size_t)dir * e.Bp + b0) * H, H, a.B - b0, H), WhgT_d, H, tile);
+        const float v = rb_reduce_once(acc0, acc1);
         if (ok) e.vu[q] = v;
         return;
     }
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(256) void enc_bwd_a_kernel(const float* mask, const
     const float rr = ok ? a.r[o] : 0.f;
     const float hprev = ok ? hp.at(b, j) : 0.f;
     const float bs = ok ? e.base[q] : 0.f;
-    rb_mm_impl<FAST>(acc0, acc1, row_src(e.dpc + ((size_t)dir * e.Bp + b0) * H, H, a.B - b0, H), WhhT_d, H, tile);
-    const float drh = rb_reduce(acc0, acc1);
+    rb_mm_sel<FAST>(acc0, acc1, row_src(e.dpc + ((size_t)dir * e.Bp + b0) * H, H, a.B - b0, H), WhhT_d, H, tile);
+    const float drh = rb_reduce_once(acc0, acc1);
     if (ok) {
         a.dxg[((size_t)t * a.B + b) * 6 * H + dir * 3 * H + 2 * H + j] = drh * hprev * rr * (1.f - rr);
         e.dhpart[q] = bs + drh * rr;
@@ -235,14 +243,18 @@ __global__ __launch_bounds__(256) void enc_bwd_b_kernel(const float* mask, const
     const bool ok = b < a.B && j < H;
     const size_t q = ((size_t)dir * e.Bp + b) * H + j;
     const float part = ok ? e.dhpart[q] + e.vu[q] + enc_dy_at(a, tp, b, dir, j) : 0.f;
+    const bool next = ok && tp >= 0 && tp < a.T;
+    EncPrep prep;
+    prep.uu = prep.cc = prep.hprev = 0.f; prep.m = 1.f;
+    if (next) prep = enc_bwd_prefetch(e, h0_d, dir, tp, b, j);        // in flight during the contraction
     const float* dpr = a.dxg + ((size_t)t * a.B + b0) * 6 * H + dir * 3 * H + 2 * H;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-    rb_mm_impl<FAST>(acc0, acc1, row_src(dpr, 6 * H, a.B - b0, H), WhgT_d + e.rofs, H, tile);
-    const float v = rb_reduce(acc0, acc1);
+    rb_mm_sel<FAST>(acc0, acc1, row_src(dpr, 6 * H, a.B - b0, H), WhgT_d + e.rofs, H, tile);
+    const float v = rb_reduce_once(acc0, acc1);
     if (ok) {
         const float dhp = part + v;
         e.dh[q] = dhp;
-        if (tp >= 0 && tp < a.T) enc_bwd_prepare(e, h0_d, dir, tp, b, j, dhp);
+        if (next) enc_bwd_prepare(e, prep, dir, tp, b, j, dhp);
     }
 }
 

@@ -5,6 +5,9 @@
 All arithmetic happens in the C-ABI library (lvsr_sgemm / lvsr_bigru_fwd / lvsr_bigru_bwd / lvsr_colsum);
 torch is used for buffers and views only.
 """
+import contextlib
+import os
+
 import torch
 
 
@@ -18,6 +21,11 @@ class Encoder(object):
         self.use_graph = use_graph
         self._saved = None
         self._packs = {}
+        # weight-gradient GEMMs on a second stream: measured SLOWER on MI355X (70.0 vs 66.4 ms per WSJ-base step: the
+        # concurrent GEMM work-groups delay the latency-bound step kernels more than the overlap saves), so off by default
+        self.overlap = os.environ.get("LVSR_OVERLAP", "0") == "1"
+        self._side = None
+        self._side_pending = False
 
     def _names(self, i, direction):
         base = "/recognizer/encoder/bidir%d/%s" % (i, direction)
@@ -50,6 +58,27 @@ class Encoder(object):
             ent["WhgT"].append(buf)
         self._packs[i] = ent
         return ent
+
+    @contextlib.contextmanager
+    def _side_stream(self):
+        """Run the enclosed launches on the encoder's second stream (GPU only), ordered after everything already queued
+        on the current stream; `join_side_stream()` orders the current stream after them.  Yields the split-K workspace to
+        use inside (the two streams must not share one)."""
+        if not self.overlap or self.lib.is_emulator or not torch.cuda.is_available():
+            yield self.ws.get("gemm_ws", (1 << 22,))
+            return
+        cur = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream(cur.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            yield self.ws.get("gemm_ws.side", (1 << 22,))
+        self._side_pending = True
+
+    def join_side_stream(self):
+        if self._side is not None and self._side_pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_pending = False
 
     def _sync_ws(self, i, B, H):
         """Scratch of the persistent cluster kernel (granule planes + abort word), or None when the layer runs as
@@ -148,30 +177,39 @@ class Encoder(object):
             dx = None
             if i > 0:
                 dx = ws.get("enc%d.dx" % i, (T, B, I))
+            # critical path first: the gradient wrt this layer's input is what the next (lower) layer's recurrence waits for
             for di, direction in enumerate(("forward", "backward")):
                 n = self._names(i, direction)
                 dc = dxg2[:, di * 3 * H: di * 3 * H + H]               # d pre-activation of the candidate
                 dg = dxg2[:, di * 3 * H + H: di * 3 * H + 3 * H]       # d pre-activation of [update|reset]
-                hcol = slice(di * H, (di + 1) * H)
-                lib.sgemm(rh2[:, hcol], dc, g[n["Whh"]], transA=True, ws=gemm_ws)
-                if T > 1:
-                    if di == 0:     # h_{t-1} = y[t-1]
-                        lib.sgemm(y2[: (T - 1) * B, hcol], dg[B:], g[n["Whg"]], transA=True, ws=gemm_ws)
-                    else:           # backward direction: previous state in scan order is y[t+1]
-                        lib.sgemm(y2[B:, hcol], dg[: (T - 1) * B], g[n["Whg"]], transA=True, ws=gemm_ws)
-                    beta = 1.0
-                else:
-                    beta = 0.0
-                # the first scan step starts from the (broadcast) initial state: rank-B update with lda = 0
-                first = dg[:B] if di == 0 else dg[(T - 1) * B:]
-                lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0)
-                lib.sgemm(x2, dc, g[n["Wi"]], transA=True, ws=gemm_ws)
-                lib.sgemm(x2, dg, g[n["Wg"]], transA=True, ws=gemm_ws)
-                lib.colsum(dc, g[n["bi"]], ws=gemm_ws)
-                lib.colsum(dg, g[n["bg"]], ws=gemm_ws)
                 if dx is not None:
                     dx2 = dx.view(T * B, I)
                     lib.sgemm(dc, p[n["Wi"]], dx2, transB=True, beta=(0.0 if di == 0 else 1.0))
                     lib.sgemm(dg, p[n["Wg"]], dx2, transB=True, beta=1.0)
+            # weight gradients are off the critical path; with LVSR_OVERLAP=1 they go to a second stream and overlap the next
+            # layer's recurrence (see __init__ for why this is not the default)
+            with self._side_stream() as side_ws:
+                for di, direction in enumerate(("forward", "backward")):
+                    n = self._names(i, direction)
+                    dc = dxg2[:, di * 3 * H: di * 3 * H + H]
+                    dg = dxg2[:, di * 3 * H + H: di * 3 * H + 3 * H]
+                    hcol = slice(di * H, (di + 1) * H)
+                    lib.sgemm(rh2[:, hcol], dc, g[n["Whh"]], transA=True, ws=side_ws)
+                    if T > 1:
+                        if di == 0:     # h_{t-1} = y[t-1]
+                            lib.sgemm(y2[: (T - 1) * B, hcol], dg[B:], g[n["Whg"]], transA=True, ws=side_ws)
+                        else:           # backward direction: previous state in scan order is y[t+1]
+                            lib.sgemm(y2[B:, hcol], dg[: (T - 1) * B], g[n["Whg"]], transA=True, ws=side_ws)
+                        beta = 1.0
+                    else:
+                        beta = 0.0
+                    # the first scan step starts from the (broadcast) initial state: rank-B update with lda = 0
+                    first = dg[:B] if di == 0 else dg[(T - 1) * B:]
+                    lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0)
+                    lib.sgemm(x2, dc, g[n["Wi"]], transA=True, ws=side_ws)
+                    lib.sgemm(x2, dg, g[n["Wg"]], transA=True, ws=side_ws)
+                    lib.colsum(dc, g[n["bi"]], ws=side_ws)
+                    lib.colsum(dg, g[n["bg"]], ws=side_ws)
             dy = dx
+        self.join_side_stream()
         return None
