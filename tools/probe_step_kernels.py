@@ -42,3 +42,64 @@ for mask in (1, 2, 3):
                         c=bufs["c"], WhhT_p=pk["WhhT"], WhgT_p=pk["WhgT"], h0=[p[nf["h0"]], p[nb["h0"]]], dy=bufs["dy"],
                         dxg=bufs["dxg"], dh_ws=bufs["dh_ws"], dh0=[z(H), z(H)], sub=1, T=T, B=B, H=H, kernel_mask=mask)
     print("H=%d bwd kernel_mask=%d: %.2f us per step" % (H, mask, timeit(f)))
+
+# hypothesis test: does a burst of dense GEMM work right before the graph slow the latency-bound chain (clock / cache state)?
+X = torch.randn(12800, 512, device=dev); Wb = torch.randn(512, 1536, device=dev); Y = torch.empty(12800, 1536, device=dev)
+def fwd_all():
+    lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", bufs["y"], True, xg=bufs["xg"], mask=None,
+            Whh_p=pk["Whh"], Whg_p=pk["Whg"], h0=[p[nf["h0"]], p[nb["h0"]]], y=bufs["y"], ysub=None, u=bufs["u"],
+            r=bufs["r"], c=bufs["c"], rh=bufs["rh"], sub=1, T=T, B=B, H=H, kernel_mask=3)
+def with_gemm():
+    for _ in range(4):
+        lib.sgemm(X, Wb, Y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); fwd_all(); e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / T
+with torch.cuda.stream(stream):
+    res = [with_gemm() for _ in range(4)]
+print("H=%d fwd both kernels right after 4 big GEMMs: %s us per step" % (H, ", ".join("%.2f" % r for r in res)))
+maskt = torch.ones(T, B, device=dev)
+def fwd_mask():
+    lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", bufs["y"], True, xg=bufs["xg"], mask=maskt,
+            Whh_p=pk["Whh"], Whg_p=pk["Whg"], h0=[p[nf["h0"]], p[nb["h0"]]], y=bufs["y"], ysub=None, u=bufs["u"],
+            r=bufs["r"], c=bufs["c"], rh=bufs["rh"], sub=1, T=T, B=B, H=H, kernel_mask=3)
+print("H=%d fwd both kernels with an all-ones mask: %.2f us per step" % (H, timeit(fwd_mask)))
+bufs["xg"].normal_(0, 2.0)
+print("H=%d fwd both kernels, xg ~ N(0,2) (mixed tanh/exp ranges): %.2f us per step" % (H, timeit(fwd_all)))
+
+# back-to-back like the real encoder forward: [4 GEMMs, graph] x 4 without host syncs in between
+def four_layers():
+    evs = []
+    for layer in range(4):
+        for _ in range(4):
+            lib.sgemm(X, Wb, Y)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fwd_all(); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) * 1e3 / T for a, b in evs]
+with torch.cuda.stream(stream):
+    four_layers()
+    print("H=%d four back-to-back [GEMMs + fwd graph]: us per step per layer:" % H, ["%.2f" % v for v in four_layers()])
+
+# hypothesis: in the real step every layer has its own ~200 MB of activations, so the working set (~1 GB) never stays in the
+# 256 MB Infinity Cache; this probe re-used one set.  Rotate over 5 sets.
+sets = []
+for k in range(5):
+    sets.append(dict(xg=z(T, B, 6 * H), y=z(T, B, 2 * H), u=torch.rand(T, B, 2 * H, device=dev), r=torch.rand(T, B, 2 * H, device=dev),
+                     c=z(T, B, 2 * H), rh=z(T, B, 2 * H)))
+def fwd_set(bs):
+    lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", bs["y"], True, xg=bs["xg"], mask=None,
+            Whh_p=pk["Whh"], Whg_p=pk["Whg"], h0=[p[nf["h0"]], p[nb["h0"]]], y=bs["y"], ysub=None, u=bs["u"],
+            r=bs["r"], c=bs["c"], rh=bs["rh"], sub=1, T=T, B=B, H=H, kernel_mask=3)
+def rotate():
+    evs = []
+    for bs in sets:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fwd_set(bs); e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    return [a.elapsed_time(b) * 1e3 / T for a, b in evs]
+with torch.cuda.stream(stream):
+    rotate()
+    print("H=%d fwd over 5 rotating buffer sets (1 GB working set): us per step:" % H, ["%.2f" % v for v in rotate()])
