@@ -9,6 +9,7 @@
 is in the C-ABI library; torch only owns buffers/views.
 """
 import math
+import os
 
 import numpy
 import torch
@@ -169,7 +170,12 @@ class SequenceGenerator(object):
                     RH=ws.get("gen.RH", (L, B, d.D)), sg=ws.get("gen.sg", (B, 2 * d.D)), xin=ws.get("gen.xin", (B, d.D)),
                     ep=ws.get("gen.ep", (B, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
         fields = self._attdec_fields(pk, A, PA, Am, L, B, bufs, phases=3, step0=0, broadcast=False)
-        fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
+        if os.environ.get("LVSR_SYNC_DEC_FWD", "1") == "1":
+            fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
+        else:
+            import ctypes as _ct
+            fwd_args = lib.make("lvsr_attdec_args", **fields)
+            lib.call("lvsr_attdec_fwd", lib.stream_for(S), _ct.byref(fwd_args), int(self.use_graph))
         WA = bufs["WA"]
         S2, WA2 = S[:L].view(L * B, d.D), WA.view(L * B, d.E)
         R1, R2, logits = self._readout(S2, WA2, L * B, "")
@@ -238,6 +244,8 @@ class SequenceGenerator(object):
         bw.f = lib.make("lvsr_attdec_args", **sv["fields"])
         import ctypes
         lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
+        if self.use_graph and os.environ.get("LVSR_SYNC_DEC_BWD", "0") == "1":
+            lib.after_graph(ds, L)
         # ---- weight gradients as batched GEMMs over all steps
         dpc, dg = DXG[:, : d.D], DXG[:, d.D:]
         RH2 = bufs["RH"].view(nrows, d.D)

@@ -231,9 +231,15 @@ class Lib(object):
             self.call(fn, self.stream_for(ref_tensor), ctypes.byref(a))
         else:
             self.call(fn, self.stream_for(ref_tensor), ctypes.byref(a), int(use_graph))
-        if _SYNC_AFTER_GRAPH and use_graph and ref_tensor.is_cuda:
-            torch.cuda.current_stream(ref_tensor.device).synchronize()
+        if use_graph:
+            self.after_graph(ref_tensor, max(fields.get("T", 0), fields.get("L", 0)))
         return a
+
+    @staticmethod
+    def after_graph(ref_tensor, steps):
+        """Block the host until a long time-loop graph has drained (see _SYNC_AFTER_GRAPH above)."""
+        if _SYNC_AFTER_GRAPH and ref_tensor.is_cuda and steps >= 16:
+            torch.cuda.current_stream(ref_tensor.device).synchronize()
 
 
 _default = None

@@ -36,7 +36,8 @@ def _enc_cfg(Hs, sub, F=40):
 @pytest.mark.parametrize("use_graph,persistent", [(False, False), (True, False), (False, True), (True, True)])
 @pytest.mark.parametrize("Hs,sub,B,T,use_mask", [([3, 3], [1, 2], 3, 13, True), ([20], [3], 17, 7, True),
                                                    ([64, 48], [2, 1], 16, 60, True), ([32], [1], 5, 40, False),
-                                                   ([130], [1], 33, 21, True)])
+                                                   ([130], [1], 33, 21, True), ([512], [2], 8, 12, True),
+                                                   ([256], [1], 16, 10, True), ([192], [1], 20, 9, False)])
 def test_encoder_forward_backward(gpu_device, Hs, sub, B, T, use_mask, use_graph, persistent):
     lib = native.get()
     cfg = _enc_cfg(Hs, sub)
@@ -140,3 +141,27 @@ def test_full_size_configs_vs_reference_golden(gpu_device, case):
 def test_beam_search_vs_reference_golden(gpu_device, case):
     from test_emu_beam import run_beam_case
     run_beam_case(case, gpu_device, None)
+
+
+def test_wsj_deep_shapes_vs_oracle(gpu_device):
+    """The 512-unit kernels paths (fixed NQ = 8 contraction, K = 1536 decoder contraction) at WSJ-deep layer shapes but short
+    sequences, against the float64 oracle (the reference itself needs ~1 h per WSJ-deep step in the Python linker)."""
+    cfg = spec.wsj_deep()
+    cfg["dims_bidir"] = [512, 512]
+    cfg["subsample"] = [1, 2]
+    params = synthetic.make_params(cfg, seed=12)
+    batch = synthetic.make_batch(cfg, 8, 30, 7, seed=21, ragged=True)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    out, grads = orc.cost_and_grads(batch)
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    cm = rec.cost_and_gradients(batch)
+    torch.cuda.synchronize()
+    ref = out["cost_matrix"].detach().numpy()
+    assert abs(float(cm.sum()) - ref.sum()) / abs(ref.sum()) < 1e-4
+    assert_allclose(cm.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+    w = rec.generator.last["weights"].cpu().numpy()
+    assert (w.argmax(axis=2) == out["weights"].detach().numpy().argmax(axis=2)).all()
+    got = rec.store.get_grads()
+    for name, g in grads.items():
+        scale = max(1e-3, numpy.abs(g).max())
+        assert numpy.abs(got[name] - g).max() / scale < 5e-4, name
