@@ -18,6 +18,7 @@
 #include "common.h"
 #include "graph_cache.h"
 #include "lvsr_hip.h"
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 typedef lvsr_bigru_fwd_args EncFwd;
@@ -59,10 +60,13 @@ __device__ __forceinline__ bool granule_poll(const u64* g, int nvalid, unsigned 
     }
 }
 
-struct PersistGeom { int C, rt, Kw, Kpad; };
-__host__ __device__ __forceinline__ PersistGeom persist_geom(int B, int H, int NQ) {
+struct PersistGeom { int C, rt, Kw, Kpad, RB; };
+// RB = utterances per cluster (<= 16, the MFMA row tile).  Smaller clusters exchange proportionally smaller phase vectors
+// (the hand-off cost grows with the polled volume), at the price of more work-groups holding a copy of the weight shard.
+__host__ __device__ __forceinline__ PersistGeom persist_geom(int B, int H, int NQ, int RB) {
     PersistGeom g;
-    g.C = (H + 15) / 16; g.rt = (B + 15) / 16; g.Kw = 16 * NQ; g.Kpad = 4 * g.Kw;
+    g.RB = RB;
+    g.C = (H + 15) / 16; g.rt = (B + RB - 1) / RB; g.Kw = 16 * NQ; g.Kpad = 4 * g.Kw;
     return g;
 }
 static int persist_nq(int H) {           // K slice per wave = 16*NQ >= ceil(H/4)
@@ -101,13 +105,13 @@ __device__ __forceinline__ void mfma_tile(f32x4& acc0, f32x4& acc1, const float 
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 template <int NQ>
-__global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* gh_all, u64* grh_all, int* abort_word) {
+__global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* gh_all, u64* grh_all, int* abort_word, int RB) {
     __shared__ float4 Bs[3 * 4 * NQ * 64];          // tiles: 0 gates-update, 1 gates-reset, 2 candidate
     __shared__ float red[2][4][16][17];
-    const PersistGeom geo = persist_geom(a.B, a.H, NQ);
+    const PersistGeom geo = persist_geom(a.B, a.H, NQ, RB);
     const int H = a.H, B = a.B, T = a.T, Kw = geo.Kw, Kpad = geo.Kpad;
     const int cl = blockIdx.x / geo.C, p = blockIdx.x % geo.C;
-    const int dir = cl / geo.rt, b0 = (cl % geo.rt) * 16, nrows = min(16, B - b0), j0 = p * 16;
+    const int dir = cl / geo.rt, b0 = (cl % geo.rt) * RB, nrows = min(RB, B - b0), j0 = p * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* Whg = a.Whg_p[dir];      // in persistent mode these are the PLAIN (H,2H) / (H,H) weights
     const float* Whh = a.Whh_p[dir];
@@ -193,13 +197,13 @@ __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int di
 
 template <int NQ>
 __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* gdh_all, u64* gdrh_all, int* abort_word, float* dh_out,
-                                                       int Bp) {
+                                                       int Bp, int RB) {
     __shared__ float4 Bs[3 * 4 * NQ * 64];          // tiles: 0 Whh^T, 1 Whg^T (update rows), 2 Whg^T (reset rows)
     __shared__ float red[4][16][17];
-    const PersistGeom geo = persist_geom(a.B, a.H, NQ);
+    const PersistGeom geo = persist_geom(a.B, a.H, NQ, RB);
     const int H = a.H, B = a.B, T = a.T, Kw = geo.Kw, Kpad = geo.Kpad;
     const int cl = blockIdx.x / geo.C, p = blockIdx.x % geo.C;
-    const int dir = cl / geo.rt, b0 = (cl % geo.rt) * 16, nrows = min(16, B - b0), j0 = p * 16;
+    const int dir = cl / geo.rt, b0 = (cl % geo.rt) * RB, nrows = min(RB, B - b0), j0 = p * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* Whg = a.WhgT_p[dir];     // persistent mode: PLAIN (H,2H) / (H,H) weights, transposed on the fly
     const float* Whh = a.WhhT_p[dir];
@@ -309,34 +313,48 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
     (dir == 0 ? out_f : out_b)[j] = s;
 }
 
-static bool persist_fits(int B, int H) {
-    const int C = (H + 15) / 16, rt = (B + 15) / 16;
-    return H <= 512 && 2 * rt * C <= PERSIST_MAX_WG;
+// utterances per cluster: the smallest of {16,8,4,2,1}-row clusters whose work-groups all fit the chip (one per CU)
+static int persist_rows(int B, int H) {
+    const int C = (H + 15) / 16;
+    if (H > 512) return 0;
+    const char* env = getenv("LVSR_PERSIST_ROWS");
+    int best = 0;
+    for (int rb = 16; rb >= 1; rb /= 2) {
+        const int rt = (B + rb - 1) / rb;
+        if (2 * rt * C <= PERSIST_MAX_WG) best = rb;
+        else break;
+    }
+    if (env && best) {
+        const int want = atoi(env);
+        if (want >= best && want <= 16 && (want & (want - 1)) == 0) best = want;
+    }
+    return best;
 }
+static bool persist_fits(int B, int H) { return persist_rows(B, H) > 0; }
 
 extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
     if (B <= 0 || H <= 0 || !persist_fits(B, H)) return 0;
     const int NQ = persist_nq(H);
-    const PersistGeom g = persist_geom(B, H, NQ);
+    const PersistGeom g = persist_geom(B, H, NQ, 1);                   // worst case: one utterance per cluster
     return 256 + (long long)2 * (2 * g.rt) * 16 * g.Kpad * 8;          // abort word + two granule planes
 }
 
 template <int NQ>
-static void launch_fwd(hipStream_t s, const EncFwd& a, u64* g0, u64* g1, int* ab) {
-    const PersistGeom g = persist_geom(a.B, a.H, NQ);
-    hipLaunchKernelGGL(enc_pfwd_kernel<NQ>, dim3(2 * g.rt * g.C), dim3(256), 0, s, a, g0, g1, ab);
+static void launch_fwd(hipStream_t s, const EncFwd& a, u64* g0, u64* g1, int* ab, int RB) {
+    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
+    hipLaunchKernelGGL(enc_pfwd_kernel<NQ>, dim3(2 * g.rt * g.C), dim3(256), 0, s, a, g0, g1, ab, RB);
 }
 template <int NQ>
-static void launch_bwd(hipStream_t s, const EncBwd0& a, u64* g0, u64* g1, int* ab, float* dh, int Bp) {
-    const PersistGeom g = persist_geom(a.B, a.H, NQ);
-    hipLaunchKernelGGL(enc_pbwd_kernel<NQ>, dim3(2 * g.rt * g.C), dim3(256), 0, s, a, g0, g1, ab, dh, Bp);
+static void launch_bwd(hipStream_t s, const EncBwd0& a, u64* g0, u64* g1, int* ab, float* dh, int Bp, int RB) {
+    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
+    hipLaunchKernelGGL(enc_pbwd_kernel<NQ>, dim3(2 * g.rt * g.C), dim3(256), 0, s, a, g0, g1, ab, dh, Bp, RB);
 }
 
 int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     EncFwd a = a0;
     LVSR_REQUIRE(persist_fits(a.B, a.H) && a.sync_ws, "lvsr_bigru_fwd: persistent mode not available for B=%d H=%d", a.B, a.H);
-    const int NQ = persist_nq(a.H);
-    const PersistGeom g = persist_geom(a.B, a.H, NQ);
+    const int NQ = persist_nq(a.H), RB = persist_rows(a.B, a.H);
+    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
     const size_t plane = (size_t)(2 * g.rt) * 16 * g.Kpad;
     int* ab = (int*)a.sync_ws;
     u64* g0 = (u64*)((char*)a.sync_ws + 256);
@@ -345,38 +363,40 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, 256 + 2 * plane * 8, s);
         switch (NQ) {
-            case 1: launch_fwd<1>(s, a, g0, g1, ab); break;
-            case 2: launch_fwd<2>(s, a, g0, g1, ab); break;
-            case 4: launch_fwd<4>(s, a, g0, g1, ab); break;
-            default: launch_fwd<8>(s, a, g0, g1, ab); break;
+            case 1: launch_fwd<1>(s, a, g0, g1, ab, RB); break;
+            case 2: launch_fwd<2>(s, a, g0, g1, ab, RB); break;
+            case 4: launch_fwd<4>(s, a, g0, g1, ab, RB); break;
+            default: launch_fwd<8>(s, a, g0, g1, ab, RB); break;
         }
     };
     GraphKey key("bigru_pfwd");
     key.add(&a, sizeof(a));
+    key.add(&RB, sizeof(RB));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_fwd(persistent)");
 }
 
 int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     LVSR_REQUIRE(persist_fits(a.B, a.H) && a.sync_ws, "lvsr_bigru_bwd: persistent mode not available for B=%d H=%d", a.B, a.H);
-    const int NQ = persist_nq(a.H);
-    const PersistGeom g = persist_geom(a.B, a.H, NQ);
+    const int NQ = persist_nq(a.H), RB = persist_rows(a.B, a.H);
+    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
     const size_t plane = (size_t)(2 * g.rt) * 16 * g.Kpad;
     int* ab = (int*)a.sync_ws;
     u64* g0 = (u64*)((char*)a.sync_ws + 256);
     u64* g1 = g0 + plane;
-    const int Bp = g.rt * 16;
+    const int Bp = ((a.B + 15) / 16) * 16;
     float* dh = a.dh_ws;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, 256 + 2 * plane * 8, s);
         switch (NQ) {
-            case 1: launch_bwd<1>(s, a, g0, g1, ab, dh, Bp); break;
-            case 2: launch_bwd<2>(s, a, g0, g1, ab, dh, Bp); break;
-            case 4: launch_bwd<4>(s, a, g0, g1, ab, dh, Bp); break;
-            default: launch_bwd<8>(s, a, g0, g1, ab, dh, Bp); break;
+            case 1: launch_bwd<1>(s, a, g0, g1, ab, dh, Bp, RB); break;
+            case 2: launch_bwd<2>(s, a, g0, g1, ab, dh, Bp, RB); break;
+            case 4: launch_bwd<4>(s, a, g0, g1, ab, dh, Bp, RB); break;
+            default: launch_bwd<8>(s, a, g0, g1, ab, dh, Bp, RB); break;
         }
         hipLaunchKernelGGL(enc_pbwd_h0_kernel, dim3((a.H + 255) / 256, 1, 2), dim3(256), 0, s, dh, Bp, a.B, a.H, a.dh0[0], a.dh0[1]);
     };
     GraphKey key("bigru_pbwd");
     key.add(&a, sizeof(a));
+    key.add(&RB, sizeof(RB));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_bwd(persistent)");
 }
