@@ -169,8 +169,20 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     for (int t = w.begin + threadIdx.x; t < w.end; t += 256) sd += al[t] * qr[t];
     sd = block_sum(sd, red);
     if (threadIdx.x < ATT_TT) {
+        // alpha = u/Z with u = f(e)*mask:  de = (q - sum alpha q)/Z * mask * f'(e);  softmax: f' = u  =>  alpha*(q - sd)
         const int t = t0 + threadIdx.x;
-        des[threadIdx.x] = (t >= w.begin && t < w.end) ? al[t] * (qr[t] - sd) : 0.f;
+        float de = 0.f;
+        if (t >= w.begin && t < w.end) {
+            if (a.normalizer == 0) {
+                de = al[t] * (qr[t] - sd);
+            } else {
+                const float e = a.EN[((size_t)i * B + b) * Tp + t], Z = a.ZB[(size_t)i * B + b];
+                const float gq = (qr[t] - sd) / Z * attdec_mask(a, i, b, t);
+                if (a.normalizer == 1) { const float sg = sigmoidf_(e); de = gq * sg * (1.f - sg); }
+                else de = e > 0.f ? gq / 1000.f : 0.f;
+            }
+        }
+        des[threadIdx.x] = de;
     }
     for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
         const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
@@ -202,6 +214,11 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
                 if (k < K) hacc[k] += cvs[k][tl] * d;
         }
         dms[tl][ml] = d;
+    }
+    if (a.e_bias && slice == 0 && threadIdx.x == 0) {           // d energy bias = sum of de (des is complete: barrier above)
+        float sb = 0.f;
+        for (int x = 0; x < ATT_TT; ++x) sb += des[x];
+        g.accEb[bt] += sb;
     }
     racc[tg][0][ml] = swacc;
     racc[tg][1][ml] = weacc;

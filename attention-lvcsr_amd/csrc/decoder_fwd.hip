@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float en[ATT_MAX_T];
     const int nslice = (a.M + ATT_MS - 1) / ATT_MS;
     const float* ep = a.ep + (size_t)b * nslice * Tp;
+    const float eb = a.e_bias ? a.e_bias[0] : 0.f;
     float mx = -3.0e38f;
     for (int t = threadIdx.x; t < Tp; t += 256) {
         float e = 0.f;
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
                 e3 += ep[(size_t)(sl + 3) * Tp + t];
             }
             for (; sl < nslice; ++sl) e0 += ep[(size_t)sl * Tp + t];
-            e = (e0 + e1) + (e2 + e3);
+            e = ((e0 + e1) + (e2 + e3)) + eb;
             mx = fmaxf(mx, e);
         }
         en[t] = e;
@@ -196,7 +197,10 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     float s = 0.f, anyone = 0.f;
     for (int t = w.begin + threadIdx.x; t < w.end; t += 256) {
         const float m = attdec_mask(a, i, b, t);
-        const float u = expf(en[t] - mx) * m;
+        float u;
+        if (a.normalizer == 0) u = expf(en[t] - mx) * m;                        // softmax: shift by the window maximum
+        else if (a.normalizer == 1) u = sigmoidf_(en[t]) * m;                     // logistic ("smooth focus")
+        else u = fmaxf(en[t] / 1000.f, 0.f) * m;                                  // relu
         al[t] = u;
         s += u;
         if (1.f - m == 0.f) anyone = 1.f;
@@ -208,6 +212,7 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     for (int t = threadIdx.x; t < Tp; t += 256) al[t] = (t >= w.begin && t < w.end) ? al[t] / Z : 0.f;
     __syncthreads();
     if (chunk == 0) {
+        if (threadIdx.x == 0 && a.ZB) a.ZB[(size_t)i * B + b] = Z;
         float* wn = a.W + ((size_t)(i + 1) * B + b) * Tp;
         for (int t = threadIdx.x; t < Tp; t += 256) wn[t] = al[t];
         if (a.K > 0 && a.prior_type != 0 && threadIdx.x == 0) a.pos[(size_t)(i + 1) * B + b] = attdec_pos_of_row(a, al);

@@ -15,6 +15,7 @@ import numpy
 import torch
 
 ACT_KIND = {"identity": 0, "maxout2": 1, "rectifier": 2, "tanh": 3}
+NORMALIZER_KIND = {"softmax": 0, "logistic": 1, "relu": 2}
 PRIOR_KIND = {"expanding": 0, "window_around_mean": 1, "window_around_median": 2}
 ATT_MS = 32     # match-dim slice per work-group in the energy kernels (csrc/decoder.h)
 
@@ -36,7 +37,7 @@ class SequenceGenerator(object):
         att = g + "/att_trans/" + ("conv_att" if dims.conv else "cont_att")
         self.n = dict(
             Wpre=att + "/preprocess.W", bpre=att + "/preprocess.b", Ws=att + "/state_trans/transform_states.W",
-            we=att + "/energy_comp/linear.W", filters=att + "/conv1d.filters", handler=att + "/handler.W",
+            we=att + "/energy_comp/linear.W", eb=att + "/energy_comp/linear.b", filters=att + "/conv1d.filters", handler=att + "/handler.W",
             Wdi=g + "/att_trans/distribute/fork_inputs.W", Wdg=g + "/att_trans/distribute/fork_gate_inputs.W",
             Whh=g + "/att_trans/transition.state_to_state", Whg=g + "/att_trans/transition.state_to_gates",
             h0=g + "/att_trans/transition.initial_state",
@@ -92,6 +93,7 @@ class SequenceGenerator(object):
             strides = dict(A_ts=B * d.E, A_bs=d.E, PA_ts=B * d.M, PA_bs=d.M, Am_ts=B, Am_bs=1)
         f = dict(Tp=Tp, B=B, L=L, E=d.E, D=d.D, M=d.M, K=d.K, c=d.c, prior_type=kind, step0=step0, phases=phases,
                  p0=pp[0], p1=pp[1], p2=pp[2], p3=pp[3], A=A, PA=PA, Am=Am, Ws_p=pk["Ws"], w_e=p[n["we"]],
+                 normalizer=NORMALIZER_KIND[d.normalizer], e_bias=p[n["eb"]] if d.energy_bias else None,
                  filters=p[n["filters"]] if d.conv else None, handler=p[n["handler"]] if d.conv else None,
                  Whg_p=pk["Whg"], Whh_p=pk["Whh"], Wdi_p=pk["Wdi"], Wdg_p=pk["Wdg"])
         f.update(strides)
@@ -164,7 +166,8 @@ class SequenceGenerator(object):
         Kc = max(d.K, 1)
         bufs = dict(xg=xg, ymask=ym, S=S, W=W,
                     pos=ws.get("gen.pos", (L + 1, B)) if (d.conv and self._prior()[0] != 0) else None,
-                    WA=ws.get("gen.WA", (L, B, d.E)), EN=ws.get("gen.EN", (L, B, Tp)), sW=ws.get("gen.sW", (L, B, d.M)),
+                    WA=ws.get("gen.WA", (L, B, d.E)), EN=ws.get("gen.EN", (L, B, Tp)), ZB=ws.get("gen.ZB", (L, B)),
+                    sW=ws.get("gen.sW", (L, B, d.M)),
                     CV=ws.get("gen.CV", (L, B, Kc, Tp)) if d.conv else None,
                     U=ws.get("gen.U", (L, B, d.D)), R=ws.get("gen.R", (L, B, d.D)), C=ws.get("gen.C", (L, B, d.D)),
                     RH=ws.get("gen.RH", (L, B, d.D)), sg=ws.get("gen.sg", (B, 2 * d.D)), xin=ws.get("gen.xin", (B, d.D)),
@@ -233,10 +236,11 @@ class SequenceGenerator(object):
         dPA = ws.get("gen.dPA", (Tp, B, d.M), zero=True)
         accH = ws.get("gen.accH", (B * ntile, Kc * d.M), zero=True)
         accWe = ws.get("gen.accWe", (B * ntile, d.M), zero=True)
+        accEb = ws.get("gen.accEb", (B * ntile, 1), zero=True)
         ds = ws.get("gen.ds", (B, d.D), zero=True)
         dalp = ws.get("gen.dalp", (B, Kc, Tp), zero=True)
         bw = lib.make("lvsr_attdec_bwd_args", WhhT_p=pk["WhhT"], WhgT_p=pk["WhgT"], WdT_p=pk["WdT"], WsT_p=pk["WsT"],
-                      dWA_r=dWA_r, dS_r=dS_r, DXG=DXG, DWA=DWA, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe,
+                      dWA_r=dWA_r, dS_r=dS_r, DXG=DXG, DWA=DWA, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe, accEb=accEb,
                       ds=ds, dalp=dalp, dspart=ws.get("gen.dspart", (B, d.D)), dsacc=ws.get("gen.dsacc", (B, d.D)),
                       Q=ws.get("gen.Q", (B, Tp)),
                       dcvp=ws.get("gen.dcvp", (B, nslice, Kc, Tp)) if d.conv else None,
@@ -274,6 +278,8 @@ class SequenceGenerator(object):
             lib.call("lvsr_scatter_add_rows", st, lib_ptr(dg), 3 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
                      lib_ptr(g[n["Wfg"]]), 2 * d.D, 0.0)
         lib.colsum(accWe, g[n["we"]].view(-1), ws=gws)
+        if d.energy_bias:
+            lib.colsum(accEb, g[n["eb"]], ws=gws)
         if d.conv:
             lib.colsum(accH, g[n["handler"]].view(-1), ws=gws)
             lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]), lib_ptr(gws),
@@ -343,7 +349,7 @@ def _generation_methods():
         Kc = max(d.K, 1)
         bufs = dict(xg=xg, ymask=None, S=Sb, W=Wb,
                     pos=ws.get("gs.pos" + tag, (2, n)) if (d.conv and self._prior()[0] != 0) else None,
-                    WA=ws.get("gs.WA" + tag, (1, n, d.E)), EN=ws.get("gs.EN" + tag, (1, n, Tp)),
+                    WA=ws.get("gs.WA" + tag, (1, n, d.E)), EN=ws.get("gs.EN" + tag, (1, n, Tp)), ZB=None,
                     sW=ws.get("gs.sW" + tag, (1, n, d.M)), CV=ws.get("gs.CV" + tag, (1, n, Kc, Tp)) if d.conv else None,
                     U=ws.get("gs.U" + tag, (1, n, d.D)), R=ws.get("gs.R" + tag, (1, n, d.D)),
                     C=ws.get("gs.C" + tag, (1, n, d.D)), RH=ws.get("gs.RH" + tag, (1, n, d.D)),

@@ -72,8 +72,11 @@ def normalize_net_config(cfg):
         out["prior"] = None
     if out["energy_normalizer"] is None:
         out["energy_normalizer"] = "softmax"
-    if out["energy_normalizer"] != "softmax":
-        raise NotImplementedError("energy_normalizer %r: only 'softmax' is built" % out["energy_normalizer"])
+    if out["energy_normalizer"] not in ("softmax", "logistic", "relu"):
+        # same error as the reference (lvsr/bricks/attention.py:203-205)
+        raise Exception("Unknown energey_normalizer: {}".format(out["energy_normalizer"]))
+    if out["attention_type"] == "content" :
+        out["energy_normalizer"] = "softmax"          # the Blocks content attention has no such option (recognizer.py:262-265)
     if out["post_merge_dims"] is not None:
         if len(out["post_merge_dims"]) != 1:
             raise NotImplementedError("only single-layer post_merge_dims is built")
@@ -118,6 +121,9 @@ class Dims(object):
             self.Pout = self.V
         self.post_merge = bool(cfg["post_merge_dims"])
         self.use_states_for_readout = bool(cfg["use_states_for_readout"])
+        self.normalizer = cfg["energy_normalizer"] if self.conv else "softmax"
+        # ShallowEnergyComputer(use_bias = energy_normalizer != 'softmax') (lvsr/bricks/attention.py:66-69)
+        self.energy_bias = self.normalizer != "softmax"
 
     def layer_input_dim(self, i):
         return self.F if i == 0 else 2 * self.Hs[i - 1]
@@ -149,6 +155,8 @@ def parameter_shapes(cfg):
     p[att + "/preprocess.b"] = (d.M,)
     p[att + "/state_trans/transform_states.W"] = (d.D, d.M)
     p[att + "/energy_comp/linear.W"] = (d.M, 1)
+    if d.energy_bias:
+        p[att + "/energy_comp/linear.b"] = (1,)
     if d.conv:
         p[att + "/conv1d.filters"] = (d.K, 2 * d.c + 1)
         p[att + "/handler.W"] = (d.K, d.M)

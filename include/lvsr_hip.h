@@ -100,7 +100,7 @@ typedef struct lvsr_attdec_args {
     int prior_type;                       /* 0 expanding, 1 window_around_mean, 2 window_around_median */
     int step0;                            /* value of the reference's `step` state at slot 0 */
     int phases;                           /* bit0: attention (glimpse) part, bit1: GRU part, of every step */
-    int pad0;
+    int normalizer;                       /* energy_normalizer: 0 softmax, 1 logistic, 2 relu (lvsr/bricks/attention.py:191-213) */
     double p0, p1, p2, p3;                /* expanding: initial_begin, initial_end, f32(min_speed), f32(max_speed); window_around_*: before, after */
     /* contexts; element (t,b,x) at base[t*ts + b*bs + x]; bs = 0 broadcasts one utterance (beam search) */
     const float* A; const float* PA; const float* Am;
@@ -108,6 +108,7 @@ typedef struct lvsr_attdec_args {
     /* attention parameters */
     const float* Ws_p;                    /* packed state_trans/transform_states.W (K=D,N=M) */
     const float* w_e;                     /* energy_comp/linear.W (M) */
+    const float* e_bias;                  /* energy_comp/linear.b (1) for the non-softmax normalisers, else NULL */
     const float* filters;                 /* conv1d.filters (K,2c+1) */
     const float* handler;                 /* handler.W (K,M) */
     /* decoder GRU parameters (packed) */
@@ -125,6 +126,7 @@ typedef struct lvsr_attdec_args {
     /* per-step outputs */
     float* WA;                            /* (L,B,E) weighted_averages */
     float* EN;                            /* (L,B,Tp) energies */
+    float* ZB;                            /* (L,B) normalisation constants (saved for backward) */
     /* saved for backward */
     float* sW;                            /* (L,B,M) transformed states */
     float* CV;                            /* (L,B,K,Tp) location-convolution features */
@@ -154,6 +156,7 @@ typedef struct lvsr_attdec_bwd_args {
     float* dPA;                           /* (Tp,B,M) in/out: accumulated gradient wrt preprocessed attended (caller zeroes) */
     float* accH;                          /* (B*ntile, K*M) in/out: per-work-group handler.W gradient partials (caller zeroes); ntile = ceil(Tp/64) */
     float* accWe;                         /* (B*ntile, M) in/out: per-work-group energy vector gradient partials (caller zeroes) */
+    float* accEb;                         /* (B*ntile) in/out: energy-bias gradient partials (caller zeroes) */
     float* ds;                            /* (B,D) in/out: running gradient wrt the state (caller zeroes; ends as grad wrt slot 0) */
     float* dalp;                          /* (B,K,Tp) in/out: running gradient wrt the alignment, one row per filter (caller zeroes) */
     float* dspart; float* dsacc;          /* (B,D) scratch */

@@ -176,6 +176,7 @@ class OracleRecognizer(object):
         Tp, B = A.shape[0], A.shape[1]
         sW = s @ p[self._att("state_trans/transform_states.W")]                       # (B,M)
         w_e = p[self._att("energy_comp/linear.W")][:, 0]
+        b_e = p[self._att("energy_comp/linear.b")][0] if d.energy_bias else 0.0      # blocks attention.py:417-431
         if not d.conv:
             match = PA + sW[None]
             e = torch.tanh(match) @ w_e                                               # (T',B)
@@ -187,9 +188,9 @@ class OracleRecognizer(object):
         c = d.c
         cv = conv1d_full(a_cut, p[self._att("conv1d.filters")])[:, :, c:a_cut.shape[1] + c]   # (B,K,Tc)
         match = PA[begin:end] + sW[None] + (cv.permute(2, 0, 1) @ p[self._att("handler.W")])
-        e_cut = torch.tanh(match) @ w_e                                               # (Tc,B)
+        e_cut = torch.tanh(match) @ w_e + b_e                                         # (Tc,B)
         m_cut = Am[begin:end] * (extra if extra is not None else 1)
-        a_new = self._weights(e_cut, m_cut)
+        a_new = self._weights(e_cut, m_cut, d.normalizer)
         wa = (a_new[:, :, None] * A[begin:end]).sum(0)
         alpha = torch.zeros(Tp, B, dtype=self.dtype)
         en = torch.zeros(Tp, B, dtype=self.dtype)
@@ -198,12 +199,19 @@ class OracleRecognizer(object):
         return wa, alpha.T, en.T
 
     @staticmethod
-    def _weights(e, mask):
-        """lvsr/bricks/attention.py:191-213 (softmax normaliser) == blocks attention.py:202-233."""
+    def _weights(e, mask, normalizer="softmax"):
+        """lvsr/bricks/attention.py:191-213 (softmax | logistic | relu normaliser); softmax == blocks attention.py:202-233."""
         if e.shape[0] == 0:
             return e
-        e = e - e.max(dim=0, keepdim=True)[0]
-        u = torch.exp(e) * mask
+        if normalizer == "softmax":
+            e = e - e.max(dim=0, keepdim=True)[0]
+            u = torch.exp(e) * mask
+        elif normalizer == "logistic":
+            u = torch.sigmoid(e) * mask
+        elif normalizer == "relu":
+            u = torch.clamp(e / 1000.0, min=0.0) * mask
+        else:
+            raise Exception("Unknown energey_normalizer: {}".format(normalizer))
         norm = u.sum(0) + (1 - mask).min(dim=0)[0].clamp(min=0).floor()   # all(1-mask) as 0/1
         return u / norm
 

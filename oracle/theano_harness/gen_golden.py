@@ -51,6 +51,7 @@ def build_reference(cfg):
         use_states_for_readout=c["use_states_for_readout"], attention_type=c["attention_type"],
         conv_n=c["conv_n"], conv_num_filters=c["conv_num_filters"], dim_matcher=c["dim_matcher"],
         prior=dict(c["prior"]) if c["prior"] else None, criterion={"name": "log_likelihood"},
+        energy_normalizer=c["energy_normalizer"] if c["attention_type"] == "content_and_conv" else None,
         bottom={"bottom_class": SpeechBottom, "activation": Rectifier(), "dims": []},
         post_merge_dims=c["post_merge_dims"],
         post_merge_activation=ACT[c["post_merge_activation"]]() if c["post_merge_dims"] else None,
@@ -185,6 +186,12 @@ CASES = {
     "tiny_conv_mean": lambda: run_case(
         "tiny_conv_mean", tiny_cfg(dict(type="window_around_mean", before=1.5, after=2.5)),
         B=3, T=13, L=5, ragged=True, param_seed=4, batch_seed=14),
+    "tiny_conv_logistic": lambda: run_case(
+        "tiny_conv_logistic", tiny_cfg(dict(type="window_around_mean", before=2, after=3), energy_normalizer="logistic"),
+        B=3, T=13, L=5, ragged=True, param_seed=21, batch_seed=31, beam=BEAMS[:2], analyze=True),
+    "tiny_conv_relu": lambda: run_case(
+        "tiny_conv_relu", tiny_cfg(None, energy_normalizer="relu", embed_outputs=True),
+        B=3, T=13, L=5, ragged=True, param_seed=23, batch_seed=32, beam=BEAMS[:1]),
     "tiny_content_embed": lambda: run_case(
         "tiny_content_embed",
         dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",
