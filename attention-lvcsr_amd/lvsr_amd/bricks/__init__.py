@@ -11,6 +11,59 @@ import os
 import torch
 
 
+class SpeechBottom(object):
+    """lvsr.bricks.recognizer.SpeechBottom (recognizer.py:105-157): Identity, or an MLP applied to every frame."""
+    ACT = {"identity": 0, "rectifier": 2, "tanh": 3}
+
+    def __init__(self, dims, store, lib, workspace):
+        self.d, self.store, self.lib, self.ws = dims, store, lib, workspace
+        self._saved = None
+
+    def apply(self, recordings, save_for_backward=True):
+        d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
+        if not d.bottom_dims:
+            return recordings
+        T, B = int(recordings.shape[0]), int(recordings.shape[1])
+        x = recordings.contiguous().view(T * B, d.F)
+        saved = []
+        for j, o in enumerate(d.bottom_dims):
+            z = ws.get("bottom%d.z" % j, (T * B, o))
+            lib.sgemm(x, p["/recognizer/bottom/bottom/linear_%d.W" % j], z, bias=p["/recognizer/bottom/bottom/linear_%d.b" % j])
+            a = ws.get("bottom%d.a" % j, (T * B, o))
+            lib.call("lvsr_act_fwd", lib.stream_for(a), self.ACT[d.bottom_act], native_ptr(z), o, T * B, o, native_ptr(a), o)
+            saved.append((x, z))
+            x = a
+        if save_for_backward:
+            self._saved = saved
+        return x.view(T, B, d.bottom_dims[-1])
+
+    def backward(self, d_out):
+        d, p, g, lib, ws = self.d, self.store.p, self.store.g, self.lib, self.ws
+        if not d.bottom_dims:
+            return
+        gws = ws.get("gemm_ws", (1 << 22,))
+        da = d_out.contiguous().view(-1, d.bottom_dims[-1])
+        n = int(da.shape[0])
+        for j in reversed(range(len(d.bottom_dims))):
+            x, z = self._saved[j]
+            o = d.bottom_dims[j]
+            dz = ws.get("bottom%d.dz" % j, (n, o))
+            lib.call("lvsr_act_bwd", lib.stream_for(dz), self.ACT[d.bottom_act], native_ptr(z), o, native_ptr(da), o, n, o,
+                     native_ptr(dz), o)
+            W = "/recognizer/bottom/bottom/linear_%d.W" % j
+            lib.sgemm(x, dz, g[W], transA=True, ws=gws)
+            lib.colsum(dz, g["/recognizer/bottom/bottom/linear_%d.b" % j], ws=gws)
+            if j > 0:
+                dx = ws.get("bottom%d.dx" % j, (n, int(x.shape[1])))
+                lib.sgemm(dz, p[W], dx, transB=True)
+                da = dx
+
+
+def native_ptr(t):
+    from ..native import ptr
+    return ptr(t)
+
+
 class Encoder(object):
     def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=False):
         self.use_persistent = bool(use_persistent) and not lib.is_emulator      # needs co-resident work-groups
@@ -145,8 +198,9 @@ class Encoder(object):
             self._saved = saved
         return x, m
 
-    def backward(self, d_encoded):
-        """d_encoded (T',B,2H_last): gradient wrt `encoded`.  Writes the encoder parameter gradients."""
+    def backward(self, d_encoded, need_input_grad=False):
+        """d_encoded (T',B,2H_last): gradient wrt `encoded`.  Writes the encoder parameter gradients; returns the gradient
+        wrt the encoder input when `need_input_grad` (a bottom MLP sits in front), else None."""
         d, p, g, lib, ws = self.d, self.store.p, self.store.g, self.lib, self.ws
         assert self._saved is not None, "apply() must run first"
         gemm_ws = ws.get("gemm_ws", (1 << 22,))
@@ -175,7 +229,7 @@ class Encoder(object):
             y2 = sv["y"].view(T * B, 2 * H)
             rh2 = sv["rh"].view(T * B, 2 * H)
             dx = None
-            if i > 0:
+            if i > 0 or need_input_grad:
                 dx = ws.get("enc%d.dx" % i, (T, B, I))
             # critical path first: the gradient wrt this layer's input is what the next (lower) layer's recurrence waits for
             for di, direction in enumerate(("forward", "backward")):
@@ -212,4 +266,4 @@ class Encoder(object):
                     lib.colsum(dg, g[n["bg"]], ws=side_ws)
             dy = dx
         self.join_side_stream()
-        return None
+        return dy

@@ -14,7 +14,7 @@ import torch
 
 from .. import spec
 from ..params import ParameterStore, Workspace
-from . import Encoder
+from . import Encoder, SpeechBottom
 from .generator import SequenceGenerator
 
 
@@ -37,6 +37,7 @@ class SpeechRecognizer(object):
         self.store = ParameterStore(cfg, self.device, params)
         self.ws = Workspace(self.device)
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
+        self.bottom = SpeechBottom(self.d, self.store, self.lib, self.ws)
         self.encoder = Encoder(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph, use_persistent=use_persistent)
         self.generator = SequenceGenerator(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph)
         # hipGraph capture cannot run on the legacy null stream: the hot path owns a side stream
@@ -130,7 +131,8 @@ class SpeechRecognizer(object):
             xm = self._t(inputs_mask, torch.float32, "recordings_mask")
             y = self._t(labels, torch.int64, "labels")
             ym = self._t(labels_mask, torch.float32, "labels_mask")
-            encoded, encoded_mask = self.encoder.apply(x, xm, save_for_backward=save_for_backward)
+            encoded, encoded_mask = self.encoder.apply(self.bottom.apply(x, save_for_backward), xm,
+                                                       save_for_backward=save_for_backward)
             self.encoded, self.encoded_mask = encoded, encoded_mask
             cm = self.generator.cost_matrix(y, ym, attended=encoded, attended_mask=encoded_mask,
                                             save_for_backward=save_for_backward)
@@ -140,7 +142,9 @@ class SpeechRecognizer(object):
         """Gradient of cost.sum() wrt all parameters -> self.store.grad (flat) / self.store.g (named views)."""
         with self._on_stream():
             d_encoded = self.generator.backward()
-            self.encoder.backward(d_encoded)
+            d_bottom = self.encoder.backward(d_encoded, need_input_grad=bool(self.d.bottom_dims))
+            if self.d.bottom_dims:
+                self.bottom.backward(d_bottom)
 
     def cost_and_gradients(self, batch):
         """One training forward+backward on a batch dict in the reference's layout.
@@ -169,7 +173,7 @@ class SpeechRecognizer(object):
         if x.ndim == 2:
             x = x[:, None, :]
         xb = self._t(x, torch.float32, "recordings")
-        encoded, encoded_mask = self.encoder.apply(xb, None, save_for_backward=False)
+        encoded, encoded_mask = self.encoder.apply(self.bottom.apply(xb, False), None, save_for_backward=False)
         self.generator.init_generation(encoded, encoded_mask)
 
     def init_beam_search(self, beam_size):

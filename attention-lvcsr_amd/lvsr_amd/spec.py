@@ -34,6 +34,8 @@ _DEFAULTS = dict(
     use_states_for_readout=True,
     data_prepend_eos=True,
     max_decoded_length_scale=1,
+    bottom_dims=None,          # SpeechBottom(dims=...): MLP in front of the encoder (recognizer.py:105-126); None/[] = Identity
+    bottom_activation="tanh",  # SpeechBottom default Tanh() (recognizer.py:116-117); the configs use Rectifier
 )
 
 DEFAULT_PRIOR = dict(type="expanding", initial_begin=0, initial_end=10000, min_speed=0, max_speed=0)
@@ -77,6 +79,9 @@ def normalize_net_config(cfg):
         raise Exception("Unknown energey_normalizer: {}".format(out["energy_normalizer"]))
     if out["attention_type"] == "content" :
         out["energy_normalizer"] = "softmax"          # the Blocks content attention has no such option (recognizer.py:262-265)
+    out["bottom_dims"] = [int(v) for v in (out["bottom_dims"] or [])]
+    if out["bottom_dims"] and out["bottom_activation"] not in ("rectifier", "tanh", "identity"):
+        raise NotImplementedError("bottom activation %r is not built" % out["bottom_activation"])
     if out["post_merge_dims"] is not None:
         if len(out["post_merge_dims"]) != 1:
             raise NotImplementedError("only single-layer post_merge_dims is built")
@@ -94,6 +99,9 @@ class Dims(object):
         cfg = normalize_net_config(cfg)
         self.cfg = cfg
         self.F = cfg["input_dim"]
+        self.bottom_dims = list(cfg["bottom_dims"])
+        self.bottom_act = cfg["bottom_activation"]
+        self.F_enc = self.bottom_dims[-1] if self.bottom_dims else self.F      # what the first BiGRU layer sees
         self.Hs = list(cfg["dims_bidir"])
         self.subsample = list(cfg["subsample"])
         self.n_layers = len(self.Hs)
@@ -126,7 +134,7 @@ class Dims(object):
         self.energy_bias = self.normalizer != "softmax"
 
     def layer_input_dim(self, i):
-        return self.F if i == 0 else 2 * self.Hs[i - 1]
+        return self.F_enc if i == 0 else 2 * self.Hs[i - 1]
 
     def subsampled_length(self, T):
         for s in self.subsample:
@@ -138,6 +146,9 @@ def parameter_shapes(cfg):
     """name -> shape, names exactly as the reference's Model.get_parameter_dict()."""
     d = Dims(cfg)
     p = OrderedDict()
+    for j, (i_, o_) in enumerate(zip([d.F] + d.bottom_dims[:-1], d.bottom_dims)):
+        p["/recognizer/bottom/bottom/linear_%d.W" % j] = (i_, o_)           # MLP named "bottom" inside the bottom brick
+        p["/recognizer/bottom/bottom/linear_%d.b" % j] = (o_,)
     for i, H in enumerate(d.Hs):
         I = d.layer_input_dim(i)
         for direction in ("forward", "backward"):
@@ -276,8 +287,17 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
         raise NotImplementedError("dims_top (MLP on top of the encoder) is not built")
     if dec_stack != 1:
         raise NotImplementedError("dec_stack > 1 is not built")
-    if bottom is not None and dict(bottom).get("dims"):
-        raise NotImplementedError("bottom MLP (bottom.dims) is not built")
+    bottom_dims, bottom_act = None, "tanh"
+    if bottom is not None:
+        bt = dict(bottom)
+        bc = _brick_name(bt.get("bottom_class"))
+        if bc is not None and bc != "SpeechBottom":
+            raise NotImplementedError("bottom_class=%s: only SpeechBottom is built" % bc)
+        bottom_dims = bt.get("dims") or None
+        if bottom_dims:
+            bottom_act = _activation_name(bt.get("activation"))
+            if bottom_act == "maxout2":
+                raise NotImplementedError("Maxout in the bottom MLP is not built")
     if isinstance(input_dims, dict):
         if list(input_dims) != ["recordings"]:
             raise NotImplementedError("only the 'recordings' input source is built")
@@ -289,7 +309,7 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
                conv_n=conv_n, conv_num_filters=conv_num_filters, prior=prior, energy_normalizer=energy_normalizer,
                post_merge_dims=post_merge_dims, embed_outputs=embed_outputs, dim_output_embedding=dim_output_embedding,
                use_states_for_readout=use_states_for_readout, data_prepend_eos=data_prepend_eos,
-               max_decoded_length_scale=max_decoded_length_scale)
+               max_decoded_length_scale=max_decoded_length_scale, bottom_dims=bottom_dims, bottom_activation=bottom_act)
     if post_merge_dims:
         cfg["post_merge_activation"] = _activation_name(post_merge_activation)
     return normalize_net_config(cfg)

@@ -107,9 +107,17 @@ class OracleRecognizer(object):
             self.p[k] = torch.tensor(v, dtype=dtype, requires_grad=True)
 
     # -- encoder: lvsr/bricks/__init__.py:54-78 ------------------------------------------------
+    def bottom(self, x):
+        """SpeechBottom.apply (lvsr/bricks/recognizer.py:105-137): MLP([activation]*len(dims), [F]+dims) or Identity."""
+        d, p = self.d, self.p
+        act = {"rectifier": torch.relu, "tanh": torch.tanh, "identity": lambda v: v}[d.bottom_act]
+        for j in range(len(d.bottom_dims)):
+            x = act(x @ p["/recognizer/bottom/bottom/linear_%d.W" % j] + p["/recognizer/bottom/bottom/linear_%d.b" % j])
+        return x
+
     def encode(self, x, x_mask):
         p, d = self.p, self.d
-        h = x
+        h = self.bottom(x)
         m = x_mask
         for i, s in enumerate(d.subsample):
             outs = []

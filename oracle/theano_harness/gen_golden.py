@@ -52,7 +52,8 @@ def build_reference(cfg):
         conv_n=c["conv_n"], conv_num_filters=c["conv_num_filters"], dim_matcher=c["dim_matcher"],
         prior=dict(c["prior"]) if c["prior"] else None, criterion={"name": "log_likelihood"},
         energy_normalizer=c["energy_normalizer"] if c["attention_type"] == "content_and_conv" else None,
-        bottom={"bottom_class": SpeechBottom, "activation": Rectifier(), "dims": []},
+        bottom={"bottom_class": SpeechBottom, "activation": ACT[c["bottom_activation"]]() if c["bottom_dims"] else Rectifier(),
+                "dims": list(c["bottom_dims"])},
         post_merge_dims=c["post_merge_dims"],
         post_merge_activation=ACT[c["post_merge_activation"]]() if c["post_merge_dims"] else None,
         embed_outputs=c["embed_outputs"], dim_output_embedding=c["dim_output_embedding"],
@@ -192,6 +193,10 @@ CASES = {
     "tiny_conv_relu": lambda: run_case(
         "tiny_conv_relu", tiny_cfg(None, energy_normalizer="relu", embed_outputs=True),
         B=3, T=13, L=5, ragged=True, param_seed=23, batch_seed=32, beam=BEAMS[:1]),
+    "tiny_conv_bottom": lambda: run_case(
+        "tiny_conv_bottom", tiny_cfg(dict(type="window_around_median", before=2, after=2), bottom_dims=[6, 4],
+                                     bottom_activation="rectifier"),
+        B=3, T=13, L=5, ragged=True, param_seed=24, batch_seed=33, beam=BEAMS[:1]),
     "tiny_content_embed": lambda: run_case(
         "tiny_content_embed",
         dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",

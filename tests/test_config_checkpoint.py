@@ -43,8 +43,11 @@ def test_unsupported_bricks_raise_not_silently_fall_back():
     base = dict(input_dims={"recordings": 40}, num_phonemes=10, dim_dec=8, dims_bidir=[4],
                 enc_transition=blocks_compat.GatedRecurrent, dec_transition=blocks_compat.GatedRecurrent)
     spec.from_reference_kwargs(**base)
+    ok = spec.from_reference_kwargs(bottom={"bottom_class": blocks_compat.SpeechBottom, "dims": [100],
+                                            "activation": blocks_compat.Rectifier()}, **base)
+    assert ok["bottom_dims"] == [100] and ok["bottom_activation"] == "rectifier"
     for bad in (dict(enc_transition=blocks_compat.SimpleRecurrent), dict(dims_top=[5]), dict(dec_stack=2),
-                dict(bottom={"dims": [100]}), dict(bidir=False)):
+                dict(bottom={"bottom_class": blocks_compat.LookupBottom}), dict(bidir=False)):
         kw = dict(base)
         kw.update(bad)
         with pytest.raises(NotImplementedError):
