@@ -1,0 +1,59 @@
+"""Batch pipeline semantics (lvsr/datasets/__init__.py:253-310) and a few training steps driven by it on the emulated
+recognizer (loss goes down)."""
+import numpy
+import torch
+
+from lvsr_amd.data import ArrayDataset, Data
+
+
+def _dataset(n=11, F=5, V=6, seed=0):
+    rng = numpy.random.RandomState(seed)
+    recs = [rng.normal(size=(rng.randint(6, 14), F)) for _ in range(n)]
+    labs = [rng.randint(0, V - 1, size=rng.randint(2, 5)) for _ in range(n)]
+    return ArrayDataset(recs, labs, num_characters=V, bos_label=V - 2)
+
+
+def test_layout_eos_bos_filter_and_sorting():
+    ds = _dataset()
+    data = Data({"train": ds, "valid": ds}, batch_size=4, validation_batch_size=3, sort_k_batches=2, max_length=12, add_bos=2)
+    batches = list(data.get_stream("train", shuffle=False))
+    kept = [i for i in range(ds.num_examples) if len(ds.recordings[i]) <= 12]
+    assert sum(b["labels"].shape[1] for b in batches) == len(kept)
+    for b in batches:
+        T, B, F = b["recordings"].shape
+        assert b["recordings"].dtype == numpy.float32 and b["labels"].dtype == numpy.int64
+        assert b["recordings"].flags["C_CONTIGUOUS"] and b["recordings_mask"].shape == (T, B)
+        assert B <= 4 and (b["recordings_mask"].sum(0) >= 1).all()
+        for j in range(B):
+            t = int(b["recordings_mask"][:, j].sum()); l = int(b["labels_mask"][:, j].sum())
+            assert (b["recordings"][t:, j] == 0).all() and (b["labels"][l:, j] == 0).all()      # zero padding
+            assert (b["labels"][:2, j] == ds.bos_label).all() and b["labels"][l - 1, j] == ds.eos_label
+    # sort-k: within every group of batch_size*k consecutive examples the input lengths are non-decreasing
+    lens = [int(b["recordings_mask"][:, j].sum()) for b in batches for j in range(b["labels"].shape[1])]
+    for g in range(0, len(lens), 8):
+        grp = lens[g: g + 8]
+        assert grp == sorted(grp)
+    valid = list(data.get_stream("valid", shuffle=False))
+    assert valid[0]["labels"].shape[1] == 3                                     # validation batch size
+    ex = list(data.get_stream("train", batches=False, shuffle=True, seed=1))
+    assert len(ex) == len(kept) and ex[0][0].ndim == 2
+
+
+def test_training_on_the_pipeline_reduces_the_cost():
+    from emu import emu_lib
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    from lvsr_amd.training import Trainer
+    ds = _dataset(n=6)
+    data = Data({"train": ds}, batch_size=3)
+    cfg = dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",
+               post_merge_dims=None, embed_outputs=True, data_prepend_eos=False)
+    rec = SpeechRecognizer(device="cpu", params=synthetic.make_params(cfg, seed=3, scale=0.5), lib=emu_lib(), net_config=cfg)
+    tr = Trainer(rec, gradient_threshold=10.0, rules=("momentum",), scale=0.05, momentum=0.0, distributed=False)
+    costs = []
+    for epoch in range(6):
+        tot = 0.0
+        for batch in data.get_stream("train", shuffle=False):
+            tot += float(tr.train_step(batch).sum())
+        costs.append(tot)
+    assert costs[-1] < costs[0] * 0.95, costs
