@@ -17,6 +17,14 @@ typedef lvsr_attdec_args AttDec;
 #define ATT_MAX_KT 16384     // conv_num_filters * attended length held in LDS (energy kernels)
 #define ATT_MAX_KF 8192      // conv_num_filters * filter width held in LDS
 
+// compile-time filter-loop bound used for K conv filters: the smallest instantiated value >= K
+inline int att_kc(int K) {
+    const int inst[7] = {0, 1, 2, 4, 8, 10, 16};
+    for (int i = 0; i < 7; ++i)
+        if (K <= inst[i]) return inst[i];
+    return 16;
+}
+
 struct Win { int begin, end; };
 int attdec_check(const AttDec& a, const char* what);
 

@@ -89,42 +89,50 @@ __global__ __launch_bounds__(256) void attbwd_gru_b_kernel(AttBwd g, int i) {
     }
 }
 
-// B3: q[b,t] = dwa[b,:] . A[t,b,:] + dalpha[b,t]   (0 outside the window); one wave per (b,t)
+// B3: q[b,t] = dwa[b,:] . A[t,b,:] + sum_k dalp[b,k,t]   (0 outside the window).  One wave per (b,t), 4 per work-group:
+// every lane issues its (up to 4) 16-byte loads of the attended row and of dwa at once; the K rows of the alignment
+// gradient ride along in lanes 0..K-1 of the same wave reduction.
 __global__ __launch_bounds__(256) void attbwd_q_kernel(AttBwd g, int i) {
     const AttDec& a = g.f;
-    const int b = blockIdx.y, t0 = blockIdx.x * ATT_TB, B = a.B, Tp = a.Tp, E = a.E;
-    const Win w = attdec_window(a, i);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* dwa = g.DWA + ((size_t)i * B + b) * E;
-    for (int tt = wave; tt < ATT_TB; tt += 4) {
-        const int t = t0 + tt;
-        if (t >= Tp) break;
-        float q = 0.f;
-        if (t >= w.begin && t < w.end) {
-            const float* ar = a.A + (size_t)t * a.A_ts + (size_t)b * a.A_bs;
-            const bool vec = ((E & 3) == 0) && ((((size_t)ar | (size_t)dwa) & 15) == 0);
-            float q1 = 0.f;
-            int e = lane * 4;
-            for (; e + 256 < E; e += 512) {             // two independent 16-B loads per lane in flight
-                const float4 x0 = ld4g(ar + e, E - e, vec), y0 = ld4g(dwa + e, E - e, vec);
-                const float4 x1 = ld4g(ar + e + 256, E - e - 256, vec), y1 = ld4g(dwa + e + 256, E - e - 256, vec);
-                q += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
-                q1 += x1.x * y1.x + x1.y * y1.y + x1.z * y1.z + x1.w * y1.w;
-            }
-            for (; e < E; e += 256) {
-                const float4 x0 = ld4g(ar + e, E - e, vec), y0 = ld4g(dwa + e, E - e, vec);
-                q += x0.x * y0.x + x0.y * y0.y + x0.z * y0.z + x0.w * y0.w;
-            }
-            q = wave_sum(q + q1);
-            for (int k = 0; k < a.K; ++k) q += g.dalp[((size_t)b * a.K + k) * Tp + t];
+    const int b = blockIdx.y, t = blockIdx.x * 4 + wave, B = a.B, Tp = a.Tp, E = a.E;
+    if (t >= Tp) return;
+    const Win w = attdec_window(a, i);
+    float q = 0.f;
+    if (t >= w.begin && t < w.end) {
+        const float* dwa = g.DWA + ((size_t)i * B + b) * E;
+        const float* ar = a.A + (size_t)t * a.A_ts + (size_t)b * a.A_bs;
+        const bool vec = ((E & 3) == 0) && ((((size_t)ar | (size_t)dwa) & 15) == 0);
+        float4 x[4], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = lane * 4 + r * 256;
+            x[r] = ld4g(ar + e, E - e, vec);
+            y[r] = ld4g(dwa + e, E - e, vec);
         }
-        if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
+        const float dal = lane < a.K ? g.dalp[((size_t)b * a.K + lane) * Tp + t] : 0.f;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            q0 += x[r].x * y[r].x + x[r].y * y[r].y + x[r].z * y[r].z + x[r].w * y[r].w;
+            q1 += x[r + 1].x * y[r + 1].x + x[r + 1].y * y[r + 1].y + x[r + 1].z * y[r + 1].z + x[r + 1].w * y[r + 1].w;
+        }
+        q = q0 + q1;
+        for (int e = lane * 4 + 1024; e < E; e += 256) {          // E > 1024: remaining columns
+            const float4 xx = ld4g(ar + e, E - e, vec), yy = ld4g(dwa + e, E - e, vec);
+            q += xx.x * yy.x + xx.y * yy.y + xx.z * yy.z + xx.w * yy.w;
+        }
+        q = wave_sum(q + dal);
     }
+    if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
 }
 
 // B4: softmax backward + energy backward.  Grid (ceil(M/32), B, ceil(T'/64)), same decomposition as the forward
 // energy kernel.  Sums over positions (dsW, handler / energy-vector gradients) leave as per-tile partials, sums
 // over the match dimension (dcv) as per-slice partials; both are folded in a fixed order by their consumers.
+// KC = compile-time bound of the filter loops: K itself when an instantiation exists (no predication: the element loop is
+// VALU-issue bound, measured 9.4 of the kernel's 20 us at K = 10 with 16 predicated iterations), else the next larger one.
+template <int KC>
 __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     __shared__ float cvs[ATT_KMAX][ATT_TT];
     __shared__ float des[ATT_TT];
@@ -155,9 +163,9 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
         pav[r] = ok ? pab[(size_t)t * a.PA_ts] : 0.f;
         dpv[r] = ok ? dpab[(size_t)t * dpa_ts] : 0.f;
     }
-    float Hk[ATT_KMAX], hacc[ATT_KMAX];
+    float Hk[KC > 0 ? KC : 1], hacc[KC > 0 ? KC : 1];
 #pragma unroll
-    for (int k = 0; k < ATT_KMAX; ++k) {
+    for (int k = 0; k < KC; ++k) {
         Hk[k] = (k < K && mok) ? a.handler[(size_t)k * M + m] : 0.f;
         hacc[k] = 0.f;
     }
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     }
     if (tg == 0) {
 #pragma unroll
-        for (int k = 0; k < ATT_KMAX; ++k) Hs[k][ml] = Hk[k];
+        for (int k = 0; k < KC; ++k) Hs[k][ml] = Hk[k];
     }
     __syncthreads();
     float swacc = 0.f, weacc = 0.f;
@@ -201,8 +209,8 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
         if (t >= w.begin && t < w.end && mok) {
             float x = pav[r] + sw_m;
 #pragma unroll
-            for (int k = 0; k < ATT_KMAX; ++k)
-                if (k < K) x += cvs[k][tl] * Hk[k];
+            for (int k = 0; k < KC; ++k)
+                if (KC == K || k < K) x += cvs[k][tl] * Hk[k];
             const float th = tanhf(x);
             const float de = des[tl];
             d = de * we_m * (1.f - th * th);
@@ -210,8 +218,8 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
             swacc += d;
             weacc += de * th;
 #pragma unroll
-            for (int k = 0; k < ATT_KMAX; ++k)
-                if (k < K) hacc[k] += cvs[k][tl] * d;
+            for (int k = 0; k < KC; ++k)
+                if (KC == K || k < K) hacc[k] += cvs[k][tl] * d;
         }
         dms[tl][ml] = d;
     }
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     racc[tg][0][ml] = swacc;
     racc[tg][1][ml] = weacc;
 #pragma unroll
-    for (int k = 0; k < ATT_KMAX; ++k) racc[tg][2 + k][ml] = hacc[k];
+    for (int k = 0; k < KC; ++k) racc[tg][2 + k][ml] = hacc[k];
     __syncthreads();
     float* dcvp = K > 0 ? g.dcvp + ((size_t)b * nslice + slice) * K * Tp : nullptr;
     for (int x = threadIdx.x; x < ATT_TT * K; x += 256) {
@@ -255,6 +263,7 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i >= nrows || k >= M) return v;
         const float* p = dswp + (size_t)i * ntile * M + k;
+#pragma unroll 4
         for (int c = 0; c < ntile; ++c) {
             const float4 x = ld4g(p + (size_t)c * M, M - k, vec);
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
@@ -397,8 +406,16 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
         for (int i = a.L - 1; i >= 0; --i) {
             hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
             hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
-            hipLaunchKernelGGL(attbwd_q_kernel, dim3(nchunk, a.B), dim3(256), 0, s, g, i);
-            hipLaunchKernelGGL(attbwd_energy_kernel, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_q_kernel, dim3((a.Tp + 3) / 4, a.B), dim3(256), 0, s, g, i);
+            switch (att_kc(a.K)) {
+                case 0: hipLaunchKernelGGL(attbwd_energy_kernel<0>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+                case 1: hipLaunchKernelGGL(attbwd_energy_kernel<1>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+                case 2: hipLaunchKernelGGL(attbwd_energy_kernel<2>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+                case 4: hipLaunchKernelGGL(attbwd_energy_kernel<4>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+                case 8: hipLaunchKernelGGL(attbwd_energy_kernel<8>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+                case 10: hipLaunchKernelGGL(attbwd_energy_kernel<10>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+                default: hipLaunchKernelGGL(attbwd_energy_kernel<16>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+            }
             hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + a.B * a.K), dim3(256), 0, s, g, i);
         }
     };

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
 // issues all of its loads (handler column, 8 PA values, conv features) before the first use, and ~4 work-groups
 // share a CU so their latencies overlap.  The slice's partial energies go to `ep`; the glimpse kernel folds the
 // slices in a fixed order.
+template <int KC>      // compile-time bound of the filter loop, see att_kc()
 __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
     __shared__ float cvs[ATT_KMAX][ATT_TT];
     __shared__ float cs[ATT_TT][ATT_MS + 1];
@@ -127,9 +128,9 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
         const int t = t0 + tg + 8 * r;
         pav[r] = (t >= w.begin && t < w.end && mok) ? pab[(size_t)t * a.PA_ts] : 0.f;
     }
-    float Hk[ATT_KMAX];
+    float Hk[KC > 0 ? KC : 1];
 #pragma unroll
-    for (int k = 0; k < ATT_KMAX; ++k) Hk[k] = (k < K && mok) ? a.handler[(size_t)k * M + m] : 0.f;
+    for (int k = 0; k < KC; ++k) Hk[k] = (k < K && mok) ? a.handler[(size_t)k * M + m] : 0.f;
     const float we_m = mok ? a.w_e[m] : 0.f;
     const float sw_m = mok ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
     for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
@@ -144,8 +145,8 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
         if (t >= w.begin && t < w.end && mok) {
             float x = pav[r] + sw_m;
 #pragma unroll
-            for (int k = 0; k < ATT_KMAX; ++k)
-                if (k < K) x += cvs[k][tl] * Hk[k];
+            for (int k = 0; k < KC; ++k)
+                if (KC == K || k < K) x += cvs[k][tl] * Hk[k];
             c = we_m * tanhf(x);
         }
         cs[tl][ml] = c;
@@ -162,15 +163,28 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
     }
 }
 
-// masked softmax over the window + glimpse; grid (ceil(E/128), B).  Chunk 0 also writes the new alignment
+// masked softmax over the window + glimpse; grid (ceil(E/32), B).  Chunk 0 also writes the new alignment
 // row (pasted into zeros) and the next window centre.
 __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float al[ATT_MAX_T];
     __shared__ float red[4];
-    __shared__ float part[8][132];
+    __shared__ float part[32][33];
     const int b = blockIdx.y, chunk = blockIdx.x, B = a.B, Tp = a.Tp, E = a.E;
     const Win w = attdec_window(a, i);
     __shared__ float en[ATT_MAX_T];
+    // The attended rows do not depend on the alignment: fetch this thread's share (8 float4 = the first 256 positions of
+    // the window) before the softmax, so the stream's latency hides behind it.  Block = 32 columns x 32 position groups.
+    const int cg = threadIdx.x & 7, tg = threadIdx.x >> 3;
+    const int col = chunk * 32 + cg * 4;
+    const float* Ab = a.A + (size_t)b * a.A_bs + col;
+    const bool vec = ((a.A_ts & 3) == 0) && ((a.A_bs & 3) == 0) && ((((size_t)a.A) & 15) == 0);
+    const int nvalid = E - col;
+    float4 pv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int t = w.begin + tg + 32 * r;
+        pv[r] = t < w.end ? ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int nslice = (a.M + ATT_MS - 1) / ATT_MS;
     const float* ep = a.ep + (size_t)b * nslice * Tp;
     const float eb = a.e_bias ? a.e_bias[0] : 0.f;
@@ -217,37 +231,26 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
         for (int t = threadIdx.x; t < Tp; t += 256) wn[t] = al[t];
         if (a.K > 0 && a.prior_type != 0 && threadIdx.x == 0) a.pos[(size_t)(i + 1) * B + b] = attdec_pos_of_row(a, al);
     }
-    const int cg = threadIdx.x & 31, tg = threadIdx.x >> 5;
-    const int col = chunk * 128 + cg * 4;
-    const float* Ab = a.A + (size_t)b * a.A_bs + col;
-    const bool vec = ((a.A_ts & 3) == 0) && ((a.A_bs & 3) == 0) && ((((size_t)a.A) & 15) == 0);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int nvalid = E - col;
-    {
-        float4 acc2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        int t = w.begin + tg;
-        for (; t + 8 < w.end; t += 16) {               // two independent 16-B loads in flight per thread
-            const float4 v0 = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
-            const float4 v1 = ld4g(Ab + (size_t)(t + 8) * a.A_ts, nvalid, vec);
-            const float p0 = al[t], p1 = al[t + 8];
-            acc.x += p0 * v0.x; acc.y += p0 * v0.y; acc.z += p0 * v0.z; acc.w += p0 * v0.w;
-            acc2.x += p1 * v1.x; acc2.y += p1 * v1.y; acc2.z += p1 * v1.z; acc2.w += p1 * v1.w;
-        }
-        for (; t < w.end; t += 8) {
-            const float4 v = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
-            const float p = al[t];
-            acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
-        }
-        acc.x += acc2.x; acc.y += acc2.y; acc.z += acc2.z; acc.w += acc2.w;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int t = w.begin + tg + 32 * r;
+        const float p = t < w.end ? al[t] : 0.f;
+        acc.x += p * pv[r].x; acc.y += p * pv[r].y; acc.z += p * pv[r].z; acc.w += p * pv[r].w;
+    }
+    for (int t = w.begin + tg + 256; t < w.end; t += 32) {          // windows longer than 256 positions
+        const float4 v = ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec);
+        const float p = al[t];
+        acc.x += p * v.x; acc.y += p * v.y; acc.z += p * v.z; acc.w += p * v.w;
     }
     part[tg][cg * 4 + 0] = acc.x; part[tg][cg * 4 + 1] = acc.y; part[tg][cg * 4 + 2] = acc.z; part[tg][cg * 4 + 3] = acc.w;
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int c2 = chunk * 128 + threadIdx.x;
+    if (threadIdx.x < 32) {
+        const int c2 = chunk * 32 + threadIdx.x;
         if (c2 < E) {
             float r = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) r += part[g][threadIdx.x];
+            for (int g = 0; g < 32; ++g) r += part[g][threadIdx.x];
             a.WA[((size_t)i * B + b) * E + c2] = r;
         }
     }
@@ -335,8 +338,17 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
             if (g.nmm + g.nconv > 0)
                 hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm + g.nconv), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
-                hipLaunchKernelGGL(attdec_energy_kernel, dim3((a.M + ATT_MS - 1) / ATT_MS, a.B, (a.Tp + ATT_TT - 1) / ATT_TT), dim3(256), 0, s, a, i);
-                hipLaunchKernelGGL(attdec_glimpse_kernel, dim3((a.E + 127) / 128, a.B), dim3(256), 0, s, a, i);
+                const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
+                switch (att_kc(a.K)) {
+                    case 0: hipLaunchKernelGGL(attdec_energy_kernel<0>, eg, dim3(256), 0, s, a, i); break;
+                    case 1: hipLaunchKernelGGL(attdec_energy_kernel<1>, eg, dim3(256), 0, s, a, i); break;
+                    case 2: hipLaunchKernelGGL(attdec_energy_kernel<2>, eg, dim3(256), 0, s, a, i); break;
+                    case 4: hipLaunchKernelGGL(attdec_energy_kernel<4>, eg, dim3(256), 0, s, a, i); break;
+                    case 8: hipLaunchKernelGGL(attdec_energy_kernel<8>, eg, dim3(256), 0, s, a, i); break;
+                    case 10: hipLaunchKernelGGL(attdec_energy_kernel<10>, eg, dim3(256), 0, s, a, i); break;
+                    default: hipLaunchKernelGGL(attdec_energy_kernel<16>, eg, dim3(256), 0, s, a, i); break;
+                }
+                hipLaunchKernelGGL(attdec_glimpse_kernel, dim3((a.E + 31) / 32, a.B), dim3(256), 0, s, a, i);
             }
             if (a.phases & 2) {
                 hipLaunchKernelGGL(attdec_gru1_kernel, dim3((a.D + 15) / 16 + (2 * a.D + 15) / 16, g.rt), dim3(256), 0, s, a, i);
