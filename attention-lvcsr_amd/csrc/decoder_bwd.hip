@@ -256,8 +256,9 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     }
 }
 
-struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of the per-work-group partials
-    const float* dswp; float* store; int ntile, M, nrows; bool vec, fast;
+struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of the per-work-group partials (read only:
+                     // a store inside the functor would order every later operand load behind it)
+    const float* __restrict__ dswp; int ntile, M, nrows; bool vec, fast;
     template <bool FAST>
     __device__ __forceinline__ float4 get(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -268,18 +269,12 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of 
             const float4 x = ld4g(p + (size_t)c * M, M - k, vec);
             v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
         }
-        if (store) {
-            float* s = store + (size_t)i * M + k;
-            s[0] = v.x;
-            if (k + 1 < M) s[1] = v.y;
-            if (k + 2 < M) s[2] = v.z;
-            if (k + 3 < M) s[3] = v.w;
-        }
         return v;
     }
 };
 
-// B5: new running gradients.  Blocks [0, nmm): ds = dsacc + dsW @ Ws^T + dS_r[i] (tile 0 also stores DSW[i]);
+// B5: new running gradients.  Blocks [0, nmm): ds = dsacc + dsW @ Ws^T + dS_r[i]; blocks [nmm, nmm+nfold): fold the
+// per-tile dsW partials into DSW[i] (kept for the transform_states weight gradient);
 // remaining blocks, one per (utterance b, filter k): fold the per-slice dcv partials of row k (stored as DCV[i]
 // for the filter gradient) and correlate with filter k inside the window:
 //   dalp[b,k,t] = sum_d f[k,c+d] * dcv[k,t+d];   the q kernel of the next (earlier) step adds the K rows up.
@@ -299,7 +294,6 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         if (ok && g.dS_r) base += g.dS_r[((size_t)i * B + b) * D + j];
         DswSrc src;
         src.dswp = g.dswp + (size_t)b0 * ntile * M;
-        src.store = tile == 0 ? g.DSW + ((size_t)i * B + b0) * M : nullptr;
         src.ntile = ntile; src.M = M; src.nrows = B - b0;
         src.vec = ((M & 3) == 0) && ((((size_t)src.dswp) & 15) == 0);
         src.fast = false;
@@ -310,6 +304,18 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         return;
     }
     blk -= nmm;
+    const int nfold = (B * M + 255) / 256;
+    if (blk < nfold) {
+        const int x = blk * 256 + threadIdx.x;
+        if (x < B * M) {
+            const int b = x / M, m = x % M;
+            float v = 0.f;
+            for (int c = 0; c < ntile; ++c) v += g.dswp[((size_t)b * ntile + c) * M + m];
+            g.DSW[((size_t)i * B + b) * M + m] = v;
+        }
+        return;
+    }
+    blk -= nfold;
     const int k = blk % K, b = blk / K, nslice = (M + ATT_MS - 1) / ATT_MS;
     const Win w = attdec_window(a, i);
     const int FW = 2 * a.c + 1;
@@ -416,7 +422,7 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
                 case 10: hipLaunchKernelGGL(attbwd_energy_kernel<10>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
                 default: hipLaunchKernelGGL(attbwd_energy_kernel<16>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
             }
-            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + a.B * a.K), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.B * a.M + 255) / 256 + a.B * a.K), dim3(256), 0, s, g, i);
         }
     };
     GraphKey key("attdec_bwd");
