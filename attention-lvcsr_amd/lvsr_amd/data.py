@@ -44,8 +44,11 @@ class ArrayDataset(object):
 
 class Data(object):
     def __init__(self, datasets, batch_size, validation_batch_size=None, sort_k_batches=None, max_length=None,
-                 normalization=None, add_eos=True, eos_label=None, add_bos=0, prepend_eos=False):
-        """datasets: {'train': ArrayDataset, 'valid': ..., ...}; normalization: (mean (F,), std (F,)) or None."""
+                 normalization=None, add_eos=True, eos_label=None, add_bos=0, prepend_eos=False, pad_frames_to=None,
+                 pad_labels_to=None):
+        """datasets: {'train': ArrayDataset, 'valid': ..., ...}; normalization: (mean (F,), std (F,)) or None.
+        pad_frames_to / pad_labels_to (not in the reference): round the padded batch lengths up to a multiple, so that the
+        time-loop hipGraphs (one per distinct (T, L)) are re-used across minibatches; masked positions are exact no-ops."""
         assert not prepend_eos                                              # lvsr/datasets/__init__.py:165
         self.datasets = datasets
         self.batch_size = batch_size
@@ -56,6 +59,8 @@ class Data(object):
         self.add_eos = add_eos
         self._eos_label = eos_label
         self.add_bos = add_bos
+        self.pad_frames_to = pad_frames_to
+        self.pad_labels_to = pad_labels_to
 
     @property
     def info_dataset(self):
@@ -122,11 +127,15 @@ class Data(object):
             yield e
 
     @staticmethod
-    def pad_batch(examples):
+    def pad_batch(examples, pad_frames_to=None, pad_labels_to=None):
         """fuel Padding + switch_first_two_axes + ForceCContiguous (:303-309)."""
         B = len(examples)
         T = max(len(r) for r, _ in examples)
         L = max(len(l) for _, l in examples)
+        if pad_frames_to:
+            T = -(-T // pad_frames_to) * pad_frames_to
+        if pad_labels_to:
+            L = -(-L // pad_labels_to) * pad_labels_to
         F = examples[0][0].shape[1]
         rec = numpy.zeros((T, B, F), numpy.float32)
         rmask = numpy.zeros((T, B), numpy.float32)
@@ -144,7 +153,7 @@ class Data(object):
         for ex in stream:
             buf.append(ex)
             if len(buf) == bs:
-                yield self.pad_batch(buf)
+                yield self.pad_batch(buf, self.pad_frames_to, self.pad_labels_to)
                 buf = []
         if buf:
-            yield self.pad_batch(buf)
+            yield self.pad_batch(buf, self.pad_frames_to, self.pad_labels_to)

@@ -11,20 +11,30 @@ from .spec import parameter_shapes
 
 
 class Workspace(object):
-    """Shape-keyed buffer cache.  Pointers must stay stable across steps because the captured
-    hipGraphs of the recurrent loops bake them in."""
+    """Named scratch buffers.  One flat allocation per name, grown geometrically and handed out as a view of the requested
+    shape: memory is bounded by the largest shape ever asked for under a name (training sees a new (T, L) almost every
+    minibatch), and the base pointer of a name stays put while its capacity suffices — captured hipGraphs bake pointers
+    in and are keyed by them, so a stable pointer means replays keep hitting.  A buffer comes back zeroed only on its
+    first allocation or with zero=True; callers must not rely on stale contents."""
 
     def __init__(self, device):
         self.device = device
-        self._bufs = {}
+        self._bufs = {}          # (name, dtype) -> flat tensor
 
     def get(self, name, shape, dtype=torch.float32, zero=False):
-        key = (name, tuple(int(s) for s in shape), dtype)
-        t = self._bufs.get(key)
-        if t is None:
-            t = torch.zeros(key[1], dtype=dtype, device=self.device)
-            self._bufs[key] = t
-        elif zero:
+        shape = tuple(int(s) for s in shape)
+        n = 1
+        for s in shape:
+            n *= s
+        key = (name, dtype)
+        flat = self._bufs.get(key)
+        if flat is None or flat.numel() < n:
+            cap = max(n, 1) if flat is None else max(n, int(flat.numel() * 1.5))
+            flat = torch.zeros(cap, dtype=dtype, device=self.device)
+            self._bufs[key] = flat
+            zero = False
+        t = flat[:n].view(shape)
+        if zero:
             t.zero_()
         return t
 

@@ -35,6 +35,10 @@ def test_layout_eos_bos_filter_and_sorting():
         assert grp == sorted(grp)
     valid = list(data.get_stream("valid", shuffle=False))
     assert valid[0]["labels"].shape[1] == 3                                     # validation batch size
+    bucketed = Data({"train": ds}, batch_size=4, pad_frames_to=8, pad_labels_to=4)
+    for b in bucketed.get_stream("train", shuffle=False):
+        assert b["recordings"].shape[0] % 8 == 0 and b["labels"].shape[0] % 4 == 0
+        assert (b["recordings_mask"].sum(0) >= 6).all()
     ex = list(data.get_stream("train", batches=False, shuffle=True, seed=1))
     assert len(ex) == len(kept) and ex[0][0].ndim == 2
 

@@ -40,3 +40,18 @@ def test_recognizer_cost_and_gradients_emulated(case):
     rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=meta["cfg"])
     cm = rec.cost_and_gradients(batch)
     check_against(rec, cm, z, out, grads)
+
+
+def test_one_recognizer_many_shapes_emulated():
+    """Workspaces are reused across minibatch shapes (views of one allocation per name): results must not depend on what
+    an earlier, larger or smaller, batch left behind."""
+    z, meta = load_golden("tiny_conv_median")
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    for k, (B, T, L) in enumerate([(3, 13, 5), (2, 9, 4), (4, 17, 6), (1, 6, 3), (3, 13, 5)]):
+        batch = synthetic.make_batch(cfg, B, T, L, seed=40 + k, ragged=True)
+        out, grads = orc.cost_and_grads(batch)
+        cm = rec.cost_and_gradients(batch)
+        check_against(rec, cm, None, out, grads)

@@ -166,3 +166,29 @@ def test_wsj_deep_shapes_vs_oracle(gpu_device):
     for name, g in grads.items():
         scale = max(1e-3, numpy.abs(g).max())
         assert numpy.abs(got[name] - g).max() / scale < 5e-4, name
+
+
+def test_one_recognizer_many_shapes_gpu(gpu_device):
+    """Same recognizer, changing minibatch shapes (workspace views, graph cache keyed by shape), incl. bucket-padded batches
+    whose extra masked frames / labels must be exact no-ops."""
+    z, meta = load_golden("small_conv_median")
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    for k, (B, T, L) in enumerate([(5, 50, 12), (3, 31, 7), (7, 64, 14), (5, 50, 12)]):
+        batch = synthetic.make_batch(cfg, B, T, L, seed=60 + k, ragged=True)
+        out, grads = orc.cost_and_grads(batch)
+        cm = rec.cost_and_gradients(batch)
+        torch.cuda.synchronize()
+        ref = out["cost_matrix"].detach().numpy()
+        assert_allclose(cm.cpu().numpy(), ref, rtol=2e-4, atol=2e-5)
+        got = rec.store.get_grads()
+        for name, g_ in grads.items():
+            scale = max(1e-3, numpy.abs(g_).max())
+            assert numpy.abs(got[name] - g_).max() / scale < 3e-4, (name, k)
+        if k == 0:      # the same batch padded to a bucket: identical costs on the real positions
+            pad = {kk: numpy.concatenate([v, numpy.zeros((6,) + v.shape[1:], v.dtype)], 0) for kk, v in batch.items()}
+            cm2 = rec.cost_and_gradients(pad).cpu().numpy()
+            assert_allclose(cm2[:L], cm.cpu().numpy(), rtol=1e-5, atol=1e-6)
+            assert (cm2[L:] == 0).all()
