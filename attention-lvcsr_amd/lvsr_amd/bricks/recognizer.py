@@ -24,6 +24,7 @@ class SpeechRecognizer(object):
         """`net_kwargs` = the reference's constructor keywords (recognizer.py:176-204), or pass an
         already-normalised `net_config` (lvsr_amd.spec).  `params` = dict name -> ndarray (Blocks names)."""
         from .. import native
+        lm_config = dict(net_kwargs.get("lm") or {})
         cfg = net_config if net_config is not None else spec.from_reference_kwargs(**net_kwargs)
         self.d = spec.Dims(cfg)
         self.cfg = self.d.cfg
@@ -43,6 +44,10 @@ class SpeechRecognizer(object):
         # hipGraph capture cannot run on the legacy null stream: the hot path owns a side stream
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.beam_size = None
+        if lm_config.get("path"):                                  # recognizer.py:322-337
+            from ..lm import language_model_from_config
+            self.set_language_model(language_model_from_config(lm_config, net_kwargs.get("character_map"), self.device,
+                                                               self.lib))
 
     # ---- plumbing ----------------------------------------------------------------------------------
     @contextlib.contextmanager

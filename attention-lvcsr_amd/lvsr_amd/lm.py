@@ -5,9 +5,13 @@ Host-side state-set walk exactly as the reference's Theano host Ops do it (lvsr/
 MAX_STATES = 7 padded state sets) wrapped like `FSTTransition` / `LanguageModel` (lvsr/bricks/language_models.py:14-72,
 107-137).  The fusion itself (`ShallowFusionReadout.readout`, language_models.py:92-104) is the device kernel
 `lvsr_shallow_fusion`.  The reference reads OpenFST binaries through PyFST; here the automaton is an in-memory arc list
-(AT&T text format reader included) — an OpenFST binary reader is SURVEY.md §8f N4.
+with an AT&T text reader and a reader/writer for OpenFST's binary `vector` / `standard` container (`read_openfst_binary`).
+
+`DeviceFSTLanguageModel` keeps the per-hypothesis state sets in device memory and does the walk in the
+HIP kernel `lvsr_fst_lm_step` over a CSR arc table, with the same interface, so beam search uses either unchanged.
 """
 import math
+import struct
 from collections import defaultdict, deque
 
 import numpy
@@ -214,6 +218,234 @@ class FSTLanguageModel(object):
         if device is not None:
             self.device_add = self.device_add.to(device)
         return self.device_add
+
+
+class DeviceFSTLanguageModel(FSTLanguageModel):
+    """FSTLanguageModel whose state sets live on the device: `transition` + look-ahead costs are one launch of
+    `lvsr_fst_lm_step` per beam step (no Python walk, no host<->device traffic except the 4-byte error word)."""
+    def __init__(self, fst, device, lib=None, **kw):
+        super(DeviceFSTLanguageModel, self).__init__(fst, **kw)
+        from . import native
+        self.lib = lib if lib is not None else native.get()
+        self.device = torch.device(device)
+        self.table = build_fst_table(fst, self.remap_table, self.out_dim)
+        self._dev = {k: torch.from_numpy(v).to(self.device) for k, v in self.table.items() if isinstance(v, numpy.ndarray)}
+        d = self._dev
+        self._fst = self.lib.make("lvsr_fst", arc_off=d["arc_off"], arc_lab=d["arc_lab"], arc_dst=d["arc_dst"],
+                                  arc_w=d["arc_w"], eps_off=d["eps_off"], eps_dst=d["eps_dst"], eps_w=d["eps_w"],
+                                  topo=d["topo"], remap=d["remap"], num_states=self.table["num_states"], V=self.out_dim,
+                                  no_transition_cost=float(self.no_transition_cost))
+        self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        start = self.fst.expand({self.fst.start: 0.0})
+        self._start = (_pad(start.keys(), NOT_STATE).astype(numpy.int64), _pad(start.values(), 0).astype(numpy.float64))
+
+    _ERRORS = {1: "FST state set larger than MAX_STATES=%d (lvsr/ops.py:23,140-142)" % MAX_STATES,
+               2: "FST candidate set outgrew the device kernel's capacity (16 states)",
+               3: "chosen character has no FST input label"}
+
+    def _step(self, states, weights, outputs):
+        import ctypes
+        from .native import ptr
+        n = states.shape[0]
+        add = torch.empty((n, self.out_dim), dtype=torch.float32, device=self.device)
+        if outputs is None:
+            ns, nw = states, weights
+        else:
+            ns, nw = torch.empty_like(states), torch.empty_like(weights)
+        if n:
+            self.lib.call("lvsr_fst_lm_step", self.lib.stream_for(states), ctypes.byref(self._fst), ptr(states), ptr(weights),
+                          ptr(outputs), n, ptr(ns) if outputs is not None else None,
+                          ptr(nw) if outputs is not None else None, ptr(add), ptr(self._err))
+            code = int(self._err.item())
+            if code:
+                self._err.zero_()
+                raise ValueError(self._ERRORS.get(code, "lvsr_fst_lm_step error %d" % code))
+        return dict(states=ns, weights=nw, add=add)
+
+    def initial_states(self, n):
+        st = torch.from_numpy(numpy.tile(self._start[0][None, :], (n, 1))).to(self.device)
+        wt = torch.from_numpy(numpy.tile(self._start[1][None, :], (n, 1))).to(self.device)
+        return self._step(st, wt, None)
+
+    def transition(self, lm_states, outputs):
+        out = torch.as_tensor(numpy.ascontiguousarray(outputs), dtype=torch.int64).to(self.device).contiguous()
+        return self._step(lm_states["states"].contiguous(), lm_states["weights"].contiguous(), out)
+
+    def take(self, lm_states, indexes):
+        idx = torch.as_tensor(numpy.ascontiguousarray(indexes), dtype=torch.int64).to(self.device)
+        return {k: v.index_select(0, idx) for k, v in lm_states.items()}
+
+    def stage(self, lm_states, device=None):
+        self.device_add = lm_states["add"]
+        return self.device_add
+
+
+def build_fst_table(fst, remap_table, V):
+    """CSR arc table for `lvsr_fst_lm_step` (include/lvsr_hip.h `lvsr_fst`)."""
+    ids = {fst.start}
+    for src, lst in fst.arcs.items():
+        ids.add(src)
+        ids.update(d for _, d, _ in lst)
+    S = max(ids) + 1
+    lab = [[] for _ in range(S)]
+    eps = [[] for _ in range(S)]
+    for src, lst in fst.arcs.items():
+        for (il, d, w) in lst:
+            (eps if il == EPSILON else lab)[src].append((il, d, w))
+    for q in range(S):
+        lab[q].sort(key=lambda a: a[0])                       # stable: arcs with equal labels keep their order
+    order = _toposort_flatten(_eps_depends(eps))
+    topo = numpy.zeros(S, dtype=numpy.int32)
+    rank = {q: i for i, q in enumerate(order)}
+    nxt = len(order)
+    for q in range(S):
+        if q in rank:
+            topo[q] = rank[q]
+        else:
+            topo[q] = nxt
+            nxt += 1
+
+    def csr(rows):
+        off = numpy.zeros(S + 1, dtype=numpy.int32)
+        for q in range(S):
+            off[q + 1] = off[q] + len(rows[q])
+        flat = [a for r in rows for a in r]
+        return (off, numpy.array([a[0] for a in flat] or [0], dtype=numpy.int32),
+                numpy.array([a[1] for a in flat] or [0], dtype=numpy.int32),
+                numpy.array([a[2] for a in flat] or [0.0], dtype=numpy.float64))
+    arc_off, arc_lab, arc_dst, arc_w = csr(lab)
+    eps_off, _, eps_dst, eps_w = csr(eps)
+    remap = numpy.full(V, -1, dtype=numpy.int32)
+    for nn_ch, fst_ch in remap_table.items():
+        if 0 <= int(nn_ch) < V:
+            remap[int(nn_ch)] = int(fst_ch)
+    return dict(arc_off=arc_off, arc_lab=arc_lab, arc_dst=arc_dst, arc_w=arc_w, eps_off=eps_off, eps_dst=eps_dst,
+                eps_w=eps_w, topo=topo, remap=remap, num_states=S)
+
+
+def _eps_depends(eps):
+    dep = defaultdict(set)
+    for q, lst in enumerate(eps):
+        for (_, d, _) in lst:
+            dep[d].add(q)
+    return dep                      # _toposort_flatten raises ValueError on an epsilon cycle
+
+
+# ---- OpenFST binary container (`fstcompile` output; what PyFST's `fst.read` loads in lvsr/ops.py:40-41) -----------
+# Layout (OpenFST src/include/fst/fst.h FstHeader::Write, vector-fst.h): int32 magic 2125659606; string fst type
+# ("vector"); string arc type ("standard"); int32 version (2); int32 flags (bit0 has isymbols, bit1 has osymbols,
+# bit2 aligned); uint64 properties; int64 start; int64 num_states; int64 num_arcs; [symbol tables]; then per state:
+# float32 final weight, int64 narcs, narcs x {int32 ilabel, int32 olabel, float32 weight, int32 nextstate}.
+# Strings are int32 length + bytes.  Symbol table: int32 magic 2125658996, string name, int64 available_key, int64 size,
+# size x {string symbol, int64 key}.  Stated from the OpenFST sources' documented format; no OpenFST binary exists in the
+# reference tree or this image, so only the writer<->reader round trip is tested (parity UNPINNED, see DESIGN.md).
+_FST_MAGIC = 2125659606
+_SYMTAB_MAGIC = 2125658996
+
+
+def _rd(fmt, buf, pos):
+    size = struct.calcsize(fmt)
+    return struct.unpack_from(fmt, buf, pos), pos + size
+
+
+def _rd_str(buf, pos):
+    (n,), pos = _rd("<i", buf, pos)
+    return buf[pos:pos + n].decode("utf-8"), pos + n
+
+
+def _rd_symtab(buf, pos):
+    (magic,), pos = _rd("<i", buf, pos)
+    if magic != _SYMTAB_MAGIC:
+        raise ValueError("bad OpenFST symbol table magic %d" % magic)
+    _, pos = _rd_str(buf, pos)
+    (_, size), pos = _rd("<qq", buf, pos)
+    table = {}
+    for _ in range(size):
+        sym, pos = _rd_str(buf, pos)
+        (key,), pos = _rd("<q", buf, pos)
+        table[sym] = key
+    return table, pos
+
+
+def read_openfst_binary(path_or_bytes):
+    """-> ArcFST from an OpenFST binary `vector` FST with `standard` (tropical, float32) arcs."""
+    buf = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    (magic,), pos = _rd("<i", buf, 0)
+    if magic != _FST_MAGIC:
+        raise ValueError("not an OpenFST binary (magic %d)" % magic)
+    fst_type, pos = _rd_str(buf, pos)
+    arc_type, pos = _rd_str(buf, pos)
+    if fst_type != "vector" or arc_type != "standard":
+        raise ValueError("unsupported OpenFST container %s/%s (need vector/standard; convert with fstconvert)"
+                         % (fst_type, arc_type))
+    (version, flags), pos = _rd("<ii", buf, pos)
+    (_props, start, num_states, _num_arcs), pos = _rd("<Qqqq", buf, pos)
+    if flags & 4:
+        raise ValueError("aligned OpenFST files are not supported")
+    f = ArcFST(start=start)
+    if flags & 1:
+        f.isyms, pos = _rd_symtab(buf, pos)
+    if flags & 2:
+        _, pos = _rd_symtab(buf, pos)
+    for q in range(num_states):
+        (final, narcs), pos = _rd("<fq", buf, pos)
+        if final != float("inf"):
+            f.final[q] = final
+        for _ in range(narcs):
+            (il, _ol, w, nxt), pos = _rd("<iifi", buf, pos)
+            f.add_arc(q, nxt, il, w)
+    return f
+
+
+def write_openfst_binary(fst, path=None):
+    """Inverse of `read_openfst_binary` (acceptor: olabel = ilabel); returns the bytes and writes them if `path`."""
+    def wstr(s_):
+        b = s_.encode("utf-8")
+        return struct.pack("<i", len(b)) + b
+    ids = {fst.start} | set(fst.arcs) | {d for lst in fst.arcs.values() for (_, d, _) in lst} | set(fst.final)
+    S = max(ids) + 1
+    narcs = sum(len(v) for v in fst.arcs.values())
+    out = [struct.pack("<i", _FST_MAGIC), wstr("vector"), wstr("standard"), struct.pack("<ii", 2, 1 if fst.isyms else 0),
+           struct.pack("<Qqqq", 0, fst.start, S, narcs)]
+    if fst.isyms:
+        out += [struct.pack("<i", _SYMTAB_MAGIC), wstr("isyms"), struct.pack("<qq", max(fst.isyms.values()) + 1, len(fst.isyms))]
+        for sym, key in sorted(fst.isyms.items(), key=lambda kv: kv[1]):
+            out += [wstr(sym), struct.pack("<q", key)]
+    for q in range(S):
+        arcs = fst.arcs.get(q, [])
+        out.append(struct.pack("<fq", fst.final.get(q, float("inf")), len(arcs)))
+        for (il, d, w) in arcs:
+            out.append(struct.pack("<iifi", il, il, w, d))
+    data = b"".join(out)
+    if path:
+        with open(path, "wb") as fh:
+            fh.write(data)
+    return data
+
+
+def language_model_from_config(lm, character_map, device, lib=None):
+    """The `lm:` block of the reference's `net:` section (lvsr/bricks/recognizer.py:322-337; LanguageModel.__init__,
+    language_models.py:107-121): {path, weight, no_transition_cost, normalize_am_weights, normalize_lm_weights,
+    normalize_tot_weights, am_beta}.  `path` is an OpenFST binary (vector/standard, with input symbols) or an AT&T text
+    file next to `<path>.isyms` ('symbol id' lines).  `device_walk: false` (ours) selects the host walk."""
+    lm = dict(lm)
+    path = lm.pop("path")
+    device_walk = lm.pop("device_walk", True)
+    lm.pop("type_", None)
+    with open(path, "rb") as fh:
+        head = fh.read(4)
+    if head == struct.pack("<i", _FST_MAGIC):
+        fst = read_openfst_binary(path)
+    else:
+        with open(path + ".isyms") as fh:
+            isyms = {p[0]: int(p[1]) for p in (line.split() for line in fh) if len(p) == 2}
+        with open(path) as fh:
+            fst = ArcFST.from_att_text(fh.read().splitlines(), isyms)
+    if not fst.isyms:
+        raise ValueError("the FST at %s carries no input symbol table" % path)
+    if device_walk:
+        return DeviceFSTLanguageModel(fst, device, lib=lib, nn_char_map=character_map, **lm)
+    return FSTLanguageModel(fst, nn_char_map=character_map, **lm)
 
 
 def char_ngram_fst(num_chars, seed=0, order=2, eps_backoff=True):

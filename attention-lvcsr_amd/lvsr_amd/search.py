@@ -36,8 +36,8 @@ class BeamSearch(object):
         with rec._on_stream():
             rec.compute_contexts(input_values["recordings"])
             st = gen.generation_initial_states(1)
+            lm_states = rec.lm_initial_states(1) if gen.language_model is not None else None
         S, W, step = st["states"], st["weights"], st["step"]
-        lm_states = rec.lm_initial_states(1) if gen.language_model is not None else None
         all_outputs = st["outputs"][None, :]
         all_costs = numpy.zeros_like(all_outputs, dtype=numpy.float32)
         done = []

@@ -279,8 +279,7 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
             raise NotImplementedError("%s=%s: only GatedRecurrent is built" % (which, tn))
     if criterion is not None and dict(criterion).get("name", "log_likelihood") != "log_likelihood":
         raise ValueError("Unknown criterion {}".format(criterion["name"]))        # recognizer.py:296-297
-    if lm:
-        raise NotImplementedError("language-model fusion is configured through lvsr_amd.lm, not the net section")
+    # `lm` / `character_map` do not change the network: SpeechRecognizer.__init__ builds the fusion model from them
     if not bidir:
         raise NotImplementedError("bidir=False is not built")
     if dims_top:

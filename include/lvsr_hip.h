@@ -213,6 +213,34 @@ int lvsr_opt_step(void* stream, const lvsr_opt_args* a);
 int lvsr_shallow_fusion(void* stream, const float* am, int ld, const float* lm_add, int n, int V, float am_beta,
                         float lm_weight, int norm_am, int norm_lm, int norm_tot, float out_scale, float* out);
 
+/* ---- FST language model on the device ---------------------------------------------------
+ * Replaces the per-hypothesis Python walks of FSTTransitionOp.perform / FSTCostsOp.perform (lvsr/ops.py:147-169,
+ * 206-225; FST.transition / FST.expand ops.py:66-97).  The automaton is a CSR arc table in device memory: labelled
+ * arcs sorted by (source state, input label), epsilon arcs (label 0, ops.py:22) in their own CSR, `topo` = rank of
+ * every state in a topological order of the epsilon sub-graph, `remap` = network character -> FST input label
+ * (language_models.py:118-121), weights = -log probabilities in f64 (the reference's Python floats). */
+typedef struct lvsr_fst {
+    const int* arc_off;                   /* (num_states+1) */
+    const int* arc_lab;                   /* (num_arcs) ascending within a state */
+    const int* arc_dst;
+    const double* arc_w;
+    const int* eps_off;                   /* (num_states+1) */
+    const int* eps_dst;
+    const double* eps_w;
+    const int* topo;                      /* (num_states) */
+    const int* remap;                     /* (V), -1 = character has no label */
+    int num_states, V;
+    double no_transition_cost;
+} lvsr_fst;
+/* states (n,7) int64 padded with -1, weights (n,7) f64 padded with 0 (MAX_STATES = 7, ops.py:23,131-145).
+ * outputs != NULL: new_states/new_weights <- epsilon-closure(transition(states, remap[outputs[b]])), then `add` (n,V) =
+ * look-ahead costs of the NEW sets; outputs == NULL: `add` = costs of `states` as given (FSTTransition.initial_states,
+ * language_models.py:52-62).  `add` may be NULL.  *err (device int, caller zeroes it) is raised to 1 when a new set has
+ * more than 7 states (the reference's ValueError), 2 when a candidate set outgrows the kernel's capacity of 16,
+ * 3 when a chosen character has no FST label. */
+int lvsr_fst_lm_step(void* stream, const lvsr_fst* f, const long long* states, const double* weights,
+                     const long long* outputs, int n, long long* new_states, double* new_weights, float* add, int* err);
+
 /* ---- mel-filterbank front end ------------------------------------------------------------------------
  * The reference runs Kaldi offline (exp/wsj/write_hdf_dataset.sh:94-104: compute-fbank-feats --use-energy=true
  * --num-mel-bins=40 | add-deltas, then global CMVN); Kaldi's source is not part of the reference tree, so these

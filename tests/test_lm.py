@@ -82,7 +82,7 @@ CFG = dict(input_dim=5, num_phonemes=6, dims_bidir=[4, 3], subsample=[1, 2], dim
            max_decoded_length_scale=1)
 
 
-def run_fused_beam(device, lib):
+def run_fused_beam(device, lib, device_lm=False):
     from oracle import lvsr_oracle as O
     from lvsr_amd import synthetic
     from lvsr_amd.bricks.recognizer import SpeechRecognizer
@@ -90,7 +90,10 @@ def run_fused_beam(device, lib):
     fst, cmap = LM.char_ngram_fst(6, seed=5)
     arcs = [(s, d, l, w) for s, lst in fst.arcs.items() for (l, d, w) in lst]
     dense = LO.DenseFST(arcs, fst.start, 6)
-    model = LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5)
+    if device_lm:
+        model = LM.DeviceFSTLanguageModel(fst, device, lib=lib, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5)
+    else:
+        model = LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5)
     rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=CFG)
     rec.set_language_model(model)
     orc = O.OracleRecognizer(CFG, params, dtype=torch.float32)
@@ -115,3 +118,154 @@ def test_beam_search_with_shallow_fusion_emulated():
 @pytest.mark.gpu
 def test_beam_search_with_shallow_fusion_gpu(gpu_device):
     run_fused_beam(gpu_device, None)
+
+
+# ---- device-side FST walk (lvsr_fst_lm_step) vs the host walk ------------------------------------------------------
+def _random_fst(num_chars, seed, n_states=9, eps_levels=True):
+    """Non-deterministic acceptor with multi-level epsilon chains (DAG) and parallel arcs."""
+    rng = numpy.random.RandomState(seed)
+    f = LM.ArcFST(start=0)
+    f.isyms = {"<eps>": 0}
+    f.isyms.update({"c%d" % i: i + 1 for i in range(num_chars)})
+    for s_ in range(n_states):
+        for c in range(num_chars):
+            for _ in range(rng.randint(0, 3)):                       # 0..2 arcs per (state, label): non-deterministic
+                f.add_arc(s_, int(rng.randint(0, n_states)), c + 1, float(rng.uniform(0.1, 4.0)))
+        if eps_levels:
+            for d in range(s_ + 1, min(n_states, s_ + 3)):           # epsilon arcs only go "up": acyclic, chains of depth > 1
+                if rng.rand() < 0.5:
+                    f.add_arc(s_, d, LM.EPSILON, float(rng.uniform(0.1, 2.0)))
+    return f, {"c%d" % i: i for i in range(num_chars)}
+
+
+def _as_sets(st):
+    states = st["states"].cpu().numpy() if torch.is_tensor(st["states"]) else st["states"]
+    weights = st["weights"].cpu().numpy() if torch.is_tensor(st["weights"]) else st["weights"]
+    return [{int(q): float(w) for q, w in zip(sr, wr) if q != LM.NOT_STATE} for sr, wr in zip(states, weights)]
+
+
+def run_device_walk(device, lib):
+    for seed, (fst, cmap) in enumerate([LM.char_ngram_fst(6, seed=5), _random_fst(5, 1), _random_fst(70, 2, n_states=5),
+                                        _random_fst(4, 3, eps_levels=False)]):
+        V = len(cmap)
+        host = LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=17.0)
+        dev = LM.DeviceFSTLanguageModel(fst, device, lib=lib, nn_char_map=cmap, no_transition_cost=17.0)
+        rng = numpy.random.RandomState(seed)
+        n = 5
+        hs, ds = host.initial_states(n), dev.initial_states(n)
+        for step in range(8):
+            assert_allclose(ds["add"].cpu().numpy(), hs["add"], rtol=2e-6, atol=2e-6)
+            for a, b in zip(_as_sets(ds), _as_sets(hs)):
+                assert set(a) == set(b)
+                for q in a:
+                    assert abs(a[q] - b[q]) < 1e-9
+            # only characters that have a successor set of legal size in every hypothesis (the beam never picks a
+            # no-transition character when a finite alternative exists; oversize sets are tested separately)
+            outs = []
+            for b in range(n):
+                ok = [c for c in range(V) if hs["add"][b, c] < 17.0]
+                outs.append(ok[rng.randint(len(ok))] if ok else 0)
+            outs = numpy.array(outs)
+            try:
+                hs2 = host.transition(hs, outs)
+            except ValueError:
+                with pytest.raises(ValueError):
+                    dev.transition(ds, outs)
+                break
+            hs, ds = hs2, dev.transition(ds, outs)
+            idx = rng.permutation(n)[:n - 1] if step == 4 else numpy.arange(hs["states"].shape[0])
+            hs, ds = host.take(hs, idx), dev.take(ds, idx)
+            n = len(idx)
+
+
+def test_device_fst_walk_emulated():
+    from emu import emu_lib
+    run_device_walk("cpu", emu_lib())
+
+
+def test_device_fst_oversize_set_raises_emulated():
+    from emu import emu_lib
+    f = LM.ArcFST(start=0)
+    f.isyms = {"<eps>": 0, "a": 1}
+    for d in range(1, 10):
+        f.add_arc(0, d, 1, 0.5)                                      # 9 successors > MAX_STATES
+    dev = LM.DeviceFSTLanguageModel(f, "cpu", lib=emu_lib(), nn_char_map={"a": 0})
+    host = LM.FSTLanguageModel(f, nn_char_map={"a": 0})
+    st = dev.initial_states(1)
+    assert_allclose(st["add"].numpy(), host.initial_states(1)["add"], rtol=1e-6)     # costs of a 9-state set are fine
+    with pytest.raises(ValueError):
+        dev.transition(st, numpy.array([0]))
+    with pytest.raises(ValueError):
+        host.transition(host.initial_states(1), numpy.array([0]))
+    cyc = LM.ArcFST(start=0)
+    cyc.isyms = {"<eps>": 0, "a": 1}
+    cyc.add_arc(0, 1, LM.EPSILON, 0.1)
+    cyc.add_arc(1, 0, LM.EPSILON, 0.1)
+    with pytest.raises(ValueError):
+        LM.build_fst_table(cyc, {0: 1}, 1)
+
+
+def test_beam_search_with_device_fst_emulated():
+    from emu import emu_lib
+    run_fused_beam("cpu", emu_lib(), device_lm=True)
+
+
+@pytest.mark.gpu
+def test_device_fst_walk_gpu(gpu_device):
+    run_device_walk(gpu_device, None)
+
+
+@pytest.mark.gpu
+def test_beam_search_with_device_fst_gpu(gpu_device):
+    run_fused_beam(gpu_device, None, device_lm=True)
+
+
+def test_openfst_binary_round_trip(tmp_path):
+    fst, _ = _random_fst(5, 7)
+    fst.final = {2: 0.25, 4: 0.0}
+    path = str(tmp_path / "lm.fst")
+    data = LM.write_openfst_binary(fst, path)
+    assert data[:4] == (2125659606).to_bytes(4, "little")
+    back = LM.read_openfst_binary(path)
+    assert back.start == fst.start and back.isyms == fst.isyms
+    assert {k: [(l, d, numpy.float32(w)) for l, d, w in v] for k, v in fst.arcs.items() if v} == \
+           {k: [(l, d, numpy.float32(w)) for l, d, w in v] for k, v in back.arcs.items() if v}
+    assert back.final == {2: 0.25, 4: 0.0}
+    with pytest.raises(ValueError):
+        LM.read_openfst_binary(b"\x00" * 64)
+
+
+def test_lm_block_of_the_net_section_builds_the_fusion_model(tmp_path):
+    """`net: {lm: {path: ..., weight: ...}, character_map: ...}` as in the reference's decode configs
+    (lvsr/bricks/recognizer.py:322-337), from an OpenFST binary and from AT&T text + symbols."""
+    from emu import emu_lib
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    fst, cmap = LM.char_ngram_fst(6, seed=5)
+    binary = str(tmp_path / "lm.fst")
+    LM.write_openfst_binary(fst, binary)
+    text = str(tmp_path / "lm.txt")
+    with open(text, "w") as fh:
+        order = [fst.start] + [q for q in fst.arcs if q != fst.start]
+        for q in order:
+            for (il, d, w) in fst.arcs[q]:
+                fh.write("%d %d %d %d %r\n" % (q, d, il, il, w))
+    with open(text + ".isyms", "w") as fh:
+        for sym, key in fst.isyms.items():
+            fh.write("%s %d\n" % (sym, key))
+    kwargs = dict(input_dims={"recordings": 5}, input_num_chars=None, eos_label=5, num_phonemes=6, dim_dec=5,
+                  dims_bidir=[4, 3], subsample=[1, 2], dim_matcher=6, attention_type="content_and_conv", conv_n=2,
+                  conv_num_filters=3, prior=dict(type="window_around_median", before=2, after=3), post_merge_dims=[8],
+                  embed_outputs=True, data_prepend_eos=False, character_map=cmap)
+    x = numpy.random.RandomState(1).normal(size=(14, 5)).astype(numpy.float32)
+    results = []
+    for lm_block in (dict(path=binary, weight=0.5, no_transition_cost=20.0),
+                     dict(path=text, weight=0.5, no_transition_cost=20.0, device_walk=False)):
+        rec = SpeechRecognizer(device="cpu", lib=emu_lib(), lm=lm_block, **kwargs)
+        rec.set_parameter_values(synthetic.make_params(rec.cfg, seed=41))
+        assert isinstance(rec.generator.language_model, LM.FSTLanguageModel)
+        assert isinstance(rec.generator.language_model, LM.DeviceFSTLanguageModel) == lm_block.get("device_walk", True)
+        rec.init_beam_search(4)
+        results.append(rec.beam_search({"recordings": x}, char_discount=0.2, stop_on="optimistic_future_cost"))
+    assert results[0][0] == results[1][0]
+    assert_allclose(results[0][1], results[1][1], rtol=1e-5, atol=1e-5)      # binary weights are float32
