@@ -3,16 +3,19 @@
 masks (fuel `Padding`, libs/fuel/fuel/transformers/__init__.py:691-720), transposition to time-major and C-contiguity.
 Output = the dictionaries `SpeechRecognizer.cost` / `Trainer.train_step` consume.
 
-The reference reads Fuel HDF5 files; h5py is not part of this image, so datasets come in as arrays (`ArrayDataset`,
-`.npz` via `ArrayDataset.from_npz`).  An HDF5 reader is SURVEY.md §8f N3.
+Sources: arrays / `.npz` (`ArrayDataset.from_npz`), Kaldi feature tables + transcripts
+(`ArrayDataset.from_kaldi`, what `bin/kaldi2fuel.py` converts), and the reference's Fuel HDF5 files
+(`ArrayDataset.from_fuel_hdf5`; needs h5py, which this image does not have — the reader raises ImportError without it).
 """
 import numpy
 
 
 class ArrayDataset(object):
     """recordings: list of (T_i, F) float arrays; labels: list of int sequences (without <eol>)."""
-    def __init__(self, recordings, labels, num_characters, eos_label=None, bos_label=None, uttids=None):
+    def __init__(self, recordings, labels, num_characters, eos_label=None, bos_label=None, uttids=None, char2num=None):
         assert len(recordings) == len(labels)
+        self.char2num = dict(char2num) if char2num is not None else None
+        self.num2char = {v: k for k, v in self.char2num.items()} if char2num is not None else None
         self.recordings = [numpy.asarray(r, dtype=numpy.float32) for r in recordings]
         self.labels = [numpy.asarray(l, dtype=numpy.int64) for l in labels]
         self.num_characters = int(num_characters)
@@ -26,6 +29,81 @@ class ArrayDataset(object):
 
     def dim(self):
         return int(self.recordings[0].shape[1])
+
+    # ---- H5PYAudioDataset helpers (lvsr/datasets/h5py.py:24-46) ----
+    def decode(self, labels, keep_eos=False):
+        return [self.num2char[int(l)] for l in labels
+                if (l != self.eos_label or keep_eos) and l != self.bos_label]
+
+    def pretty_print(self, labels, example=None):
+        return "".join(" " if c == "<spc>" else c for c in self.decode(labels))
+
+    def monospace_print(self, labels):
+        sub = {"<spc>": "_", "<noise>": "~", "<eol>": "$", "<bol>": "^"}
+        return "".join(sub.get(c, c) for c in self.decode(labels, keep_eos=True))
+
+    @classmethod
+    def from_kaldi(cls, feats, text, char2num, tokens="chars", keep=None):
+        """feats: `.scp` or `.ark` of (T,F) matrices; text: Kaldi `text` file 'uttid word word ...'; char2num: the
+        `value_map` of the reference's HDF5 label source (symbol -> id, with '<eol>' and optionally '<spc>', '<noise>',
+        '<bol>').  tokens='chars' spells the transcript out character by character with '<spc>' between words
+        (the WSJ recipe); 'words' maps whitespace tokens (phone strings, TIMIT).  Utterances are joined on the key."""
+        from . import kaldi_io
+        reader = kaldi_io.read_mat_scp if feats.endswith(".scp") else kaldi_io.read_mat_ark
+        trans = dict(kaldi_io.read_text(text))
+        recs, labs, ids = [], [], []
+        for key, mat in reader(feats):
+            if key not in trans or (keep is not None and key not in keep):
+                continue
+            words = trans[key]
+            if tokens == "chars":
+                syms = []
+                for wi, w in enumerate(words):
+                    if wi:
+                        syms.append("<spc>")
+                    syms.extend([w] if w in char2num and len(w) > 1 else list(w))
+            else:
+                syms = list(words)
+            labs.append([char2num[s] for s in syms])
+            recs.append(mat)
+            ids.append(key)
+        return cls(recs, labs, len(char2num), eos_label=char2num["<eol>"], bos_label=char2num.get("<bol>"), uttids=ids,
+                   char2num=char2num)
+
+    @classmethod
+    def from_fuel_hdf5(cls, path, split, sources_map=None):
+        """The reference's dataset file (Fuel `H5PYDataset` layout written by bin/kaldi2fuel.py:103-360): per source a
+        vlen dataset `<source>` of flattened examples with `<source>_shapes` (n, ndim) int32, the label source carrying
+        a `value_map` attribute (symbol, id) records, and the `split` attribute table (split, source, start, stop,
+        indices, available, comment) (lvsr/datasets/h5py.py:5-23, fuel H5PYDataset.create_split_array)."""
+        try:
+            import h5py
+        except ImportError:
+            raise ImportError("reading Fuel HDF5 datasets needs h5py, which is not installed; convert the Kaldi tables "
+                              "with ArrayDataset.from_kaldi or ship an .npz (ArrayDataset.from_npz)")
+        smap = dict(recordings="recordings", labels="labels")
+        smap.update(sources_map or {})
+        with h5py.File(path, "r") as f:
+            start, stop, indices = 0, None, None
+            for row in f.attrs["split"]:
+                rs = row["split"].decode() if isinstance(row["split"], bytes) else row["split"]
+                src = row["source"].decode() if isinstance(row["source"], bytes) else row["source"]
+                if rs == split and src == smap["recordings"] and row["available"]:
+                    start, stop = int(row["start"]), int(row["stop"])
+                    if row["indices"]:
+                        indices = numpy.asarray(f[row["indices"]])
+            if stop is None:
+                raise KeyError("split %r not found in %s" % (split, path))
+            idx = indices if indices is not None else numpy.arange(start, stop)
+            rec_ds, lab_ds = f[smap["recordings"]], f[smap["labels"]]
+            shapes = f[smap["recordings"] + "_shapes"]
+            recs = [numpy.asarray(rec_ds[i], dtype=numpy.float32).reshape(tuple(shapes[i])) for i in idx]
+            labs = [numpy.asarray(lab_ds[i], dtype=numpy.int64) for i in idx]
+            vm = {}
+            for k, v in lab_ds.attrs["value_map"]:
+                vm[k.decode() if isinstance(k, bytes) else str(k)] = int(v)
+            ids = [u.decode() if isinstance(u, bytes) else u for u in (f["uttids"][i] for i in idx)] if "uttids" in f else None
+        return cls(recs, labs, len(vm), eos_label=vm["<eol>"], bos_label=vm.get("<bol>"), uttids=ids, char2num=vm)
 
     @classmethod
     def from_npz(cls, path, **kw):

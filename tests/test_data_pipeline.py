@@ -1,6 +1,7 @@
 """Batch pipeline semantics (lvsr/datasets/__init__.py:253-310) and a few training steps driven by it on the emulated
 recognizer (loss goes down)."""
 import numpy
+import pytest
 import torch
 
 from lvsr_amd.data import ArrayDataset, Data
@@ -61,3 +62,47 @@ def test_training_on_the_pipeline_reduces_the_cost():
             tot += float(tr.train_step(batch).sum())
         costs.append(tot)
     assert costs[-1] < costs[0] * 0.95, costs
+
+
+def test_kaldi_tables_round_trip_and_dataset(tmp_path):
+    from lvsr_amd import kaldi_io
+    rng = numpy.random.RandomState(0)
+    mats = [("utt%d" % i, rng.normal(size=(5 + 3 * i, 4)).astype(numpy.float32)) for i in range(4)]
+    mats.append(("vec", rng.normal(size=7)))                                       # float64 vector
+    ark, scp = str(tmp_path / "feats.ark"), str(tmp_path / "feats.scp")
+    kaldi_io.write_mat_ark(ark, mats, scp=scp)
+    for reader, src in ((kaldi_io.read_mat_ark, ark), (kaldi_io.read_mat_scp, scp)):
+        got = list(reader(src))
+        assert [k for k, _ in got] == [k for k, _ in mats]
+        for (_, a), (_, b) in zip(got, mats):
+            assert a.dtype == b.dtype and numpy.array_equal(a, b)
+    # text-format archive (copy-feats ark,t:)
+    txt = str(tmp_path / "feats.txt")
+    with open(txt, "w") as fh:
+        for k, m in mats[:2]:
+            fh.write("%s  [\n" % k)
+            for r, row in enumerate(m):
+                fh.write("  " + " ".join(repr(float(v)) for v in row) + (" ]\n" if r == len(m) - 1 else "\n"))
+    got = list(kaldi_io.read_mat_ark(txt))
+    assert [k for k, _ in got] == ["utt0", "utt1"] and numpy.allclose(got[1][1], mats[1][1])
+    with open(str(tmp_path / "c.ark"), "wb") as fh:
+        fh.write(b"k \x00BCM \x04")
+    with pytest.raises(ValueError):
+        list(kaldi_io.read_mat_ark(str(tmp_path / "c.ark")))
+    # transcripts -> character labels as in the WSJ recipe
+    text = str(tmp_path / "text")
+    with open(text, "w") as fh:
+        fh.write("utt0 AB A\nutt1 <noise> B\nutt3 BA\nother X\n")
+    c2n = {"A": 0, "B": 1, "<spc>": 2, "<noise>": 3, "<eol>": 4}
+    ds = ArrayDataset.from_kaldi(ark, text, c2n)
+    assert ds.uttids == ["utt0", "utt1", "utt3"] and ds.eos_label == 4 and ds.num_characters == 5
+    assert ds.labels[0].tolist() == [0, 1, 2, 0] and ds.labels[1].tolist() == [3, 2, 1]
+    assert ds.pretty_print(ds.labels[0]) == "AB A" and ds.monospace_print([3, 2, 1, 4]) == "~_B$"
+    mean, std = kaldi_io.compute_cmvn_stats(ds.recordings)
+    allf = numpy.concatenate(ds.recordings)
+    assert numpy.allclose(mean, allf.mean(0), atol=1e-6) and numpy.allclose(std, allf.std(0), atol=1e-5)
+    data = Data({"train": ds}, batch_size=2, normalization=(mean, std))
+    b = next(iter(data.get_stream("train", shuffle=False)))
+    assert b["recordings"].shape[1:] == (2, 4) and b["labels"][-1].max() == 4
+    with pytest.raises(ImportError):
+        ArrayDataset.from_fuel_hdf5(str(tmp_path / "x.h5"), "train")
