@@ -110,23 +110,28 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
             }
 }
 
-// ---- 128x128x16 tile, v_mfma_f32_32x32x2_f32, register-prefetch double buffering ------------------------------------
+// ---- 128x128x32 tile, v_mfma_f32_32x32x2_f32, register-prefetch double buffering ------------------------------------
 // Used when the output is at least one full tile: 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32 blocks (64 accumulator
 // registers).  Operands are staged k-major in LDS ([k][m], [k][n]) so each MFMA operand read is a conflict-free row of
 // 32 consecutive floats; the next k-tile is fetched from global memory into registers (float4 along the contiguous
 // dimension) while the current one is consumed.
+// Measured (tools/gemm_shapes.py): with a 16-deep k-tile one tile ran at 1.75 us per k-iteration against 0.85 us of MFMA
+// issue: the prefetch, issued one iteration ahead, did not cover the HBM latency.  32-deep k-tiles give the
+// loads 1.7 us of MFMA work to hide behind and halve the barriers; the block -> tile map below keeps the tiles that share
+// operand panels on one XCD (blocks are dealt to XCDs round-robin, each XCD has its own L2).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM 128
 #define GN 128
-#define GK 16
+#define GK 32
+#define GU (GK / 8)                    // float4 units per thread and operand tile
 #define GLD (GM + 4)
 
-// one 128x16 (or 16x128) operand tile: 512 float4 units, 2 per thread.  CONTIG_K: element (x,k) at p[x*ld + k].
+// one 128xGK (or GKx128) operand tile: GK*32 float4 units, GU per thread.  CONTIG_K: element (x,k) at p[x*ld + k].
 template <bool CONTIG_K>
 __device__ __forceinline__ void gemm_tile_load(const float* __restrict__ p, int ld, int x0, int X, int k0, int kend, bool vec,
-                                               float4 (&r)[2]) {
+                                               float4 (&r)[GU]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < GU; ++h) {
         const int u = threadIdx.x + h * 256;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (CONTIG_K) {
@@ -139,10 +144,22 @@ __device__ __forceinline__ void gemm_tile_load(const float* __restrict__ p, int 
         r[h] = v;
     }
 }
+// the same tile when it is known to be complete, in bounds and 16-B aligned: straight-line dwordx4 loads.  (The guarded
+// form compiles to exec-masked branches whose results are merged right behind them, i.e. the wave waits for its
+// "prefetch" before it starts the MFMAs of the current tile — measured as exactly half the MFMA rate.)
 template <bool CONTIG_K>
-__device__ __forceinline__ void gemm_tile_store(float (*S)[GLD], const float4 (&r)[2]) {
+__device__ __forceinline__ void gemm_tile_load_fast(const float* __restrict__ p, int ld, int x0, int k0, float4 (&r)[GU]) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < GU; ++h) {
+        const int u = threadIdx.x + h * 256;
+        if (CONTIG_K) r[h] = *(const float4*)(p + (size_t)(x0 + (u & 127)) * ld + k0 + (u >> 7) * 4);
+        else r[h] = *(const float4*)(p + (size_t)(k0 + (u >> 5)) * ld + x0 + (u & 31) * 4);
+    }
+}
+template <bool CONTIG_K>
+__device__ __forceinline__ void gemm_tile_store(float (*S)[GLD], const float4 (&r)[GU]) {
+#pragma unroll
+    for (int h = 0; h < GU; ++h) {
         const int u = threadIdx.x + h * 256;
         if (CONTIG_K) {
             const int x = u & 127, k = (u >> 7) * 4;
@@ -154,13 +171,27 @@ __device__ __forceinline__ void gemm_tile_store(float (*S)[GLD], const float4 (&
     }
 }
 
-template <bool TA, bool TB>
+// FAST (host-selected): operands 16-B aligned with ld % 4 == 0.  Blocks whose 128x128 tile lies inside the matrix then take
+// the unguarded loads for every complete k-tile; edge blocks and a ragged last k-tile of a chunk take the guarded ones.
+template <bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
-    const int kbeg = blockIdx.z * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    // XCD-aware tile order: launch-linear block L runs on XCD L % 8; give every XCD one contiguous run of the
+    // (k-split, m-tile, n-tile) sequence, n fastest, so tiles sharing an A panel / a k-chunk meet in one L2
+    int bx, by, bz;
+    {
+        const int total = gridDim.x * gridDim.y * gridDim.z;
+        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = L & 7, per = total >> 3, rem = total & 7;
+        const int t = xcd * per + min(xcd, rem) + (L >> 3);
+        bx = t % gridDim.x;
+        by = (t / gridDim.x) % gridDim.y;
+        bz = t / (gridDim.x * gridDim.y);
+    }
+    const int m0 = by * GM, n0 = bx * GN;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const bool vecA = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0);
     const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
@@ -171,10 +202,16 @@ __global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[2], rb[2];
+    float4 ra[GU], rb[GU];
     // A: not transposed -> (m,k) at A[m*lda+k] (contiguous k); transposed -> A[k*lda+m] (contiguous m)
-    gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
-    gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+    const bool inside = FAST && m0 + GM <= g.M && n0 + GN <= g.N;
+    if (inside && kbeg + GK <= kend) {
+        gemm_tile_load_fast<!TA>(g.A, g.lda, m0, kbeg, ra);
+        gemm_tile_load_fast<TB>(g.B, g.ldb, n0, kbeg, rb);
+    } else {
+        gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
+        gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+    }
     gemm_tile_store<!TA>(As[0], ra);
     gemm_tile_store<TB>(Bs[0], rb);
     __syncthreads();
@@ -182,18 +219,34 @@ __global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
         if (more) {
-            gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
-            gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
+            if (inside && k0 + 2 * GK <= kend) {
+                gemm_tile_load_fast<!TA>(g.A, g.lda, m0, k0 + GK, ra);
+                gemm_tile_load_fast<TB>(g.B, g.ldb, n0, k0 + GK, rb);
+            } else {
+                gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
+                gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
+            }
         }
+        // operand fetch of MFMA step s+1 is issued before the four MFMAs of step s (the scheduler otherwise emits
+        // read -> wait -> 4 MFMA per step and the LDS latency is paid 16 times per k-tile)
+        const int kr0 = lane >> 5, li = lane & 31;
+        float pa[2][2], pb[2][2];
+        pa[0][0] = As[cur][kr0][wm + li]; pa[0][1] = As[cur][kr0][wm + 32 + li];
+        pb[0][0] = Bs[cur][kr0][wn + li]; pb[0][1] = Bs[cur][kr0][wn + 32 + li];
 #pragma unroll
-        for (int ks = 0; ks < GK; ks += 2) {
-            const int kr = ks + (lane >> 5), li = lane & 31;
-            const float a0 = As[cur][kr][wm + li], a1 = As[cur][kr][wm + 32 + li];
-            const float b0 = Bs[cur][kr][wn + li], b1 = Bs[cur][kr][wn + 32 + li];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        for (int s = 0; s < GK / 2; ++s) {
+            const int c = s & 1, n = c ^ 1;
+            if (s + 1 < GK / 2) {
+                const int kr = 2 * (s + 1) + kr0;
+                pa[n][0] = As[cur][kr][wm + li]; pa[n][1] = As[cur][kr][wm + 32 + li];
+                pb[n][0] = Bs[cur][kr][wn + li]; pb[n][1] = Bs[cur][kr][wn + 32 + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][0], pb[c][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][0], pb[c][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][1], pb[c][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][1], pb[c][1], acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
             gemm_tile_store<!TA>(As[cur ^ 1], ra);
@@ -213,7 +266,7 @@ __global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
                 const int n = n0 + wn + j * 32 + (lane & 31);
                 if (m < g.M && n < g.N) {
                     if (g.ksplit > 1) {
-                        g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                        g.part[((size_t)bz * g.M + m) * g.N + n] = acc[i][j][r];
                     } else {
                         float v = g.alpha * acc[i][j][r];
                         if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
@@ -341,14 +394,18 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
     hipStream_t st = (hipStream_t)stream;
     if (!big) {
         hipLaunchKernelGGL(lvsr_sgemm_kernel, grid, dim3(256), 0, st, g);
-    } else if (!transA && !transB) {
-        hipLaunchKernelGGL((lvsr_sgemm128_kernel<false, false>), grid, dim3(256), 0, st, g);
-    } else if (transA && !transB) {
-        hipLaunchKernelGGL((lvsr_sgemm128_kernel<true, false>), grid, dim3(256), 0, st, g);
-    } else if (!transA && transB) {
-        hipLaunchKernelGGL((lvsr_sgemm128_kernel<false, true>), grid, dim3(256), 0, st, g);
     } else {
-        hipLaunchKernelGGL((lvsr_sgemm128_kernel<true, true>), grid, dim3(256), 0, st, g);
+        const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && (((size_t)A) & 15) == 0 && (((size_t)B) & 15) == 0;
+#define LVSR_GEMM128(TA_, TB_)                                                                              \
+    do {                                                                                                    \
+        if (fast) hipLaunchKernelGGL((lvsr_sgemm128_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, g);    \
+        else hipLaunchKernelGGL((lvsr_sgemm128_kernel<TA_, TB_, false>), grid, dim3(256), 0, st, g);        \
+    } while (0)
+        if (!transA && !transB) LVSR_GEMM128(false, false);
+        else if (transA && !transB) LVSR_GEMM128(true, false);
+        else if (!transA && transB) LVSR_GEMM128(false, true);
+        else LVSR_GEMM128(true, true);
+#undef LVSR_GEMM128
     }
     if (g.ksplit > 1) {
         int nb = (int)(((size_t)M * N + 255) / 256);

@@ -8,7 +8,7 @@ from emu import emu_lib
 
 
 @pytest.mark.parametrize("transA,transB", [(False, False), (True, False), (False, True), (True, True)])
-@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (65, 130, 33), (130, 141, 37), (96, 128, 16)])
+@pytest.mark.parametrize("M,N,K", [(70, 37, 29), (16, 16, 4), (65, 130, 33), (130, 141, 37), (96, 128, 16), (300, 390, 70), (256, 128, 80)])
 def test_sgemm_layouts(transA, transB, M, N, K):
     lib = emu_lib()
     rng = numpy.random.RandomState(0)
