@@ -23,6 +23,8 @@ struct GemmArgs {
     int ksplit;        // number of K splits (grid.z); >1 => write raw partials to `part`
     int kchunk;        // K elements per split (multiple of BK)
     float* part;       // (ksplit, M, N) workspace
+    int batch;         // > 1: grid.z indexes independent problems (no split-K), operands advance by sA/sB/sC elements
+    long long sA, sB, sC;
 };
 
 __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
@@ -30,7 +32,12 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
     __shared__ float Bs[BK][LDS_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int kbeg = blockIdx.z * g.kchunk;
+    int zsplit = blockIdx.z;
+    if (g.batch > 1) {
+        g.A += blockIdx.z * g.sA; g.B += blockIdx.z * g.sB; g.C += blockIdx.z * g.sC;
+        zsplit = 0;
+    }
+    const int kbeg = zsplit * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
     const int rowbase = (wave >> 1) * 32, colbase = (wave & 1) * 32;
     f32x4 acc[2][2];
@@ -99,7 +106,7 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
                 const int n = n0 + colbase + j * 16 + (lane & 15);
                 if (m < g.M && n < g.N) {
                     if (g.ksplit > 1) {
-                        g.part[((size_t)blockIdx.z * g.M + m) * g.N + n] = acc[i][j][r];
+                        g.part[((size_t)zsplit * g.M + m) * g.N + n] = acc[i][j][r];
                     } else {
                         float v = g.alpha * acc[i][j][r];
                         if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
@@ -189,6 +196,10 @@ __global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
         bx = t % gridDim.x;
         by = (t / gridDim.x) % gridDim.y;
         bz = t / (gridDim.x * gridDim.y);
+    }
+    if (g.batch > 1) {
+        g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
+        bz = 0;
     }
     const int m0 = by * GM, n0 = bx * GN;
     const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
@@ -361,12 +372,14 @@ __global__ __launch_bounds__(256) void lvsr_pack_b_kernel(const float* W, int ld
 
 extern "C" {
 
-int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
-               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
-               long long ws_bytes) {
-    LVSR_REQUIRE(M >= 0 && N >= 0 && K >= 0, "lvsr_sgemm: negative dimension");
+static int sgemm_launch(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                        const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+                        long long ws_bytes, int batch, long long sA, long long sB, long long sC) {
+    LVSR_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 1, "lvsr_sgemm: negative dimension");
     if (M == 0 || N == 0) return LVSR_OK;
     GemmArgs g;
+    g.batch = batch; g.sA = sA; g.sB = sB; g.sC = sC;
+    if (batch > 1) ws = nullptr;
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB;
     g.alpha = alpha; g.beta = beta; g.ksplit = 1; g.kchunk = 0; g.part = nullptr;
@@ -390,12 +403,13 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
             g.part = ws;
         }
     }
-    dim3 grid((N + tn - 1) / tn, (M + tm - 1) / tm, g.ksplit);
+    dim3 grid((N + tn - 1) / tn, (M + tm - 1) / tm, batch > 1 ? batch : g.ksplit);
     hipStream_t st = (hipStream_t)stream;
     if (!big) {
         hipLaunchKernelGGL(lvsr_sgemm_kernel, grid, dim3(256), 0, st, g);
     } else {
-        const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && (((size_t)A) & 15) == 0 && (((size_t)B) & 15) == 0;
+        const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && (((size_t)A) & 15) == 0 && (((size_t)B) & 15) == 0 &&
+                          (batch == 1 || ((sA & 3) == 0 && (sB & 3) == 0));
 #define LVSR_GEMM128(TA_, TB_)                                                                              \
     do {                                                                                                    \
         if (fast) hipLaunchKernelGGL((lvsr_sgemm128_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, g);    \
@@ -413,6 +427,21 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
         hipLaunchKernelGGL(lvsr_sgemm_splitk_reduce, dim3(nb), dim3(256), 0, st, g);
     }
     return lvsr_check_launch("lvsr_sgemm");
+}
+
+int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+               const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
+               long long ws_bytes) {
+    return sgemm_launch(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, bias, ws, ws_bytes, 1, 0, 0, 0);
+}
+
+int lvsr_sgemm_batched(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                       long long strideA, const float* B, int ldb, long long strideB, float beta, float* C, int ldc,
+                       long long strideC, int batch) {
+    LVSR_REQUIRE(batch >= 0, "lvsr_sgemm_batched: negative batch");
+    if (batch == 0) return LVSR_OK;
+    return sgemm_launch(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, nullptr, 0, batch,
+                        strideA, strideB, strideC);
 }
 
 int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,

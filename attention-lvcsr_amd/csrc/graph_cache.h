@@ -36,7 +36,7 @@ int lvsr_run_graph(hipStream_t s, int use_graph, const GraphKey& key, F&& enqueu
             hipError_t e = hipStreamEndCapture(s, &graph);
             if (e == hipSuccess && graph) {
                 e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-                hipGraphDestroy(graph);
+                (void)hipGraphDestroy(graph);
             }
             if (e != hipSuccess || !exec) {
                 (void)hipGetLastError();

@@ -50,7 +50,7 @@ void lvsr_graph_store(const GraphKey& key, hipGraphExec_t exec) {
     std::lock_guard<std::mutex> lk(g_mu);
     while (g_graphs.size() >= kMaxGraphs) {
         auto victim = g_graphs.find(g_lru.back());
-        if (victim->second.exec) hipGraphExecDestroy(victim->second.exec);
+        if (victim->second.exec) (void)hipGraphExecDestroy(victim->second.exec);
         g_graphs.erase(victim);
         g_lru.pop_back();
     }
@@ -63,7 +63,7 @@ extern "C" {
 void lvsr_graph_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& kv : g_graphs)
-        if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     g_graphs.clear();
     g_lru.clear();
 }

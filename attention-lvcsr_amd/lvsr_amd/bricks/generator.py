@@ -291,10 +291,9 @@ class SequenceGenerator(object):
         dA = ws.get("gen.dA", (Tp, B, d.E))
         lib.sgemm(dPA2, p[n["Wpre"]], dA.view(Tp * B, d.E), transB=True)
         W = bufs["W"]
-        for b in range(B):
-            # dA[:, b, :] += alpha_b^T (T',L) @ dwa_b (L,E)
-            lib.sgemm(W[1:, b, :], DWA[:, b, :], dA[:, b, :], transA=True, beta=1.0, M=Tp, N=d.E, K=L,
-                      lda=B * Tp, ldb=B * d.E, ldc=B * d.E)
+        # dA[:, b, :] += alpha_b^T (T',L) @ dwa_b (L,E) for every utterance b: one batched launch
+        lib.call("lvsr_sgemm_batched", lib.stream_for(dA), 1, 0, Tp, d.E, L, 1.0, lib_ptr(W[1:]), B * Tp, Tp,
+                 lib_ptr(DWA), B * d.E, d.E, 1.0, lib_ptr(dA), B * d.E, d.E, B)
         return dA
 
 

@@ -35,6 +35,12 @@ int lvsr_graph_count(void);
 int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                long long ws_bytes);
+/* `batch` independent products in one launch: problem i uses A + i*strideA, B + i*strideB, C + i*strideC (elements).
+ * Here: the per-utterance alignment^T x glimpse-gradient products of the attended-sequence gradient
+ * (d compute_weighted_averages, libs/blocks/blocks/bricks/attention.py:236-256). */
+int lvsr_sgemm_batched(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
+                       long long strideA, const float* B, int ldb, long long strideB, float beta, float* C, int ldc,
+                       long long strideC, int batch);
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]  (bias gradients); ws: optional workspace for the row-split partials */
 int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,
                 long long ws_bytes);

@@ -58,3 +58,19 @@ def test_colsum_and_transpose():
     Y = torch.empty(70, 37)
     lib.transpose(X, Y)
     assert (Y == X.T).all()
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(20, 24, 9, 3), (130, 128, 40, 5), (200, 256, 36, 4)])
+def test_sgemm_batched(M, N, K, batch):
+    """lvsr_sgemm_batched on interleaved (time, utterance, feature) tensors, as the generator's backward uses it."""
+    from lvsr_amd.native import ptr
+    lib = emu_lib()
+    rng = numpy.random.RandomState(3)
+    A = torch.tensor(rng.normal(size=(K, batch, M)), dtype=torch.float32)        # problem b: A[:, b, :]^T  (M x K)
+    Bm = torch.tensor(rng.normal(size=(K, batch, N)), dtype=torch.float32)       # problem b: B[:, b, :]    (K x N)
+    C0 = torch.tensor(rng.normal(size=(M, batch, N)), dtype=torch.float32)
+    C = C0.clone()
+    lib.call("lvsr_sgemm_batched", lib.stream_for(C), 1, 0, M, N, K, 0.5, ptr(A), batch * M, M, ptr(Bm), batch * N, N, 1.0,
+             ptr(C), batch * N, N, batch)
+    ref = 0.5 * torch.einsum("kbm,kbn->mbn", A.double(), Bm.double()) + C0.double()
+    assert_allclose(C.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
