@@ -10,6 +10,7 @@
 // for the tall-skinny weight-gradient shapes (K = T*B rows).
 #include "common.h"
 #include "lvsr_hip.h"
+#include "graph_cache.h"
 
 #define BM 64
 #define BN 64
@@ -484,6 +485,27 @@ int lvsr_pack_b(void* stream, const float* W, int ldw, int K, int N, int trans, 
     hipLaunchKernelGGL(lvsr_pack_b_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, W, ldw, K, N, trans, packed, Kw,
                        NQ, total);
     return lvsr_check_launch("lvsr_pack_b");
+}
+
+int lvsr_pack_b_many(void* stream, const lvsr_pack_desc* descs, int n, int use_graph) {
+    LVSR_REQUIRE(n >= 0 && (n == 0 || descs), "lvsr_pack_b_many: bad arguments");
+    if (n == 0) return LVSR_OK;
+    for (int i = 0; i < n; ++i)
+        LVSR_REQUIRE(descs[i].K > 0 && descs[i].N > 0 && descs[i].W && descs[i].packed, "lvsr_pack_b_many: bad descriptor %d", i);
+    hipStream_t s = (hipStream_t)stream;
+    auto enqueue = [&]() {
+        for (int i = 0; i < n; ++i) {
+            const lvsr_pack_desc& d = descs[i];
+            const int Kw = lvsr_pack_kw(d.K), NQ = Kw / 16;
+            const long long total = lvsr_pack_size(d.K, d.N);
+            int nb = (int)((total + 255) / 256);
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(lvsr_pack_b_kernel, dim3(nb), dim3(256), 0, s, d.W, d.ldw, d.K, d.N, d.trans, d.packed, Kw, NQ, total);
+        }
+    };
+    GraphKey key("pack_many");
+    key.add(descs, sizeof(lvsr_pack_desc) * (size_t)n);
+    return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_pack_b_many");
 }
 
 }  // extern "C"

@@ -18,9 +18,11 @@ struct GraphKey {
 hipGraphExec_t lvsr_graph_lookup(const GraphKey& key, bool* known_bad);
 void lvsr_graph_store(const GraphKey& key, hipGraphExec_t exec);   // exec == nullptr marks "cannot capture"
 
+bool lvsr_stream_is_capturing(hipStream_t s);
+
 template <class F>
 int lvsr_run_graph(hipStream_t s, int use_graph, const GraphKey& key, F&& enqueue, const char* what) {
-    if (!use_graph) {
+    if (!use_graph || lvsr_stream_is_capturing(s)) {       // inside an lvsr_region_begin/end capture: just record the launches
         enqueue();
         return lvsr_check_launch(what);
     }

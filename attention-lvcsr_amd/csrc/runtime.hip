@@ -58,7 +58,79 @@ void lvsr_graph_store(const GraphKey& key, hipGraphExec_t exec) {
     g_graphs[key.bytes] = Entry{exec, g_lru.begin()};
 }
 
+bool lvsr_stream_is_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st == hipStreamCaptureStatusActive;
+}
+
+static thread_local std::string g_region_key;
+
 extern "C" {
+// ---- graph regions: several library calls (and whatever else the host enqueues on the stream) as ONE cached graph --
+// begin: 1 = a cached graph for `key` was launched, the caller skips its enqueue code; 0 = capture started, the caller
+// enqueues as usual and then calls lvsr_region_end; 2 = capture impossible (e.g. legacy stream), enqueue eagerly, no end.
+int lvsr_region_begin(void* stream, const char* key, long long key_bytes) {
+    LVSR_REQUIRE(key && key_bytes > 0, "lvsr_region_begin: empty key");
+    hipStream_t s = (hipStream_t)stream;
+    GraphKey k("region:");
+    k.add(key, (size_t)key_bytes);
+    bool bad = false;
+    hipGraphExec_t exec = lvsr_graph_lookup(k, &bad);
+    if (exec) {
+        if (hipGraphLaunch(exec, s) != hipSuccess) {
+            lvsr_set_error("lvsr_region_begin: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+            return LVSR_ERR_HIP;
+        }
+        return 1;
+    }
+    if (bad || lvsr_stream_is_capturing(s)) return 2;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        lvsr_graph_store(k, nullptr);
+        return 2;
+    }
+    g_region_key = k.bytes;
+    return 0;
+}
+
+// end: instantiate, cache under the key of the matching begin and launch.  keep = 0 discards the capture instead (the
+// caller noticed something that must not be replayed, e.g. a device allocation inside the region) and marks the key as
+// not capturable; the caller then enqueues again eagerly.
+int lvsr_region_end(void* stream, int keep) {
+    hipStream_t s = (hipStream_t)stream;
+    LVSR_REQUIRE(!g_region_key.empty(), "lvsr_region_end without lvsr_region_begin");
+    GraphKey k("");
+    k.bytes = g_region_key;
+    g_region_key.clear();
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (e == hipSuccess && graph && keep) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!keep) {
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        lvsr_graph_store(k, nullptr);
+        return LVSR_OK;
+    }
+    if (e != hipSuccess || !exec) {
+        lvsr_set_error("lvsr_region_end: capture failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        lvsr_graph_store(k, nullptr);
+        return LVSR_ERR_HIP;
+    }
+    lvsr_graph_store(k, exec);
+    if (hipGraphLaunch(exec, s) != hipSuccess) {
+        lvsr_set_error("lvsr_region_end: hipGraphLaunch failed: %s", hipGetErrorString(hipGetLastError()));
+        return LVSR_ERR_HIP;
+    }
+    return LVSR_OK;
+}
+
 // Drop every cached graph (call when workspaces are freed / pointers may be recycled).
 void lvsr_graph_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);

@@ -74,6 +74,7 @@ class Encoder(object):
         self.use_graph = use_graph
         self._saved = None
         self._packs = {}
+        self._pack_cache = {}
         # weight-gradient GEMMs on a second stream: measured SLOWER on MI355X (70.0 vs 66.4 ms per WSJ-base step: the
         # concurrent GEMM work-groups delay the latency-bound step kernels more than the overlap saves), so off by default
         self.overlap = os.environ.get("LVSR_OVERLAP", "0") == "1"
@@ -88,29 +89,32 @@ class Encoder(object):
                     h0=base + "/gatedrecurrent.initial_state")
 
     def _packed(self, i):
-        """Packed (MFMA operand order) copies of the recurrent weights of layer i, refreshed when the
-        parameters changed (store.version)."""
-        ent = self._packs.get(i)
-        if ent is not None and ent["version"] == self.store.version:
-            return ent
-        H, p, lib, ws = self.d.Hs[i], self.store.p, self.lib, self.ws
-        ent = dict(version=self.store.version, Whh=[], Whg=[], WhhT=[], WhgT=[])
-        for di, direction in enumerate(("forward", "backward")):
-            n = self._names(i, direction)
-            for key, W, trans in (("Whh", p[n["Whh"]], False), ("Whg", p[n["Whg"]], False), ("WhhT", p[n["Whh"]], True)):
-                K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
-                buf = ws.get("enc%d.%d.%s_p" % (i, di, key), (lib.pack_size(K, N),))
-                lib.pack_b(W, buf, trans=trans)
-                ent[key].append(buf)
-            # state_to_gates^T as two (K=H,N=H) blocks: update rows, then reset rows
-            sz = lib.pack_size(H, H)
-            buf = ws.get("enc%d.%d.WhgT_p" % (i, di), (2 * sz,))
-            Wg = p[n["Whg"]]
-            lib.pack_b(Wg[:, :H], buf[:sz], trans=True)
-            lib.pack_b(Wg[:, H:], buf[sz:], trans=True)
-            ent["WhgT"].append(buf)
-        self._packs[i] = ent
-        return ent
+        """Packed (MFMA operand order) copies of the recurrent weights of layer i.  All layers are refreshed together, in one
+        library call, the first time a layer is asked for after the parameters changed (store.version)."""
+        if self._packs.get("version") != self.store.version or self.lib.capturing:
+            p, lib, ws = self.store.p, self.lib, self.ws
+            packs, jobs = dict(version=self.store.version), []
+            for li in range(self.d.n_layers):
+                H = self.d.Hs[li]
+                ent = dict(Whh=[], Whg=[], WhhT=[], WhgT=[])
+                for di, direction in enumerate(("forward", "backward")):
+                    n = self._names(li, direction)
+                    for key, W, trans in (("Whh", p[n["Whh"]], False), ("Whg", p[n["Whg"]], False), ("WhhT", p[n["Whh"]], True)):
+                        K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
+                        buf = ws.get("enc%d.%d.%s_p" % (li, di, key), (lib.pack_size(K, N),))
+                        jobs.append((W, buf, trans))
+                        ent[key].append(buf)
+                    # state_to_gates^T as two (K=H,N=H) blocks: update rows, then reset rows
+                    sz = lib.pack_size(H, H)
+                    buf = ws.get("enc%d.%d.WhgT_p" % (li, di), (2 * sz,))
+                    Wg = p[n["Whg"]]
+                    jobs.append((Wg[:, :H], buf[:sz], True))
+                    jobs.append((Wg[:, H:], buf[sz:], True))
+                    ent["WhgT"].append(buf)
+                packs[li] = ent
+            lib.pack_many(jobs, use_graph=self.use_graph, cache=self._pack_cache)
+            self._packs = packs
+        return self._packs[i]
 
     @contextlib.contextmanager
     def _side_stream(self):

@@ -32,6 +32,7 @@ class SequenceGenerator(object):
         self.ws = workspace
         self.use_graph = use_graph
         self._packs = None
+        self._pack_cache = {}
         self._saved = None
         g = "/recognizer/generator"
         att = g + "/att_trans/" + ("conv_att" if dims.conv else "cont_att")
@@ -50,15 +51,16 @@ class SequenceGenerator(object):
 
     # ---- packed operand copies ------------------------------------------------------------------
     def _packed(self):
-        if self._packs is not None and self._packs["version"] == self.store.version:
+        if self._packs is not None and self._packs["version"] == self.store.version and not self.lib.capturing:
             return self._packs
         p, lib, ws, n, d = self.store.p, self.lib, self.ws, self.n, self.d
         ent = dict(version=self.store.version)
+        jobs = []
 
         def pack(key, W, trans=False):
             K, N = (W.shape[1], W.shape[0]) if trans else (W.shape[0], W.shape[1])
             buf = ws.get("gen.%s_p" % key, (lib.pack_size(K, N),))
-            lib.pack_b(W, buf, trans=trans)
+            jobs.append((W, buf, trans))
             ent[key] = buf
         pack("Ws", p[n["Ws"]]); pack("WsT", p[n["Ws"]], True)
         pack("Whg", p[n["Whg"]]); pack("WhgT", p[n["Whg"]], True)
@@ -68,6 +70,7 @@ class SequenceGenerator(object):
         wd[:, : d.D].copy_(p[n["Wdi"]])
         wd[:, d.D:].copy_(p[n["Wdg"]])
         pack("WdT", wd, True)
+        lib.pack_many(jobs, use_graph=self.use_graph, cache=self._pack_cache)
         self._packs = ent
         return ent
 

@@ -56,6 +56,9 @@ class SpeechRecognizer(object):
             yield
             return
         cur = torch.cuda.current_stream(self.device)
+        if cur == self.stream:                                      # re-entrant
+            yield
+            return
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
             yield
@@ -132,16 +135,20 @@ class SpeechRecognizer(object):
         if kw:
             raise TypeError("unknown inputs: %s" % sorted(kw))
         with self._on_stream():
-            x = self._t(recordings, torch.float32, "recordings")
-            xm = self._t(inputs_mask, torch.float32, "recordings_mask")
-            y = self._t(labels, torch.int64, "labels")
-            ym = self._t(labels_mask, torch.float32, "labels_mask")
-            encoded, encoded_mask = self.encoder.apply(self.bottom.apply(x, save_for_backward), xm,
-                                                       save_for_backward=save_for_backward)
-            self.encoded, self.encoded_mask = encoded, encoded_mask
-            cm = self.generator.cost_matrix(y, ym, attended=encoded, attended_mask=encoded_mask,
-                                            save_for_backward=save_for_backward)
+            x, xm, y, ym = self._stage(recordings, inputs_mask, labels, labels_mask)
+            cm = self._forward(x, xm, y, ym, save_for_backward)
         return cm
+
+    def _stage(self, recordings, inputs_mask, labels, labels_mask):
+        return (self._t(recordings, torch.float32, "recordings"), self._t(inputs_mask, torch.float32, "recordings_mask"),
+                self._t(labels, torch.int64, "labels"), self._t(labels_mask, torch.float32, "labels_mask"))
+
+    def _forward(self, x, xm, y, ym, save_for_backward=True):
+        encoded, encoded_mask = self.encoder.apply(self.bottom.apply(x, save_for_backward), xm,
+                                                   save_for_backward=save_for_backward)
+        self.encoded, self.encoded_mask = encoded, encoded_mask
+        return self.generator.cost_matrix(y, ym, attended=encoded, attended_mask=encoded_mask,
+                                          save_for_backward=save_for_backward)
 
     def backward(self):
         """Gradient of cost.sum() wrt all parameters -> self.store.grad (flat) / self.store.g (named views)."""
@@ -151,13 +158,26 @@ class SpeechRecognizer(object):
             if self.d.bottom_dims:
                 self.bottom.backward(d_bottom)
 
-    def cost_and_gradients(self, batch):
+    def cost_and_gradients(self, batch, tail=None, tail_key=None, region=True):
         """One training forward+backward on a batch dict in the reference's layout.
-        Returns (cost.sum() as a 0-d device tensor); gradients of that sum are in self.store.grad."""
-        cm = self.cost(recordings=batch["recordings"], inputs_mask=batch.get("recordings_mask"),
-                       labels=batch["labels"], labels_mask=batch.get("labels_mask"))
-        self.backward()
-        return cm
+        Returns the cost matrix (L,B) on the device; gradients of its sum are in self.store.grad.
+        `tail` (optional callable, described by the hashable `tail_key`) enqueues more work behind the backward pass — the
+        optimiser step — inside the same graph region: the whole step is then ONE hipGraph launch per minibatch shape."""
+        with self._on_stream():
+            x, xm, y, ym = self._stage(batch["recordings"], batch.get("recordings_mask"), batch["labels"],
+                                       batch.get("labels_mask"))
+
+            def enqueue():
+                cm = self._forward(x, xm, y, ym)
+                self.backward()
+                if tail is not None:
+                    tail()
+                return cm
+            key = ("train_step", id(self), tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
+            volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
+                        self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
+            plain = region and self.use_graph and not self.encoder.use_persistent and not self.encoder.overlap
+            return self.lib.region(key, x, enabled=plain, volatile=volatile).run(enqueue)
 
     # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------
     def analyze(self, inputs, groundtruth, prediction=None):

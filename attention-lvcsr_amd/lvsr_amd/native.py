@@ -25,6 +25,10 @@ _GRAPH_STREAM = os.environ.get("LVSR_GRAPH_STREAM", "0") == "1"
 _SYNC_AFTER_GRAPH = os.environ.get("LVSR_SYNC_AFTER_GRAPH", "1") == "1"
 _SYNC_BEFORE_GRAPH = os.environ.get("LVSR_SYNC_BEFORE_GRAPH", "0") == "1"
 
+# Whole-step graph regions (lvsr_region_begin/end): one hipGraph launch per training step.  LVSR_STEP_GRAPH=0 keeps the
+# per-layer time-loop graphs with eager launches between them.
+_STEP_GRAPH = os.environ.get("LVSR_STEP_GRAPH", "1") == "1"
+
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
             "long long": ctypes.c_longlong, "char": ctypes.c_char}
 
@@ -134,6 +138,8 @@ class Lib(object):
         self._dll = ctypes.CDLL(path)
         self.is_emulator = os.path.basename(path) != os.path.basename(DEFAULT_LIB)
         self._gstream = None
+        self.capturing = False          # inside a Region capture: no host synchronisation, no nested graphs
+        self._regions = {}
         self.structs, self.functions = parse_header()
         for name, (res, args, _) in self.functions.items():
             try:
@@ -213,12 +219,31 @@ class Lib(object):
         assert packed.numel() >= self.pack_size(K, N)
         self.call("lvsr_pack_b", self.stream_for(packed), ptr(W), W.stride(0), K, N, int(trans), ptr(packed))
 
+    def pack_many(self, jobs, use_graph=False, cache=None):
+        """jobs: [(W 2-D tensor, packed 1-D tensor, trans)] -> one lvsr_pack_b_many call.  `cache` (a dict owned by the caller)
+        keeps the descriptor array between calls while the tensors stay where they are."""
+        if not jobs:
+            return
+        sig = tuple((W.data_ptr(), W.stride(0), W.shape[0], W.shape[1], P.data_ptr(), int(t)) for W, P, t in jobs)
+        arr = None if cache is None or cache.get("sig") != sig else cache.get("arr")
+        if arr is None:
+            cls = self.structs["lvsr_pack_desc"]
+            arr = (cls * len(jobs))()
+            for d, (W, P, t) in zip(arr, jobs):
+                K, N = (W.shape[1], W.shape[0]) if t else (W.shape[0], W.shape[1])
+                assert W.stride(1) == 1 and P.numel() >= self.pack_size(K, N)
+                d.W, d.packed, d.ldw, d.K, d.N, d.trans = W.data_ptr(), P.data_ptr(), W.stride(0), K, N, int(t)
+            if cache is not None:
+                cache["sig"], cache["arr"] = sig, arr
+        ref = jobs[0][1]
+        self.call("lvsr_pack_b_many", self.stream_for(ref), arr, len(jobs), int(bool(use_graph) and ref.is_cuda))
+
     def run(self, fn, struct_name, ref_tensor, use_graph=None, **fields):
         """Call an args-struct entry point: fn(stream, &args[, use_graph])."""
         a = self.make(struct_name, **fields)
-        if _SYNC_BEFORE_GRAPH and use_graph and ref_tensor.is_cuda:
+        if _SYNC_BEFORE_GRAPH and use_graph and ref_tensor.is_cuda and not self.capturing:
             torch.cuda.current_stream(ref_tensor.device).synchronize()      # experiment knob, see DESIGN.md
-        if _GRAPH_STREAM and use_graph and ref_tensor.is_cuda:
+        if _GRAPH_STREAM and use_graph and ref_tensor.is_cuda and not self.capturing:
             cur = torch.cuda.current_stream(ref_tensor.device)
             if self._gstream is None:
                 self._gstream = torch.cuda.Stream(ref_tensor.device)
@@ -235,11 +260,93 @@ class Lib(object):
             self.after_graph(ref_tensor, max(fields.get("T", 0), fields.get("L", 0)))
         return a
 
-    @staticmethod
-    def after_graph(ref_tensor, steps):
+    def after_graph(self, ref_tensor, steps):
         """Block the host until a long time-loop graph has drained (see _SYNC_AFTER_GRAPH above)."""
-        if _SYNC_AFTER_GRAPH and ref_tensor.is_cuda and steps >= 16:
+        if _SYNC_AFTER_GRAPH and ref_tensor.is_cuda and steps >= 16 and not self.capturing:
             torch.cuda.current_stream(ref_tensor.device).synchronize()
+
+    def region(self, key, ref_tensor, enabled=True, volatile=()):
+        return Region(self, key, ref_tensor, enabled, volatile)
+
+
+class Region(object):
+    """One cached hipGraph for everything the host enqueues between `begin()` and `end()`:
+
+        out = lib.region(key, tensor).run(fn)
+
+    where fn() enqueues (library calls, tensor copies/fills on the current stream) and returns whatever the caller needs
+    back on a replay (tensors living in stable workspaces).
+
+    `key` + `volatile` must name every pointer, shape and scalar the enqueue code depends on.  The first time a `key` is
+    seen the body runs eagerly (so every workspace exists), the second time it is captured, afterwards replayed; a changed
+    `volatile` part (workspace generation: buffers were re-allocated) re-captures without another eager pass.  A capture during
+    which the caching allocator handed out memory is dropped (a replay would write to memory it does not own) and the key
+    is enqueued again eagerly, and stays eager.  Disabled on the emulator / CPU tensors, with LVSR_STEP_GRAPH=0, and inside another region."""
+    def __init__(self, lib, key, ref, enabled, volatile=()):
+        self.lib, self.ref = lib, ref
+        soft = repr(key).encode()
+        self.kb = soft + b"|" + repr(volatile).encode()
+        self.enabled = bool(enabled) and _STEP_GRAPH and ref.is_cuda and not lib.is_emulator and not lib.capturing
+        self.state = "eager"
+        self.slot = lib._regions.setdefault(soft, dict(seen=0, result=None)) if self.enabled else dict(seen=0, result=None)
+
+    @property
+    def result(self):
+        return self.slot["result"]
+
+    @result.setter
+    def result(self, v):
+        self.slot["result"] = v
+
+    def begin(self):
+        if not self.enabled:
+            return True
+        self.slot["seen"] += 1
+        if self.slot["seen"] == 1 or self.slot.get("bad"):
+            return True
+        lib = self.lib
+        rc = lib._lvsr_region_begin(lib.stream_for(self.ref), self.kb, len(self.kb))
+        if rc < 0:
+            raise NativeError("lvsr_region_begin failed (%d): %s" % (rc, lib.last_error()))
+        if rc == 1:
+            self.state = "replayed"
+            lib.after_graph(self.ref, 1 << 20)
+            return False
+        if rc == 2:
+            self.slot["bad"] = True
+            return True
+        self.state = "capturing"
+        lib.capturing = True
+        self._allocs = torch.cuda.memory_stats(self.ref.device).get("allocation.all.allocated", 0)
+        return True
+
+    def end(self):
+        if self.state != "capturing":
+            return True
+        lib = self.lib
+        lib.capturing = False
+        clean = torch.cuda.memory_stats(self.ref.device).get("allocation.all.allocated", 0) == self._allocs
+        rc = lib._lvsr_region_end(lib.stream_for(self.ref), int(clean))
+        self.state = "captured"
+        if rc != 0:
+            self.slot["bad"] = True
+            raise NativeError("lvsr_region_end failed (%d): %s" % (rc, lib.last_error()))
+        if not clean:
+            self.slot["bad"] = True
+            return False
+        lib.after_graph(self.ref, 1 << 20)
+        return True
+
+    def run(self, fn):
+        if self.begin():
+            ok = True
+            try:
+                self.result = fn()
+            finally:
+                ok = self.end()
+            if not ok:
+                self.result = fn()
+        return self.result
 
 
 _default = None

@@ -20,6 +20,7 @@ class Workspace(object):
     def __init__(self, device):
         self.device = device
         self._bufs = {}          # (name, dtype) -> flat tensor
+        self.generation = 0      # bumped whenever a buffer is (re)allocated: pointers handed out earlier may be stale
 
     def get(self, name, shape, dtype=torch.float32, zero=False):
         shape = tuple(int(s) for s in shape)
@@ -31,6 +32,7 @@ class Workspace(object):
         if flat is None or flat.numel() < n:
             cap = max(n, 1) if flat is None else max(n, int(flat.numel() * 1.5))
             flat = torch.zeros(cap, dtype=dtype, device=self.device)
+            self.generation += 1
             self._bufs[key] = flat
             zero = False
         t = flat[:n].view(shape)

@@ -58,22 +58,37 @@ class Trainer(object):
         """L2 norm of the (scaled, all-reduced) gradient of the last step: the reference's `total_gradient_norm`."""
         return float(self.scratch[0])
 
+    def _enqueue_optimizer(self, global_batch_size):
+        st, lib = self.rec.store, self.rec.lib
+        a = lib.make("lvsr_opt_args", param=st.flat, grad=st.grad, velocity=self.velocity, ms_step=self.ms_step,
+                     ms_dx=self.ms_dx, step=self.step_buf, segments=self.segments, segflag=self.segflag,
+                     scratch=self.scratch, n=st.flat.numel(), nseg=int(self.segments.shape[0]), max_cols=self.max_cols,
+                     grad_scale=1.0 / float(global_batch_size), **self.conf)
+        lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
+
     def apply_gradients(self, global_batch_size):
-        rec, st, lib = self.rec, self.rec.store, self.rec.lib
+        rec, st = self.rec, self.rec.store
         with rec._on_stream():
             if self.distributed and self.world > 1:
                 # ONE collective per step over the flat gradient bucket (sum); RCCL when the tensors are on GPUs
                 torch.distributed.all_reduce(st.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
-            a = lib.make("lvsr_opt_args", param=st.flat, grad=st.grad, velocity=self.velocity, ms_step=self.ms_step,
-                         ms_dx=self.ms_dx, step=self.step_buf, segments=self.segments, segflag=self.segflag,
-                         scratch=self.scratch, n=st.flat.numel(), nseg=int(self.segments.shape[0]), max_cols=self.max_cols,
-                         grad_scale=1.0 / float(global_batch_size), **self.conf)
-            lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
+            self._enqueue_optimizer(global_batch_size)
             st.version += 1
 
     def train_step(self, batch, global_batch_size=None):
-        """batch = this rank's shard (reference layout).  Returns the local cost.sum() as a device tensor."""
+        """batch = this rank's shard (reference layout).  Returns the local cost matrix as a device tensor.
+        Single process: forward, backward and the optimiser step are one graph region (one launch per step); with data
+        parallelism the region ends before the all-reduce and the optimiser follows it."""
         B_local = int(batch["labels"].shape[1])
-        cm = self.rec.cost_and_gradients(batch)
-        self.apply_gradients(global_batch_size if global_batch_size is not None else B_local * self.world)
+        gbs = global_batch_size if global_batch_size is not None else B_local * self.world
+        if self.distributed and self.world > 1:
+            # per-layer graphs + eager launches (measured equal in speed to the whole-step region: the step is bound by the
+            # device-side chain of dependent kernels, not by the host); the region stays a single-process feature until it
+            # has run next to RCCL's proxy threads on a multi-GPU box
+            cm = self.rec.cost_and_gradients(batch, region=False)
+            self.apply_gradients(gbs)
+            return cm
+        tail_key = ("opt", id(self), float(gbs), tuple(sorted(self.conf.items())))
+        cm = self.rec.cost_and_gradients(batch, tail=lambda: self._enqueue_optimizer(gbs), tail_key=tail_key)
+        self.rec.store.version += 1
         return cm

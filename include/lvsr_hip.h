@@ -29,6 +29,14 @@ const char* lvsr_last_error(void);
 int lvsr_abi_version(void);
 void lvsr_graph_clear(void);   /* drop cached hipGraphs (call before freeing buffers they reference) */
 int lvsr_graph_count(void);
+/* Graph regions: everything enqueued on `stream` between begin and end (library calls, copies, fills) becomes ONE cached
+ * hipGraph keyed by `key` (the caller's description of every pointer, size and scalar the enqueue code depends on).
+ * begin returns 1 = cached graph launched (skip the enqueue code and the end call), 0 = capturing (enqueue, then call
+ * end), 2 = not capturable (enqueue eagerly, no end call).  end(keep=1) instantiates, caches and launches;
+ * end(keep=0) drops the capture and marks the key not capturable.  Entry points called with use_graph=1 inside a region
+ * just record their launches.  Used for the whole training step: one launch per step instead of ~25 graphs + ~150 kernels. */
+int lvsr_region_begin(void* stream, const char* key, long long key_bytes);
+int lvsr_region_end(void* stream, int keep);
 
 /* ---- dense helpers (Linear bricks: libs/blocks/blocks/bricks/simple.py:59-76) ------------------ */
 /* C[M,N] = alpha*op(A)[M,K]*op(B)[K,N] + beta*C + bias[N]; fp32 MFMA; ws: optional split-K workspace */
@@ -51,6 +59,14 @@ int lvsr_transpose(void* stream, const float* in, int rows, int cols, float* out
  * waves of a work-group, 16 B per lane per load.  lvsr_pack_size = number of floats of the packed copy. */
 long long lvsr_pack_size(int K, int N);
 int lvsr_pack_b(void* stream, const float* W, int ldw, int K, int N, int trans, float* packed);
+/* All packed copies of a model in one call (they are refreshed after every optimiser step): n independent lvsr_pack_b
+ * jobs; with use_graph the n launches are captured once per descriptor list and replayed as one hipGraph. */
+typedef struct lvsr_pack_desc {
+    const float* W;
+    float* packed;
+    int ldw, K, N, trans;
+} lvsr_pack_desc;
+int lvsr_pack_b_many(void* stream, const lvsr_pack_desc* descs, int n, int use_graph);
 
 /* ---- encoder: one bidirectional GRU layer ---------------------------------------------------------
  * GatedRecurrent.apply (libs/blocks/blocks/bricks/recurrent.py:608-620) under scan (:178-231),

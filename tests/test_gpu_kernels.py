@@ -192,3 +192,31 @@ def test_one_recognizer_many_shapes_gpu(gpu_device):
             cm2 = rec.cost_and_gradients(pad).cpu().numpy()
             assert_allclose(cm2[:L], cm.cpu().numpy(), rtol=1e-5, atol=1e-6)
             assert (cm2[L:] == 0).all()
+
+
+def test_whole_step_graph_region_gpu(gpu_device):
+    """Trainer.train_step on the GPU = one graph region per minibatch shape (eager pass, capture, then replays), with the
+    optimiser inside.  Five steps on changing batches of two shapes must track the same trainer run through the emulated
+    library step by step (costs) and end at the same parameters."""
+    from emu import emu_lib
+    from lvsr_amd.training import Trainer
+    z, meta = load_golden("tiny_conv_median")
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    conf = dict(gradient_threshold=100.0, rules=("momentum", "adadelta"), scale=0.1, momentum=0.0, decay_rate=0.95, epsilon=1e-8,
+                max_norm=1.0)
+    recs = [SpeechRecognizer(device=gpu_device, params=params, net_config=cfg),
+            SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)]
+    trainers = [Trainer(r, **conf) for r in recs]
+    shapes = [(4, 40, 9), (4, 40, 9), (3, 28, 6), (4, 40, 9), (4, 40, 9), (3, 28, 6), (4, 40, 9), (3, 28, 6)]
+    for k, (B, T, L) in enumerate(shapes):
+        batch = synthetic.make_batch(cfg, B, T, L, seed=90 + k, ragged=True)
+        costs = [float(t.train_step(batch).sum()) for t in trainers]
+        assert abs(costs[0] - costs[1]) <= 2e-4 * abs(costs[1]), (k, costs)
+    assert recs[0].lib._regions, "no graph region was recorded"
+    states = [s for s in recs[0].lib._regions.values()]
+    assert any(s["seen"] >= 3 for s in states) and not any(s.get("bad") for s in states)
+    a, b = recs[0].get_parameter_values(), recs[1].get_parameter_values()
+    for name in a:
+        scale = max(1e-3, numpy.abs(b[name]).max())
+        assert numpy.abs(a[name] - b[name]).max() / scale < 2e-3, name
