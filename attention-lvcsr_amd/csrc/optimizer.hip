@@ -7,7 +7,10 @@
 //   AdaDelta(decay_rate, epsilon)      :464-515
 //   Restrict(VariableClipping(max_norm, axis=0), WEIGHT-role parameters)   :646-720, :864-893
 //   RemoveNotFinite(scaler)            :829-861  (per parameter tensor)
-// followed by parameter -= step (GradientDescent, :284-287 / :244-256).
+//   BurnIn(num_steps)                  lvsr/algorithms.py:19-43
+// followed by parameter -= step (GradientDescent, :284-287 / :244-256), and the AdaptiveClipping extension
+// (lvsr/extensions.py:64-91) that re-tunes the StepClipping threshold after every batch: here a few scalar operations
+// of the norm kernel on device-resident state, so the whole step stays graph-replayable.
 #include "common.h"
 #include "lvsr_hip.h"
 #include <string.h>
@@ -42,8 +45,29 @@ __global__ __launch_bounds__(256) void opt_norm_kernel(Opt o, int nparts) {
     s = blk_sum256(s, red);
     if (threadIdx.x == 0) {
         const float norm = sqrtf(s);
+        double* cs = o.clip_state;
+        const float thr = cs ? (float)cs[0] : o.clip_threshold;        // Theano shared floatX
         o.scratch[0] = norm;
-        o.scratch[1] = (o.clip_threshold > 0.f && !(norm < o.clip_threshold)) ? o.clip_threshold / norm : 1.f;
+        o.scratch[1] = (thr > 0.f && !(norm < thr)) ? thr / norm : 1.f;
+        float burn = 0.f;
+        if (cs) {
+            if (cs[4] > 0.0) { burn = 1.f; cs[4] -= 1.0; }
+            // AdaptiveClipping.after_batch; a non-finite (or zero) norm is skipped: in the reference log(nan) poisons the
+            // running statistics and with them every later threshold (deliberate deviation)
+            if (o.adaptive_clipping && norm > 0.f && norm - norm == 0.f) {
+                const double d = (double)o.adaptive_decay, init = (double)o.clip_threshold, bp = (double)o.adaptive_burnin;
+                const double ln = log((double)norm);
+                cs[3] += 1.0;
+                cs[1] = d * cs[1] + (1.0 - d) * ln;
+                cs[2] = d * cs[2] + (1.0 - d) * ln * ln;
+                const double var = cs[2] - cs[1] * cs[1];
+                double t = exp(cs[1] + sqrt(var > 0.0 ? var : 0.0));
+                const double conf = (cs[3] < bp ? cs[3] : bp) / bp;
+                t = conf * t + (1.0 - conf) * init;
+                cs[0] = t < 5.0 * init ? t : 5.0 * init;
+            }
+        }
+        o.scratch[2] = burn;                                           // the partial sums are consumed
     }
 }
 
@@ -116,6 +140,7 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(Opt o) {
     const long long* seg = o.segments + 4 * (long long)blockIdx.y;
     const long long off = seg[0], n = seg[1] * seg[2];
     const int bad = o.remove_not_finite ? o.segflag[blockIdx.y] : 0;
+    if (o.clip_state && o.scratch[2] != 0.f) return;                   // BurnIn: the step is multiplied by zero
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float p = o.param[off + i];
         const float s = bad ? (1.f - o.nonfinite_scaler) * p : o.step[off + i];
@@ -131,6 +156,8 @@ extern "C" int lvsr_opt_step(void* stream, const lvsr_opt_args* args) {
                  "lvsr_opt_step: missing buffers");
     LVSR_REQUIRE(!o.use_momentum || o.velocity, "lvsr_opt_step: momentum needs a velocity buffer");
     LVSR_REQUIRE(!o.use_adadelta || (o.ms_step && o.ms_dx), "lvsr_opt_step: AdaDelta needs its two accumulators");
+    LVSR_REQUIRE(!o.adaptive_clipping || (o.clip_state && o.clip_threshold > 0.f && o.adaptive_burnin > 0),
+                 "lvsr_opt_step: adaptive clipping needs clip_state, an initial threshold and a burn-in period");
     hipStream_t s = (hipStream_t)stream;
     const int nparts = 256;
     int nb = (int)((o.n + 255) / 256);

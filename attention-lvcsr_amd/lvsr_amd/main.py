@@ -1,0 +1,124 @@
+"""Thin stage driver: what `lvsr.main.train` / `train_multistage` do with the path
+(lvsr/main.py:140-703, 896-922), without the Blocks main loop, its extensions, plotting or logging back-ends:
+
+  * one stage = build the recognizer from the stage's `net:` section, load parameters (`params`, or the previous stage's
+    checkpoint `<save_path>/<previous stage><restart_from>.zip`), build the step rules from `training:` / `regularization:`
+    (+ AdaptiveClipping, lvsr/main.py:616-619), iterate `data.get_stream("train")` until `num_batches` / `num_epochs`
+    (FinishAfter, :624-626), validate after every epoch, keep `<stage>.zip` (last) and `<stage>_best_ll.zip` (best
+    validation cost; the reference's TrackTheBest + Checkpoint conditions :606-660), stop on `patience`
+    (lvsr/extensions.py `Patience`: no new best for max(min_epochs, patience_factor x epoch-of-best) epochs);
+  * stages run in `number` order, each starting from its predecessor (train_multistage :896-922).
+
+The character-error-rate monitor (`search_every_epochs`, `<stage>_best.zip`) runs through `lvsr_amd.decode.search` when
+`monitoring.search_every_epochs` is set.  Returns a log (list of dict rows), the reference's `main_loop.log` in spirit.
+"""
+import os
+
+import numpy
+
+from .bricks.recognizer import SpeechRecognizer
+from .training import Trainer
+
+
+def validate(recognizer, data, part="valid"):
+    """Mean cost per utterance over a data part (validation monitor of `cost`, lvsr/main.py:556-570)."""
+    total, count = 0.0, 0
+    for batch in data.get_stream(part, shuffle=False):
+        cm = recognizer.cost(recordings=batch["recordings"], inputs_mask=batch["recordings_mask"], labels=batch["labels"],
+                             labels_mask=batch["labels_mask"], save_for_backward=False)
+        total += float(cm.sum())
+        count += int(batch["labels"].shape[1])
+    return total / max(1, count)
+
+
+def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=None, distributed=None, search_subset=10):
+    """One stage.  `config`: a (stage) configuration mapping with `net`, `training`, optional `regularization`,
+    `monitoring`, `initialization`; `data`: lvsr_amd.data.Data.  Returns (recognizer, log)."""
+    from .config import Configuration
+    log = [] if log is None else log
+    train_conf, mon = dict(config.get("training", {})), dict(config.get("monitoring", {}))
+    net = dict(config["net"])
+    kw = Configuration.net_kwargs(config, data.num_features(), data.num_labels, eos_label=data.eos_label) \
+        if isinstance(config, Configuration) else dict(net, input_dims={"recordings": data.num_features()},
+                                                       num_phonemes=data.num_labels, eos_label=data.eos_label)
+    kw.setdefault("data_prepend_eos", False)
+    rec = SpeechRecognizer(device=device, lib=lib, **kw)
+    if config.get("initialization"):
+        rec.initialize(config["initialization"])
+    if params:
+        rec.load_params(params)
+    trainer = Trainer.from_config(rec, train_conf, config.get("regularization"), distributed=distributed)
+    root, ext = os.path.splitext(save_path)
+    best_ll, best_per, best_epoch = float("inf"), float("inf"), 0
+    num_batches, num_epochs = train_conf.get("num_batches"), train_conf.get("num_epochs")
+    patience = train_conf.get("patience")
+    iterations, epoch, done = 0, 0, False
+    has_valid = "valid" in data.datasets
+    while not done:
+        costs = []
+        for batch in data.get_stream("train", shuffle=True, seed=epoch):
+            cm = trainer.train_step(batch)
+            iterations += 1
+            row = dict(iterations_done=iterations, epochs_done=epoch, train_cost=float(cm.sum()) / int(batch["labels"].shape[1]),
+                       total_gradient_norm=trainer.gradient_norm(), gradient_norm_threshold=trainer.gradient_threshold())
+            costs.append(row["train_cost"])
+            log.append(row)
+            if not numpy.isfinite(row["total_gradient_norm"]):        # FinishAfter(...).add_condition(_gradient_norm_is_none)
+                row["training_finish_requested"] = "gradient norm is not finite"
+                done = True
+                break
+            if num_batches and iterations >= num_batches:
+                done = True
+                break
+        epoch += 1
+        row = dict(iterations_done=iterations, epochs_done=epoch, average_train_cost=float(numpy.mean(costs)) if costs else None)
+        if has_valid:
+            row["valid_cost"] = validate(rec, data, "valid")
+            if row["valid_cost"] < best_ll:
+                best_ll, best_epoch = row["valid_cost"], epoch
+                row["best_valid_cost_so_far"] = True
+                rec.save_params(root + "_best_ll" + ext)
+            every = mon.get("search_every_epochs")
+            if every and epoch % every == 0:
+                from .decode import search
+                ds = data.datasets["valid"]
+                utts = [(ds.recordings[i], list(ds.labels[i]) + [data.eos_label]) for i in range(min(search_subset, ds.num_examples))]
+                res = search(rec, utts, beam_size=mon.get("search", {}).get("beam_size", 10))
+                row["valid_per"] = res["cer"]
+                if res["cer"] < best_per:
+                    best_per, best_epoch = res["cer"], epoch
+                    row["best_valid_per_so_far"] = True
+                    rec.save_params(root + "_best" + ext)
+        rec.save_params(save_path)
+        log.append(row)
+        if num_epochs and epoch >= num_epochs:
+            done = True
+        if patience and has_valid:
+            allowed = max(patience.get("min_epochs", 0), patience.get("patience_factor", 1.5) * best_epoch)
+            if epoch > allowed:
+                row["patience_epoch"] = True
+                done = True
+        if not costs:
+            done = True
+    return rec, log
+
+
+def train_multistage(config, data, save_path, params=None, start_stage=None, **kwargs):
+    """lvsr/main.py:896-922: stages in `number` order; stage k > 0 restarts from `<save_path>/<stage k-1><restart_from>.zip`."""
+    if not getattr(config, "multi_stage", False):
+        return train(config, data, save_path, params, **kwargs)
+    if not start_stage and not os.path.isdir(save_path):
+        os.mkdir(save_path)
+    stages = list(config.ordered_stages.items())
+    first = list(config.ordered_stages).index(start_stage) if start_stage else 0
+    rec, log = None, []
+    for number in range(first, len(stages)):
+        name, stage_config = stages[number]
+        stage_save_path = "{}/{}.zip".format(save_path, name)
+        if number and not params:
+            stage_params = "{}/{}{}.zip".format(save_path, stages[number - 1][0], stage_config["training"].get("restart_from", ""))
+        else:
+            stage_params, params = params, None
+        log.append(dict(stage=name))
+        rec, log = train(stage_config, data, stage_save_path, stage_params, log=log, **kwargs)
+    return rec, log

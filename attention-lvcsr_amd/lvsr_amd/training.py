@@ -20,7 +20,10 @@ def _is_weight(name):
 class Trainer(object):
     def __init__(self, recognizer, gradient_threshold=None, rules=("momentum",), scale=0.1, momentum=0.0,
                  decay_rate=0.95, epsilon=1e-8, max_norm=0.0, max_norm_exclude_lookup=False, nonfinite_scaler=0.0,
-                 process_group=None, distributed=None):
+                 burn_in_steps=0, adaptive_clipping=None, process_group=None, distributed=None):
+        """Keywords = `training:` / `regularization:` keys of the reference's config (lvsr/main.py:480-519).
+        `adaptive_clipping`: None, True or dict(decay_rate=0.998, burnin_period=500) — the AdaptiveClipping extension the
+        reference's `train()` always installs on top of `gradient_threshold` (lvsr/main.py:616-619)."""
         self.rec = recognizer
         st = recognizer.store
         dev = st.device
@@ -47,12 +50,38 @@ class Trainer(object):
         self.segments = torch.tensor(seg, dtype=torch.int64, device=dev)
         self.segflag = torch.zeros(len(seg), dtype=torch.int32, device=dev)
         self.scratch = torch.zeros(2 + 256, dtype=torch.float32, device=dev)
+        self.clip_state = None
+        if adaptive_clipping or burn_in_steps:
+            ac = dict(decay_rate=0.998, burnin_period=500)
+            if isinstance(adaptive_clipping, dict):
+                ac.update(adaptive_clipping)
+            if adaptive_clipping and not self.conf["clip_threshold"] > 0:
+                raise ValueError("adaptive clipping needs gradient_threshold (its initial threshold)")
+            self.clip_state = torch.tensor([self.conf["clip_threshold"], 0.0, 0.0, 0.0, float(burn_in_steps or 0), 0, 0, 0],
+                                           dtype=torch.float64, device=dev)
+            self.conf.update(adaptive_clipping=int(bool(adaptive_clipping)), adaptive_burnin=int(ac["burnin_period"]),
+                             adaptive_decay=float(ac["decay_rate"]))
         if distributed is None:
             distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.distributed = distributed
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if distributed else 1
         self.rank = torch.distributed.get_rank(process_group) if distributed else 0
+
+    @classmethod
+    def from_config(cls, recognizer, training, regularization=None, adaptive_clipping=True, **kw):
+        """Build the step rules the way lvsr/main.py:480-519 reads `config['training']` / `config['regularization']`."""
+        reg = regularization or {}
+        return cls(recognizer, gradient_threshold=training.get("gradient_threshold"), rules=tuple(training.get("rules", ["momentum"])),
+                   scale=training.get("scale", 0.1), momentum=training.get("momentum", 0.0),
+                   decay_rate=training.get("decay_rate", 0.95), epsilon=training.get("epsilon", 1e-8),
+                   max_norm=reg.get("max_norm", 0.0) or 0.0, max_norm_exclude_lookup=reg.get("max_norm_exclude_lookup", False),
+                   burn_in_steps=training.get("burn_in_steps", 0),
+                   adaptive_clipping=adaptive_clipping and bool(training.get("gradient_threshold")), **kw)
+
+    def gradient_threshold(self):
+        """The StepClipping threshold in force for the next step (moves when adaptive clipping is on)."""
+        return float(self.clip_state[0]) if self.clip_state is not None else self.conf["clip_threshold"]
 
     def gradient_norm(self):
         """L2 norm of the (scaled, all-reduced) gradient of the last step: the reference's `total_gradient_norm`."""
@@ -63,7 +92,7 @@ class Trainer(object):
         a = lib.make("lvsr_opt_args", param=st.flat, grad=st.grad, velocity=self.velocity, ms_step=self.ms_step,
                      ms_dx=self.ms_dx, step=self.step_buf, segments=self.segments, segflag=self.segflag,
                      scratch=self.scratch, n=st.flat.numel(), nseg=int(self.segments.shape[0]), max_cols=self.max_cols,
-                     grad_scale=1.0 / float(global_batch_size), **self.conf)
+                     grad_scale=1.0 / float(global_batch_size), clip_state=self.clip_state, **self.conf)
         lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
 
     def apply_gradients(self, global_batch_size):

@@ -213,7 +213,7 @@ int lvsr_softmax_nll(void* stream, const float* logits, int ld, const long long*
 
 /* ---- optimiser step on the flat buffers -----------------------------------------------------------
  * StepClipping -> Momentum(scale) -> AdaDelta -> Restrict(VariableClipping(axis=0), WEIGHT params) ->
- * RemoveNotFinite -> parameter -= step  (lvsr/main.py:480-519; libs/blocks/blocks/algorithms/__init__.py:
+ * RemoveNotFinite -> [BurnIn] -> parameter -= step  (lvsr/main.py:480-519; libs/blocks/blocks/algorithms/__init__.py:
  * 378-515, 610-720, 829-893).  `grad` holds d(sum cost); grad_scale = 1/batch_size (lvsr/main.py:340-345). */
 typedef struct lvsr_opt_args {
     float* param; const float* grad;      /* flat (n) */
@@ -226,6 +226,15 @@ typedef struct lvsr_opt_args {
     int nseg, max_cols;
     int use_momentum, use_adadelta, remove_not_finite, pad0;
     float grad_scale, clip_threshold, learning_rate, momentum, decay_rate, epsilon, max_norm, nonfinite_scaler;
+    /* Device-resident schedule state (NULL = off), so that a replayed step graph needs no host round trip:
+     *   [0] StepClipping threshold in force, [1] mean log gradient norm, [2] mean squared log norm, [3] iterations done
+     *       -- AdaptiveClipping.after_batch (lvsr/extensions.py:64-91; wired with decay 0.998, burn-in 500,
+     *       lvsr/main.py:616-619), evaluated on the device right after the norm of this step is known;
+     *   [4] BurnIn steps left (lvsr/algorithms.py:19-43): while > 0 the applied step is zero, rule state still updates.
+     * The caller initialises [0] = clip_threshold, [1..3] = 0, [4] = burn_in_steps. */
+    double* clip_state;
+    int adaptive_clipping, adaptive_burnin;
+    float adaptive_decay, pad1;
 } lvsr_opt_args;
 int lvsr_opt_step(void* stream, const lvsr_opt_args* a);
 

@@ -76,6 +76,28 @@ def remove_not_finite(parameter, step, scaler=1):
     return numpy.asarray(step, f32)
 
 
+class AdaptiveClipping(object):
+    """AdaptiveClipping.after_batch, lvsr/extensions.py:64-91 (Python floats; wired with decay_rate=0.998,
+    burnin_period=500 in lvsr/main.py:616-619).  `threshold` is what StepClipping uses for the NEXT batch."""
+    def __init__(self, initial_threshold, burnin_period=100, decay_rate=0.99):
+        self.initial, self.burnin, self.decay = float(initial_threshold), burnin_period, decay_rate
+        self.mean = self.mean2 = 0.0
+        self.iterations_done = 0
+        self.threshold = float(initial_threshold)
+
+    def after_batch(self, total_gradient_norm):
+        import math
+        self.iterations_done += 1
+        g = math.log(float(total_gradient_norm))
+        self.mean = self.decay * self.mean + (1 - self.decay) * g
+        self.mean2 = self.decay * self.mean2 + (1 - self.decay) * g ** 2
+        std = max(self.mean2 - self.mean ** 2, 0.0) ** .5
+        threshold = math.exp(self.mean + 1 * std)
+        confidence = min(self.burnin, self.iterations_done) / float(self.burnin)
+        threshold = confidence * threshold + (1 - confidence) * self.initial
+        self.threshold = float(f32(min(threshold, 5 * self.initial)))            # shared floatX
+
+
 def is_weight(name):
     """WEIGHT-role parameters (Linear.W, GRU state_to_state / state_to_gates, LookupTable.W); biases, initial
     states and conv1d.filters (allocated without a role, lvsr/bricks/attention.py:31-33) are not."""
@@ -86,8 +108,11 @@ class TrainingRules(object):
     """CompositeRule([StepClipping] + [Momentum, AdaDelta] + [Restrict(VariableClipping)] + [RemoveNotFinite(0.0)])
     as assembled in lvsr/main.py:480-519, followed by `parameter -= step` (GradientDescent)."""
     def __init__(self, gradient_threshold=None, rules=("momentum",), scale=0.1, momentum=0.0, decay_rate=0.95,
-                 epsilon=1e-8, max_norm=0.0, max_norm_exclude_lookup=False, nonfinite_scaler=0.0):
+                 epsilon=1e-8, max_norm=0.0, max_norm_exclude_lookup=False, nonfinite_scaler=0.0, burn_in_steps=0,
+                 adaptive_clipping=None):
         self.thr = gradient_threshold
+        self.burn = int(burn_in_steps or 0)                              # BurnIn, lvsr/algorithms.py:19-43
+        self.adaptive = AdaptiveClipping(gradient_threshold, **adaptive_clipping) if adaptive_clipping else None
         self.core = []
         if "momentum" in rules:
             self.core.append(Momentum(scale, momentum))
@@ -96,7 +121,12 @@ class TrainingRules(object):
         self.max_norm, self.excl, self.scaler = max_norm, max_norm_exclude_lookup, nonfinite_scaler
 
     def step(self, params, grads):
-        steps = step_clipping(OrderedDict((k, numpy.asarray(grads[k], f32)) for k in params), self.thr)
+        gl = OrderedDict((k, numpy.asarray(grads[k], f32)) for k in params)
+        steps = step_clipping(gl, self.adaptive.threshold if self.adaptive else self.thr)
+        if self.adaptive:       # total_gradient_norm = l2 norm of the raw gradients (GradientDescent, algorithms/__init__.py:232-236)
+            self.adaptive.after_batch(numpy.sqrt(sum((g ** 2).sum(dtype=f32) for g in gl.values()), dtype=f32))
+        burn = self.burn > 0
+        self.burn = max(0, self.burn - 1)
         for rule in self.core:
             steps = rule.compute_steps(steps)
         new = OrderedDict()
@@ -105,5 +135,7 @@ class TrainingRules(object):
             if self.max_norm and self.max_norm > 0 and is_weight(k) and not (self.excl and "lookuptable" in k):
                 s = variable_clipping(p, s, self.max_norm, axis=0)
             s = remove_not_finite(p, s, self.scaler)
+            if burn:
+                s = s * f32(0)
             new[k] = (numpy.asarray(p, f32) - s).astype(f32)
         return new

@@ -1,5 +1,7 @@
 """Batch pipeline semantics (lvsr/datasets/__init__.py:253-310) and a few training steps driven by it on the emulated
 recognizer (loss goes down)."""
+import os
+
 import numpy
 import pytest
 import torch
@@ -106,3 +108,63 @@ def test_kaldi_tables_round_trip_and_dataset(tmp_path):
     assert b["recordings"].shape[1:] == (2, 4) and b["labels"][-1].max() == 4
     with pytest.raises(ImportError):
         ArrayDataset.from_fuel_hdf5(str(tmp_path / "x.h5"), "train")
+
+
+def test_multistage_driver_on_the_emulated_recognizer(tmp_path):
+    """train_multistage (lvsr/main.py:896-922): stages in `number` order, stage 2 restarts from `<stage1><restart_from>.zip`,
+    per-epoch validation, `_best_ll` checkpoints, FinishAfter(num_batches / num_epochs), AdaptiveClipping always on."""
+    from emu import emu_lib
+    from lvsr_amd import config, main
+    y = tmp_path / "two_stage.yaml"
+    y.write_text("""
+net:
+  dims_bidir: [4]
+  dim_dec: 5
+  dim_matcher: 6
+  attention_type: content
+  embed_outputs: true
+  enc_transition: !!python/name:blocks.bricks.recurrent.GatedRecurrent
+  dec_transition: !!python/name:blocks.bricks.recurrent.GatedRecurrent
+initialization:
+  /recognizer:
+    weights_init: !!python/object/apply:blocks.initialization.IsotropicGaussian [0.3]
+    biases_init: !!python/object/apply:blocks.initialization.Constant [0.0]
+    rec_weights_init: !!python/object/apply:blocks.initialization.Orthogonal []
+    initial_states_init: !!python/object/apply:blocks.initialization.IsotropicGaussian [0.001]
+training:
+  gradient_threshold: 10.0
+  scale: 0.05
+  momentum: 0.0
+  rules: [momentum]
+regularization:
+  max_norm: 3.0
+stages:
+  pretraining:
+    number: 0
+    training:
+      num_epochs: 2
+  main:
+    number: 1
+    training:
+      num_batches: 3
+      restart_from: _best_ll
+      scale: 0.02
+""")
+    cfg = config.Configuration(str(y))
+    ds = _dataset(n=6)
+    data = Data({"train": ds, "valid": ds}, batch_size=3)
+    save = str(tmp_path / "run")
+    rec, log = main.train_multistage(cfg, data, save, device="cpu", lib=emu_lib(), distributed=False)
+    assert sorted(os.listdir(save)) == ["main.zip", "main_best_ll.zip", "pretraining.zip", "pretraining_best_ll.zip"]
+    stages = [r["stage"] for r in log if "stage" in r]
+    assert stages == ["pretraining", "main"]
+    batch_rows = [r for r in log if "train_cost" in r]
+    assert len(batch_rows) == 2 * 2 + 3 and batch_rows[-1]["iterations_done"] == 3          # 2 epochs x 2 batches, then 3 batches
+    assert all(r["gradient_norm_threshold"] > 0 for r in batch_rows)
+    valid = [r["valid_cost"] for r in log if "valid_cost" in r]
+    assert valid[1] < valid[0]                                                             # it learns
+    # stage 2 started from stage 1's best-likelihood checkpoint, not from a fresh initialisation
+    from lvsr_amd.checkpoint import load_parameters
+    a, b = load_parameters(save + "/pretraining_best_ll.zip"), load_parameters(save + "/main.zip")
+    name = "/recognizer/generator/readout/bias.b" if "/recognizer/generator/readout/bias.b" in a else sorted(a)[0]
+    assert numpy.abs(a[name] - b[name]).max() < 0.2 and set(a) == set(b)

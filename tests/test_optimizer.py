@@ -63,14 +63,14 @@ RULES = dict(gradient_threshold=2.0, rules=("momentum", "adadelta"), scale=0.5, 
              epsilon=1e-6, max_norm=0.9)
 
 
-def run_fused_vs_oracle(device, lib, poison=False):
+def run_fused_vs_oracle(device, lib, poison=False, rules=RULES, steps=3):
     params = synthetic.make_params(CFG, seed=21)
     rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=CFG)
-    tr = Trainer(rec, distributed=False, **RULES)
-    orc = OO.TrainingRules(**RULES)
+    tr = Trainer(rec, distributed=False, **rules)
+    orc = OO.TrainingRules(**rules)
     cur = OrderedDict((k, v.copy()) for k, v in params.items())
     rng = numpy.random.RandomState(3)
-    for it in range(3):
+    for it in range(steps):
         grads = OrderedDict((k, rng.normal(0, 1.0, v.shape).astype(numpy.float32)) for k, v in cur.items())
         if poison and it == 1:
             grads["/recognizer/generator/readout/post_merge/bias.b"][2] = numpy.nan
@@ -88,11 +88,45 @@ def run_fused_vs_oracle(device, lib, poison=False):
         got = rec.store.get_values()
         for k in cur:
             assert_allclose(got[k], cur[k], rtol=2e-5, atol=2e-6, err_msg="%s it %d" % (k, it))
+        if orc.adaptive:
+            assert_allclose(tr.gradient_threshold(), orc.adaptive.threshold, rtol=1e-6)
 
 
 def test_fused_step_emulated():
     from emu import emu_lib
     run_fused_vs_oracle("cpu", emu_lib())
+
+
+ADAPTIVE = dict(RULES, gradient_threshold=30.0, burn_in_steps=2, adaptive_clipping=dict(decay_rate=0.9, burnin_period=4))
+
+
+def test_adaptive_clipping_known_answers():
+    """AdaptiveClipping.after_batch by hand (lvsr/extensions.py:76-91)."""
+    import math
+    ac = OO.AdaptiveClipping(10.0, burnin_period=2, decay_rate=0.5)
+    ac.after_batch(math.e)                       # log norm = 1: mean .5, mean2 .5, std .5, exp(1) at confidence 1/2
+    assert_allclose(ac.threshold, 0.5 * math.exp(1.0) + 0.5 * 10.0, rtol=1e-6)
+    ac.after_batch(math.e)                       # mean .75, mean2 .75, std sqrt(.1875); confidence 1
+    assert_allclose(ac.threshold, math.exp(0.75 + math.sqrt(0.1875)), rtol=1e-6)
+    big = OO.AdaptiveClipping(1.0, burnin_period=1, decay_rate=0.0)
+    big.after_batch(1e6)
+    assert big.threshold == 5.0                  # capped at 5 x the initial threshold
+
+
+def test_fused_step_adaptive_clipping_and_burn_in_emulated():
+    from emu import emu_lib
+    run_fused_vs_oracle("cpu", emu_lib(), rules=ADAPTIVE, steps=6)
+
+
+def test_trainer_from_reference_config_sections():
+    from emu import emu_lib
+    rec = SpeechRecognizer(device="cpu", params=synthetic.make_params(CFG, seed=21), lib=emu_lib(), net_config=CFG)
+    tr = Trainer.from_config(rec, dict(gradient_threshold=100.0, scale=0.1, momentum=0.0, rules=["momentum", "adadelta"],
+                                       decay_rate=0.95, epsilon=1e-8, burn_in_steps=3), dict(max_norm=1.0), distributed=False)
+    assert tr.conf["use_adadelta"] and tr.conf["adaptive_clipping"] and tr.conf["adaptive_burnin"] == 500
+    assert tr.gradient_threshold() == 100.0 and float(tr.clip_state[4]) == 3.0
+    plain = Trainer.from_config(rec, dict(scale=0.1), distributed=False)
+    assert plain.clip_state is None and plain.conf["clip_threshold"] == 0.0
 
 
 def test_fused_step_nonfinite_emulated():
@@ -104,3 +138,4 @@ def test_fused_step_nonfinite_emulated():
 def test_fused_step_gpu(gpu_device):
     run_fused_vs_oracle(gpu_device, None)
     run_fused_vs_oracle(gpu_device, None, poison=True)
+    run_fused_vs_oracle(gpu_device, None, rules=ADAPTIVE, steps=6)
