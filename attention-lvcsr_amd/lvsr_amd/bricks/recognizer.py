@@ -173,11 +173,11 @@ class SpeechRecognizer(object):
                 if tail is not None:
                     tail()
                 return cm
-            key = ("train_step", id(self), tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
+            key = ("train_step", tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
             volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
                         self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
             plain = region and self.use_graph and not self.encoder.use_persistent and not self.encoder.overlap
-            return self.lib.region(key, x, enabled=plain, volatile=volatile).run(enqueue)
+            return self.lib.region(self, key, x, enabled=plain, volatile=volatile).run(enqueue)
 
     # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------
     def analyze(self, inputs, groundtruth, prediction=None):

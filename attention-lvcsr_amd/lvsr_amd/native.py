@@ -139,7 +139,6 @@ class Lib(object):
         self.is_emulator = os.path.basename(path) != os.path.basename(DEFAULT_LIB)
         self._gstream = None
         self.capturing = False          # inside a Region capture: no host synchronisation, no nested graphs
-        self._regions = {}
         self.structs, self.functions = parse_header()
         for name, (res, args, _) in self.functions.items():
             try:
@@ -265,8 +264,17 @@ class Lib(object):
         if _SYNC_AFTER_GRAPH and ref_tensor.is_cuda and steps >= 16 and not self.capturing:
             torch.cuda.current_stream(ref_tensor.device).synchronize()
 
-    def region(self, key, ref_tensor, enabled=True, volatile=()):
-        return Region(self, key, ref_tensor, enabled, volatile)
+    def region(self, owner, key, ref_tensor, enabled=True, volatile=()):
+        """`owner`: the object whose buffers the region's launches reference (it carries the bookkeeping, so it dies with
+        it, and a process-unique token, so a later object at a recycled address can never hit its graphs)."""
+        return Region(self, owner, key, ref_tensor, enabled, volatile)
+
+    _uid = [0]
+
+    @classmethod
+    def unique_token(cls):
+        cls._uid[0] += 1
+        return cls._uid[0]
 
 
 class Region(object):
@@ -282,13 +290,15 @@ class Region(object):
     `volatile` part (workspace generation: buffers were re-allocated) re-captures without another eager pass.  A capture during
     which the caching allocator handed out memory is dropped (a replay would write to memory it does not own) and the key
     is enqueued again eagerly, and stays eager.  Disabled on the emulator / CPU tensors, with LVSR_STEP_GRAPH=0, and inside another region."""
-    def __init__(self, lib, key, ref, enabled, volatile=()):
+    def __init__(self, lib, owner, key, ref, enabled, volatile=()):
         self.lib, self.ref = lib, ref
-        soft = repr(key).encode()
+        if not hasattr(owner, "_region_token"):
+            owner._region_token, owner._regions = lib.unique_token(), {}
+        soft = repr((owner._region_token, key)).encode()
         self.kb = soft + b"|" + repr(volatile).encode()
         self.enabled = bool(enabled) and _STEP_GRAPH and ref.is_cuda and not lib.is_emulator and not lib.capturing
         self.state = "eager"
-        self.slot = lib._regions.setdefault(soft, dict(seen=0, result=None)) if self.enabled else dict(seen=0, result=None)
+        self.slot = owner._regions.setdefault(soft, dict(seen=0, result=None)) if self.enabled else dict(seen=0, result=None)
 
     @property
     def result(self):

@@ -25,6 +25,7 @@ class Trainer(object):
         `adaptive_clipping`: None, True or dict(decay_rate=0.998, burnin_period=500) — the AdaptiveClipping extension the
         reference's `train()` always installs on top of `gradient_threshold` (lvsr/main.py:616-619)."""
         self.rec = recognizer
+        self._token = recognizer.lib.unique_token()        # names this trainer's buffers in graph-region keys
         st = recognizer.store
         dev = st.device
         self.conf = dict(clip_threshold=float(gradient_threshold or 0.0), use_momentum=int("momentum" in rules),
@@ -117,7 +118,7 @@ class Trainer(object):
             cm = self.rec.cost_and_gradients(batch, region=False)
             self.apply_gradients(gbs)
             return cm
-        tail_key = ("opt", id(self), float(gbs), tuple(sorted(self.conf.items())))
+        tail_key = ("opt", self._token, float(gbs), tuple(sorted(self.conf.items())))
         cm = self.rec.cost_and_gradients(batch, tail=lambda: self._enqueue_optimizer(gbs), tail_key=tail_key)
         self.rec.store.version += 1
         return cm

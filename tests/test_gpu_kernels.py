@@ -213,8 +213,8 @@ def test_whole_step_graph_region_gpu(gpu_device):
         batch = synthetic.make_batch(cfg, B, T, L, seed=90 + k, ragged=True)
         costs = [float(t.train_step(batch).sum()) for t in trainers]
         assert abs(costs[0] - costs[1]) <= 2e-4 * abs(costs[1]), (k, costs)
-    assert recs[0].lib._regions, "no graph region was recorded"
-    states = [s for s in recs[0].lib._regions.values()]
+    assert recs[0]._regions, "no graph region was recorded"
+    states = [s for s in recs[0]._regions.values()]
     assert any(s["seen"] >= 3 for s in states) and not any(s.get("bad") for s in states)
     a, b = recs[0].get_parameter_values(), recs[1].get_parameter_values()
     for name in a:

@@ -16,5 +16,5 @@ for s in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     cm = tr.train_step(batch)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
-    st = [(v["seen"], v.get("bad")) for v in rec.lib._regions.values()]
+    st = [(v["seen"], v.get("bad")) for v in rec._regions.values()]
     print("step %d: %.2f ms  cost %.3f  regions %s  graphs %d  ws.generation %d" % (s, dt, float(cm.sum()) / B, st, rec.lib._lvsr_graph_count(), rec.ws.generation), flush=True)
