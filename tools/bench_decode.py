@@ -14,13 +14,17 @@ ap.add_argument("--utts", type=int, default=8)
 ap.add_argument("--frames", type=int, default=800)
 ap.add_argument("--beam", type=int, default=16)
 ap.add_argument("--no-lm", action="store_true")
+ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
 args = ap.parse_args()
 cfg = spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100))
 cfg["max_decoded_length_scale"] = 3.0
 rec = SpeechRecognizer(device="cuda:0", params=synthetic.make_params(cfg, seed=10, scale=1.0), net_config=cfg)
 if not args.no_lm:
     fst, cmap = LM.char_ngram_fst(33, seed=7)
-    rec.set_language_model(LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
+    if args.host_lm:
+        rec.set_language_model(LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
+    else:
+        rec.set_language_model(LM.DeviceFSTLanguageModel(fst, "cuda:0", nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
 rec.init_beam_search(args.beam)
 rng = numpy.random.RandomState(1234)
 done, steps, t0 = 0, 0, None
