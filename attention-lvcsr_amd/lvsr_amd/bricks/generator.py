@@ -8,6 +8,7 @@
 (sequence_generators.py:317-326); `backward()` is the counterpart of theano.grad through it.  All arithmetic
 is in the C-ABI library; torch only owns buffers/views.
 """
+import ctypes
 import math
 import os
 
@@ -33,6 +34,7 @@ class SequenceGenerator(object):
         self.use_graph = use_graph
         self._packs = None
         self._pack_cache = {}
+        self._gen_cache = {}
         self._saved = None
         g = "/recognizer/generator"
         att = g + "/att_trans/" + ("conv_att" if dims.conv else "cont_att")
@@ -336,30 +338,42 @@ def _generation_methods():
         d, lib, ws, g = self.d, self.lib, self.ws, self._gen
         n, Tp = int(S.shape[0]), g["Tp"]
         pk = self._packed()
-        tag = ".n%d" % n
-        Sb = ws.get("gs.S" + tag, (2, n, d.D))
-        Wb = ws.get("gs.W" + tag, (2, n, Tp))
-        Sb[0].copy_(S)
-        Wb[0].copy_(W)
-        xg = None
+        # the buffer views and the argument block of a (beam width, phases) pair are built once per set of contexts: the
+        # search loop calls this twice per emitted character and the Python bookkeeping was ~0.4 ms of each step
+        key = (n, phases, g["A"].data_ptr(), g["PA"].data_ptr(), g["Am"].data_ptr(), Tp, id(pk))
+        ent = self._gen_cache.get(key)
+        if ent is None or ent["generation"] != ws.generation:
+            tag = ".n%d" % n
+            Sb = ws.get("gs.S" + tag, (2, n, d.D))
+            Wb = ws.get("gs.W" + tag, (2, n, Tp))
+            xg = y = fb = None
+            if phases & 2:
+                xg = ws.get("gs.xg" + tag, (n, 3 * d.D))
+                y = ws.get("gs.y" + tag, (n,), torch.int64)
+                fb = ws.get("gs.fb" + tag, (n, d.FB)) if d.embed else None
+            Kc = max(d.K, 1)
+            bufs = dict(xg=xg, ymask=None, S=Sb, W=Wb,
+                        pos=ws.get("gs.pos" + tag, (2, n)) if (d.conv and self._prior()[0] != 0) else None,
+                        WA=ws.get("gs.WA" + tag, (1, n, d.E)), EN=ws.get("gs.EN" + tag, (1, n, Tp)), ZB=None,
+                        sW=ws.get("gs.sW" + tag, (1, n, d.M)), CV=ws.get("gs.CV" + tag, (1, n, Kc, Tp)) if d.conv else None,
+                        U=ws.get("gs.U" + tag, (1, n, d.D)), R=ws.get("gs.R" + tag, (1, n, d.D)),
+                        C=ws.get("gs.C" + tag, (1, n, d.D)), RH=ws.get("gs.RH" + tag, (1, n, d.D)),
+                        sg=ws.get("gs.sg" + tag, (n, 2 * d.D)), xin=ws.get("gs.xin" + tag, (n, d.D)),
+                        ep=ws.get("gs.ep" + tag, (n, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
+            fields = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, n, bufs, phases=phases, step0=int(step0), broadcast=True)
+            ent = dict(generation=ws.generation, bufs=bufs, args=lib.make("lvsr_attdec_args", **fields), y=y, fb=fb, xg=xg,
+                       S0=Sb[0], W0=Wb[0])
+            if len(self._gen_cache) > 64:
+                self._gen_cache.clear()
+            self._gen_cache[key] = ent
+        ent["S0"].copy_(S)
+        ent["W0"].copy_(W)
         if phases & 2:
-            xg = ws.get("gs.xg" + tag, (n, 3 * d.D))
-            y = ws.get("gs.y" + tag, (n,), torch.int64)
-            y.copy_(torch.as_tensor(outputs, dtype=torch.int64), non_blocking=False)
-            fb = ws.get("gs.fb" + tag, (n, d.FB)) if d.embed else None
-            self._feedback_fork(y, n, xg, fb)
-        Kc = max(d.K, 1)
-        bufs = dict(xg=xg, ymask=None, S=Sb, W=Wb,
-                    pos=ws.get("gs.pos" + tag, (2, n)) if (d.conv and self._prior()[0] != 0) else None,
-                    WA=ws.get("gs.WA" + tag, (1, n, d.E)), EN=ws.get("gs.EN" + tag, (1, n, Tp)), ZB=None,
-                    sW=ws.get("gs.sW" + tag, (1, n, d.M)), CV=ws.get("gs.CV" + tag, (1, n, Kc, Tp)) if d.conv else None,
-                    U=ws.get("gs.U" + tag, (1, n, d.D)), R=ws.get("gs.R" + tag, (1, n, d.D)),
-                    C=ws.get("gs.C" + tag, (1, n, d.D)), RH=ws.get("gs.RH" + tag, (1, n, d.D)),
-                    sg=ws.get("gs.sg" + tag, (n, 2 * d.D)), xin=ws.get("gs.xin" + tag, (n, d.D)),
-                    ep=ws.get("gs.ep" + tag, (n, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
-        fields = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, n, bufs, phases=phases, step0=int(step0), broadcast=True)
-        lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", Sb, False, **fields)
-        return bufs
+            ent["y"].copy_(torch.as_tensor(outputs, dtype=torch.int64), non_blocking=False)
+            self._feedback_fork(ent["y"], n, ent["xg"], ent["fb"])
+        ent["args"].step0 = int(step0)
+        lib.call("lvsr_attdec_fwd", lib.stream_for(ent["S0"]), ctypes.byref(ent["args"]), 0)
+        return ent["bufs"]
 
     def generation_logprobs(self, S, W, step0):
         """logprobs_computer (search.py:126-134): take_glimpses -> readout -> -log_softmax; (n,V) device tensor."""
@@ -384,7 +398,14 @@ def _generation_methods():
         """next_state_computer (search.py:112-124): take_glimpses AGAIN on the re-arranged hypotheses (the window
         of the location prior depends on the batch it is computed for) + compute_states with the chosen outputs."""
         bufs = self._gen_run(S, W, step0, phases=3, outputs=outputs)
-        return dict(states=bufs["S"][1], weights=bufs["W"][1], step=int(step0) + 1,
+        # hand the new states out in buffers no later generation call writes to (the step buffers are reused by the very
+        # next generation_logprobs, which would otherwise overwrite the alignments the caller still holds)
+        n = int(S.shape[0])
+        So = self.ws.get("gs.Sout.n%d" % n, tuple(bufs["S"][1].shape))
+        Wo = self.ws.get("gs.Wout.n%d" % n, tuple(bufs["W"][1].shape))
+        So.copy_(bufs["S"][1])
+        Wo.copy_(bufs["W"][1])
+        return dict(states=So, weights=Wo, step=int(step0) + 1,
                     weighted_averages=bufs["WA"][0], outputs=numpy.asarray(outputs))
 
     return dict(init_generation=init_generation, generation_initial_states=generation_initial_states, _gen_run=_gen_run,

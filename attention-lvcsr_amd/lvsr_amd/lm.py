@@ -271,8 +271,10 @@ class DeviceFSTLanguageModel(FSTLanguageModel):
         out = torch.as_tensor(numpy.ascontiguousarray(outputs), dtype=torch.int64).to(self.device).contiguous()
         return self._step(lm_states["states"].contiguous(), lm_states["weights"].contiguous(), out)
 
+    on_device = True
+
     def take(self, lm_states, indexes):
-        idx = torch.as_tensor(numpy.ascontiguousarray(indexes), dtype=torch.int64).to(self.device)
+        idx = indexes if torch.is_tensor(indexes) else torch.as_tensor(numpy.ascontiguousarray(indexes), dtype=torch.int64).to(self.device)
         return {k: v.index_select(0, idx) for k, v in lm_states.items()}
 
     def stage(self, lm_states, device=None):

@@ -42,7 +42,9 @@ class BeamSearch(object):
         all_costs = numpy.zeros_like(all_outputs, dtype=numpy.float32)
         done = []
         min_cost = 1000
-        take = lambda t, idx: t.index_select(0, torch.as_tensor(numpy.asarray(idx), dtype=torch.int64, device=dev))
+        # one host->device copy of an index vector per use site, shared by the decoder state, the alignments and the LM state
+        to_dev = lambda idx: torch.as_tensor(numpy.ascontiguousarray(idx), dtype=torch.int64).to(dev)
+        lm_take = lambda st, idx, idx_t: gen.language_model.take(st, idx_t if getattr(gen.language_model, "on_device", False) else idx)
         for i in range(max_length):
             if S.shape[0] == 0:
                 break
@@ -77,9 +79,10 @@ class BeamSearch(object):
             (indexes, outputs), chosen_costs = self._smallest(next_costs, self.beam_size)
             # Rearrange everything
             with rec._on_stream():
-                S, W = take(S, indexes), take(W, indexes)
+                idx_t = to_dev(indexes)
+                S, W = S.index_select(0, idx_t), W.index_select(0, idx_t)
                 if lm_states is not None:
-                    lm_states = gen.language_model.take(lm_states, indexes)
+                    lm_states = lm_take(lm_states, indexes, idx_t)
                 all_outputs = numpy.take(all_outputs, indexes, axis=1)
                 all_costs = numpy.take(all_costs, indexes, axis=1)
                 # Record chosen output and compute new states
@@ -96,12 +99,14 @@ class BeamSearch(object):
                 if validate_solution_function is None or validate_solution_function(input_values, all_outputs[:, idx]):
                     done.append((all_outputs[:, idx], all_costs[:, idx]))
             unfinished = numpy.where(mask == 1)[0]
-            with rec._on_stream():
-                S, W = take(S, unfinished), take(W, unfinished)
-                if lm_states is not None:
-                    lm_states = gen.language_model.take(lm_states, unfinished)
-            all_outputs = numpy.take(all_outputs, unfinished, axis=1)
-            all_costs = numpy.take(all_costs, unfinished, axis=1)
+            if len(unfinished) != len(mask):                # nothing to drop in most steps: keep the tensors as they are
+                with rec._on_stream():
+                    idx_t = to_dev(unfinished)
+                    S, W = S.index_select(0, idx_t), W.index_select(0, idx_t)
+                    if lm_states is not None:
+                        lm_states = lm_take(lm_states, unfinished, idx_t)
+                all_outputs = numpy.take(all_outputs, unfinished, axis=1)
+                all_costs = numpy.take(all_costs, unfinished, axis=1)
         if not done:
             raise CandidateNotFoundError()
         done = sorted(done, key=lambda x: x[1][-1] - char_discount * len(x[1]))

@@ -1,5 +1,6 @@
 """Beam search through the emulated HIP generation step vs the hypotheses the reference produced (golden fixtures)."""
 import numpy
+import torch
 import pytest
 from numpy.testing import assert_allclose
 
@@ -44,3 +45,23 @@ def run_beam_case(case, device, lib):
 @pytest.mark.parametrize("case", CASES)
 def test_beam_search_emulated(case):
     run_beam_case(case, "cpu", emu_lib())
+
+
+def test_generation_states_are_not_overwritten_by_the_next_step():
+    """The beam search keeps the tensors `generation_next_states` returned across the next `generation_logprobs` call (it
+    only re-gathers them when hypotheses are dropped): they must not alias the step buffers."""
+    z, meta = load_golden("tiny_conv_median")
+    cfg = meta["cfg"]
+    rec = SpeechRecognizer(device="cpu", params=synthetic.make_params(cfg, seed=5, scale=meta["scale"]), lib=emu_lib(), net_config=cfg)
+    gen = rec.generator
+    x = numpy.random.RandomState(0).normal(size=(24, cfg["input_dim"])).astype(numpy.float32)
+    rec.compute_contexts(x)
+    st = gen.generation_initial_states(3)
+    S, W = st["states"], st["weights"]
+    for step in range(3):
+        gen.generation_logprobs(S, W, step)
+        nxt = gen.generation_next_states(S, W, step, numpy.array([1, 2, 0]))
+        S, W = nxt["states"], nxt["weights"]
+        keepS, keepW = S.clone(), W.clone()
+        gen.generation_logprobs(S, W, step + 1)
+        assert torch.equal(S, keepS) and torch.equal(W, keepW)

@@ -55,3 +55,24 @@ def test_one_recognizer_many_shapes_emulated():
         out, grads = orc.cost_and_grads(batch)
         cm = rec.cost_and_gradients(batch)
         check_against(rec, cm, None, out, grads)
+
+
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_content_embed"])
+def test_degenerate_sizes_emulated(case):
+    """Smallest inputs the path accepts: one utterance, one label, an attended sequence of one position (T equal to the
+    subsampling factor), a batch in which one utterance has a single real frame and a single real label."""
+    z, meta = load_golden(case)
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    sub = int(numpy.prod(cfg.get("subsample") or [1]))
+    for k, (B, T, L) in enumerate([(1, sub, 1), (1, sub + 1, 2), (2, 2 * sub, 1)]):
+        batch = synthetic.make_batch(cfg, B, T, L, seed=70 + k, ragged=False)
+        if B == 2:                                   # second utterance: one real frame, one real label
+            batch["recordings_mask"][1:, 1] = 0
+            batch["recordings"][1:, 1] = 0
+            batch["labels_mask"][1:, 1] = 0
+        out, grads = orc.cost_and_grads(batch)
+        cm = rec.cost_and_gradients(batch)
+        check_against(rec, cm, None, out, grads)
