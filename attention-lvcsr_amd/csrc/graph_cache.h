@@ -19,10 +19,12 @@ hipGraphExec_t lvsr_graph_lookup(const GraphKey& key, bool* known_bad);
 void lvsr_graph_store(const GraphKey& key, hipGraphExec_t exec);   // exec == nullptr marks "cannot capture"
 
 bool lvsr_stream_is_capturing(hipStream_t s);
+bool lvsr_graphs_suppressed();
 
 template <class F>
 int lvsr_run_graph(hipStream_t s, int use_graph, const GraphKey& key, F&& enqueue, const char* what) {
-    if (!use_graph || lvsr_stream_is_capturing(s)) {       // inside an lvsr_region_begin/end capture: just record the launches
+    // inside an lvsr_region_begin/end capture just record the launches; lvsr_graph_suppress(1): eager launches only
+    if (!use_graph || lvsr_graphs_suppressed() || lvsr_stream_is_capturing(s)) {
         enqueue();
         return lvsr_check_launch(what);
     }

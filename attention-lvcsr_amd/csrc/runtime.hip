@@ -32,7 +32,7 @@ struct Entry { hipGraphExec_t exec; std::list<std::string>::iterator it; };
 std::mutex g_mu;
 std::unordered_map<std::string, Entry> g_graphs;
 std::list<std::string> g_lru;
-const size_t kMaxGraphs = 96;
+const size_t kMaxGraphs = 256;
 }  // namespace
 
 hipGraphExec_t lvsr_graph_lookup(const GraphKey& key, bool* known_bad) {
@@ -68,6 +68,8 @@ bool lvsr_stream_is_capturing(hipStream_t s) {
 }
 
 static thread_local std::string g_region_key;
+static thread_local int g_suppress = 0;
+bool lvsr_graphs_suppressed() { return g_suppress != 0; }
 
 extern "C" {
 // ---- graph regions: several library calls (and whatever else the host enqueues on the stream) as ONE cached graph --
@@ -130,6 +132,10 @@ int lvsr_region_end(void* stream, int keep) {
     }
     return LVSR_OK;
 }
+
+// While on, entry points called with use_graph = 1 launch eagerly and cache nothing (used for the one eager pass that
+// precedes the capture of a region: its inner time-loop graphs would never be replayed).
+void lvsr_graph_suppress(int on) { g_suppress = on; }
 
 // Drop every cached graph (call when workspaces are freed / pointers may be recycled).
 void lvsr_graph_clear(void) {

@@ -312,7 +312,13 @@ class Region(object):
         if not self.enabled:
             return True
         self.slot["seen"] += 1
-        if self.slot["seen"] == 1 or self.slot.get("bad"):
+        if self.slot.get("bad"):
+            return True
+        if self.slot["seen"] == 1:
+            # the eager pass that lets every workspace come into being: its inner time-loop graphs would never be replayed
+            # (the region is captured next time), so do not build them
+            self.state = "first"
+            self.lib._lvsr_graph_suppress(1)
             return True
         lib = self.lib
         rc = lib._lvsr_region_begin(lib.stream_for(self.ref), self.kb, len(self.kb))
@@ -331,6 +337,10 @@ class Region(object):
         return True
 
     def end(self):
+        if self.state == "first":
+            self.lib._lvsr_graph_suppress(0)
+            self.state = "eager"
+            return True
         if self.state != "capturing":
             return True
         lib = self.lib

@@ -35,6 +35,7 @@ int lvsr_graph_count(void);
  * end), 2 = not capturable (enqueue eagerly, no end call).  end(keep=1) instantiates, caches and launches;
  * end(keep=0) drops the capture and marks the key not capturable.  Entry points called with use_graph=1 inside a region
  * just record their launches.  Used for the whole training step: one launch per step instead of ~25 graphs + ~150 kernels. */
+void lvsr_graph_suppress(int on);   /* 1: use_graph arguments are ignored (eager launches, nothing cached) until switched off */
 int lvsr_region_begin(void* stream, const char* key, long long key_bytes);
 int lvsr_region_end(void* stream, int keep);
 
