@@ -36,6 +36,11 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
     `monitoring`, `initialization`; `data`: lvsr_amd.data.Data.  Returns (recognizer, log)."""
     from .config import Configuration
     log = [] if log is None else log
+    reg = dict(config.get("regularization") or {})
+    unbuilt = [k for k in ("dropout", "noise", "adaptive_noise") if reg.get(k)] + \
+              [k for k in ("penalty_coof", "decay") if (reg.get(k) or 0) > 0]
+    if unbuilt:        # lvsr/main.py:395-470 rewrites the Theano graph for these; silently ignoring them would change the recipe
+        raise NotImplementedError("regularization.%s is not built (only max_norm is)" % ", regularization.".join(unbuilt))
     train_conf, mon = dict(config.get("training", {})), dict(config.get("monitoring", {}))
     net = dict(config["net"])
     kw = Configuration.net_kwargs(config, data.num_features(), data.num_labels, eos_label=data.eos_label) \

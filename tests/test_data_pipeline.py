@@ -163,6 +163,9 @@ stages:
     assert all(r["gradient_norm_threshold"] > 0 for r in batch_rows)
     valid = [r["valid_cost"] for r in log if "valid_cost" in r]
     assert valid[1] < valid[0]                                                             # it learns
+    with pytest.raises(NotImplementedError):
+        main.train(dict(cfg.ordered_stages["main"], regularization={"noise": 0.075}), data, save + "/x.zip", device="cpu",
+                   lib=emu_lib(), distributed=False)
     # stage 2 started from stage 1's best-likelihood checkpoint, not from a fresh initialisation
     from lvsr_amd.checkpoint import load_parameters
     a, b = load_parameters(save + "/pretraining_best_ll.zip"), load_parameters(save + "/main.zip")
