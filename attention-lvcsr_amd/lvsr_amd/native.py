@@ -308,6 +308,9 @@ class Region(object):
     def result(self, v):
         self.slot["result"] = v
 
+    def _alloc_count(self):
+        return torch.cuda.memory_stats(self.ref.device).get("allocation.all.allocated", 0)
+
     def begin(self):
         if not self.enabled:
             return True
@@ -333,7 +336,7 @@ class Region(object):
             return True
         self.state = "capturing"
         lib.capturing = True
-        self._allocs = torch.cuda.memory_stats(self.ref.device).get("allocation.all.allocated", 0)
+        self._allocs = self._alloc_count()
         return True
 
     def end(self):
@@ -345,7 +348,7 @@ class Region(object):
             return True
         lib = self.lib
         lib.capturing = False
-        clean = torch.cuda.memory_stats(self.ref.device).get("allocation.all.allocated", 0) == self._allocs
+        clean = self._alloc_count() == self._allocs
         rc = lib._lvsr_region_end(lib.stream_for(self.ref), int(clean))
         self.state = "captured"
         if rc != 0:
