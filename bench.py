@@ -65,6 +65,26 @@ def recurrent_kernel_probe(rec, dims, T, B):
     return avg, flops
 
 
+def gemm_probe(rec, dims, T, B):
+    """The step's largest dense contraction (a layer's gate projection, (T*B, 2H_prev) x (2H_prev, 2H)) timed alone with HIP
+    events on the recognizer's stream: the MFMA-bound part of the path, reported beside the latency-bound dominant kernel."""
+    lib = rec.lib
+    M, K, N = T * B, 2 * dims.Hs[0], 2 * dims.Hs[0]
+    dev = rec.device
+    A, Bm, C = (torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), torch.empty(M, N, device=dev))
+    with torch.cuda.stream(rec.stream):
+        for _ in range(3):
+            lib.sgemm(A, Bm, C)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(rec.stream)
+        for _ in range(20):
+            lib.sgemm(A, Bm, C)
+        e1.record(rec.stream)
+        e1.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / 20
+    return dict(kernel="lvsr_sgemm128_kernel", shape=[M, N, K], launch_us=sec * 1e6, achieved=2.0 * M * N * K / sec / 1e12, unit="TFLOP/s")
+
+
 def cpu_baseline(cfg, params, B, T, L):
     """The CPU oracle (torch fp32 restatement of the reference's algorithm, oracle/lvsr_oracle.py) timed on this
     box's host cores on ONE full minibatch of the same workload (forward + backward)."""
@@ -169,6 +189,8 @@ def main():
                     frac=flops / avg_launch / 1e12 / peak, traffic=traffic, launch_us=avg_launch * 1e6, flops_per_launch=flops,
                     whole_step_tflops=value / world * train_flop_per_frame / 1e12,
                     whole_step_frac=value / world * train_flop_per_frame / 1e12 / peak)
+        roof["dense_gemm"] = gemm_probe(rec, dims, T, B)
+        roof["dense_gemm"]["frac"] = roof["dense_gemm"]["achieved"] / peak
         out = dict(metric="encoder+attention+decoder training frames/sec (whole node)", value=value, unit="frames/s",
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
