@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--workload", default="wsj_base")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ragged", action="store_true",
+                    help="secondary run of SURVEY.md 8(d): utterance lengths ~U{T/2..T}, zero padded; counts real frames only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -141,10 +143,11 @@ def main():
     nstage = min(nsteps, 4)
     staged = []
     for s in range(nstage):
-        gb = synthetic.make_batch(cfg, B * world, T, L, seed=1234 + s)
+        gb = synthetic.make_batch(cfg, B * world, T, L, seed=1234 + s, ragged=args.ragged)
         sh = synthetic.shard_batch(gb, rank, world)
         staged.append({k: torch.from_numpy(v).to(dev) for k, v in sh.items()})
-    frames_per_step = float(sum(float(b["recordings_mask"].sum()) for b in staged[:1])) * world  # all-ones masks: B*T per rank
+    # real (unpadded) frames per step: B*T per rank with the default all-ones masks; the mean over the staged batches when ragged
+    frames_per_step = float(sum(float(b["recordings_mask"].sum()) for b in staged)) / len(staged) * world
     torch.cuda.synchronize()
 
     def barrier():
@@ -198,7 +201,7 @@ def main():
                        args.workload, B, T, dims.F, L, "x".join(str(h) for h in dims.Hs) + " BiGRU subsample " +
                        str(dims.subsample) + ", " + cfg["attention_type"] + " attention, %d-unit GRU decoder" % dims.D),
                        global_batch=B * world, per_gpu_batch=B, frames_per_step=frames_per_step,
-                       parallelism="dp%d" % world, optimizer="clip100+adadelta+maxnorm1", hip_graph=not args.no_graph,
+                       ragged=bool(args.ragged), parallelism="dp%d" % world, optimizer="clip100+adadelta+maxnorm1", hip_graph=not args.no_graph,
                        priming_steps=PRIME,
                        final_cost_per_utterance=last_cost / B),
                    roofline=roof)
