@@ -1,8 +1,11 @@
 """CPU ORACLE of the FST language model walk and shallow fusion.  TEST INFRASTRUCTURE — NOT PRODUCT CODE.
 
-PARITY UNPINNED for the FST walk: the reference's implementation (lvsr/ops.py:51-97,147-225) needs PyFST/OpenFST,
-which are absent here, so no reference-generated fixture exists.  This oracle is an INDEPENDENT dense formulation of the
-same semantics (log-semiring matrices instead of dict walks): state sets are weight vectors over all states,
+Parity status of the FST walk: PINNED to the reference's own code — `oracle/theano_harness/gen_fst_golden.py` runs
+lvsr/ops.py (FST.transition / FST.expand / FSTTransitionOp.perform / FSTCostsOp.perform) from the scratch copy and records
+state sets, weights and look-ahead costs along random walks in tests/golden/fst_walk.npz; this oracle, the product's host
+walk and its device kernel are all checked against that fixture (tests/test_lm.py).  Only the automaton CONTAINER is a
+stand-in there (PyFST / OpenFST cannot be installed: an AT&T-text parser exposing the attributes ops.py touches), so
+reading OpenFST binary files remains unpinned.  This oracle is an INDEPENDENT dense formulation of the same semantics (log-semiring matrices instead of dict walks): state sets are weight vectors over all states,
 `transition` = vector (x) arc-matrix of one label, `expand` = epsilon closure by repeated relaxation; costs as in
 FSTCostsOp (:206-225).  Fusion follows ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104) + LMEmitter.
 """

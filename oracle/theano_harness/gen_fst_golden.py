@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/fst_walk.npz from the REFERENCE's own FST walk (lvsr/ops.py: FST.transition / FST.expand /
+FSTTransitionOp.perform / FSTCostsOp.perform), run from the scratch copy (make_scratch.py).  TEST INFRASTRUCTURE ONLY.
+
+PyFST / OpenFST cannot be installed here, so the automaton CONTAINER is a stand-in (`fst.py` stub of make_scratch.py:
+an AT&T text parser exposing the attributes ops.py touches); everything recorded below is computed by the reference's
+code.  The automata are written out as plain arc arrays, so the tests rebuild them without the reference.
+
+    oracle/theano_harness/run_fst_gen.sh [out.npz]
+"""
+import json
+import math
+import os
+import sys
+import tempfile
+
+import numpy
+
+import lvsr.ops as ops
+
+
+def char_ngram(num_chars, seed):
+    """Same construction as lvsr_amd.lm.char_ngram_fst (restated here: this script must not import the product)."""
+    rng = numpy.random.RandomState(seed)
+    arcs = []
+    backoff = num_chars + 1
+    uni = rng.dirichlet(numpy.ones(num_chars) * 2.0)
+    for c in range(num_chars):
+        arcs.append((backoff, 1 + c, c + 1, -math.log(uni[c])))
+    for s in [0] + list(range(1, num_chars + 1)):
+        keep = rng.choice(num_chars, size=max(2, num_chars // 2), replace=False)
+        p = rng.dirichlet(numpy.ones(len(keep)))
+        for c, pc in zip(keep, p):
+            arcs.append((s, 1 + int(c), int(c) + 1, -math.log(0.8 * pc)))
+        arcs.append((s, backoff, ops.EPSILON, -math.log(0.2)))
+    return arcs, 0
+
+
+def random_fst(num_chars, seed, n_states=9):
+    rng = numpy.random.RandomState(seed)
+    arcs = []
+    for s in range(n_states):
+        for c in range(num_chars):
+            for _ in range(rng.randint(0, 3)):
+                arcs.append((s, int(rng.randint(0, n_states)), c + 1, float(rng.uniform(0.1, 4.0))))
+        for d in range(s + 1, min(n_states, s + 3)):
+            if rng.rand() < 0.5:
+                arcs.append((s, d, ops.EPSILON, float(rng.uniform(0.1, 2.0))))
+    if not any(a[0] == 0 for a in arcs):
+        arcs.insert(0, (0, 1, 1, 1.0))
+    return arcs, 0
+
+
+def write_att(arcs, num_chars, path, start=0):
+    arcs = [a for a in arcs if a[0] == start] + [a for a in arcs if a[0] != start]   # the first source state is the start
+    with open(path, "w") as fh:
+        for (s, d, il, w) in arcs:
+            fh.write("%d %d %d %d %r\n" % (s, d, il, il, float(w)))
+    with open(path + ".isyms", "w") as fh:
+        fh.write("<eps> 0\n")
+        for c in range(num_chars):
+            fh.write("c%d %d\n" % (c, c + 1))
+
+
+def walk(arcs, num_chars, seed, n=4, steps=8, no_transition_cost=17.0):
+    tmp = tempfile.mkdtemp()
+    path = os.path.join(tmp, "lm.fst.txt")
+    write_att(arcs, num_chars, path)
+    f = ops.FST(path)
+    f.load()
+    assert f.fst.start == 0
+    remap = {c: f.isyms["c%d" % c] for c in range(num_chars)}
+    trans, costs = ops.FSTTransitionOp(f, remap), ops.FSTCostsOp(f, remap, no_transition_cost)
+    start = f.expand({f.fst.start: 0})
+    st = numpy.tile(trans.pad(list(start.keys()), ops.NOT_STATE)[None, :], (n, 1)).astype("int64")
+    wt = numpy.tile(trans.pad(list(start.values()), 0)[None, :], (n, 1)).astype("float64")
+    rng = numpy.random.RandomState(seed)
+    rec = dict(states=[], weights=[], costs=[], outputs=[])
+    for step in range(steps):
+        out = [[None]]
+        try:
+            costs.perform(None, [st, wt], out)
+        except KeyError:                         # a full set of 7 states has no NOT_STATE entry to delete (ops.py:212)
+            break
+        add = out[0][0]
+        rec["states"].append(st.copy()); rec["weights"].append(wt.copy()); rec["costs"].append(add.copy())
+        chosen = []
+        for b in range(n):
+            ok = [c for c in range(num_chars) if add[b, c] < no_transition_cost]
+            chosen.append(ok[rng.randint(len(ok))] if ok else 0)
+        chosen = numpy.array(chosen)
+        out2 = [[None], [None]]
+        try:
+            trans.perform(None, [st, wt, chosen], out2)
+        except (ValueError, KeyError):           # a set of >= 7 states: numpy.pad / del states_dict[NOT_STATE] fail (ops.py:140-152)
+            break
+        rec["outputs"].append(chosen)
+        st, wt = out2[0][0], out2[1][0]
+    return {k: numpy.array(v) for k, v in rec.items()}
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else "fst_walk.npz"
+    cases = [("ngram6", char_ngram(6, 5), 6, 11), ("random5", random_fst(5, 1), 5, 12), ("random70", random_fst(70, 2, 5), 70, 13),
+             ("noeps4", ([a for a in random_fst(4, 3)[0] if a[2] != ops.EPSILON], 0), 4, 14)]
+    blob, meta = {}, {}
+    for name, (arcs, start), V, seed in cases:
+        r = walk(arcs, V, seed)
+        blob[name + "_arcs"] = numpy.array([(s, d, il, w) for (s, d, il, w) in arcs], dtype=numpy.float64)
+        for k, v in r.items():
+            blob["%s_%s" % (name, k)] = v
+        meta[name] = dict(num_chars=V, start=start, steps=int(len(r["outputs"])), recorded=int(len(r["costs"])), no_transition_cost=17.0)
+    blob["meta"] = numpy.array(json.dumps(dict(cases=meta, source="lvsr/ops.py FST walk via the fst.py container stand-in")))
+    numpy.savez_compressed(out, **blob)
+    print("wrote", out, {k: v["steps"] for k, v in meta.items()})
+
+
+if __name__ == "__main__":
+    main()

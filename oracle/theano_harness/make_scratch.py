@@ -79,6 +79,32 @@ STUBS = {
         "        data = {k: (v - ready) for k, v in data.items() if k not in ready}\n"
         "    assert not data, 'cyclic dependency'\n"
         "    return out\n"),
+    # PyFST stand-in for lvsr/ops.py (the real one binds OpenFST, which is not installable here): `fst.read(path)` parses an
+    # AT&T text acceptor ('src dst ilabel olabel weight' / 'final [weight]') with '<path>.isyms' ('symbol id' lines) and
+    # exposes exactly the attributes ops.py touches: .start, .isyms.items(), fst[state] -> arcs with .ilabel/.nextstate/
+    # .weight, state.final.  Only the CONTAINER is shimmed; the walk that gen_fst_golden.py records is the reference's code.
+    "fst.py": (
+        "class _Arc(object):\n"
+        "    def __init__(self, il, ol, w, nxt):\n        self.ilabel, self.olabel, self.weight, self.nextstate = il, ol, w, nxt\n"
+        "class _State(list):\n    final = float('inf')\n"
+        "class _Fst(object):\n"
+        "    def __init__(self):\n        self.states, self.start, self.isyms = {}, None, {}\n"
+        "    def __getitem__(self, q):\n        return self.states.setdefault(q, _State())\n"
+        "class SymbolTable(dict):\n"
+        "    def __init__(self, eps='<eps>'):\n        dict.__init__(self); self[eps] = 0\n"
+        "def read(path):\n"
+        "    f = _Fst()\n"
+        "    for line in open(path):\n"
+        "        p = line.split()\n"
+        "        if not p:\n            continue\n"
+        "        if len(p) <= 2:\n            f[int(p[0])].final = float(p[1]) if len(p) == 2 else 0.0\n            continue\n"
+        "        src, dst = int(p[0]), int(p[1])\n"
+        "        if f.start is None:\n            f.start = src\n"
+        "        f[src].append(_Arc(int(p[2]), int(p[3]), float(p[4]) if len(p) > 4 else 0.0, dst))\n"
+        "        f[dst]\n"
+        "    for line in open(path + '.isyms'):\n"
+        "        s, i = line.split()\n        f.isyms[s] = int(i)\n"
+        "    return f\n"),
     "fuel/__init__.py": "",
     "fuel/utils.py": (
         "def do_not_pickle_attributes(*names):\n"
@@ -132,6 +158,9 @@ def main():
             r"\2if numpy.all(x == x_):\n\3break")], 1)
     # python-2-isms inside lvsr that the bricks-only import touches
     patch(os.path.join(pkg, "lvsr/bricks/recognizer.py"), [(r"\bxrange\b", "range")])
+    # Python 2 orders None below every number, so `max(args)` in FST.combine_weights ignores the `None` that FST.expand
+    # passes for a state not yet in the set; Python 3 raises instead
+    patch(os.path.join(pkg, "lvsr/ops.py"), [(r"m = max\(args\)", "m = max(a for a in args if a is not None)")], 1)
     print("scratch reference at", DST)
     print("run with: THEANO_FLAGS=device=cpu,floatX=float32,cxx=,optimizer_excluding=fusion,"
           "base_compiledir=/tmp/theano_cc PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=%s:%s python3 ..." % (pkg, shims))

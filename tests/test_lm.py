@@ -1,5 +1,6 @@
 """FST language model walk (host) and shallow-fusion kernel vs oracle/lm_oracle.py (independent dense formulation;
-parity with the reference's PyFST path is UNPINNED — PyFST is not installable here)."""
+and vs tests/golden/fst_walk.npz, recorded from the reference's own walk code, lvsr/ops.py, with only the PyFST container
+shimmed — oracle/theano_harness/gen_fst_golden.py)."""
 import numpy
 import pytest
 import torch
@@ -269,3 +270,68 @@ def test_lm_block_of_the_net_section_builds_the_fusion_model(tmp_path):
         results.append(rec.beam_search({"recordings": x}, char_discount=0.2, stop_on="optimistic_future_cost"))
     assert results[0][0] == results[1][0]
     assert_allclose(results[0][1], results[1][1], rtol=1e-5, atol=1e-5)      # binary weights are float32
+
+
+# ---- pinned to the reference's own walk (tests/golden/fst_walk.npz, oracle/theano_harness/gen_fst_golden.py) -----------
+def _golden_fst_cases():
+    import json
+    from conftest import golden_path
+    z = numpy.load(golden_path("fst_walk"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))["cases"]
+    for name, m in meta.items():
+        f = LM.ArcFST(start=m["start"])
+        V = m["num_chars"]
+        f.isyms = {"<eps>": 0}
+        f.isyms.update({"c%d" % i: i + 1 for i in range(V)})
+        for s, d, il, w in z[name + "_arcs"]:
+            f.add_arc(int(s), int(d), int(il), float(w))
+        yield name, m, f, {"c%d" % i: i for i in range(V)}, z
+
+
+def _walk_against_golden(make_model):
+    checked = 0
+    for name, m, fst, cmap, z in _golden_fst_cases():
+        model = make_model(fst, cmap, m["no_transition_cost"])
+        st = model.initial_states(z[name + "_states"].shape[1])
+        for step in range(m["recorded"]):
+            ref_sets = [{int(q): float(w) for q, w in zip(sr, wr) if q != LM.NOT_STATE}
+                        for sr, wr in zip(z[name + "_states"][step], z[name + "_weights"][step])]
+            got_sets = _as_sets(st)
+            for a, b in zip(got_sets, ref_sets):
+                assert set(a) == set(b), (name, step)
+                for q in a:
+                    assert abs(a[q] - b[q]) < 1e-9, (name, step, q)
+            add = st["add"].cpu().numpy() if torch.is_tensor(st["add"]) else st["add"]
+            assert_allclose(add, z[name + "_costs"][step], rtol=2e-6, atol=2e-6, err_msg="%s step %d" % (name, step))
+            checked += 1
+            if step < m["steps"]:
+                st = model.transition(st, z[name + "_outputs"][step])
+    assert checked >= 20
+
+
+def test_host_fst_walk_matches_the_reference_walk():
+    _walk_against_golden(lambda fst, cmap, ntc: LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=ntc))
+
+
+def test_dense_lm_oracle_matches_the_reference_walk():
+    for name, m, fst, cmap, z in _golden_fst_cases():
+        arcs = [(s, d, l, w) for s, lst in fst.arcs.items() for (l, d, w) in lst]
+        dense = LO.DenseFST(arcs, fst.start, m["num_chars"])
+        remap = {i: i + 1 for i in range(m["num_chars"])}
+        vecs = [dense.initial() for _ in range(z[name + "_states"].shape[1])]
+        for step in range(m["recorded"]):
+            for b, v in enumerate(vecs):
+                assert_allclose(dense.costs(v, remap, m["no_transition_cost"]), z[name + "_costs"][step][b], rtol=1e-5, atol=1e-5)
+            if step < m["steps"]:
+                vecs = [dense.step(v, remap[int(o)]) for v, o in zip(vecs, z[name + "_outputs"][step])]
+
+
+def test_device_fst_walk_matches_the_reference_walk_emulated():
+    from emu import emu_lib
+    _walk_against_golden(lambda fst, cmap, ntc: LM.DeviceFSTLanguageModel(fst, "cpu", lib=emu_lib(), nn_char_map=cmap,
+                                                                          no_transition_cost=ntc))
+
+
+@pytest.mark.gpu
+def test_device_fst_walk_matches_the_reference_walk_gpu(gpu_device):
+    _walk_against_golden(lambda fst, cmap, ntc: LM.DeviceFSTLanguageModel(fst, gpu_device, nn_char_map=cmap, no_transition_cost=ntc))
