@@ -7,7 +7,9 @@ walk and its device kernel are all checked against that fixture (tests/test_lm.p
 stand-in there (PyFST / OpenFST cannot be installed: an AT&T-text parser exposing the attributes ops.py touches), so
 reading OpenFST binary files remains unpinned.  This oracle is an INDEPENDENT dense formulation of the same semantics (log-semiring matrices instead of dict walks): state sets are weight vectors over all states,
 `transition` = vector (x) arc-matrix of one label, `expand` = epsilon closure by repeated relaxation; costs as in
-FSTCostsOp (:206-225).  Fusion follows ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104) + LMEmitter.
+FSTCostsOp (:206-225).  Fusion follows ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104) + LMEmitter
+and is PINNED too: the same fixture holds the reference bricks' output (evaluated by Theano) for all 8 normalisation flag
+combinations x 2 weightings.
 """
 import numpy
 

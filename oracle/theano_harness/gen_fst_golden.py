@@ -99,6 +99,37 @@ def walk(arcs, num_chars, seed, n=4, steps=8, no_transition_cost=17.0):
     return {k: numpy.array(v) for k, v in rec.items()}
 
 
+def fusion_goldens(blob):
+    """ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104) + LMEmitter.costs (:168-169) evaluated by Theano for
+    every normalisation flag combination; the merge / post-merge bricks are identities so the acoustic input passes through."""
+    import theano
+    from theano import tensor
+    from blocks.bricks import Identity
+    from blocks.bricks.parallel import Merge
+    from lvsr.bricks.language_models import ShallowFusionReadout, LMEmitter
+    rng = numpy.random.RandomState(7)
+    n, V = 5, 9
+    am = (3.0 * rng.normal(size=(n, V))).astype("float32")
+    add = rng.uniform(0.0, 6.0, size=(n, V)).astype("float32")
+    add[1, 2] = add[3, 0] = 20.0                                  # no-transition costs
+    blob["fusion_am"], blob["fusion_add"] = am, add
+    combos = []
+    for flags in [(a, l, t) for a in (0, 1) for l in (0, 1) for t in (0, 1)]:
+        for am_beta, lm_weight in ((1.0, 0.5), (0.7, 1.3)):
+            r = ShallowFusionReadout(lm_costs_name="lm_add", lm_weight=lm_weight, normalize_am_weights=bool(flags[0]),
+                                     normalize_lm_weights=bool(flags[1]), normalize_tot_weights=bool(flags[2]), am_beta=am_beta,
+                                     readout_dim=V, source_names=["am"], merge=Merge(["am"], [V], V, prototype=Identity()),
+                                     post_merge=Identity(), emitter=LMEmitter(), name="readout")
+            r.source_dims = [V]                                    # SequenceGenerator pushes these normally
+            x, y = tensor.matrix("am"), tensor.matrix("lm_add")
+            costs = r.emitter.costs(r.readout(am=x, lm_add=y))
+            f = theano.function([x, y], costs)
+            key = "fusion_%d%d%d_%g_%g" % (flags + (am_beta, lm_weight))
+            blob[key] = f(am, add)
+            combos.append([int(flags[0]), int(flags[1]), int(flags[2]), am_beta, lm_weight, key])
+    return combos
+
+
 def main():
     out = sys.argv[1] if len(sys.argv) > 1 else "fst_walk.npz"
     cases = [("ngram6", char_ngram(6, 5), 6, 11), ("random5", random_fst(5, 1), 5, 12), ("random70", random_fst(70, 2, 5), 70, 13),
@@ -110,7 +141,8 @@ def main():
         for k, v in r.items():
             blob["%s_%s" % (name, k)] = v
         meta[name] = dict(num_chars=V, start=start, steps=int(len(r["outputs"])), recorded=int(len(r["costs"])), no_transition_cost=17.0)
-    blob["meta"] = numpy.array(json.dumps(dict(cases=meta, source="lvsr/ops.py FST walk via the fst.py container stand-in")))
+    fusion = fusion_goldens(blob)
+    blob["meta"] = numpy.array(json.dumps(dict(cases=meta, fusion=fusion, source="lvsr/ops.py FST walk via the fst.py container stand-in")))
     numpy.savez_compressed(out, **blob)
     print("wrote", out, {k: v["steps"] for k, v in meta.items()})
 

@@ -335,3 +335,33 @@ def test_device_fst_walk_matches_the_reference_walk_emulated():
 @pytest.mark.gpu
 def test_device_fst_walk_matches_the_reference_walk_gpu(gpu_device):
     _walk_against_golden(lambda fst, cmap, ntc: LM.DeviceFSTLanguageModel(fst, gpu_device, nn_char_map=cmap, no_transition_cost=ntc))
+
+
+def _fusion_vs_reference(device, lib):
+    """ShallowFusionReadout.readout + LMEmitter.costs as evaluated by the reference's Theano bricks (fst_walk.npz)."""
+    import json
+    from conftest import golden_path
+    from lvsr_amd.native import ptr
+    z = numpy.load(golden_path("fst_walk"), allow_pickle=False)
+    combos = json.loads(str(z["meta"]))["fusion"]
+    assert len(combos) == 16
+    am, add = torch.tensor(z["fusion_am"], device=device), torch.tensor(z["fusion_add"], device=device)
+    n, V = am.shape
+    for na, nl, nt, am_beta, lm_weight, key in combos:
+        ref = z[key]
+        assert_allclose(-LO.shallow_fusion(z["fusion_am"], z["fusion_add"], lm_weight, am_beta, bool(na), bool(nl), bool(nt)), ref,
+                        rtol=1e-5, atol=1e-5, err_msg="oracle " + key)
+        out = torch.empty(n, V, device=device)
+        lib.call("lvsr_shallow_fusion", lib.stream_for(out), ptr(am), V, ptr(add), n, V, am_beta, lm_weight, na, nl, nt, -1.0, ptr(out))
+        assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-5, err_msg="kernel " + key)
+
+
+def test_shallow_fusion_matches_the_reference_bricks_emulated():
+    from emu import emu_lib
+    _fusion_vs_reference("cpu", emu_lib())
+
+
+@pytest.mark.gpu
+def test_shallow_fusion_matches_the_reference_bricks_gpu(gpu_device):
+    from lvsr_amd import native
+    _fusion_vs_reference(gpu_device, native.get())
