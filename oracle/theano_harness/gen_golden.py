@@ -42,7 +42,7 @@ OUT = os.path.join(REPO, "tests", "golden")
 ACT = {"maxout2": lambda: Maxout(2), "rectifier": Rectifier, "tanh": Tanh}
 
 
-def build_reference(cfg):
+def build_reference(cfg, **extra):
     c = spec.normalize_net_config(cfg)
     kw = dict(
         input_dims={"recordings": c["input_dim"]}, input_num_chars={}, eos_label=c["eos_label"],
@@ -59,6 +59,7 @@ def build_reference(cfg):
         embed_outputs=c["embed_outputs"], dim_output_embedding=c["dim_output_embedding"],
         data_prepend_eos=c["data_prepend_eos"], max_decoded_length_scale=c["max_decoded_length_scale"],
         name="recognizer")
+    kw.update(extra)
     rec = SpeechRecognizer(**kw)
     rec.weights_init = IsotropicGaussian(0.01)
     rec.biases_init = Constant(0.0)
@@ -151,6 +152,62 @@ def run_case(name, cfg, B, T, L, ragged, param_seed, batch_seed, scale=1.0, stor
     sys.stdout.flush()
 
 
+def run_lm_case(name, cfg, T, param_seed, fst_seed, beams, lm_kwargs, scale=1.0, utterances=3):
+    """Beam search WITH shallow fusion through the reference's own bricks (LanguageModel / FSTTransition / FSTCostsOp /
+    ShallowFusionReadout, lvsr/bricks/language_models.py, lvsr/ops.py); the PyFST container is the harness stand-in
+    (make_scratch.py `fst.py`).  The automaton travels in the fixture as an arc array."""
+    import math
+    import tempfile
+    V = cfg["num_phonemes"]
+    rng = numpy.random.RandomState(fst_seed)
+    arcs, backoff = [], V + 1
+    uni = rng.dirichlet(numpy.ones(V) * 2.0)
+    for s_ in [0] + list(range(1, V + 1)):
+        keep = rng.choice(V, size=max(2, V // 2), replace=False)
+        pr = rng.dirichlet(numpy.ones(len(keep)))
+        for c, pc in zip(keep, pr):
+            arcs.append((s_, 1 + int(c), int(c) + 1, -math.log(0.8 * pc)))
+        arcs.append((s_, backoff, 0, -math.log(0.2)))
+    for c in range(V):
+        arcs.append((backoff, 1 + c, c + 1, -math.log(uni[c])))
+    path = os.path.join(tempfile.mkdtemp(), "lm.fst.txt")
+    with open(path, "w") as fh:
+        for (a, b, il, w) in arcs:
+            fh.write("%d %d %d %d %r\n" % (a, b, il, il, float(w)))
+    with open(path + ".isyms", "w") as fh:
+        fh.write("<eps> 0\n")
+        for c in range(V):
+            fh.write("c%d %d\n" % (c, c + 1))
+    cmap = {"c%d" % c: c for c in range(V)}
+    rec = build_reference(cfg, lm=dict(path=path, **lm_kwargs), character_map=cmap)
+    cg = rec.get_cost_graph(batch=True)
+    params = Model(cg.outputs[0].sum()).get_parameter_dict()
+    values = synthetic.make_params(cfg, seed=param_seed, scale=scale)
+    for k, v in params.items():
+        if k in values:
+            v.set_value(values[k])
+    missing = set(values) - set(params)
+    assert not missing, missing
+    out, results = {}, []
+    for u in range(utterances):
+        x = numpy.random.RandomState(100 + u).normal(size=(T, cfg["input_dim"])).astype("float32")
+        out["x%d" % u] = x
+        for bs in beams:
+            rec.init_beam_search(bs["beam_size"])
+            kw = {k2: v2 for k2, v2 in bs.items() if k2 != "beam_size"}
+            try:
+                o, c = rec.beam_search({"recordings": x}, **kw)
+                results.append(dict(utt=u, settings=bs, outputs=[[int(t) for t in h] for h in o], costs=[float(v) for v in c]))
+            except Exception as e:
+                results.append(dict(utt=u, settings=bs, outputs=None, costs=None, error=type(e).__name__))
+    out["arcs"] = numpy.array(arcs, dtype=numpy.float64)
+    out["meta"] = numpy.array(json.dumps(dict(name=name, cfg=cfg, T=T, param_seed=param_seed, scale=scale, lm=lm_kwargs,
+                                              beam=results)))
+    numpy.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("[golden] %s: %s" % (name, [(r["utt"], r.get("error") or [len(h) for h in r["outputs"]][:3]) for r in results]))
+    sys.stdout.flush()
+
+
 def tiny_cfg(prior, **kw):
     cfg = dict(input_dim=5, num_phonemes=6, dims_bidir=[3, 3], subsample=[1, 2], dim_dec=4, dim_matcher=7,
                attention_type="content_and_conv", conv_n=2, conv_num_filters=3, prior=prior,
@@ -221,6 +278,11 @@ CASES = {
         "small_conv_expanding",
         small_cfg(dict(type="expanding", initial_begin=0, initial_end=4, min_speed=0.6, max_speed=2.2)),
         B=5, T=50, L=12, ragged=True, param_seed=12, batch_seed=19),
+    "tiny_conv_lm": lambda: run_lm_case(
+        "tiny_conv_lm", tiny_cfg(dict(type="window_around_median", before=2, after=3), embed_outputs=True), T=14,
+        param_seed=41, fst_seed=5, scale=6.0, utterances=4, lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
+        beams=[dict(beam_size=4, char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost"),
+               dict(beam_size=3, char_discount=1.0, round_to_inf=15.0, stop_on="patience")]),
     "timit_tiny": lambda: run_case(
         "timit_tiny", spec.timit_tiny(), B=2, T=200, L=40, ragged=False, param_seed=9, batch_seed=1234,
         store_full=False),

@@ -108,7 +108,15 @@ STUBS = {
     "fuel/__init__.py": "",
     "fuel/utils.py": (
         "def do_not_pickle_attributes(*names):\n"
-        "    def deco(cls):\n        return cls\n"
+        "    # fuel.utils: the named attributes are not pickled and are (re)created by load() on first access\n"
+        "    def deco(cls):\n"
+        "        def __getattr__(self, name):\n"
+        "            if name in names and 'load' in dir(type(self)):\n"
+        "                self.load()\n"
+        "                return self.__dict__[name]\n"
+        "            raise AttributeError(name)\n"
+        "        cls.__getattr__ = __getattr__\n"
+        "        return cls\n"
         "    return deco\n"),
 }
 
@@ -161,6 +169,10 @@ def main():
     # Python 2 orders None below every number, so `max(args)` in FST.combine_weights ignores the `None` that FST.expand
     # passes for a state not yet in the set; Python 3 raises instead
     patch(os.path.join(pkg, "lvsr/ops.py"), [(r"m = max\(args\)", "m = max(a for a in args if a is not None)")], 1)
+    # dict views are not sequences in Python 3 (FSTTransition.initial_states hands them to numpy.pad)
+    patch(os.path.join(pkg, "lvsr/bricks/language_models.py"),
+          [(r"self\.transition\.pad\(states_dict\.keys\(\), NOT_STATE\)", "self.transition.pad(list(states_dict.keys()), NOT_STATE)"),
+           (r"self\.transition\.pad\(states_dict\.values\(\), 0\)", "self.transition.pad(list(states_dict.values()), 0)")], 2)
     print("scratch reference at", DST)
     print("run with: THEANO_FLAGS=device=cpu,floatX=float32,cxx=,optimizer_excluding=fusion,"
           "base_compiledir=/tmp/theano_cc PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=%s:%s python3 ..." % (pkg, shims))

@@ -365,3 +365,53 @@ def test_shallow_fusion_matches_the_reference_bricks_emulated():
 def test_shallow_fusion_matches_the_reference_bricks_gpu(gpu_device):
     from lvsr_amd import native
     _fusion_vs_reference(gpu_device, native.get())
+
+
+# ---- beam search WITH shallow fusion vs hypotheses the reference itself produced (tests/golden/tiny_conv_lm.npz) -------
+def _lm_beam_vs_reference(device, lib, device_lm):
+    import json
+    from conftest import golden_path
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    from lvsr_amd.search import CandidateNotFoundError
+    z = numpy.load(golden_path("tiny_conv_lm"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    cfg = meta["cfg"]
+    V = cfg["num_phonemes"]
+    fst = LM.ArcFST(start=0)
+    fst.isyms = {"<eps>": 0}
+    fst.isyms.update({"c%d" % i: i + 1 for i in range(V)})
+    for s, d, il, w in z["arcs"]:
+        fst.add_arc(int(s), int(d), int(il), float(w))
+    cmap = {"c%d" % i: i for i in range(V)}
+    kw = dict(nn_char_map=cmap, **meta["lm"])
+    model = LM.DeviceFSTLanguageModel(fst, device, lib=lib, **kw) if device_lm else LM.FSTLanguageModel(fst, **kw)
+    rec = SpeechRecognizer(device=device, params=synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"]),
+                           lib=lib, net_config=cfg)
+    rec.set_language_model(model)
+    checked = 0
+    for r in meta["beam"]:
+        s = dict(r["settings"])
+        rec.init_beam_search(s.pop("beam_size"))
+        x = z["x%d" % r["utt"]]
+        if r.get("error"):
+            with pytest.raises(CandidateNotFoundError):
+                rec.beam_search({"recordings": x}, **s)
+            continue
+        outs, costs = rec.beam_search({"recordings": x}, **s)
+        assert outs == r["outputs"], (r["utt"], s)                               # bit-exact hypotheses
+        assert_allclose(costs, r["costs"], rtol=5e-5, atol=5e-5)
+        checked += len(outs)
+    assert checked >= 10
+
+
+@pytest.mark.parametrize("device_lm", [False, True])
+def test_lm_beam_search_matches_the_reference_emulated(device_lm):
+    from emu import emu_lib
+    _lm_beam_vs_reference("cpu", emu_lib(), device_lm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_lm", [False, True])
+def test_lm_beam_search_matches_the_reference_gpu(gpu_device, device_lm):
+    _lm_beam_vs_reference(gpu_device, None, device_lm)
