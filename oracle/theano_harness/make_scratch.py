@@ -105,6 +105,7 @@ STUBS = {
         "    for line in open(path + '.isyms'):\n"
         "        s, i = line.split()\n        f.isyms[s] = int(i)\n"
         "    return f\n"),
+    "progressbar.py": "# imported by blocks.extensions (ProgressBar extension, never instantiated by the harness)\n",
     "fuel/__init__.py": "",
     "fuel/utils.py": (
         "def do_not_pickle_attributes(*names):\n"

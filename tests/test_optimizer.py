@@ -139,3 +139,57 @@ def test_fused_step_gpu(gpu_device):
     run_fused_vs_oracle(gpu_device, None)
     run_fused_vs_oracle(gpu_device, None, poison=True)
     run_fused_vs_oracle(gpu_device, None, rules=ADAPTIVE, steps=6)
+
+
+# ---- pinned to the reference's own AdaptiveClipping / BurnIn classes (tests/golden/adaptive_clipping.npz) -------------
+def _adaptive_golden():
+    import json
+    from conftest import golden_path
+    z = numpy.load(golden_path("adaptive_clipping"), allow_pickle=False)
+    return z, json.loads(str(z["meta"]))
+
+
+def test_adaptive_clipping_oracle_matches_the_reference_class():
+    z, meta = _adaptive_golden()
+    for key in ("wired", "short"):
+        m = meta[key]
+        ac = OO.AdaptiveClipping(m["initial"], burnin_period=m["burnin_period"], decay_rate=m["decay_rate"])
+        got = []
+        for g in z["norms"]:
+            ac.after_batch(g)
+            got.append(ac.threshold)
+        assert_allclose(got, z[key], rtol=1e-6)
+    assert z["burn_in"][:, 0].tolist() == [0, 0, 0, 1, 1, 1]             # BurnIn(3): three zeroed steps, then untouched
+
+
+def run_adaptive_kernel_vs_reference(device, lib):
+    """Feed the fused optimiser gradients whose norms are the golden's sequence: the device-resident threshold must follow
+    the thresholds the reference's AdaptiveClipping set, and BurnIn must freeze the parameters for its first steps."""
+    z, meta = _adaptive_golden()
+    m = meta["short"]
+    params = synthetic.make_params(CFG, seed=21)
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=CFG)
+    tr = Trainer(rec, distributed=False, gradient_threshold=m["initial"], rules=("momentum",), scale=0.01, burn_in_steps=3,
+                 adaptive_clipping=dict(decay_rate=m["decay_rate"], burnin_period=m["burnin_period"]))
+    n = rec.store.grad.numel()
+    before = rec.store.flat.clone()
+    direction = torch.randn(n, generator=torch.Generator().manual_seed(1)).to(rec.store.grad.device)
+    direction /= direction.norm()
+    for it, g in enumerate(z["norms"][:12]):
+        rec.store.grad.copy_(direction * float(g))
+        tr.apply_gradients(global_batch_size=1)
+        assert_allclose(tr.gradient_norm(), float(g), rtol=1e-5)
+        assert_allclose(tr.gradient_threshold(), z["short"][it], rtol=2e-5)
+        if it < 3:
+            assert torch.equal(rec.store.flat, before), "BurnIn step %d moved the parameters" % it
+    assert not torch.equal(rec.store.flat, before)
+
+
+def test_adaptive_clipping_kernel_matches_the_reference_class_emulated():
+    from emu import emu_lib
+    run_adaptive_kernel_vs_reference("cpu", emu_lib())
+
+
+@pytest.mark.gpu
+def test_adaptive_clipping_kernel_matches_the_reference_class_gpu(gpu_device):
+    run_adaptive_kernel_vs_reference(gpu_device, None)
