@@ -57,6 +57,10 @@ class LookupBottom(_Marker):
     pass
 
 
+class H5PYAudioDatasetTimit(_Marker):   # lvsr.datasets.h5py.H5PYAudioDatasetTimit (exp/timit configs: `data.dataset_class`)
+    pass
+
+
 class H5PYAudioDataset(_Marker):        # lvsr.datasets.h5py.H5PYAudioDataset — data layer is out of scope
     pass
 
@@ -132,6 +136,7 @@ REGISTRY = {
     "blocks.bricks.Logistic": Logistic, "blocks.bricks.Maxout": Maxout,
     "lvsr.bricks.recognizer.SpeechBottom": SpeechBottom, "lvsr.bricks.recognizer.LookupBottom": LookupBottom,
     "lvsr.datasets.h5py.H5PYAudioDataset": H5PYAudioDataset,
+    "lvsr.datasets.h5py.H5PYAudioDatasetTimit": H5PYAudioDatasetTimit,
     "blocks.initialization.Constant": Constant, "blocks.initialization.IsotropicGaussian": IsotropicGaussian,
     "blocks.initialization.Uniform": Uniform, "blocks.initialization.Orthogonal": Orthogonal,
 }

@@ -120,7 +120,9 @@ def validate(config):
 
 class Configuration(dict):
     """lvsr/config.py:52-92."""
-    def __init__(self, config_path, schema_path=None, config_changes=()):
+    def __init__(self, config_path, schema_path=None, config_changes=(), validate_keys=True):
+        """`schema_path` is accepted for signature compatibility; the key sets of lvsr/configs/schema.yaml are built in and
+        checked unless `validate_keys=False` (the reference validates only when a schema path is given)."""
         with open(config_path, "rt") as src:
             config = read_config(src)
         make_config_changes(config, config_changes)
@@ -132,14 +134,14 @@ class Configuration(dict):
             for name, changes in ordered_changes.items():
                 current_config = copy.deepcopy(config)
                 del current_config["stages"]
-                changes = dict(changes)
-                del changes["number"]
+                del changes["number"]            # in place, as lvsr/config.py:79 does: self["stages"][name] loses it too
                 merge_recursively(current_config, changes)
                 self.ordered_stages[name] = current_config
-        validate(config)
-        if self.multi_stage:
-            for stage in self.ordered_stages.values():
-                validate(stage)
+        if validate_keys:
+            validate(config)
+            if self.multi_stage:
+                for stage in self.ordered_stages.values():
+                    validate(stage)
         super(Configuration, self).__init__(config)
 
     def net_kwargs(self, input_dim, num_phonemes, eos_label=None, stage=None, **extra):

@@ -289,9 +289,12 @@ CASES = {
     "wsj_base": lambda: run_case(
         "wsj_base", spec.wsj_base(), B=16, T=800, L=100, ragged=False, param_seed=10, batch_seed=1234,
         store_full=False),
+    "wsj_deep": lambda: run_case(
+        "wsj_deep", spec.wsj_deep(), B=8, T=1500, L=190, ragged=False, param_seed=11, batch_seed=1234,
+        store_full=False),
 }
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or [k for k in CASES if k != "wsj_base"]
+    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep")]
     for k in which:
         CASES[k]()

@@ -105,6 +105,8 @@ STUBS = {
         "    for line in open(path + '.isyms'):\n"
         "        s, i = line.split()\n        f.isyms[s] = int(i)\n"
         "    return f\n"),
+    "pykwalify/__init__.py": "",
+    "pykwalify/core.py": "class Core(object):\n    def __init__(self, **kw):\n        pass\n    def validate(self, **kw):\n        return True\n",
     "progressbar.py": "# imported by blocks.extensions (ProgressBar extension, never instantiated by the harness)\n",
     "fuel/__init__.py": "",
     "fuel/utils.py": (
@@ -170,6 +172,12 @@ def main():
     # Python 2 orders None below every number, so `max(args)` in FST.combine_weights ignores the `None` that FST.expand
     # passes for a state not yet in the set; Python 3 raises instead
     patch(os.path.join(pkg, "lvsr/ops.py"), [(r"m = max\(args\)", "m = max(a for a in args if a is not None)")], 1)
+    # lvsr/config.py: tuple-parameter lambda (Python 2 only) and yaml.load() without a Loader (PyYAML >= 6 requires one;
+    # the full loader is what PyYAML used by default when the reference was written)
+    patch(os.path.join(pkg, "lvsr/config.py"),
+          [(r"lambda \(k, v\): v\['number'\]", "lambda kv: kv[1]['number']"),
+           (r"yaml\.load\(file_\)", "yaml.load(file_, Loader=yaml.Loader)"),
+           (r"yaml\.load\(value\)", "yaml.load(value, Loader=yaml.Loader)")], 3)
     # dict views are not sequences in Python 3 (FSTTransition.initial_states hands them to numpy.pad)
     patch(os.path.join(pkg, "lvsr/bricks/language_models.py"),
           [(r"self\.transition\.pad\(states_dict\.keys\(\), NOT_STATE\)", "self.transition.pad(list(states_dict.keys()), NOT_STATE)"),

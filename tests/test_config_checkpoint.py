@@ -107,3 +107,45 @@ def test_reference_wsj_configs_load_unchanged():
             assert net["dims_bidir"] == [256] * 4 and net["conv_n"] == 100 and net["post_merge_activation"] == "maxout2"
             assert spec.count_parameters(net) == 5348731      # SURVEY.md §8d (F=123)
     assert ok > 20
+
+
+def _plain(x):
+    """Same reduction as oracle/theano_harness/gen_config_golden.py: python objects -> class names."""
+    if isinstance(x, dict):
+        return {str(k): _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    if isinstance(x, type):
+        return {"__class__": x.__name__}
+    if x is None or isinstance(x, (bool, int, float, str)):
+        return x
+    out = {"__instance__": type(x).__name__}
+    if hasattr(x, "num_pieces"):
+        out["num_pieces"] = x.num_pieces
+    return out
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/exp/wsj/configs"), reason="reference tree not present")
+def test_loader_agrees_with_the_reference_loader_on_every_reference_config():
+    """tests/golden/configs.json.gz = what the reference's own `lvsr.config.Configuration` makes of every YAML it ships (parent
+    chains, merges, dotted overrides, stage expansion), generated by oracle/theano_harness/gen_config_golden.py."""
+    import json
+    from conftest import GOLDEN
+    os.environ["LVSR"] = "/root/reference"
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "configs.json.gz"), "rt") as fh:
+        golden = json.load(fh)
+    assert len(golden) >= 100
+    compared = 0
+    for key, ref in sorted(golden.items()):
+        rel, tag = key.split("|")
+        changes = [("training.scale", "0.25"), ("net.dim_dec", "20")] if tag == "overrides" else []
+        # key validation off: a dozen stale experiment files carry a `vocabulary` section that the schema does not know
+        cfg = config.Configuration(os.path.join("/root/reference", rel), None, changes, validate_keys=False)
+        assert "error" not in ref, key
+        assert _plain(dict(cfg)) == ref["config"], key
+        assert bool(cfg.multi_stage) == ref["multi_stage"], key
+        if cfg.multi_stage:
+            assert [[k, _plain(v)] for k, v in cfg.ordered_stages.items()] == ref["stages"], key
+        compared += 1
+    assert compared == len(golden)
