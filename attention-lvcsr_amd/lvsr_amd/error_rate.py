@@ -7,31 +7,33 @@ INFINITY = 10 ** 9
 
 
 def _edit_distance_matrix(y, y_hat):
-    """dist[i, j] = edit distance between y[:i] and y_hat[:j]; action[i, j] = last action of an optimal chain
-    (lvsr/error_rate.py:11-55; ties resolved in the reference's order: insertion, deletion, substitution, copy — the later
-    match wins, and an insertion inherits the action of the cell above)."""
-    n, m = len(y), len(y_hat)
-    dist = numpy.zeros((n + 1, m + 1), dtype="int64")
-    action = dist.copy()
-    dist[:, 0] = numpy.arange(n + 1)
-    dist[0, :] = numpy.arange(m + 1)
+    """dist[i, j] = edit distance between y[:i] and y_hat[:j]; action[i, j] = last action of an optimal chain turning
+    y_hat[:j] into y[:i], with the reference's tie rule (lvsr/error_rate.py:11-55 tests copy last, so it wins; then
+    substitution, then deletion; a pure insertion inherits the action of the cell above).
+
+    Row-at-a-time: the horizontal (deletion) dependency of a row is a running minimum, cur[j] = j + min_{k<=j}(t[k] - k),
+    where t holds the best of the diagonal and vertical moves; the actions are read off the finished distance table."""
+    a = numpy.asarray(list(y), dtype=object)
+    b = numpy.asarray(list(y_hat), dtype=object)
+    n, m = len(a), len(b)
+    cols = numpy.arange(m + 1, dtype="int64")
+    dist = numpy.empty((n + 1, m + 1), dtype="int64")
+    action = numpy.zeros((n + 1, m + 1), dtype="int64")
+    dist[0] = cols
     for i in range(1, n + 1):
-        for j in range(1, m + 1):
-            differ = y[i - 1] != y_hat[j - 1]
-            insertion = dist[i - 1, j] + 1
-            deletion = dist[i, j - 1] + 1
-            substitution = dist[i - 1, j - 1] + 1 if differ else INFINITY
-            copy = dist[i - 1, j - 1] if not differ else INFINITY
-            best = min(insertion, deletion, substitution, copy)
-            dist[i, j] = best
-            if best == insertion:
-                action[i, j] = action[i - 1, j]
-            if best == deletion:
-                action[i, j] = DELETION
-            if best == substitution:
-                action[i, j] = SUBSTITUTION
-            if best == copy:
-                action[i, j] = COPY
+        up = dist[i - 1]
+        mismatch = (b != a[i - 1]).astype("int64") if m else numpy.zeros(0, dtype="int64")
+        t = numpy.empty(m + 1, dtype="int64")
+        t[0] = i
+        t[1:] = numpy.minimum(up[:-1] + mismatch, up[1:] + 1)
+        row = numpy.minimum.accumulate(t - cols) + cols
+        dist[i] = row
+        if m:
+            diag_hit = row[1:] == up[:-1] + mismatch                       # copy (mismatch 0) or substitution (1)
+            left_hit = row[1:] == row[:-1] + 1                             # deletion
+            act = numpy.where(diag_hit, numpy.where(mismatch == 1, SUBSTITUTION, COPY),
+                              numpy.where(left_hit, DELETION, action[i - 1, 1:]))
+            action[i, 1:] = act
     return dist, action
 
 

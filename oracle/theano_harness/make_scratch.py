@@ -169,6 +169,7 @@ def main():
             r"\2if numpy.all(x == x_):\n\3break")], 1)
     # python-2-isms inside lvsr that the bricks-only import touches
     patch(os.path.join(pkg, "lvsr/bricks/recognizer.py"), [(r"\bxrange\b", "range")])
+    patch(os.path.join(pkg, "lvsr/error_rate.py"), [(r"\bxrange\b", "range")])
     # Python 2 orders None below every number, so `max(args)` in FST.combine_weights ignores the `None` that FST.expand
     # passes for a state not yet in the set; Python 3 raises instead
     patch(os.path.join(pkg, "lvsr/ops.py"), [(r"m = max\(args\)", "m = max(a for a in args if a is not None)")], 1)

@@ -38,3 +38,33 @@ def test_decode_driver_emulated():
     for row in rep["per_utterance"]:
         assert numpy.isfinite(row["groundtruth_cost"])
         assert row["char_errors"] == ER.edit_distance(row["groundtruth"], row["recognized"])
+
+
+def test_host_side_pieces_match_the_reference_functions():
+    """tests/golden/misc_reference.npz (oracle/theano_harness/gen_misc_golden.py): the reference's own edit-distance tables,
+    alignment diagnostics (Theano-evaluated) and initialisation schemes."""
+    import json
+    import numpy
+    from conftest import golden_path
+    from lvsr_amd import blocks_compat as BC
+    z = numpy.load(golden_path("misc_reference"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    for k, p in enumerate(meta["pairs"]):
+        dist, action = ER._edit_distance_matrix(p["y"], p["y_hat"])
+        assert (dist == z["ed%d_dist" % k]).all() and (action == z["ed%d_action" % k]).all(), p
+        if p["wer"] is not None:
+            assert ER.wer(p["y"], p["y_hat"]) == p["wer"]
+    w, m = z["expr_weights"], z["expr_mask"]
+    assert_allclose(ER.weights_std(w), z["weights_std"], rtol=2e-4)
+    assert_allclose(ER.weights_std(w, m), z["weights_std_masked"], rtol=2e-4)
+    assert_allclose(ER.monotonicity_penalty(w), z["monotonicity_penalty"], rtol=1e-5)
+    assert_allclose(ER.monotonicity_penalty(w, m), z["monotonicity_penalty_masked"], rtol=1e-5)
+    assert_allclose(ER.entropy(w, m), z["entropy"], rtol=1e-5)
+    schemes = dict(constant=BC.Constant(0.3), gauss=BC.IsotropicGaussian(0.1, 0.2), uniform_width=BC.Uniform(width=0.4),
+                   uniform_std=BC.Uniform(mean=1.0, std=0.2), orth_square=BC.Orthogonal(), orth_wide=BC.Orthogonal(),
+                   orth_tall=BC.Orthogonal())
+    for name, shape in meta["inits"]:
+        got = schemes[name].generate(numpy.random.RandomState(5), tuple(shape))
+        ref = z["init_" + name]
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        assert_allclose(got, ref, rtol=1e-6, atol=1e-7, err_msg=name)
