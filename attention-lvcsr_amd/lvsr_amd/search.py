@@ -1,7 +1,18 @@
-"""Beam search over the HIP generation step: host-side bookkeeping identical to the reference's (modified)
-`blocks.search.BeamSearch` (libs/blocks/blocks/search.py:19-407: `char_discount`, `round_to_inf`, `stop_on`,
-shrinking beam, numpy tie order in `_smallest`), with the two compiled Theano functions it calls per step
-replaced by `SequenceGenerator.generation_logprobs` / `generation_next_states` on the device.
+"""Beam search over the HIP generation step.
+
+What must agree with the reference's (modified) `blocks.search.BeamSearch` (libs/blocks/blocks/search.py:19-407) is the
+RESULT — the hypotheses and their costs, bit for bit — so the selection rules are kept exactly:
+  * candidates = cumulative cost + step cost over (live hypothesis, character); the `beam_size` smallest are taken with
+    `argpartition` then `argsort` (numpy's tie order is part of parity, search.py:221-242);
+  * a hypothesis ending in `<eol>` is finished when its last step cost is below `round_to_inf` (and the optional
+    `validate_solution_function` accepts it); finished hypotheses leave the beam, so the beam shrinks;
+  * ranking of finished hypotheses: final cumulative cost minus `char_discount` per emitted position;
+  * `stop_on='patience'`: stop after 30 consecutive steps without a better best finished hypothesis;
+    `stop_on='optimistic_future_cost'`: stop once the `beam_size`-th finished hypothesis (in order of completion — the
+    reference does not sort in this mode) beats min(live cumulative cost) - `char_discount` * `max_length`;
+  * no finished hypothesis at all -> CandidateNotFoundError.
+The two compiled Theano functions the reference calls per step are `SequenceGenerator.generation_logprobs` /
+`generation_next_states` on the device; everything else here is host bookkeeping in float32 like the reference's.
 """
 import numpy
 import torch
@@ -12,125 +23,134 @@ class CandidateNotFoundError(Exception):
     pass
 
 
+class _Finished(object):
+    """A completed hypothesis: the token column and the running-cost column of the beam at the step it ended."""
+    __slots__ = ("tokens", "running")
+
+    def __init__(self, tokens, running):
+        self.tokens, self.running = tokens, running
+
+    def score(self, char_discount):
+        return self.running[-1] - char_discount * len(self.running)
+
+
 class BeamSearch(object):
+    PATIENCE = 30
+
     def __init__(self, beam_size, recognizer):
         self.beam_size = beam_size
         self.rec = recognizer
 
     @staticmethod
     def _smallest(matrix, k):
-        """search.py:221-242, verbatim semantics (argpartition then argsort: numpy's tie order is part of parity)."""
-        flatten = matrix.flatten()
-        if flatten.shape[0] > k:
-            args = numpy.argpartition(flatten, k)[:k]
-        else:
-            args = numpy.arange(flatten.shape[0])
-        args = args[numpy.argsort(flatten[args])]
-        return numpy.unravel_index(args, matrix.shape), flatten[args]
+        """Indices (row, column) and values of the k smallest entries, ascending; ties as numpy breaks them."""
+        flat = matrix.reshape(-1)
+        pick = numpy.argpartition(flat, k)[:k] if flat.size > k else numpy.arange(flat.size)
+        pick = pick[numpy.argsort(flat[pick])]
+        return numpy.unravel_index(pick, matrix.shape), flat[pick]
 
     def search(self, input_values, eol_symbol, max_length, ignore_first_eol=False, as_arrays=False, char_discount=0,
                round_to_inf=1e9, stop_on="patience", validate_solution_function=None):
-        """search.py:244-399.  `input_values` = {'recordings': (T,1,F) ndarray}."""
+        """`input_values` = {'recordings': (T,F) ndarray}.  Returns (outputs, costs) lists, best first, or the padded
+        (outputs, mask, step costs) arrays with `as_arrays`."""
+        if stop_on not in ("patience", "optimistic_future_cost"):
+            raise ValueError("Unknown stopping criterion {}".format(stop_on))
         rec, gen = self.rec, self.rec.generator
+        lm = gen.language_model
         dev = rec.device
+        lm_on_device = getattr(lm, "on_device", False)
+
+        def to_dev(idx):
+            return torch.as_tensor(numpy.ascontiguousarray(idx), dtype=torch.int64).to(dev)
+
         with rec._on_stream():
             rec.compute_contexts(input_values["recordings"])
-            st = gen.generation_initial_states(1)
-            lm_states = rec.lm_initial_states(1) if gen.language_model is not None else None
-        S, W, step = st["states"], st["weights"], st["step"]
-        all_outputs = st["outputs"][None, :]
-        all_costs = numpy.zeros_like(all_outputs, dtype=numpy.float32)
-        done = []
-        min_cost = 1000
-        # one host->device copy of an index vector per use site, shared by the decoder state, the alignments and the LM state
-        to_dev = lambda idx: torch.as_tensor(numpy.ascontiguousarray(idx), dtype=torch.int64).to(dev)
-        lm_take = lambda st, idx, idx_t: gen.language_model.take(st, idx_t if getattr(gen.language_model, "on_device", False) else idx)
-        for i in range(max_length):
+            start = gen.generation_initial_states(1)
+            lm_states = rec.lm_initial_states(1) if lm is not None else None
+        S, W, step = start["states"], start["weights"], start["step"]
+        tokens = start["outputs"][None, :]                          # (positions so far + 1, live hypotheses)
+        running = numpy.zeros(tokens.shape, dtype=numpy.float32)     # cumulative costs, same layout
+        finished = []
+        best_seen, patience = 1000, None
+
+        for position in range(max_length):
             if S.shape[0] == 0:
                 break
+            # ---- stopping rules
             if stop_on == "patience":
-                done = sorted(done, key=lambda x: x[1][-1] - char_discount * len(x[1]))
-                done = done[:self.beam_size]
-                if done:
-                    current_best_cost = done[0][1][-1] - char_discount * len(done[0][1])
-                    if current_best_cost < min_cost:
-                        min_cost = current_best_cost
-                        patience = 30
+                finished.sort(key=lambda f: f.score(char_discount))
+                del finished[self.beam_size:]
+                if finished:
+                    leader = finished[0].score(char_discount)
+                    if leader < best_seen:
+                        best_seen, patience = leader, self.PATIENCE
                     else:
+                        if patience is None:      # the reference decrements before it ever assigns (first cost >= 1000)
+                            raise UnboundLocalError("local variable 'patience' referenced before assignment")
                         patience -= 1
                         if patience == 0:
                             break
-            elif stop_on == "optimistic_future_cost":
-                if len(done) >= self.beam_size:
-                    optimistic_future_cost = all_costs[-1, :].min() - char_discount * max_length
-                    last_in_done = done[self.beam_size - 1][1]
-                    last_in_done_cost = last_in_done[-1] - char_discount * len(last_in_done)
-                    if last_in_done_cost < optimistic_future_cost:
-                        break
-            else:
-                raise ValueError("Unknown stopping criterion {}".format(stop_on))
+            elif len(finished) >= self.beam_size:
+                bound = running[-1].min() - char_discount * max_length
+                if finished[self.beam_size - 1].score(char_discount) < bound:
+                    break
+            # ---- expand: cost of every continuation of every live hypothesis
             with rec._on_stream():
                 if lm_states is not None:
-                    gen.language_model.stage(lm_states, dev)
-                nl = gen.generation_logprobs(S, W, step)
-            logprobs = nl.cpu().numpy().astype(numpy.float32)
-            assert numpy.isfinite(logprobs).all()
-            next_costs = all_costs[-1, :, None] + logprobs
-            (indexes, outputs), chosen_costs = self._smallest(next_costs, self.beam_size)
-            # Rearrange everything
+                    lm.stage(lm_states, dev)
+                neglogp = gen.generation_logprobs(S, W, step)
+            step_costs = neglogp.cpu().numpy().astype(numpy.float32)
+            assert numpy.isfinite(step_costs).all()
+            (parents, chars), chosen = self._smallest(running[-1][:, None] + step_costs, self.beam_size)
+            # ---- re-arrange the beam along the chosen parents and advance it by the chosen characters
             with rec._on_stream():
-                idx_t = to_dev(indexes)
-                S, W = S.index_select(0, idx_t), W.index_select(0, idx_t)
+                parents_t = to_dev(parents)
+                S, W = S.index_select(0, parents_t), W.index_select(0, parents_t)
                 if lm_states is not None:
-                    lm_states = lm_take(lm_states, indexes, idx_t)
-                all_outputs = numpy.take(all_outputs, indexes, axis=1)
-                all_costs = numpy.take(all_costs, indexes, axis=1)
-                # Record chosen output and compute new states
-                st = gen.generation_next_states(S, W, step, outputs)
+                    lm_states = lm.take(lm_states, parents_t if lm_on_device else parents)
+                nxt = gen.generation_next_states(S, W, step, chars)
                 if lm_states is not None:
-                    lm_states = gen.language_model.transition(lm_states, outputs)
-            S, W, step = st["states"], st["weights"], st["step"]
-            all_outputs = numpy.vstack([all_outputs, outputs[None, :]])
-            all_costs = numpy.vstack([all_costs, chosen_costs[None, :]])
-            mask = outputs != eol_symbol
-            if ignore_first_eol and i == 0:
-                mask[:] = 1
-            for idx in numpy.where((all_outputs[-1] == eol_symbol) & (all_costs[-1] - all_costs[-2] < round_to_inf))[0]:
-                if validate_solution_function is None or validate_solution_function(input_values, all_outputs[:, idx]):
-                    done.append((all_outputs[:, idx], all_costs[:, idx]))
-            unfinished = numpy.where(mask == 1)[0]
-            if len(unfinished) != len(mask):                # nothing to drop in most steps: keep the tensors as they are
+                    lm_states = lm.transition(lm_states, chars)
+            S, W, step = nxt["states"], nxt["weights"], nxt["step"]
+            tokens = numpy.concatenate([tokens[:, parents], chars[None, :]], axis=0)
+            running = numpy.concatenate([running[:, parents], chosen[None, :]], axis=0)
+            # ---- hypotheses that just emitted <eol> finish (unless the step was "infinitely" expensive) and leave the beam
+            ended = chars == eol_symbol
+            affordable = (running[-1] - running[-2]) < round_to_inf
+            for col in numpy.flatnonzero(ended & affordable):
+                if validate_solution_function is None or validate_solution_function(input_values, tokens[:, col]):
+                    finished.append(_Finished(tokens[:, col], running[:, col]))
+            alive = numpy.ones_like(ended) if (ignore_first_eol and position == 0) else ~ended
+            if not alive.all():
+                keep = numpy.flatnonzero(alive)
                 with rec._on_stream():
-                    idx_t = to_dev(unfinished)
-                    S, W = S.index_select(0, idx_t), W.index_select(0, idx_t)
+                    keep_t = to_dev(keep)
+                    S, W = S.index_select(0, keep_t), W.index_select(0, keep_t)
                     if lm_states is not None:
-                        lm_states = lm_take(lm_states, unfinished, idx_t)
-                all_outputs = numpy.take(all_outputs, unfinished, axis=1)
-                all_costs = numpy.take(all_costs, unfinished, axis=1)
-        if not done:
+                        lm_states = lm.take(lm_states, keep_t if lm_on_device else keep)
+                tokens, running = tokens[:, keep], running[:, keep]
+
+        if not finished:
             raise CandidateNotFoundError()
-        done = sorted(done, key=lambda x: x[1][-1] - char_discount * len(x[1]))
-        max_len = max((seq[0].shape[0] for seq in done))
-        all_outputs = numpy.zeros((max_len, len(done)))
-        all_masks = numpy.zeros((max_len, len(done)))
-        all_costs = numpy.zeros((max_len, len(done)))
-        for i, (seq, cost) in enumerate(done):
-            all_outputs[:len(seq), i] = seq
-            all_masks[:len(seq), i] = 1
-            all_costs[:len(cost), i] = cost
-            all_costs[len(cost):, i] = cost[-1]
-        all_outputs = all_outputs[1:]
-        all_masks = all_masks[1:]
-        all_costs = all_costs[1:] - all_costs[:-1]
-        result = all_outputs, all_masks, all_costs
-        if as_arrays:
-            return result
-        return self.result_to_lists(result)
+        finished.sort(key=lambda f: f.score(char_discount))
+        longest = max(len(f.tokens) for f in finished)
+        out_tokens = numpy.zeros((longest, len(finished)))
+        out_mask = numpy.zeros((longest, len(finished)))
+        out_running = numpy.zeros((longest, len(finished)))
+        for col, f in enumerate(finished):
+            n = len(f.tokens)
+            out_tokens[:n, col] = f.tokens
+            out_mask[:n, col] = 1
+            out_running[:n, col] = f.running
+            out_running[n:, col] = f.running[-1]
+        # drop the initial pseudo-token; step costs = differences of the running costs
+        result = out_tokens[1:], out_mask[1:], out_running[1:] - out_running[:-1]
+        return result if as_arrays else self.result_to_lists(result)
 
     @staticmethod
     def result_to_lists(result):
-        """search.py:401-407"""
-        outputs, masks, costs = [array.T for array in result]
-        outputs = [list(output[:int(mask.sum())]) for output, mask in zip(outputs, masks)]
-        costs = list(costs.T.sum(axis=0))
-        return outputs, costs
+        """(outputs, mask, step costs) arrays -> ([tokens of hypothesis k], [total cost of hypothesis k])."""
+        tokens, mask, step_costs = result
+        lengths = mask.sum(axis=0).astype(int)
+        outputs = [list(tokens[:n, k]) for k, n in enumerate(lengths)]
+        return outputs, list(step_costs.sum(axis=0))
