@@ -87,19 +87,22 @@ def gemm_probe(rec, dims, T, B):
 
 def cpu_baseline(cfg, params, B, T, L):
     """The CPU oracle (torch fp32 restatement of the reference's algorithm, oracle/lvsr_oracle.py) timed on this
-    box's host cores on ONE full minibatch of the same workload (forward + backward)."""
+    box's host cores on whole minibatches of the same workload (forward + backward)."""
     from oracle import lvsr_oracle as O
     from lvsr_amd import synthetic
     batch = synthetic.make_batch(cfg, B, T, L, seed=1234)
     orc = O.OracleRecognizer(cfg, params, dtype=torch.float32)
     ncores = min(8, os.cpu_count() or 1)        # the per-step matrices are small: more threads only add overhead
     torch.set_num_threads(ncores)
-    t0 = time.time()
-    orc.cost_and_grads(batch)
+    # bounded sample: whole minibatches until ~12 s of CPU work have been done (at least one, at most four)
+    reps, t0 = 0, time.time()
+    while reps < 1 or (time.time() - t0 < 12.0 and reps < 4):
+        orc.cost_and_grads(batch)
+        reps += 1
     dt = time.time() - t0
-    return dict(value=B * T / dt, unit="frames/s", cores=ncores, kind="port",
-                sample="1 forward+backward of one %dx%d-frame minibatch (%s) = %.1f s of CPU work; torch-CPU fp32 "
-                       "restatement of the reference's Theano graph" % (B, T, "same synthetic batch shape", dt))
+    return dict(value=reps * B * T / dt, unit="frames/s", cores=ncores, kind="port",
+                sample="%d forward+backward passes over one %dx%d-frame minibatch (%s) = %.1f s of CPU work; torch-CPU fp32 "
+                       "restatement of the reference's Theano graph" % (reps, B, T, "same synthetic batch shape", dt))
 
 
 def main():
