@@ -146,7 +146,8 @@ def test_beam_search_vs_reference_golden(gpu_device, case):
 
 def test_wsj_deep_shapes_vs_oracle(gpu_device):
     """The 512-unit kernels paths (fixed NQ = 8 contraction, K = 1536 decoder contraction) at WSJ-deep layer shapes but short
-    sequences, against the float64 oracle (the reference itself needs ~1 h per WSJ-deep step in the Python linker)."""
+    sequences and a ragged batch, against the float64 oracle (the full-size WSJ-deep step is checked against the reference's own
+    output in test_full_size_configs_vs_reference_golden)."""
     cfg = spec.wsj_deep()
     cfg["dims_bidir"] = [512, 512]
     cfg["subsample"] = [1, 2]
