@@ -9,7 +9,6 @@
 is in the C-ABI library; torch only owns buffers/views.
 """
 import ctypes
-import math
 import os
 
 import numpy

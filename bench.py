@@ -11,7 +11,6 @@ rank r takes utterances r::N of the seeded global batch).  value = real (unpadde
 second.  Rank 0 prints ONE JSON line on stdout; everything else goes to stderr.
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
