@@ -53,14 +53,14 @@ def build(force=False, verbose=False):
 
 
 def build_emu(force=False):
-    deps = SRCS + HDRS + [os.path.join(EMU_INC, "hip", "hip_runtime.h")]
+    deps = SRCS + HDRS + [os.path.join(EMU_INC, "hip", "hip_runtime.h")] + sorted(glob.glob(os.path.join(EMU_INC, "*.cpp")))
     if not force and not _stale(EMU_OUT, deps):
         return EMU_OUT
     cxx = os.path.join(ROCM, "lib", "llvm", "bin", "clang++")
     bdir = os.path.join(EMU_INC, "build")
     os.makedirs(bdir, exist_ok=True)
     objs, procs = [], []
-    for s in SRCS:
+    for s in SRCS + sorted(glob.glob(os.path.join(EMU_INC, "*.cpp"))):
         o = os.path.join(bdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + HDRS + [os.path.join(EMU_INC, "hip", "hip_runtime.h")]):

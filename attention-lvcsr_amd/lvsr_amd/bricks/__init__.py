@@ -66,7 +66,8 @@ def native_ptr(t):
 
 class Encoder(object):
     def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=False):
-        self.use_persistent = bool(use_persistent) and not lib.is_emulator      # needs co-resident work-groups
+        # needs co-resident work-groups: the GPU, or the emulator with concurrent work-groups switched on (tests)
+        self.use_persistent = bool(use_persistent) and (not lib.is_emulator or lib.emulates_concurrency())
         self.d = dims
         self.store = store
         self.lib = lib

@@ -150,6 +150,12 @@ class Lib(object):
             setattr(self, "_" + name, fn)
 
     # ---- plumbing -----------------------------------------------------------------------------
+    def emulates_concurrency(self):
+        """Test emulator only: are work-groups of a launch run concurrently (tests/hipemu, hipemu_set_concurrent)?"""
+        if not self.is_emulator or not hasattr(self._dll, "hipemu_get_concurrent"):
+            return False
+        return bool(self._dll.hipemu_get_concurrent())
+
     def stream_for(self, t):
         if t.is_cuda:
             return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)

@@ -7,6 +7,11 @@
 // work-groups executed one after another, wave64 collectives (__shfl*, MFMA 16x16x4 f32) and
 // __syncthreads implemented as fiber barriers.  It checks indexing / algorithm logic of the kernel
 // sources against the oracle at tiny sizes before GPU time is spent.  Nothing in the product loads it.
+//
+// Work-groups normally run one after another on the calling thread.  hipemu_set_concurrent(1) (tests/hipemu/
+// hipemu_support.cpp) makes a launch of 2..64 work-groups run every work-group on its own OS thread (fibers inside),
+// so kernels whose work-groups wait for each other (csrc/encoder_persist.hip: granule hand-offs) can be exercised:
+// LDS (`__shared__`) and all per-block emulator state are thread_local, the agent-scope atomics are real atomics.
 #pragma once
 #include <ucontext.h>
 #include <cmath>
@@ -16,13 +21,14 @@
 #include <cstring>
 #include <algorithm>
 #include <functional>
+#include <thread>
 #include <vector>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static
+#define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define __restrict__
 
@@ -62,9 +68,10 @@ struct State {
     std::vector<long long> xl;
     std::function<void()> body;
 };
-inline State& st() { static State s; return s; }
-inline hipemu_uint3& tidx() { static hipemu_uint3 v; return v; }
-inline hipemu_uint3& bidx() { static hipemu_uint3 v; return v; }
+inline State& st() { static thread_local State s; return s; }
+inline int& concurrent_flag() { static int f = 0; return f; }
+inline hipemu_uint3& tidx() { static thread_local hipemu_uint3 v; return v; }
+inline hipemu_uint3& bidx() { static thread_local hipemu_uint3 v; return v; }
 inline dim3& bdim() { static dim3 v; return v; }
 inline dim3& gdim() { static dim3 v; return v; }
 struct Saved { hipemu_uint3 t; };
@@ -101,7 +108,7 @@ inline void trampoline() {
     s.fibers[s.cur].done = true;
     swapcontext(&s.fibers[s.cur].ctx, &s.sched);
 }
-inline void run_block(int nthreads, const std::function<void()>& body) {
+inline void run_block(int nthreads, const std::function<void()>& body, size_t STK = 256 * 1024) {
     State& s = st();
     s.nthreads = nthreads;
     s.body = body;
@@ -111,7 +118,6 @@ inline void run_block(int nthreads, const std::function<void()>& body) {
     s.wave_gen.assign(nw, 0);
     s.xa.assign(nthreads, 0.f); s.xb.assign(nthreads, 0.f); s.xd.assign(nthreads, 0.0); s.xl.assign(nthreads, 0);
     if ((int)s.fibers.size() < nthreads) s.fibers.resize(nthreads);
-    const size_t STK = 256 * 1024;
     for (int i = 0; i < nthreads; ++i) {
         Fiber& f = s.fibers[i];
         if (f.stack.size() != STK) f.stack.resize(STK);
@@ -139,6 +145,20 @@ template <typename F>
 inline void launch(dim3 grid, dim3 block, F&& f) {
     gdim() = grid; bdim() = block;
     int nthreads = block.x * block.y * block.z;
+    const unsigned nblocks = grid.x * grid.y * grid.z;
+    if (concurrent_flag() && nblocks > 1 && nblocks <= 64) {
+        std::function<void()> body = f;
+        std::vector<std::thread> workers;
+        for (unsigned z = 0; z < grid.z; ++z)
+            for (unsigned y = 0; y < grid.y; ++y)
+                for (unsigned x = 0; x < grid.x; ++x)
+                    workers.emplace_back([x, y, z, nthreads, &body]() {
+                        bidx().x = x; bidx().y = y; bidx().z = z;
+                        run_block(nthreads, body, 128 * 1024);
+                    });
+        for (auto& w : workers) w.join();
+        return;
+    }
     for (unsigned z = 0; z < grid.z; ++z)
         for (unsigned y = 0; y < grid.y; ++y)
             for (unsigned x = 0; x < grid.x; ++x) {
@@ -211,11 +231,11 @@ inline int __shfl_down(int v, unsigned d, int width = 64) {
     return (int)hipemu::shfl_generic<long long, long long>(v, src);
 }
 
-// ---- agent-scope atomics / wave votes used by the persistent kernels (compile support only: the emulator runs
-// work-groups one after another, so kernels that wait for OTHER work-groups must not be launched on it) ----
+// ---- agent-scope atomics / wave votes used by the persistent kernels.  Kernels that wait for OTHER work-groups need
+// hipemu_set_concurrent(1); with work-groups run one after another they would spin until their own bound trips ----
 #define __HIP_MEMORY_SCOPE_AGENT 4
-template <typename T, typename V> inline void hipemu_atomic_store(T* p, V v) { *p = (T)v; }
-template <typename T> inline T hipemu_atomic_load(const T* p) { return *p; }
+template <typename T, typename V> inline void hipemu_atomic_store(T* p, V v) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
+template <typename T> inline T hipemu_atomic_load(const T* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p)
 inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); }

@@ -1,0 +1,65 @@
+"""The persistent cluster BiGRU kernels (csrc/encoder_persist.hip: one launch per layer and pass, work-groups exchanging the
+phase vectors through {epoch,value} granules) on the emulator with concurrent work-groups (one OS thread per work-group),
+against the float64 oracle and against the step kernels.  On the GPU they are covered by tests/test_gpu_kernels.py."""
+import os
+
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from emu import emu_lib
+from oracle import lvsr_oracle as O
+from lvsr_amd import spec, synthetic
+from lvsr_amd.bricks import Encoder
+from lvsr_amd.params import ParameterStore, Workspace
+
+
+@pytest.fixture
+def concurrent_lib():
+    lib = emu_lib()
+    lib._dll.hipemu_set_concurrent(1)
+    old = os.environ.get("LVSR_PERSIST_ROWS")
+    os.environ["LVSR_PERSIST_ROWS"] = "16"          # one cluster per direction and 16-utterance row tile: few OS threads
+    try:
+        yield lib
+    finally:
+        lib._dll.hipemu_set_concurrent(0)
+        if old is None:
+            os.environ.pop("LVSR_PERSIST_ROWS", None)
+        else:
+            os.environ["LVSR_PERSIST_ROWS"] = old
+
+
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask", [([20], [1], 3, 7, True), ([32, 16], [2, 1], 5, 8, True), ([40], [1], 17, 5, False)])
+def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask):
+    lib = concurrent_lib
+    cfg = dict(input_dim=6, num_phonemes=6, dims_bidir=Hs, subsample=sub, dim_dec=4, dim_matcher=7,
+               attention_type="content", post_merge_dims=None, embed_outputs=True)
+    params = synthetic.make_params(cfg, seed=3)
+    batch = synthetic.make_batch(cfg, B, T, 4, seed=5, ragged=True)
+    x = torch.from_numpy(batch["recordings"])
+    m = torch.from_numpy(batch["recordings_mask"]) if use_mask else None
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    results = {}
+    for persistent in (True, False):
+        store = ParameterStore(cfg, torch.device("cpu"), params)
+        enc = Encoder(spec.Dims(cfg), store, lib, Workspace(torch.device("cpu")), use_graph=False, use_persistent=persistent)
+        assert enc.use_persistent == persistent
+        y, ym = enc.apply(x, m)
+        dy = torch.from_numpy(numpy.random.RandomState(9).normal(size=tuple(y.shape)).astype(numpy.float32))
+        enc.backward(dy)
+        if persistent:
+            enc.check_persistent()
+            assert any(k[0].endswith(".sync") for k in enc.ws._bufs), "persistent mode did not engage"
+        results[persistent] = (y.clone(), store.get_grads(), dy)
+    y_p, g_p, dy = results[True]
+    y_s, g_s, _ = results[False]
+    assert_allclose(y_p.numpy(), y_s.numpy(), rtol=1e-5, atol=1e-6)
+    enc_ref, _ = orc.encode(torch.from_numpy(batch["recordings"]).double(),
+                            torch.from_numpy(batch["recordings_mask"]).double() if use_mask else None)
+    assert_allclose(y_p.numpy(), enc_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    for name in g_s:
+        if "/encoder/" in name:
+            scale = max(1e-3, numpy.abs(g_s[name]).max())
+            assert numpy.abs(g_p[name] - g_s[name]).max() / scale < 2e-5, name
