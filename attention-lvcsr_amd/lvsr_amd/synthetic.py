@@ -53,7 +53,7 @@ def make_batch(cfg, B, T, L, seed=1234, ragged=False):
     x = rng.normal(0.0, 1.0, (T, B, d.F)).astype(numpy.float32)
     if ragged:
         t_len = rng.randint(max(1, T // 2), T + 1, size=B)
-        l_len = rng.randint(max(2, L // 2), L + 1, size=B)
+        l_len = rng.randint(min(L, max(2, L // 2)), L + 1, size=B)
         t_len[0] = T
         l_len[0] = L
     else:

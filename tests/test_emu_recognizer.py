@@ -76,3 +76,11 @@ def test_degenerate_sizes_emulated(case):
         out, grads = orc.cost_and_grads(batch)
         cm = rec.cost_and_gradients(batch)
         check_against(rec, cm, None, out, grads)
+
+
+def test_synthetic_ragged_batches_of_minimal_length():
+    """make_batch(ragged=True) used to draw label lengths from an empty range when L = 1 (found by tools/fuzz_emu.py)."""
+    cfg = dict(input_dim=3, num_phonemes=5, dims_bidir=[4], dim_dec=3, dim_matcher=4, attention_type="content")
+    for L in (1, 2, 3):
+        b = synthetic.make_batch(cfg, 4, 6, L, seed=1, ragged=True)
+        assert b["labels"].shape == (L, 4) and (b["labels_mask"].sum(0) >= 1).all() and b["labels_mask"][:, 0].sum() == L
