@@ -61,33 +61,41 @@ def yaml_load(stream):
 
 
 def read_config(file_):
-    """lvsr/config.py:9-21: resolve `parent` links (paths may use $LVSR etc.)."""
-    config = yaml_load(file_)
-    if "parent" in config:
-        with open(os.path.expandvars(config["parent"])) as src:
-            changes = dict(config)
-            config = read_config(src)
-            merge_recursively(config, changes)
-    return config
+    """A YAML file with its `parent:` chain resolved (lvsr/config.py:9-21; parent paths may use $LVSR etc.): the oldest
+    ancestor is the base, every descendant is merged over it in turn."""
+    chain = []
+    layer = yaml_load(file_)
+    while True:
+        chain.append(layer)
+        parent = layer.get("parent")
+        if parent is None:
+            break
+        with open(os.path.expandvars(parent)) as src:
+            layer = yaml_load(src)
+    merged = chain.pop()
+    while chain:
+        merge_recursively(merged, dict(chain.pop()))
+    return merged
 
 
 def merge_recursively(config, changes):
-    """lvsr/config.py:24-30"""
-    for key, value in changes.items():
-        if isinstance(value, dict) and isinstance(config.get(key), dict):
-            merge_recursively(config[key], value)
+    """Overlay `changes` on `config` in place: mappings merge key by key, anything else replaces (lvsr/config.py:24-30)."""
+    for key, new in changes.items():
+        old = config.get(key)
+        if isinstance(new, dict) and isinstance(old, dict):
+            merge_recursively(old, new)
         else:
-            config[key] = value
+            config[key] = new
 
 
 def make_config_changes(config, changes):
-    """lvsr/config.py:33-49: `changes` = [(dotted.path, yaml-value-string), ...]."""
-    for path, value in changes:
-        parts = path.split(".")
-        assign_to = config
-        for part in parts[:-1]:
-            assign_to = assign_to[part]
-        assign_to[parts[-1]] = yaml_load(value) if isinstance(value, str) else value
+    """Command-line overrides (lvsr/config.py:33-49): `changes` = [("dotted.path", "yaml text"), ...]."""
+    for dotted, text in changes:
+        *parents, leaf = dotted.split(".")
+        node = config
+        for name in parents:
+            node = node[name]
+        node[leaf] = yaml_load(text) if isinstance(text, str) else text
 
 
 # key sets of lvsr/configs/schema.yaml for the sections of this path
@@ -128,15 +136,14 @@ class Configuration(dict):
         make_config_changes(config, config_changes)
         self.multi_stage = "stages" in config
         if self.multi_stage:
-            stages = [(k, v) for k, v in config["stages"].items() if v]
-            ordered_changes = OrderedDict(sorted(stages, key=lambda kv: kv[1]["number"]))
+            # stages with content, in `number` order; each is the whole configuration with the stage's changes merged in
+            active = sorted(((name, ch) for name, ch in config["stages"].items() if ch), key=lambda item: item[1]["number"])
             self.ordered_stages = OrderedDict()
-            for name, changes in ordered_changes.items():
-                current_config = copy.deepcopy(config)
-                del current_config["stages"]
-                del changes["number"]            # in place, as lvsr/config.py:79 does: self["stages"][name] loses it too
-                merge_recursively(current_config, changes)
-                self.ordered_stages[name] = current_config
+            for name, stage_changes in active:
+                stage_changes.pop("number")       # in place, as lvsr/config.py:79 does: self["stages"][name] loses it too
+                staged = copy.deepcopy({k: v for k, v in config.items() if k != "stages"})
+                merge_recursively(staged, stage_changes)
+                self.ordered_stages[name] = staged
         if validate_keys:
             validate(config)
             if self.multi_stage:
