@@ -104,27 +104,31 @@ class Uniform(NdarrayInitialization):
         return rng.uniform(self._mean - w, self._mean + w, size=shape).astype(numpy.float32)
 
 
+def _random_rotation(rng, n):
+    """Orthogonal factor of an (n, n) standard-normal draw, columns sign-fixed by the diagonal of R (unique QR)."""
+    q, r = numpy.linalg.qr(rng.randn(n, n).astype(numpy.float32))
+    return q * numpy.sign(numpy.diag(r))
+
+
 class Orthogonal(NdarrayInitialization):
-    """initialization.py:163-209: QR of a Gaussian matrix, signs fixed by the diagonal of R."""
+    """initialization.py:163-209.  Square: one random rotation.  Rectangular (rows, cols): the product of the leading
+    min(rows, cols) columns of a (rows x rows) rotation with the leading rows of a (cols x cols) rotation, drawn in that
+    order from the same generator (the order of the two draws is what makes the values reproducible)."""
     def __init__(self, scale=1):
         self.scale = scale
 
     def generate(self, rng, shape):
         if len(shape) != 2:
             raise ValueError
-        if shape[0] == shape[1]:
-            M = rng.randn(*shape).astype(numpy.float32)
-            Q, R = numpy.linalg.qr(M)
-            Q = Q * numpy.sign(numpy.diag(R))
-            return (Q * self.scale).astype(numpy.float32)
-        M1 = rng.randn(shape[0], shape[0]).astype(numpy.float32)
-        M2 = rng.randn(shape[1], shape[1]).astype(numpy.float32)
-        Q1, R1 = numpy.linalg.qr(M1)
-        Q2, R2 = numpy.linalg.qr(M2)
-        Q1 = Q1 * numpy.sign(numpy.diag(R1))
-        Q2 = Q2 * numpy.sign(numpy.diag(R2))
-        n_min = min(shape[0], shape[1])
-        return (numpy.dot(Q1[:, :n_min], Q2[:n_min, :]) * self.scale).astype(numpy.float32)
+        rows, cols = shape
+        if rows == cols:
+            out = _random_rotation(rng, rows)
+        else:
+            left = _random_rotation(rng, rows)
+            right = _random_rotation(rng, cols)
+            k = min(rows, cols)
+            out = left[:, :k] @ right[:k, :]
+        return (out * self.scale).astype(numpy.float32)
 
 
 # python path (as written in the reference's YAML tags) -> class
