@@ -64,7 +64,7 @@ def build_emu(force=False):
         o = os.path.join(bdir, os.path.basename(s) + ".o")
         objs.append(o)
         if force or _stale(o, [s] + HDRS + [os.path.join(EMU_INC, "hip", "hip_runtime.h")]):
-            cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-Wno-unused-value", "-I", EMU_INC,
+            cmd = [cxx, "-x", "c++", "-std=c++17", "-O1", "-g", "-fPIC", "-Wno-unused-value", "-Wno-psabi", "-I", EMU_INC,
                    "-I", os.path.join(REPO, "include"), "-c", s, "-o", o]
             procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:

@@ -24,6 +24,14 @@ int lvsr_check_launch(const char* what);
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// value of lane (l ^ 1) / (l ^ 2) inside each quad of lanes: one DPP move (quad_perm), no LDS crossbar
+__device__ __forceinline__ float lvsr_dpp_quad_xor1(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0xB1, 0xf, 0xf, true));   // quad_perm:[1,0,3,2]
+}
+__device__ __forceinline__ float lvsr_dpp_quad_xor2(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

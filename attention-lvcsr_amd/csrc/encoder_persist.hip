@@ -1,306 +1,423 @@
 // Persistent BiGRU layer kernels (forward and BPTT) for gfx950: ONE launch per layer and pass instead of two launches per
-// time step.
+// time step; recurrent weights live in REGISTERS for the whole sequence, the hidden state in LDS.
 //
-// The recurrence is latency bound (2 800 dependent steps per pass on WSJ-base); with step kernels every phase of a step
-// pays a kernel boundary plus a cold start of the body (~3.4 us measured).  Here a cluster of C = ceil(H/16) work-groups
-// per (direction, 16-utterance row tile) stays resident, one per CU: work-group p owns hidden units [16p, 16p+16), keeps
-// the three 16-column weight tiles it needs (H x 48 floats: 48 KiB at H = 256, 96 KiB at H = 512) in LDS in MFMA operand
-// order for the whole sequence, and the only per-step global traffic on the critical path is the exchange of the phase
-// vector (h_t, then r*h_t; BPTT: dh_t, then d(r*h)_t: B x H floats) between the work-groups of the cluster:
-//   * hand-off = 8-byte {epoch, value} granules written with relaxed agent-scope atomic stores (sc1, write-through) and
-//     polled with relaxed agent-scope atomic loads (MI355X_MICROARCH.md "handoff-1to1": ~0.8-1.0 us per hop; no fences,
-//     no flags; placement independent: nothing assumes which XCD a work-group runs on);
-//   * epoch = step index + 1, buffers zeroed by a memset node before every launch (graph-replay safe);
-//   * a phase vector is only overwritten after every consumer has read the previous one (the producer needs all of the
-//     consumers' next-phase granules first), so single buffering is enough;
+// The recurrence is latency bound (2 800 dependent steps per pass on WSJ-base) and needs every hidden unit of the previous
+// phase twice per step (h -> gates, r*h -> candidate; BPTT: dpre_c -> d(r*h), dpre_r -> dh).  What one such exchange costs
+// inside a launch grows with the number of work-groups that take part and with the size of the vector
+// (profiles/r01_handoff_probe.txt), so the decomposition keeps both minimal:
+//   * utterances are independent, so a cluster serves only RB of them (RB = 1 at WSJ-base): the contraction is a GEMV and
+//     runs on the VALU (v_pk_fma_f32), not on MFMA tiles that would be 15/16 empty;
+//   * a thread keeps 3*KS weights (KS = 64: 192 VGPRs) for the whole sequence: thread (unit, q) owns rows
+//     [q*KS, (q+1)*KS) of the unit's three weight columns, the KSPLIT threads of a unit are adjacent lanes and fold their
+//     partial sums with DPP.  A 256-thread work-group therefore holds 192 KiB of weights = 256/KSPLIT units, and a
+//     (direction, row group) cluster is only P = H*KSPLIT/256 work-groups (4 at H = 256, 16 at H = 512, ONE at H <= 128:
+//     no exchange at all), one per CU;
+//   * the phase vector (RB x H floats) travels as 8-byte {epoch, value} granules: relaxed agent-scope atomic stores
+//     (sc1, write-through) polled with relaxed agent-scope atomic loads (MI355X_MICROARCH.md "handoff-1to1", granule
+//     form R2: no fences, no flags, placement independent).  All 256 threads sweep the plane coalesced (RB*H/256 loads
+//     per lane) into LDS; every thread then reads its K slice from LDS as broadcast ds_read_b128;
+//   * only what the NEXT exchange waits for is computed before publishing (reset gate forward, d(r*h) backward); the update
+//     gate / the dpre_u contraction run in the shadow of the hand-off;
+//   * epoch = step + 1, planes zeroed by a memset node before every launch (graph-replay safe); a plane is overwritten only
+//     after every consumer has read it (the producer needs all consumers' next-phase granules first), so single buffering
+//     is enough — except dpre_u, which is gathered off the critical path and is double buffered;
 //   * every spin is bounded: a work-group that waits too long raises the abort word and all work-groups leave.
-// Saved tensors (u, r, c, rh, y) go out with plain stores off the critical path.
+// Saved tensors (u, r, c, rh, y / dxg) go out with plain stores off the critical path; the per-step operands that do not
+// depend on the recurrence are prefetched one step ahead.
 #include "common.h"
 #include "graph_cache.h"
 #include "lvsr_hip.h"
 #include <stdlib.h>
 
 typedef unsigned long long u64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef lvsr_bigru_fwd_args EncFwd;
 typedef lvsr_bigru_bwd_args EncBwd0;
 
 #define PERSIST_SPIN_LIMIT (1u << 21)
-#define PERSIST_MAX_WG 240
+#define PERSIST_MAX_WG 224
 
-__device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v) {
-    __hip_atomic_store(p, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// The work-groups of a cluster are numbered so that they land on ONE XCD (block b runs on XCD b % 8: observed on MI355X,
+// not promised by HIP — nothing depends on it but speed: 2.7 instead of 3.2 us per step at H = 256).
+// Experiment switches (LVSR_PERSIST_FLAGS, read per call): 1 = do not write the saved tensors (timing only, results unusable
+// for BPTT), 2 = consecutive blocks form a cluster instead (members spread over the XCDs), 4 = publish with plain stores
+// (they stay in the XCD's L2: only correct when the XCD placement holds; measured SLOWER than write-through sc1 stores)
+#define PF_NOSAVE 1
+#define PF_SPREAD 2
+#define PF_PLAIN 4
+__device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v, int flags = 0) {
+    const u64 w = ((u64)epoch << 32) | (u64)__float_as_uint(v);
+    if (flags & PF_PLAIN) *(volatile u64*)p = w;
+    else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// cluster / member index of a work-group
+__device__ __forceinline__ void cluster_of_block(int P, int flags, int& cl, int& p) {
+    const int b = blockIdx.x, ncl = gridDim.x / P;
+    if (!(flags & PF_SPREAD) && ncl % 8 == 0) { cl = (b % 8) + 8 * (b / (8 * P)); p = (b / 8) % P; }
+    else { cl = b / P; p = b % P; }
 }
 
-// Each lane reads its N consecutive granules until every valid one carries `epoch`.  Wave-uniform result.
-template <int N>
-__device__ __forceinline__ bool granule_poll(const u64* g, int nvalid, unsigned epoch, float (&v)[N], int* abort_word) {
+// sum over the KSPLIT adjacent lanes that share a unit; every lane of the group gets the total
+template <int KSPLIT>
+__device__ __forceinline__ float group_sum(float v) {
+    if (KSPLIT >= 2) v += lvsr_dpp_quad_xor1(v);
+    if (KSPLIT >= 4) v += lvsr_dpp_quad_xor2(v);
+    if (KSPLIT >= 8) v += __shfl_xor(v, 4, 64);
+    if (KSPLIT >= 16) v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// All 256 threads sweep the NG granules of one phase vector until every one carries `epoch`, then scatter the values
+// into the LDS operand buffer dst[row][q][k] (row stride KSPLIT*LDH, slice stride LDH).  Uniform result per work-group is
+// established by the caller's barrier; returns false when the cluster gave up.
+template <int NG, int HP, int KS, int LDH, int KSPLIT>
+__device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float* dst, int* abort_word) {
+    constexpr int NPOLL = (NG + 255) / 256;
+    const int tid = threadIdx.x;
+    u64 w[NPOLL];
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
 #pragma unroll
-        for (int x = 0; x < N; ++x) {
-            if (x < nvalid) {
-                const u64 w = __hip_atomic_load(g + x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v[x] = __uint_as_float((unsigned)w);
-                ok = ok && ((unsigned)(w >> 32) == epoch);
-            } else {
-                v[x] = 0.f;
-            }
+        for (int i = 0; i < NPOLL; ++i) {
+            const int idx = tid + 256 * i;
+            if (NG % 256 == 0 || idx < NG) w[i] = __hip_atomic_load(g + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else w[i] = (u64)epoch << 32;
         }
-        if (__all(ok)) return true;
+#pragma unroll
+        for (int i = 0; i < NPOLL; ++i) ok = ok && ((unsigned)(w[i] >> 32) == epoch);
+        if (__all(ok)) break;
         ++spins;
-        if ((spins & 255u) == 0u) {
+        if ((spins & 127u) == 0u) {
             if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
             if (spins > PERSIST_SPIN_LIMIT) {
                 __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
+    }
+#pragma unroll
+    for (int i = 0; i < NPOLL; ++i) {
+        const int idx = tid + 256 * i;
+        if (NG % 256 == 0 || idx < NG) {
+            const int row = idx / HP, k = idx % HP;
+            dst[(row * KSPLIT + k / KS) * LDH + (k % KS)] = __uint_as_float((unsigned)w[i]);
+        }
+    }
+    return true;
+}
+
+// acc[r] += sum_x w[x] * v[r][q][x]  over this thread's K slice (pairs of k in one v_pk_fma_f32)
+template <int KS, int RB, int LDH, int KSPLIT>
+__device__ __forceinline__ void slice_dot(const f32x2 (&w)[KS / 2], const float* buf, int q, float (&out)[RB]) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const float4* hv = (const float4*)(buf + (r * KSPLIT + q) * LDH);
+        f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+        for (int x = 0; x < KS / 4; ++x) {
+            const float4 h4 = hv[x];
+            const f32x2 lo = {h4.x, h4.y}, hi = {h4.z, h4.w};
+            a0 = w[2 * x] * lo + a0;
+            a1 = w[2 * x + 1] * hi + a1;
+        }
+        out[r] = group_sum<KSPLIT>((a0.x + a1.x) + (a0.y + a1.y));
     }
 }
 
-struct PersistGeom { int C, rt, Kw, Kpad, RB; };
-// RB = utterances per cluster (<= 16, the MFMA row tile).  Smaller clusters exchange proportionally smaller phase vectors
-// (the hand-off cost grows with the polled volume), at the price of more work-groups holding a copy of the weight shard.
-__host__ __device__ __forceinline__ PersistGeom persist_geom(int B, int H, int NQ, int RB) {
-    PersistGeom g;
-    g.RB = RB;
-    g.C = (H + 15) / 16; g.rt = (B + RB - 1) / RB; g.Kw = 16 * NQ; g.Kpad = 4 * g.Kw;
-    return g;
-}
-static int persist_nq(int H) {           // K slice per wave = 16*NQ >= ceil(H/4)
-    const int need = (((H + 3) / 4) + 15) / 16;
-    int nq = 1;
-    while (nq < need) nq *= 2;
-    return nq;
+// the element of sums[] this lane owns in pass i of the epilogue (rows q, q+KSPLIT, ...), without dynamic indexing
+template <int RB, int KSPLIT>
+__device__ __forceinline__ float pick_row(const float (&s)[RB], int q, int i) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+        if (r % KSPLIT == q && r / KSPLIT == i) v = s[r];
+    return v;
 }
 
-// sum the 4 per-wave partial 16x16 tiles staged in `red`; thread tid -> (row tid>>4, col tid&15)
-__device__ __forceinline__ void stage_tile(float (*red)[16][17], f32x4 a0, f32x4 a1) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = a0[r] + a1[r];
-}
-__device__ __forceinline__ float fold_tile(float (*red)[16][17]) {
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-    return ((red[0][row][col] + red[1][row][col]) + red[2][row][col]) + red[3][row][col];
-}
-
-template <int NQ>
-__device__ __forceinline__ void mfma_tile(f32x4& acc0, f32x4& acc1, const float (&av)[4 * NQ], const float4* __restrict__ bs) {
-    // bs: this wave's packed operand of one tile: [q][lane] float4
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const float4 b = bs[q * 64 + lane];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 0], b.x, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b.y, acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b.z, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b.w, acc1, 0, 0, 0);
+struct PersistGeom { int KS, KSPLIT, HP, UNITS, P, RB, rt, grid; long long plane; };
+// Variant for a hidden size: the smallest padded size HP = KS*KSPLIT >= H among the built ones; RB = the smallest number of
+// utterances per cluster (1, 2, 4, 8) whose grid fits the chip with one work-group per CU.
+static bool persist_geom(int B, int H, PersistGeom& g) {
+    if (H <= 128) { g.KS = 64; g.KSPLIT = 2; }
+    else if (H <= 256) { g.KS = 64; g.KSPLIT = 4; }
+    else if (H <= 512) { g.KS = 64; g.KSPLIT = 8; }
+    else return false;
+    g.HP = g.KS * g.KSPLIT; g.UNITS = 256 / g.KSPLIT; g.P = g.HP / g.UNITS;
+    const char* env = getenv("LVSR_PERSIST_ROWS");
+    const int want = env ? min(8, atoi(env)) : 0;
+    g.RB = 0;
+    for (int rb = 1; rb <= 8; rb *= 2) {
+        const int rt = (B + rb - 1) / rb;
+        if (2 * rt * g.P <= PERSIST_MAX_WG && rb >= want) { g.RB = rb; break; }
     }
+    if (!g.RB) return false;
+    g.rt = (B + g.RB - 1) / g.RB;
+    g.grid = 2 * g.rt * g.P;
+    g.plane = (long long)g.RB * g.HP;
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int NQ>
-__global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* gh_all, u64* grh_all, int* abort_word, int RB) {
-    __shared__ float4 Bs[3 * 4 * NQ * 64];          // tiles: 0 gates-update, 1 gates-reset, 2 candidate
-    __shared__ float red[2][4][16][17];
-    const PersistGeom geo = persist_geom(a.B, a.H, NQ, RB);
-    const int H = a.H, B = a.B, T = a.T, Kw = geo.Kw, Kpad = geo.Kpad;
-    const int cl = blockIdx.x / geo.C, p = blockIdx.x % geo.C;
-    const int dir = cl / geo.rt, b0 = (cl % geo.rt) * RB, nrows = min(RB, B - b0), j0 = p * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* Whg = a.Whg_p[dir];      // in persistent mode these are the PLAIN (H,2H) / (H,H) weights
-    const float* Whh = a.Whh_p[dir];
-    for (int idx = threadIdx.x; idx < 3 * 4 * NQ * 64; idx += 256) {
-        const int ln = idx & 63, q = (idx >> 6) % NQ, wv = ((idx >> 6) / NQ) & 3, tile = (idx >> 6) / NQ / 4;
-        const int col = j0 + (ln & 15);
-        float w[4];
+template <int KS, int KSPLIT, int RB>
+__global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
+    constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
+    constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
+    __shared__ __attribute__((aligned(16))) float hbuf[2][RB * KSPLIT * LDH];
+    const int H = a.H, B = a.B, T = a.T;
+    const int rt = (B + RB - 1) / RB;
+    int cl, p;
+    cluster_of_block(P, flags, cl, p);
+    const bool save = !(flags & PF_NOSAVE);
+    const int dir = cl / rt, b0 = (cl % rt) * RB;
+    const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
+    const bool junit = j < H;
+    // ---- this thread's weight slice, in registers for the whole sequence
+    f32x2 wr[KS / 2], wu[KS / 2], wc[KS / 2];
+    {
+        const float* Whg = a.Whg_p[dir];      // persistent mode: the PLAIN (H,2H) / (H,H) weights
+        const float* Whh = a.Whh_p[dir];
+        const size_t jc = (size_t)min(j, H - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = wv * Kw + (ln >> 4) * (Kw >> 2) + 4 * q + r;
-            float x = 0.f;
-            if (k < H && col < H) x = tile == 2 ? Whh[(size_t)k * H + col] : Whg[(size_t)k * 2 * H + tile * H + col];
-            w[r] = x;
+        for (int x = 0; x < KS / 2; ++x) {
+            float v[6];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {      // clamped addresses, zeroed afterwards: straight-line loads, all in flight at once
+                const int k = k0 + 2 * x + e;
+                const float keep = (junit && k < H) ? 1.f : 0.f;
+                const size_t kc = (size_t)min(k, H - 1);
+                v[e] = Whg[kc * 2 * H + jc] * keep;
+                v[2 + e] = Whg[kc * 2 * H + H + jc] * keep;
+                v[4 + e] = Whh[kc * H + jc] * keep;
+            }
+            wu[x] = (f32x2){v[0], v[1]}; wr[x] = (f32x2){v[2], v[3]}; wc[x] = (f32x2){v[4], v[5]};
         }
-        Bs[idx] = make_float4(w[0], w[1], w[2], w[3]);
     }
-    __syncthreads();
-    const int eb = threadIdx.x >> 4, ej = threadIdx.x & 15, b = b0 + eb, j = j0 + ej;
-    const bool valid = eb < nrows && j < H;
-    float hown = valid ? a.h0[dir][j] : 0.f;
-    u64* gh = gh_all + (size_t)cl * 16 * Kpad;
-    u64* grh = grh_all + (size_t)cl * 16 * Kpad;
-    const int i = lane & 15, kk = lane >> 4, kbase = wave * Kw + kk * (Kw >> 2);
-    const int nvalid = i < nrows ? max(0, min(4 * NQ, H - kbase)) : 0;
-    const float4* bsw = Bs + (size_t)wave * NQ * 64;
+    u64* gh = planes + (size_t)cl * 2 * NG;
+    u64* grh = gh + NG;
+    // ---- epilogue ownership: lane q of a unit's group handles rows q, q+KSPLIT, ...
+    float hown[NR], n_xin[NR], n_gu[NR], n_gr[NR], n_m[NR];
+    bool rvalid[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = q + i * KSPLIT;
+        rvalid[i] = junit && r < RB && b0 + r < B;
+        hown[i] = rvalid[i] ? a.h0[dir][j] : 0.f;
+        n_xin[i] = n_gu[i] = n_gr[i] = 0.f; n_m[i] = 1.f;
+        if (rvalid[i]) {
+            const int t = dir == 0 ? 0 : T - 1;
+            const size_t row = (size_t)t * B + b0 + r;
+            const float* xr = a.xg + row * 6 * H + dir * 3 * H;
+            n_xin[i] = xr[j]; n_gu[i] = xr[H + j]; n_gr[i] = xr[2 * H + j];
+            if (a.mask) n_m[i] = a.mask[row];
+        }
+    }
+    // h_{-1} = initial state, broadcast over the rows
+    for (int idx = tid; idx < RB * HP; idx += 256) {
+        const int row = idx / HP, k = idx % HP;
+        hbuf[0][(row * KSPLIT + k / KS) * LDH + (k % KS)] = k < H ? a.h0[dir][k] : 0.f;
+    }
     for (int n = 0; n < T; ++n) {
         const int t = dir == 0 ? n : T - 1 - n;
-        const size_t row = (size_t)t * B + b;
-        float gin_u = 0.f, gin_r = 0.f, xin = 0.f, m = 1.f;
-        if (valid) {
-            const float* xr = a.xg + row * 6 * H + dir * 3 * H;
-            xin = xr[j]; gin_u = xr[H + j]; gin_r = xr[2 * H + j];
-            if (a.mask) m = a.mask[row];
-        }
-        float av[4 * NQ];
-        if (n == 0) {
+        float xin[NR], gu[NR], gr[NR], m[NR];
 #pragma unroll
-            for (int x = 0; x < 4 * NQ; ++x) av[x] = x < nvalid ? a.h0[dir][kbase + x] : 0.f;
-        } else if (!granule_poll<4 * NQ>(gh + (size_t)i * Kpad + kbase, nvalid, (unsigned)n, av, abort_word)) {
-            return;
-        }
-        f32x4 u0 = F32X4_ZERO, u1 = F32X4_ZERO, r0 = F32X4_ZERO, r1 = F32X4_ZERO;
-        mfma_tile<NQ>(u0, u1, av, bsw + 0 * 4 * NQ * 64);
-        mfma_tile<NQ>(r0, r1, av, bsw + 1 * 4 * NQ * 64);
-        stage_tile(red[0], u0, u1);
-        stage_tile(red[1], r0, r1);
+        for (int i = 0; i < NR; ++i) { xin[i] = n_xin[i]; gu[i] = n_gu[i]; gr[i] = n_gr[i]; m[i] = n_m[i]; }
+        if (n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT>(gh, (unsigned)n, hbuf[0], abort_word)) return;
         __syncthreads();
-        const float uu = sigmoidf_(fold_tile(red[0]) + gin_u);
-        const float rr = sigmoidf_(fold_tile(red[1]) + gin_r);
-        const float rh = rr * hown;
-        if (valid) {
-            granule_store(grh + (size_t)eb * Kpad + j, (unsigned)(n + 1), rh);
-            const size_t o = row * 2 * H + dir * H + j;
-            a.u[o] = uu; a.r[o] = rr; a.rh[o] = rh;
+        // ---- reset gate: the only thing the next exchange waits for
+        float s[RB], rr[NR], uu[NR];
+        slice_dot<KS, RB, LDH, KSPLIT>(wr, hbuf[0], q, s);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = q + i * KSPLIT;
+            if (r < RB) {
+                rr[i] = sigmoidf_(pick_row<RB, KSPLIT>(s, q, i) + gr[i]);
+                const float rh = rvalid[i] ? rr[i] * hown[i] : 0.f;
+                granule_store(grh + (size_t)r * HP + j, (unsigned)(n + 1), rh, flags);
+                if (rvalid[i] && save) {
+                    const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
+                    a.r[o] = rr[i]; a.rh[o] = rh;
+                }
+            }
         }
-        if (!granule_poll<4 * NQ>(grh + (size_t)i * Kpad + kbase, nvalid, (unsigned)(n + 1), av, abort_word)) return;
-        f32x4 c0 = F32X4_ZERO, c1 = F32X4_ZERO;
-        mfma_tile<NQ>(c0, c1, av, bsw + 2 * 4 * NQ * 64);
-        __syncthreads();                       // everyone is done reading red[0] of the gates phase
-        stage_tile(red[0], c0, c1);
+        // ---- update gate, in the shadow of the hand-off
+        slice_dot<KS, RB, LDH, KSPLIT>(wu, hbuf[0], q, s);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = q + i * KSPLIT;
+            if (r < RB) {
+                uu[i] = sigmoidf_(pick_row<RB, KSPLIT>(s, q, i) + gu[i]);
+                if (rvalid[i] && save) a.u[((size_t)t * B + b0 + r) * 2 * H + dir * H + j] = uu[i];
+            }
+        }
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(grh, (unsigned)(n + 1), hbuf[1], abort_word)) return;
         __syncthreads();
-        const float cand = tanhf(fold_tile(red[0]) + xin);
-        float hn = cand * uu + hown * (1.f - uu);
-        hn = m * hn + (1.f - m) * hown;
-        if (valid) {
-            granule_store(gh + (size_t)eb * Kpad + j, (unsigned)(n + 1), hn);
-            const size_t o = row * 2 * H + dir * H + j;
-            a.c[o] = cand; a.y[o] = hn;
-            if (a.ysub && (t % a.sub) == 0) a.ysub[((size_t)(t / a.sub) * B + b) * 2 * H + dir * H + j] = hn;
+        // ---- candidate, state update, mask blend
+        slice_dot<KS, RB, LDH, KSPLIT>(wc, hbuf[1], q, s);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = q + i * KSPLIT;
+            if (r < RB) {
+                const float cand = tanhf(pick_row<RB, KSPLIT>(s, q, i) + xin[i]);
+                float hn = cand * uu[i] + hown[i] * (1.f - uu[i]);
+                hn = m[i] * hn + (1.f - m[i]) * hown[i];
+                if (!rvalid[i]) hn = 0.f;
+                if (n + 1 < T) granule_store(gh + (size_t)r * HP + j, (unsigned)(n + 1), hn, flags);
+                if (rvalid[i]) {
+                    const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
+                    if (save) a.c[o] = cand;
+                    a.y[o] = hn;
+                    if (a.ysub && (t % a.sub) == 0) a.ysub[((size_t)(t / a.sub) * B + b0 + r) * 2 * H + dir * H + j] = hn;
+                }
+                hown[i] = hn;
+            }
         }
-        hown = hn;
-        __syncthreads();                       // red[] is reused by the next step's gates phase
+        // ---- operands of the next step (independent of the recurrence): in flight during the next hand-off
+        if (n + 1 < T) {
+            const int tn = dir == 0 ? n + 1 : T - 2 - n;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                if (rvalid[i]) {
+                    const size_t row = (size_t)tn * B + b0 + q + i * KSPLIT;
+                    const float* xr = a.xg + row * 6 * H + dir * 3 * H;
+                    n_xin[i] = xr[j]; n_gu[i] = xr[H + j]; n_gr[i] = xr[2 * H + j];
+                    if (a.mask) n_m[i] = a.mask[row];
+                }
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward (BPTT); same math as enc_bwd_a/b in encoder.hip
+// backward (BPTT).  Per step (forward direction walks t = T-1..0, backward direction t = 0..T-1):
+//   dhn = m*dh; dpre_c = dhn*u*(1-c^2); dpre_u = dhn*(c-h_prev)*u*(1-u)
+//   drh = dpre_c @ Whh^T;  dpre_r = drh*h_prev*r*(1-r)
+//   dh_prev = dhn*(1-u) + (1-m)*dh + drh*r + dpre_u @ Whg[:, :H]^T + dpre_r @ Whg[:, H:]^T + dy[t_prev]
+//   dxg[t] = [dpre_c | dpre_u | dpre_r]
+// Thread (unit i, slice q) keeps ROW i of the three weight blocks (the transposed products contract over columns).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int dir, int j) {
     if (t < 0 || t >= a.T || (t % a.sub) != 0) return 0.f;
     return a.dy[((size_t)(t / a.sub) * a.B + b) * 2 * a.H + dir * a.H + j];
 }
 
-template <int NQ>
-__global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* gdh_all, u64* gdrh_all, int* abort_word, float* dh_out,
-                                                       int Bp, int RB) {
-    __shared__ float4 Bs[3 * 4 * NQ * 64];          // tiles: 0 Whh^T, 1 Whg^T (update rows), 2 Whg^T (reset rows)
-    __shared__ float red[4][16][17];
-    const PersistGeom geo = persist_geom(a.B, a.H, NQ, RB);
-    const int H = a.H, B = a.B, T = a.T, Kw = geo.Kw, Kpad = geo.Kpad;
-    const int cl = blockIdx.x / geo.C, p = blockIdx.x % geo.C;
-    const int dir = cl / geo.rt, b0 = (cl % geo.rt) * RB, nrows = min(RB, B - b0), j0 = p * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* Whg = a.WhgT_p[dir];     // persistent mode: PLAIN (H,2H) / (H,H) weights, transposed on the fly
-    const float* Whh = a.WhhT_p[dir];
-    for (int idx = threadIdx.x; idx < 3 * 4 * NQ * 64; idx += 256) {
-        const int ln = idx & 63, q = (idx >> 6) % NQ, wv = ((idx >> 6) / NQ) & 3, tile = (idx >> 6) / NQ / 4;
-        const int col = j0 + (ln & 15);          // output unit
-        float w[4];
+template <int KS, int KSPLIT, int RB>
+__global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
+    constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
+    constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
+    __shared__ __attribute__((aligned(16))) float vbuf[3][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
+    const int H = a.H, B = a.B, T = a.T;
+    const int rt = (B + RB - 1) / RB;
+    int cl, p;
+    cluster_of_block(P, flags, cl, p);
+    const bool save = !(flags & PF_NOSAVE);
+    const int dir = cl / rt, b0 = (cl % rt) * RB;
+    const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
+    const bool junit = j < H;
+    f32x2 wa[KS / 2], wbu[KS / 2], wbr[KS / 2];
+    {
+        const float* Whg = a.WhgT_p[dir];     // persistent mode: PLAIN (H,2H) / (H,H) weights, rows read in place
+        const float* Whh = a.WhhT_p[dir];
+        const size_t jc = (size_t)min(j, H - 1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = wv * Kw + (ln >> 4) * (Kw >> 2) + 4 * q + r;     // contracted unit
-            float x = 0.f;
-            if (k < H && col < H) x = tile == 0 ? Whh[(size_t)col * H + k] : Whg[(size_t)col * 2 * H + (tile - 1) * H + k];
-            w[r] = x;
+        for (int x = 0; x < KS / 2; ++x) {
+            float v[6];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = k0 + 2 * x + e;
+                const float keep = (junit && k < H) ? 1.f : 0.f;
+                const size_t kc = (size_t)min(k, H - 1);
+                v[e] = Whh[jc * H + kc] * keep;
+                v[2 + e] = Whg[jc * 2 * H + kc] * keep;
+                v[4 + e] = Whg[jc * 2 * H + H + kc] * keep;
+            }
+            wa[x] = (f32x2){v[0], v[1]}; wbu[x] = (f32x2){v[2], v[3]}; wbr[x] = (f32x2){v[4], v[5]};
         }
-        Bs[idx] = make_float4(w[0], w[1], w[2], w[3]);
     }
-    __syncthreads();
-    const int eb = threadIdx.x >> 4, ej = threadIdx.x & 15, b = b0 + eb, j = j0 + ej;
-    const bool valid = eb < nrows && j < H;
-    u64* gdh = gdh_all + (size_t)cl * 16 * Kpad;
-    u64* gdrh = gdrh_all + (size_t)cl * 16 * Kpad;
-    const int i = lane & 15, kk = lane >> 4, kbase = wave * Kw + kk * (Kw >> 2);
-    const int nvalid = i < nrows ? max(0, min(4 * NQ, H - kbase)) : 0;
-    const float4* bsw = Bs + (size_t)wave * NQ * 64;
+    u64* gc = planes + (size_t)cl * 4 * NG;        // dpre_c
+    u64* gr = gc + NG;                             // dpre_r
+    u64* gu0 = gc + 2 * NG;                        // dpre_u, two planes by step parity
     const int t_first = dir == 0 ? T - 1 : 0;
-    float dhown = valid ? pb_dy_at(a, t_first, b, dir, j) : 0.f;
-    for (int n = 0; n < T; ++n) {
-        const int t = dir == 0 ? T - 1 - n : n, tp = dir == 0 ? t - 1 : t + 1;
-        const bool first = tp < 0 || tp >= T;                 // previous state in scan order is the initial state
-        // operands that do not depend on the recurrence: this lane's K range of row i ...
-        float pu[4 * NQ], pc[4 * NQ], pr[4 * NQ], ph[4 * NQ];
-        const float mi = (i < nrows && a.mask) ? a.mask[(size_t)t * B + b0 + i] : 1.f;
-        {
-            const size_t ro = ((size_t)t * B + b0 + i) * 2 * H + dir * H + kbase;
-            const float* hp = first ? a.h0[dir] + kbase : a.y + ((size_t)tp * B + b0 + i) * 2 * H + dir * H + kbase;
+    float dh[NR], n_u[NR], n_c[NR], n_r[NR], n_hp[NR], n_m[NR], n_dy[NR];
+    bool rvalid[NR];
+    auto prefetch = [&](int t, int i) {
+        const int b = b0 + q + i * KSPLIT;
+        const int tp = dir == 0 ? t - 1 : t + 1;
+        const size_t o = ((size_t)t * B + b) * 2 * H + dir * H + j;
+        n_u[i] = a.u[o]; n_c[i] = a.c[o]; n_r[i] = a.r[o];
+        n_hp[i] = (tp < 0 || tp >= T) ? a.h0[dir][j] : a.y[((size_t)tp * B + b) * 2 * H + dir * H + j];
+        n_m[i] = a.mask ? a.mask[(size_t)t * B + b] : 1.f;
+        n_dy[i] = pb_dy_at(a, tp, b, dir, j);
+    };
 #pragma unroll
-            for (int x = 0; x < 4 * NQ; ++x) {
-                const bool okx = x < nvalid;
-                pu[x] = okx ? a.u[ro + x] : 0.f;
-                pc[x] = okx ? a.c[ro + x] : 0.f;
-                pr[x] = okx ? a.r[ro + x] : 0.f;
-                ph[x] = okx ? hp[x] : 0.f;
+    for (int i = 0; i < NR; ++i) {
+        const int r = q + i * KSPLIT;
+        rvalid[i] = junit && r < RB && b0 + r < B;
+        dh[i] = rvalid[i] ? pb_dy_at(a, t_first, b0 + r, dir, j) : 0.f;
+        n_u[i] = n_c[i] = n_r[i] = n_hp[i] = n_dy[i] = 0.f; n_m[i] = 1.f;
+        if (rvalid[i]) prefetch(t_first, i);
+    }
+    for (int n = 0; n < T; ++n) {
+        const int t = dir == 0 ? T - 1 - n : n;
+        float uu[NR], cc[NR], rr[NR], hp[NR], part[NR];
+        u64* gu = gu0 + (size_t)(n & 1) * NG;
+        // ---- everything of this step that depends on dh elementwise only; publish dpre_c and dpre_u
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int r = q + i * KSPLIT;
+            uu[i] = n_u[i]; cc[i] = n_c[i]; rr[i] = n_r[i]; hp[i] = n_hp[i];
+            if (r < RB) {
+                const float dhn = n_m[i] * dh[i];
+                const float dpc = rvalid[i] ? dhn * uu[i] * (1.f - cc[i] * cc[i]) : 0.f;
+                const float dpu = rvalid[i] ? dhn * (cc[i] - hp[i]) * uu[i] * (1.f - uu[i]) : 0.f;
+                granule_store(gc + (size_t)r * HP + j, (unsigned)(n + 1), dpc, flags);
+                granule_store(gu + (size_t)r * HP + j, (unsigned)(n + 1), dpu, flags);
+                part[i] = dhn * (1.f - uu[i]) + (1.f - n_m[i]) * dh[i] + n_dy[i];
+                if (rvalid[i] && save) {
+                    float* dx = a.dxg + ((size_t)t * B + b0 + r) * 6 * H + dir * 3 * H;
+                    dx[j] = dpc; dx[H + j] = dpu;
+                }
             }
         }
-        // ... and this thread's own element
-        float uu = 0.f, rr = 0.f, cc = 0.f, hprev = 0.f, m = 1.f, dyp = 0.f;
-        const size_t o = ((size_t)t * B + b) * 2 * H + dir * H + j;
-        if (valid) {
-            uu = a.u[o]; rr = a.r[o]; cc = a.c[o];
-            hprev = first ? a.h0[dir][j] : a.y[((size_t)tp * B + b) * 2 * H + dir * H + j];
-            if (a.mask) m = a.mask[(size_t)t * B + b];
-            dyp = pb_dy_at(a, tp, b, dir, j);
-        }
-        float av[4 * NQ];
-        if (n == 0) {
+        // operands of the next step: in flight during the hand-offs
+        if (n + 1 < T) {
 #pragma unroll
-            for (int x = 0; x < 4 * NQ; ++x) av[x] = x < nvalid ? pb_dy_at(a, t_first, b0 + i, dir, kbase + x) : 0.f;
-        } else if (!granule_poll<4 * NQ>(gdh + (size_t)i * Kpad + kbase, nvalid, (unsigned)n, av, abort_word)) {
-            return;
+            for (int i = 0; i < NR; ++i)
+                if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
         }
-        float dpu[4 * NQ];
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
+        __syncthreads();
+        float s[RB], vu[RB];
+        slice_dot<KS, RB, LDH, KSPLIT>(wa, vbuf[0], q, s);                     // d(r*h)
 #pragma unroll
-        for (int x = 0; x < 4 * NQ; ++x) {
-            const float dhn = av[x] * mi;
-            dpu[x] = dhn * (pc[x] - ph[x]) * pu[x] * (1.f - pu[x]);
-            av[x] = dhn * pu[x] * (1.f - pc[x] * pc[x]);                      // dpc
+        for (int i = 0; i < NR; ++i) {
+            const int r = q + i * KSPLIT;
+            if (r < RB) {
+                const float drh = pick_row<RB, KSPLIT>(s, q, i);
+                const float dpr = rvalid[i] ? drh * hp[i] * rr[i] * (1.f - rr[i]) : 0.f;
+                granule_store(gr + (size_t)r * HP + j, (unsigned)(n + 1), dpr, flags);
+                part[i] += drh * rr[i];
+                if (rvalid[i] && save) a.dxg[((size_t)t * B + b0 + r) * 6 * H + dir * 3 * H + 2 * H + j] = dpr;
+            }
         }
-        f32x4 a0 = F32X4_ZERO, a1 = F32X4_ZERO;
-        mfma_tile<NQ>(a0, a1, av, bsw + 0 * 4 * NQ * 64);
-        stage_tile(red, a0, a1);
+        // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(gu, (unsigned)(n + 1), vbuf[1], abort_word)) return;
         __syncthreads();
-        const float drh = fold_tile(red);
-        const float dhn = m * dhown;
-        float part = 0.f;
-        if (valid) {
-            granule_store(gdrh + (size_t)eb * Kpad + j, (unsigned)(n + 1), drh);
-            float* dx = a.dxg + ((size_t)t * B + b) * 6 * H + dir * 3 * H;
-            dx[j] = dhn * uu * (1.f - cc * cc);
-            dx[H + j] = dhn * (cc - hprev) * uu * (1.f - uu);
-            dx[2 * H + j] = drh * hprev * rr * (1.f - rr);
-            part = dhn * (1.f - uu) + (1.f - m) * dhown + drh * rr + dyp;
-        }
-        if (!granule_poll<4 * NQ>(gdrh + (size_t)i * Kpad + kbase, nvalid, (unsigned)(n + 1), av, abort_word)) return;
+        slice_dot<KS, RB, LDH, KSPLIT>(wbu, vbuf[1], q, vu);
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
+        __syncthreads();
+        slice_dot<KS, RB, LDH, KSPLIT>(wbr, vbuf[2], q, s);
 #pragma unroll
-        for (int x = 0; x < 4 * NQ; ++x) av[x] = av[x] * ph[x] * pr[x] * (1.f - pr[x]);      // dpr
-        f32x4 d0 = F32X4_ZERO, d1 = F32X4_ZERO;
-        mfma_tile<NQ>(d0, d1, dpu, bsw + 1 * 4 * NQ * 64);
-        mfma_tile<NQ>(d0, d1, av, bsw + 2 * 4 * NQ * 64);
-        __syncthreads();
-        stage_tile(red, d0, d1);
-        __syncthreads();
-        const float dhp = part + fold_tile(red);
-        if (valid) granule_store(gdh + (size_t)eb * Kpad + j, (unsigned)(n + 1), dhp);
-        dhown = dhp;
-        __syncthreads();
+        for (int i = 0; i < NR; ++i) {
+            const int r = q + i * KSPLIT;
+            if (r < RB) dh[i] = rvalid[i] ? part[i] + pick_row<RB, KSPLIT>(vu, q, i) + pick_row<RB, KSPLIT>(s, q, i) : 0.f;
+        }
     }
-    if (valid) dh_out[((size_t)dir * Bp + b) * H + j] = dhown;       // gradient wrt the initial state, per utterance
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+        if (rvalid[i]) dh_out[((size_t)dir * Bp + b0 + q + i * KSPLIT) * H + j] = dh[i];       // d initial state, per utterance
 }
 
 // d initial_state[dir][j] = sum_b dh[dir][b][j]
@@ -313,90 +430,90 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
     (dir == 0 ? out_f : out_b)[j] = s;
 }
 
-// utterances per cluster: the smallest of {16,8,4,2,1}-row clusters whose work-groups all fit the chip (one per CU)
-static int persist_rows(int B, int H) {
-    const int C = (H + 15) / 16;
-    if (H > 512) return 0;
-    const char* env = getenv("LVSR_PERSIST_ROWS");
-    int best = 0;
-    for (int rb = 16; rb >= 1; rb /= 2) {
-        const int rt = (B + rb - 1) / rb;
-        if (2 * rt * C <= PERSIST_MAX_WG) best = rb;
-        else break;
-    }
-    if (env && best) {
-        const int want = atoi(env);
-        if (want >= best && want <= 16 && (want & (want - 1)) == 0) best = want;
-    }
-    return best;
+static int persist_flags() {
+    const char* env = getenv("LVSR_PERSIST_FLAGS");
+    return env ? atoi(env) : 0;
 }
-static bool persist_fits(int B, int H) { return persist_rows(B, H) > 0; }
+
+// utterances per cluster the persistent kernels would use for (B,H); 0 = not available
+extern "C" int lvsr_bigru_persist_rows(int B, int H) {
+    PersistGeom g;
+    if (B <= 0 || H <= 0 || !persist_geom(B, H, g)) return 0;
+    return g.RB;
+}
 
 extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
-    if (B <= 0 || H <= 0 || !persist_fits(B, H)) return 0;
-    const int NQ = persist_nq(H);
-    const PersistGeom g = persist_geom(B, H, NQ, 1);                   // worst case: one utterance per cluster
-    return 256 + (long long)2 * (2 * g.rt) * 16 * g.Kpad * 8;          // abort word + two granule planes
+    PersistGeom g;
+    if (B <= 0 || H <= 0) return 0;
+    // sized for one utterance per cluster (the largest number of clusters) so LVSR_PERSIST_ROWS cannot outgrow it
+    if (!persist_geom(B, H, g)) return 0;
+    return 256 + (long long)2 * (B + 16) * 4 * g.HP * 8;              // abort word + 4 planes per (direction, utterance)
 }
 
-template <int NQ>
-static void launch_fwd(hipStream_t s, const EncFwd& a, u64* g0, u64* g1, int* ab, int RB) {
-    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
-    hipLaunchKernelGGL(enc_pfwd_kernel<NQ>, dim3(2 * g.rt * g.C), dim3(256), 0, s, a, g0, g1, ab, RB);
+template <int KS, int KSPLIT>
+static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, int* ab, int flags) {
+    switch (g.RB) {
+        case 1: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        case 2: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 2>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        case 4: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 4>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        default: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 8>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+    }
 }
-template <int NQ>
-static void launch_bwd(hipStream_t s, const EncBwd0& a, u64* g0, u64* g1, int* ab, float* dh, int Bp, int RB) {
-    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
-    hipLaunchKernelGGL(enc_pbwd_kernel<NQ>, dim3(2 * g.rt * g.C), dim3(256), 0, s, a, g0, g1, ab, dh, Bp, RB);
+template <int KS, int KSPLIT>
+static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, int* ab, float* dh, int Bp, int flags) {
+    switch (g.RB) {
+        case 1: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        case 2: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 2>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        case 4: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 4>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        default: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 8>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+    }
 }
 
 int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     EncFwd a = a0;
-    LVSR_REQUIRE(persist_fits(a.B, a.H) && a.sync_ws, "lvsr_bigru_fwd: persistent mode not available for B=%d H=%d", a.B, a.H);
-    const int NQ = persist_nq(a.H), RB = persist_rows(a.B, a.H);
-    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
-    const size_t plane = (size_t)(2 * g.rt) * 16 * g.Kpad;
+    PersistGeom g;
+    LVSR_REQUIRE(persist_geom(a.B, a.H, g) && a.sync_ws, "lvsr_bigru_fwd: persistent mode not available for B=%d H=%d", a.B, a.H);
     int* ab = (int*)a.sync_ws;
-    u64* g0 = (u64*)((char*)a.sync_ws + 256);
-    u64* g1 = g0 + plane;
+    u64* planes = (u64*)((char*)a.sync_ws + 256);
+    const size_t bytes = 256 + (size_t)2 * g.rt * 2 * g.plane * 8;
     if (a.sub == 1) a.ysub = nullptr;
+    const int flags = persist_flags();
     auto enqueue = [&]() {
-        (void)hipMemsetAsync(a.sync_ws, 0, 256 + 2 * plane * 8, s);
-        switch (NQ) {
-            case 1: launch_fwd<1>(s, a, g0, g1, ab, RB); break;
-            case 2: launch_fwd<2>(s, a, g0, g1, ab, RB); break;
-            case 4: launch_fwd<4>(s, a, g0, g1, ab, RB); break;
-            default: launch_fwd<8>(s, a, g0, g1, ab, RB); break;
+        (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
+        switch (g.KSPLIT) {
+            case 2: launch_fwd<64, 2>(s, a, g, planes, ab, flags); break;
+            case 4: launch_fwd<64, 4>(s, a, g, planes, ab, flags); break;
+            default: launch_fwd<64, 8>(s, a, g, planes, ab, flags); break;
         }
     };
     GraphKey key("bigru_pfwd");
     key.add(&a, sizeof(a));
-    key.add(&RB, sizeof(RB));
+    key.add(&g.RB, sizeof(g.RB));
+    key.add(&flags, sizeof(flags));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_fwd(persistent)");
 }
 
 int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
-    LVSR_REQUIRE(persist_fits(a.B, a.H) && a.sync_ws, "lvsr_bigru_bwd: persistent mode not available for B=%d H=%d", a.B, a.H);
-    const int NQ = persist_nq(a.H), RB = persist_rows(a.B, a.H);
-    const PersistGeom g = persist_geom(a.B, a.H, NQ, RB);
-    const size_t plane = (size_t)(2 * g.rt) * 16 * g.Kpad;
+    PersistGeom g;
+    LVSR_REQUIRE(persist_geom(a.B, a.H, g) && a.sync_ws, "lvsr_bigru_bwd: persistent mode not available for B=%d H=%d", a.B, a.H);
     int* ab = (int*)a.sync_ws;
-    u64* g0 = (u64*)((char*)a.sync_ws + 256);
-    u64* g1 = g0 + plane;
+    u64* planes = (u64*)((char*)a.sync_ws + 256);
+    const size_t bytes = 256 + (size_t)2 * g.rt * 4 * g.plane * 8;
     const int Bp = ((a.B + 15) / 16) * 16;
     float* dh = a.dh_ws;
+    const int flags = persist_flags();
     auto enqueue = [&]() {
-        (void)hipMemsetAsync(a.sync_ws, 0, 256 + 2 * plane * 8, s);
-        switch (NQ) {
-            case 1: launch_bwd<1>(s, a, g0, g1, ab, dh, Bp, RB); break;
-            case 2: launch_bwd<2>(s, a, g0, g1, ab, dh, Bp, RB); break;
-            case 4: launch_bwd<4>(s, a, g0, g1, ab, dh, Bp, RB); break;
-            default: launch_bwd<8>(s, a, g0, g1, ab, dh, Bp, RB); break;
+        (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
+        switch (g.KSPLIT) {
+            case 2: launch_bwd<64, 2>(s, a, g, planes, ab, dh, Bp, flags); break;
+            case 4: launch_bwd<64, 4>(s, a, g, planes, ab, dh, Bp, flags); break;
+            default: launch_bwd<64, 8>(s, a, g, planes, ab, dh, Bp, flags); break;
         }
         hipLaunchKernelGGL(enc_pbwd_h0_kernel, dim3((a.H + 255) / 256, 1, 2), dim3(256), 0, s, dh, Bp, a.B, a.H, a.dh0[0], a.dh0[1]);
     };
     GraphKey key("bigru_pbwd");
     key.add(&a, sizeof(a));
-    key.add(&RB, sizeof(RB));
+    key.add(&g.RB, sizeof(g.RB));
+    key.add(&flags, sizeof(flags));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_bwd(persistent)");
 }

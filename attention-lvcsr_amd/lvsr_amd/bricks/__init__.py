@@ -65,9 +65,21 @@ def native_ptr(t):
 
 
 class Encoder(object):
-    def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=False):
+    # the persistent cluster kernels win while a cluster serves at most this many utterances (measured on MI355X, H = 256,
+    # T = 800: 2.0 / 2.7 / 7.5 us per forward step at 1 / 2 / 4 utterances per cluster against 6.3 for the step kernels)
+    PERSIST_MAX_ROWS = 2
+
+    def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=None):
+        """use_persistent: True / False force the persistent cluster kernels (csrc/encoder_persist.hip) on or off (where
+        the shape allows them); None (default) = on the GPU whenever a cluster serves at most PERSIST_MAX_ROWS utterances,
+        otherwise two step kernels per time step."""
         # needs co-resident work-groups: the GPU, or the emulator with concurrent work-groups switched on (tests)
-        self.use_persistent = bool(use_persistent) and (not lib.is_emulator or lib.emulates_concurrency())
+        can = not lib.is_emulator or lib.emulates_concurrency()
+        env = os.environ.get("LVSR_PERSISTENT")
+        if use_persistent is None and env is not None:
+            use_persistent = env == "1"
+        self.persist_auto = use_persistent is None
+        self.use_persistent = can and (not lib.is_emulator if use_persistent is None else bool(use_persistent))
         self.d = dims
         self.store = store
         self.lib = lib
@@ -145,6 +157,8 @@ class Encoder(object):
             return None
         nbytes = int(self.lib._lvsr_bigru_persist_ws_bytes(int(B), int(H)))
         if nbytes <= 0:
+            return None
+        if self.persist_auto and int(self.lib._lvsr_bigru_persist_rows(int(B), int(H))) > self.PERSIST_MAX_ROWS:
             return None
         return self.ws.get("enc%d.sync" % i, ((nbytes + 3) // 4,), torch.int32)
 

@@ -19,7 +19,7 @@ from .generator import SequenceGenerator
 
 
 class SpeechRecognizer(object):
-    def __init__(self, device="cuda:0", params=None, lib=None, use_graph=True, use_persistent=False, net_config=None,
+    def __init__(self, device="cuda:0", params=None, lib=None, use_graph=True, use_persistent=None, net_config=None,
                  **net_kwargs):
         """`net_kwargs` = the reference's constructor keywords (recognizer.py:176-204), or pass an
         already-normalised `net_config` (lvsr_amd.spec).  `params` = dict name -> ndarray (Blocks names)."""
@@ -176,7 +176,7 @@ class SpeechRecognizer(object):
             key = ("train_step", tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
             volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
                         self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
-            plain = region and self.use_graph and not self.encoder.use_persistent and not self.encoder.overlap
+            plain = region and self.use_graph and not self.encoder.overlap
             return self.lib.region(self, key, x, enabled=plain, volatile=volatile).run(enqueue)
 
     # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------

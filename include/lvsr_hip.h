@@ -83,7 +83,8 @@ typedef struct lvsr_bigru_fwd_args {
     float* u; float* r; float* c; float* rh;   /* (T,B,2H) saved gates / candidate / r*h_prev for BPTT */
     int sub, T, B, H;
     int kernel_mask;        /* 0 or 3: both step kernels; 1 / 2: only the gates / candidate kernel (timing probes) */
-    int persistent;         /* 1: one persistent launch for the whole time loop (needs sync_ws), 0: two kernels per step */
+    int persistent;         /* 1: one persistent launch for the whole time loop (needs sync_ws; Whh_p / Whg_p are then the
+                               PLAIN (H,H) / (H,2H) weights), 0: two kernels per step */
     void* sync_ws;          /* lvsr_bigru_persist_ws_bytes(B,H) bytes of device scratch for the persistent mode */
 } lvsr_bigru_fwd_args;
 int lvsr_bigru_fwd(void* stream, const lvsr_bigru_fwd_args* a, int use_graph);
@@ -104,11 +105,14 @@ typedef struct lvsr_bigru_bwd_args {
     void* sync_ws;
 } lvsr_bigru_bwd_args;
 int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* a, int use_graph);
-/* Persistent mode: the layer's recurrent weights are sharded by hidden unit over a cluster of work-groups (one per CU,
- * 16 units each) that keep their shard in LDS for the whole sequence and exchange h / r*h (forward) or dh / d(r*h)
- * (backward) once per phase through 8-byte {epoch,value} granules.  Returns 0 when (B,H) cannot run persistently
- * (cluster does not fit the chip): use the step kernels then.  After the stream has drained, the first int of sync_ws
- * is non-zero if a work-group gave up waiting (results invalid). */
+/* Persistent mode (csrc/encoder_persist.hip): a cluster of P = ceil(H/64)^2/4 work-groups (1 at H <= 128, 4 at H <= 256, 16 at
+ * H <= 512; one per CU) serves `rows` utterances of one direction; every thread keeps 192 recurrent weights in registers
+ * for the whole sequence and the cluster exchanges h / r*h (forward) or dpre_c, dpre_u / dpre_r (backward) once per phase
+ * through 8-byte {epoch,value} granules.  lvsr_bigru_persist_ws_bytes returns 0 when (B,H) cannot run persistently (H > 512
+ * or the clusters do not fit the chip): use the step kernels then.  lvsr_bigru_persist_rows = utterances per cluster that
+ * would be used (the per-step cost grows with it: the host prefers the step kernels above 2).  After the stream has drained,
+ * the first int of sync_ws is non-zero if a work-group gave up waiting (results invalid). */
+int lvsr_bigru_persist_rows(int B, int H);
 long long lvsr_bigru_persist_ws_bytes(int B, int H);
 
 /* ---- attention decoder (teacher forced or one generation step) ------------------------------------

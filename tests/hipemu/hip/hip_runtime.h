@@ -247,6 +247,13 @@ inline int __all(int pred) {
     (void)l;
     return acc;
 }
+// v_mov_b32 with a DPP quad_perm control (ctrl < 0x100): lane l reads lane (l & ~3) + ((ctrl >> 2*(l&3)) & 3)
+inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
+    int l = hipemu::lane_id();
+    if (ctrl >= 0x100) { fprintf(stderr, "hipemu: only quad_perm DPP controls are emulated\n"); abort(); }
+    return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
+}
+#define __builtin_amdgcn_mov_dpp hipemu_mov_dpp
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 

@@ -16,11 +16,12 @@ from lvsr_amd.params import ParameterStore, Workspace
 
 
 @pytest.fixture
-def concurrent_lib():
+def concurrent_lib(request):
     lib = emu_lib()
     lib._dll.hipemu_set_concurrent(1)
     old = os.environ.get("LVSR_PERSIST_ROWS")
-    os.environ["LVSR_PERSIST_ROWS"] = "16"          # one cluster per direction and 16-utterance row tile: few OS threads
+    # utterances per cluster (1, 2, 4 or 8): decides how many work-groups (OS threads here) a launch has
+    os.environ["LVSR_PERSIST_ROWS"] = str(request.node.callspec.params.get("rows", 8))
     try:
         yield lib
     finally:
@@ -31,8 +32,12 @@ def concurrent_lib():
             os.environ["LVSR_PERSIST_ROWS"] = old
 
 
-@pytest.mark.parametrize("Hs,sub,B,T,use_mask", [([20], [1], 3, 7, True), ([32, 16], [2, 1], 5, 8, True), ([40], [1], 17, 5, False)])
-def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask):
+# H <= 128: one work-group per cluster (no exchange); 128 < H <= 256: 4 work-groups exchange the phase vectors;
+# H > 256: 16 work-groups (launches of more than 64 work-groups are not run concurrently by the emulator: B and rows chosen so)
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows", [([20], [1], 3, 7, True, 1), ([32, 16], [2, 1], 5, 8, True, 2),
+                                                        ([40], [1], 17, 5, False, 8), ([140], [1], 3, 6, True, 1),
+                                                        ([130, 24], [1, 2], 6, 5, True, 4), ([260], [1], 3, 4, True, 2)])
+def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask, rows):
     lib = concurrent_lib
     cfg = dict(input_dim=6, num_phonemes=6, dims_bidir=Hs, subsample=sub, dim_dec=4, dim_matcher=7,
                attention_type="content", post_merge_dims=None, embed_outputs=True)

@@ -53,10 +53,16 @@ def test_graph_replay_equals_eager_bitwise(gpu_device, setup):
 
 def test_persistent_cluster_kernels_agree_with_step_kernels(gpu_device, setup):
     s = setup
+    # the fixture's recognizer picks the encoder kernels itself; compare forced step kernels with forced persistent ones
     per = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_persistent=True)
     cm = per.cost_and_gradients(s["batch"]).cpu().numpy()
     torch.cuda.synchronize()
     per.encoder.check_persistent()
+    assert any(k[0].endswith(".sync") for k in per.ws._bufs), "persistent mode did not engage"
+    stp = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_persistent=False)
+    cm_s = stp.cost_and_gradients(s["batch"]).cpu().numpy()
+    assert not any(k[0].endswith(".sync") for k in stp.ws._bufs)
+    assert_allclose(cm, cm_s, rtol=1e-3, atol=1e-3)
     assert abs(cm.sum() - s["cm"].sum()) / abs(s["cm"].sum()) < 1e-5
     assert_allclose(cm, s["cm"], rtol=1e-3, atol=1e-3)
     g = per.store.get_grads()
