@@ -187,8 +187,8 @@ class Encoder(object):
             c = ws.get("enc%d.c" % i, (T, B, 2 * H))
             rh = ws.get("enc%d.rh" % i, (T, B, 2 * H))
             x2, xg2 = x.view(T * B, I), xg.view(T * B, 6 * H)
-            pk = self._packed(i)
             sync = self._sync_ws(i, B, H)
+            pk = self._packed(i) if sync is None else None     # the persistent kernels read the plain weights
             h0s = []
             for di, direction in enumerate(("forward", "backward")):
                 n = self._names(i, direction)
@@ -232,9 +232,9 @@ class Encoder(object):
             dxg = ws.get("enc%d.dxg" % i, (T, B, 6 * H))
             Bp = (B + 15) // 16 * 16
             dh_ws = ws.get("enc%d.dh" % i, (12 * Bp * H,))
-            pk = self._packed(i)
             nf, nb = self._names(i, "forward"), self._names(i, "backward")
             sync = self._sync_ws(i, B, H)
+            pk = self._packed(i) if sync is None else None
             if sync is not None:
                 WhhT, WhgT = [p[nf["Whh"]], p[nb["Whh"]]], [p[nf["Whg"]], p[nb["Whg"]]]
             else:

@@ -158,6 +158,8 @@ class Configuration(dict):
         kw = copy.deepcopy(dict(cfg["net"]))
         kw.update(input_dims={"recordings": input_dim}, input_num_chars={}, num_phonemes=num_phonemes,
                   eos_label=num_phonemes - 1 if eos_label is None else eos_label)
-        kw.setdefault("data_prepend_eos", bool(cfg.get("data", {}).get("prepend_eos", True)))
+        # create_model passes data.prepend_eos (lvsr/main.py:219); Data defaults it to False and asserts it is never True
+        # (lvsr/datasets/__init__.py:163-166) — NOT the brick's own default of True
+        kw.setdefault("data_prepend_eos", bool((cfg.get("data") or {}).get("prepend_eos", False)))
         kw.update(extra)
         return kw

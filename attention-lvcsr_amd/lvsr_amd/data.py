@@ -172,8 +172,13 @@ class Data(object):
                 continue
             yield rec, lab.astype(numpy.int64)
 
-    def get_stream(self, part, batches=True, shuffle=True, num_examples=None, rng=None, seed=None):
-        """Generator over one epoch: examples (recordings (T,F), labels (L,)) or, with batches=True, padded dictionaries."""
+    def get_stream(self, part, batches=True, shuffle=True, num_examples=None, rng=None, seed=None, rank=0, world=1):
+        """Generator over one epoch: examples (recordings (T,F), labels (L,)) or, with batches=True, padded dictionaries.
+        Data parallelism (rank, world; not in the reference, whose stream lvsr/datasets/__init__.py:253-310 feeds one device):
+        every rank walks the SAME seeded stream of global minibatches (`batch_size` utterances, same shuffle, same sort-k
+        chunks) and keeps utterances rank::world of each; the padded lengths are those of the global minibatch, so all ranks
+        run the same shapes, and every dictionary carries `global_batch_size` (the divisor of the summed cost,
+        lvsr/main.py:340-345).  A trailing minibatch with fewer utterances than ranks is dropped."""
         ds = self.datasets[part]
         n = ds.num_examples if num_examples is None else num_examples
         order = numpy.arange(n)
@@ -190,7 +195,7 @@ class Data(object):
         if not batches:
             return stream
         bs = self.batch_size if part == "train" else self.validation_batch_size
-        return self._batches(stream, bs)
+        return self._batches(stream, bs, rank, world)
 
     @staticmethod
     def _sort_k(stream, chunk):
@@ -205,11 +210,11 @@ class Data(object):
             yield e
 
     @staticmethod
-    def pad_batch(examples, pad_frames_to=None, pad_labels_to=None):
+    def pad_batch(examples, pad_frames_to=None, pad_labels_to=None, min_frames=0, min_labels=0):
         """fuel Padding + switch_first_two_axes + ForceCContiguous (:303-309)."""
         B = len(examples)
-        T = max(len(r) for r, _ in examples)
-        L = max(len(l) for _, l in examples)
+        T = max(min_frames, max(len(r) for r, _ in examples))
+        L = max(min_labels, max(len(l) for _, l in examples))
         if pad_frames_to:
             T = -(-T // pad_frames_to) * pad_frames_to
         if pad_labels_to:
@@ -226,12 +231,25 @@ class Data(object):
             lmask[: len(l), b] = 1.0
         return dict(recordings=rec, recordings_mask=rmask, labels=lab, labels_mask=lmask)
 
-    def _batches(self, stream, bs):
+    def _batches(self, stream, bs, rank=0, world=1):
+        def emit(buf):
+            if world == 1:
+                return self.pad_batch(buf, self.pad_frames_to, self.pad_labels_to)
+            if len(buf) < world:
+                return None
+            # pad to the lengths of the GLOBAL minibatch, then keep this rank's columns
+            T = max(len(r) for r, _ in buf)
+            L = max(len(l) for _, l in buf)
+            full = self.pad_batch(buf[rank::world], self.pad_frames_to, self.pad_labels_to, T, L)
+            full["global_batch_size"] = len(buf)
+            return full
         buf = []
         for ex in stream:
             buf.append(ex)
             if len(buf) == bs:
-                yield self.pad_batch(buf, self.pad_frames_to, self.pad_labels_to)
+                yield emit(buf)
                 buf = []
         if buf:
-            yield self.pad_batch(buf, self.pad_frames_to, self.pad_labels_to)
+            b = emit(buf)
+            if b is not None:
+                yield b

@@ -20,6 +20,25 @@ from .bricks.recognizer import SpeechRecognizer
 from .training import Trainer
 
 
+def _dist_state(distributed):
+    """(rank, world, barrier) of the data-parallel job this process belongs to (a single process: 0, 1, no-op)."""
+    import torch
+    if distributed is None:
+        distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if not distributed:
+        return 0, 1, (lambda: None)
+    return torch.distributed.get_rank(), torch.distributed.get_world_size(), torch.distributed.barrier
+
+
+def _save_atomically(recognizer, path):
+    """Checkpoints are written to a temporary name and renamed: a reader (the next stage, another rank) never sees a
+    half-written tar."""
+    root, ext = os.path.splitext(path)
+    tmp = "%s.tmp%d%s" % (root, os.getpid(), ext)
+    recognizer.save_params(tmp)
+    os.replace(tmp, path)
+
+
 def validate(recognizer, data, part="valid"):
     """Mean cost per utterance over a data part (validation monitor of `cost`, lvsr/main.py:556-570)."""
     total, count = 0.0, 0
@@ -48,11 +67,15 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                                                        num_phonemes=data.num_labels, eos_label=data.eos_label)
     kw.setdefault("data_prepend_eos", False)
     rec = SpeechRecognizer(device=device, lib=lib, **kw)
+    if not config.get("initialization") and not params:
+        # the reference fails on config['initialization'] (lvsr/main.py:225); training from all-zero parameters is never meant
+        raise KeyError("neither an `initialization` section nor `params` to start from")
     if config.get("initialization"):
         rec.initialize(config["initialization"])
     if params:
         rec.load_params(params)
-    trainer = Trainer.from_config(rec, train_conf, config.get("regularization"), distributed=distributed)
+    rank, world, barrier = _dist_state(distributed)
+    trainer = Trainer.from_config(rec, train_conf, config.get("regularization"), distributed=world > 1 or bool(distributed))
     root, ext = os.path.splitext(save_path)
     best_ll, best_per, best_epoch = float("inf"), float("inf"), 0
     num_batches, num_epochs = train_conf.get("num_batches"), train_conf.get("num_epochs")
@@ -61,8 +84,10 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
     has_valid = "valid" in data.datasets
     while not done:
         costs = []
-        for batch in data.get_stream("train", shuffle=True, seed=epoch):
-            cm = trainer.train_step(batch)
+        # data parallel: every rank walks the same seeded stream and keeps utterances rank::world of each global minibatch
+        for batch in data.get_stream("train", shuffle=True, seed=epoch, rank=rank, world=world):
+            gbs = batch.pop("global_batch_size", None)
+            cm = trainer.train_step(batch, global_batch_size=gbs)
             iterations += 1
             row = dict(iterations_done=iterations, epochs_done=epoch, train_cost=float(cm.sum()) / int(batch["labels"].shape[1]),
                        total_gradient_norm=trainer.gradient_norm(), gradient_norm_threshold=trainer.gradient_threshold())
@@ -78,11 +103,14 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
         epoch += 1
         row = dict(iterations_done=iterations, epochs_done=epoch, average_train_cost=float(numpy.mean(costs)) if costs else None)
         if has_valid:
+            # replicas are identical: every rank computes the same validation cost (keeps the stopping rules in step without
+            # another collective); only rank 0 writes files
             row["valid_cost"] = validate(rec, data, "valid")
             if row["valid_cost"] < best_ll:
                 best_ll, best_epoch = row["valid_cost"], epoch
                 row["best_valid_cost_so_far"] = True
-                rec.save_params(root + "_best_ll" + ext)
+                if rank == 0:
+                    _save_atomically(rec, root + "_best_ll" + ext)
             every = mon.get("search_every_epochs")
             if every and epoch % every == 0:
                 from .decode import search
@@ -93,8 +121,11 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                 if res["cer"] < best_per:
                     best_per, best_epoch = res["cer"], epoch
                     row["best_valid_per_so_far"] = True
-                    rec.save_params(root + "_best" + ext)
-        rec.save_params(save_path)
+                    if rank == 0:
+                        _save_atomically(rec, root + "_best" + ext)
+        if rank == 0:
+            _save_atomically(rec, save_path)
+        barrier()                 # the next stage (any rank) may read the checkpoint as soon as its training returns
         log.append(row)
         if num_epochs and epoch >= num_epochs:
             done = True

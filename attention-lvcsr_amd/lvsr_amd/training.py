@@ -8,6 +8,7 @@ RCCL collective over the flat gradient buffer, then divided by the GLOBAL batch 
 kernel; all ranks apply identical updates.
 """
 import ctypes
+import os
 
 import numpy
 import torch
@@ -68,6 +69,10 @@ class Trainer(object):
         self.group = process_group
         self.world = torch.distributed.get_world_size(process_group) if distributed else 1
         self.rank = torch.distributed.get_rank(process_group) if distributed else 0
+        # data parallel: forward + backward of a minibatch shape replay as ONE hipGraph launch, the all-reduce and the fused
+        # optimiser follow eagerly on the same stream (LVSR_DP_REGION=0: per-layer graphs + eager launches instead)
+        self.dp_region = os.environ.get("LVSR_DP_REGION", "1") == "1"
+        self._comm = None
 
     @classmethod
     def from_config(cls, recognizer, training, regularization=None, adaptive_clipping=True, **kw):
@@ -96,28 +101,51 @@ class Trainer(object):
                      grad_scale=1.0 / float(global_batch_size), clip_state=self.clip_state, **self.conf)
         lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
 
+    def _all_reduce_gradients(self):
+        """ONE collective per step over the flat gradient bucket (sum); RCCL over xGMI when the tensors are on GPUs.
+        On a GPU it is issued on a communication stream of its own, ordered after / before the compute stream with events:
+        ProcessGroupNCCL's watchdog thread polls the collective's end event, and HIP refuses hipEventQuery on an event whose
+        stream has meanwhile entered hipGraph capture (hipErrorCapturedEvent kills the process: tools/probes/
+        nccl_capture_probe.py) — the compute stream captures the next minibatch shape's graph, the communication stream
+        never captures."""
+        g = self.rec.store.grad
+        if not g.is_cuda:
+            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            return
+        cur = torch.cuda.current_stream(g.device)
+        if self._comm is None:
+            self._comm = torch.cuda.Stream(g.device)
+        self._comm.wait_stream(cur)
+        with torch.cuda.stream(self._comm):
+            torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.group)
+        cur.wait_stream(self._comm)
+
     def apply_gradients(self, global_batch_size):
         rec, st = self.rec, self.rec.store
         with rec._on_stream():
-            if self.distributed and self.world > 1:
-                # ONE collective per step over the flat gradient bucket (sum); RCCL when the tensors are on GPUs
-                torch.distributed.all_reduce(st.grad, op=torch.distributed.ReduceOp.SUM, group=self.group)
+            if self.distributed:
+                self._all_reduce_gradients()
             self._enqueue_optimizer(global_batch_size)
             st.version += 1
 
     def train_step(self, batch, global_batch_size=None):
         """batch = this rank's shard (reference layout).  Returns the local cost matrix as a device tensor.
         Single process: forward, backward and the optimiser step are one graph region (one launch per step); with data
-        parallelism the region ends before the all-reduce and the optimiser follows it."""
+        parallelism the region ends before the all-reduce and the optimiser follows it.  `global_batch_size` = number of
+        utterances of the whole (all ranks) minibatch, the divisor of the summed cost (lvsr/main.py:340-345); when omitted
+        under data parallelism it is obtained by reducing the shard sizes."""
         B_local = int(batch["labels"].shape[1])
-        gbs = global_batch_size if global_batch_size is not None else B_local * self.world
-        if self.distributed and self.world > 1:
-            # per-layer graphs + eager launches (measured equal in speed to the whole-step region: the step is bound by the
-            # device-side chain of dependent kernels, not by the host); the region stays a single-process feature until it
-            # has run next to RCCL's proxy threads on a multi-GPU box
-            cm = self.rec.cost_and_gradients(batch, region=False)
-            self.apply_gradients(gbs)
+        if self.distributed:
+            if global_batch_size is None:
+                # shards may differ in size (a global batch that does not divide over the ranks): the divisor of the summed
+                # gradient must be the same number on every rank, so it is reduced too (one 8-byte collective)
+                n = torch.tensor([B_local], dtype=torch.int64, device=self.rec.store.grad.device)
+                torch.distributed.all_reduce(n, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                global_batch_size = int(n[0])
+            cm = self.rec.cost_and_gradients(batch, region=self.dp_region)
+            self.apply_gradients(global_batch_size)
             return cm
+        gbs = global_batch_size if global_batch_size is not None else B_local
         tail_key = ("opt", self._token, float(gbs), tuple(sorted(self.conf.items())))
         cm = self.rec.cost_and_gradients(batch, tail=lambda: self._enqueue_optimizer(gbs), tail_key=tail_key)
         self.rec.store.version += 1

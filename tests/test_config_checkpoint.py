@@ -149,3 +149,15 @@ def test_loader_agrees_with_the_reference_loader_on_every_reference_config():
             assert [[k, _plain(v)] for k, v in cfg.ordered_stages.items()] == ref["stages"], key
         compared += 1
     assert compared == len(golden)
+
+
+def test_net_kwargs_take_prepend_eos_from_the_data_section_default_false():
+    """create_model passes data.prepend_eos (lvsr/main.py:219), which Data defaults to False and forbids to be True
+    (lvsr/datasets/__init__.py:163-166): a config without the key must not switch `ignore_first_eol` on in beam search."""
+    from lvsr_amd import config
+    cfg = config.Configuration(os.path.join(os.path.dirname(__file__), "fixtures", "child.yaml"))
+    assert "prepend_eos" not in (cfg.get("data") or {})
+    assert cfg.net_kwargs(40, 33)["data_prepend_eos"] is False
+    shipped = "/root/reference/exp/wsj/configs/wsj_paper.yaml"
+    if os.path.exists(shipped):
+        assert config.Configuration(shipped).net_kwargs(123, 33)["data_prepend_eos"] is False

@@ -78,3 +78,72 @@ def test_two_rank_step_matches_single_process(tmp_path):
     single = rec.store.get_values()
     for k in names:
         assert_allclose(r0[k], single[k.replace("|", "/")], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+# ---- the stage driver under data parallelism: rank-sharded stream, rank-0 checkpoints ------------------------------
+TRAIN_CFG = dict(net=dict(dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content", embed_outputs=True),
+                 training=dict(gradient_threshold=10.0, scale=0.05, momentum=0.0, rules=["momentum"], num_epochs=2),
+                 regularization=dict(max_norm=3.0))
+
+
+def _toy_data():
+    from lvsr_amd.data import ArrayDataset, Data
+    rng = numpy.random.RandomState(4)
+    recs = [rng.normal(size=(6 + (i % 5), 5)).astype(numpy.float32) for i in range(10)]
+    labs = [rng.randint(0, 5, size=2 + (i % 3)) for i in range(10)]
+    ds = ArrayDataset(recs, labs, 6)
+    return Data({"train": ds, "valid": ds}, batch_size=4)
+
+
+def _start_params():
+    from lvsr_amd import synthetic
+    cfg = dict(TRAIN_CFG["net"], input_dim=5, num_phonemes=6, post_merge_dims=None, data_prepend_eos=False)
+    return synthetic.make_params(cfg, seed=8, scale=0.5)
+
+
+def _train_worker(rank, world, port, out_dir):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "attention-lvcsr_amd")]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    from emu import emu_lib
+    from lvsr_amd import main
+    from lvsr_amd.checkpoint import save_parameters
+    start = os.path.join(out_dir, "start.npz")
+    if rank == 0:
+        save_parameters(start, _start_params())
+    torch.distributed.barrier()
+    rec, log = main.train(TRAIN_CFG, _toy_data(), os.path.join(out_dir, "dp.zip"), params=start, device="cpu", lib=emu_lib())
+    numpy.savez(os.path.join(out_dir, "final%d.npz" % rank), valid=numpy.array([r["valid_cost"] for r in log if "valid_cost" in r]),
+                **{k.replace("/", "|"): v for k, v in rec.store.get_values().items()})
+    torch.distributed.destroy_process_group()
+
+
+def test_stage_driver_two_ranks_equals_single_process(tmp_path):
+    """lvsr_amd.main.train with 2 ranks: same stream on both, utterances r::2 of every global minibatch, gradients reduced
+    once per step, identical replicas, ONE set of checkpoint files (rank 0, written atomically) — and the same parameters
+    as the single-process run over the unsharded minibatches."""
+    from emu import emu_lib
+    from lvsr_amd import main
+    from lvsr_amd.checkpoint import load_parameters, save_parameters
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = numpy.load(str(tmp_path / "final0.npz")), numpy.load(str(tmp_path / "final1.npz"))
+    names = [k for k in r0.files if k != "valid"]
+    for k in names:
+        assert (r0[k] == r1[k]).all(), "ranks diverged on %s" % k
+    assert sorted(f for f in os.listdir(str(tmp_path)) if f.startswith("dp")) == ["dp.zip", "dp_best_ll.zip"]
+    saved = load_parameters(str(tmp_path / "dp.zip"))
+    for k in names:
+        assert numpy.array_equal(saved[k.replace("|", "/")], r0[k])
+    start = str(tmp_path / "start1.npz")
+    save_parameters(start, _start_params())
+    rec, log = main.train(TRAIN_CFG, _toy_data(), str(tmp_path / "single.zip"), params=start, device="cpu", lib=emu_lib(),
+                          distributed=False)
+    single = rec.store.get_values()
+    # the 10th utterance: minibatches of 4, 4, 2 -> the last one divides over 2 ranks, nothing is dropped
+    for k in names:
+        assert_allclose(r0[k], single[k.replace("|", "/")], rtol=2e-4, atol=2e-5, err_msg=k)
+    assert_allclose(r0["valid"], [r["valid_cost"] for r in log if "valid_cost" in r], rtol=1e-4)
+    with pytest.raises(KeyError):
+        main.train(TRAIN_CFG, _toy_data(), str(tmp_path / "x.zip"), device="cpu", lib=emu_lib(), distributed=False)

@@ -46,6 +46,30 @@ def test_layout_eos_bos_filter_and_sorting():
     assert len(ex) == len(kept) and ex[0][0].ndim == 2
 
 
+def test_rank_sharded_streams_partition_the_global_minibatches():
+    """Data.get_stream(rank=, world=): the ranks' shards of every global minibatch are its utterances r::world, padded to the
+    GLOBAL lengths (identical shapes on all ranks), and carry the global batch size; a trailing minibatch smaller than the
+    number of ranks is dropped on every rank alike."""
+    ds = _dataset(n=11)
+    for sort_k in (None, 2):
+        data = Data({"train": ds}, batch_size=4, sort_k_batches=sort_k)
+        whole = list(data.get_stream("train", shuffle=True, seed=3))
+        world = 3
+        shards = [list(data.get_stream("train", shuffle=True, seed=3, rank=r, world=world)) for r in range(world)]
+        assert len(whole) == 3 and whole[-1]["labels"].shape[1] == 3
+        assert all(len(s) == 3 for s in shards)
+        for i, gb in enumerate(whole):
+            n = gb["labels"].shape[1]
+            for r in range(world):
+                sh = shards[r][i]
+                assert sh["global_batch_size"] == n
+                for k in ("recordings", "recordings_mask", "labels", "labels_mask"):
+                    assert numpy.array_equal(sh[k], gb[k][:, r::world]), (k, i, r)
+    # 9 examples in minibatches of 4: the last one holds a single utterance, fewer than the 2 ranks -> dropped everywhere
+    data = Data({"train": _dataset(n=9)}, batch_size=4)
+    assert [len(list(data.get_stream("train", shuffle=False, rank=r, world=2))) for r in range(2)] == [2, 2]
+
+
 def test_training_on_the_pipeline_reduces_the_cost():
     from emu import emu_lib
     from lvsr_amd import synthetic

@@ -15,7 +15,7 @@ print("last step: %d kernels, wall %.2f ms, sum of kernel durations %.2f ms" % (
 groups = collections.OrderedDict()
 def grp(n):
     n = n[5:] if n.startswith("void ") else n
-    for k in ("enc_gates", "enc_cand", "enc_bwd_a", "enc_bwd_b", "lvsr_sgemm", "lvsr_colsum", "attdec", "attbwd", "opt_", "lvsr_pack"):
+    for k in ("enc_pfwd", "enc_pbwd", "enc_gates", "enc_cand", "enc_bwd_a", "enc_bwd_b", "lvsr_sgemm", "lvsr_colsum", "attdec", "attbwd", "opt_", "lvsr_pack"):
         if n.startswith(k):
             return k
     return "other"
