@@ -35,7 +35,7 @@ __device__ __forceinline__ Win attdec_window(const AttDec& a, int i) {
     if (a.K == 0) return w;
     if (a.prior_type == 0) {
         // int64 step * floatX constant -> float64 arithmetic on the f32-rounded speeds (:127-132,160-161)
-        const double step = (double)(a.step0 + i);
+        const double step = (double)(a.step0 + i + (a.step_dev ? *a.step_dev : 0));
         double bg = a.p0 + step * a.p2, en = a.p1 + step * a.p3;
         bg = fmax(0.0, fmin((double)(a.Tp - 1), bg));
         en = fmax(0.0, fmin((double)a.Tp, en));

@@ -135,7 +135,193 @@ __global__ __launch_bounds__(256) void shallow_fusion_kernel(const float* am, in
     for (int v = lane; v < V; v += 64) o[v] = out_scale * (((am_beta * a[v] - lse_a) + lm_weight * (-l[v] - lse_l)) - lse_t);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Generation-time readout + emitter of a few rows (beam hypotheses / sampled utterances) in ONE launch:
+//   r1 = bias1 + s @ W_ms + wa @ W_mw  ->  activation  ->  logits = r2 @ W_out + b_out  ->  step costs
+// (Readout.readout, libs/blocks/blocks/bricks/sequence_generators.py:614-619 + post-merge, lvsr/bricks/recognizer.py:
+// 298-320; SoftmaxEmitter.costs :788-791, or ShallowFusionReadout + LMEmitter, lvsr/bricks/language_models.py:92-184;
+// SoftmaxEmitter.emit :770-776 by inverse CDF on a given uniform).  One work-group per row; the three small GEMMs this
+// replaces cost 23 us EACH at 16 rows, more than the rest of the beam step together.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float row_lse(const float* x, int V, float scale, int lane);
+#define RS_MAX_IN 4096
+#define RS_MAX_P 2048
+#define RS_MAX_V 2048
+
+// out[j] = bias[j] + sum_k x[k] * W[k*N + j] for j < N; x, out in LDS.  The 256 threads are CP column groups x G slices of K;
+// with N % 4 == 0 a thread owns FOUR adjacent columns (one 16-byte load per k) and 8 loads are in flight per thread, which is
+// what hides the L2 latency of this weight stream (33 -> 8 us for the 768 x 256 merge at 16 rows).
+__device__ void wg_matvec(const float* x, int K, const float* W, int N, const float* bias, float* out, float* part /*[4][256]*/) {
+    const bool vec = (N % 4 == 0) && ((((size_t)W) & 15) == 0);
+    const int cols = vec ? N / 4 : N;
+    int CP = 1;
+    while (CP < cols && CP < 256) CP <<= 1;
+    const int G = 256 / CP, jl = threadIdx.x % CP, g = threadIdx.x / CP;
+    const int per = (K + G - 1) / G, k0 = g * per, k1 = min(K, k0 + per);
+    for (int j0 = 0; j0 < cols; j0 += CP) {
+        const int j = j0 + jl;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (j < cols) {
+            if (vec) {
+                const float4* w = (const float4*)W + j;
+                const int N4 = N / 4;
+                int k = k0;
+                for (; k + 7 < k1; k += 8) {
+                    float4 wv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k + u) * N4];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float xv = x[k + u];
+                        a0 += xv * wv[u].x; a1 += xv * wv[u].y; a2 += xv * wv[u].z; a3 += xv * wv[u].w;
+                    }
+                }
+                for (; k < k1; ++k) {
+                    const float4 wv = w[(size_t)k * N4];
+                    const float xv = x[k];
+                    a0 += xv * wv.x; a1 += xv * wv.y; a2 += xv * wv.z; a3 += xv * wv.w;
+                }
+            } else {
+                const float* w = W + j;
+                int k = k0;
+                for (; k + 3 < k1; k += 4) {
+                    a0 += x[k] * w[(size_t)k * N];
+                    a1 += x[k + 1] * w[(size_t)(k + 1) * N];
+                    a2 += x[k + 2] * w[(size_t)(k + 2) * N];
+                    a3 += x[k + 3] * w[(size_t)(k + 3) * N];
+                }
+                for (; k < k1; ++k) a0 += x[k] * w[(size_t)k * N];
+            }
+        }
+        __syncthreads();
+        if (vec) {
+            part[threadIdx.x] = a0; part[256 + threadIdx.x] = a1; part[512 + threadIdx.x] = a2; part[768 + threadIdx.x] = a3;
+        } else {
+            part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (vec) {
+            // CP * 4 outputs of this pass, folded by the first CP * 4 threads (or in several rounds)
+            for (int o = threadIdx.x; o < CP * 4; o += 256) {
+                const int q = o >> 2, e = o & 3, jj = (j0 + q) * 4 + e;
+                if (j0 + q < cols) {
+                    float v = bias ? bias[jj] : 0.f;
+                    for (int gg = 0; gg < G; ++gg) v += part[e * 256 + gg * CP + q];
+                    out[jj] = v;
+                }
+            }
+        } else if (g == 0 && j < cols) {
+            float v = bias ? bias[j] : 0.f;
+            for (int gg = 0; gg < G; ++gg) v += part[gg * CP + jl];
+            out[j] = v;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void readout_step_kernel(lvsr_readout_step_args a) {
+    __shared__ float xin[RS_MAX_IN];
+    __shared__ float r1[RS_MAX_P];
+    __shared__ float lg[RS_MAX_V];
+    __shared__ float part[4 * 256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int nin = (a.Wms ? a.D : 0) + a.E;
+    // inputs: [s | wa] against the stacked weight [W_ms ; W_mw] — two passes over the same output instead of a stacked copy
+    for (int k = tid; k < a.E; k += 256) xin[k] = a.WA[(size_t)r * a.ldwa + k];
+    for (int k = tid; k < (a.Wms ? a.D : 0); k += 256) xin[a.E + k] = a.S[(size_t)r * a.lds + k];
+    __syncthreads();
+    wg_matvec(xin, a.E, a.Wmw, a.P, a.bias1, r1, part);
+    if (a.Wms) {
+        float* tmp = lg;                      // P <= RS_MAX_V is checked by the host when W_ms is given
+        wg_matvec(xin + a.E, a.D, a.Wms, a.P, nullptr, tmp, part);
+        for (int j = tid; j < a.P; j += 256) r1[j] += tmp[j];
+        __syncthreads();
+    }
+    (void)nin;
+    const float* logits = r1;
+    if (a.Wout) {
+        // activation in place (maxout halves the width)
+        const int Pout = a.act == 1 ? a.P / 2 : a.P;
+        float v[RS_MAX_P / 256];
+        for (int j = tid, q = 0; j < Pout; j += 256, ++q) {
+            if (a.act == 1) v[q] = fmaxf(r1[2 * j], r1[2 * j + 1]);
+            else if (a.act == 2) v[q] = r1[j] > 0.f ? r1[j] : 0.f;
+            else if (a.act == 3) v[q] = tanhf(r1[j]);
+            else v[q] = r1[j];
+        }
+        __syncthreads();
+        for (int j = tid, q = 0; j < Pout; j += 256, ++q) r1[j] = v[q];
+        __syncthreads();
+        wg_matvec(r1, Pout, a.Wout, a.V, a.bout, lg, part);
+        logits = lg;
+    }
+    if (a.logits) for (int v = tid; v < a.V; v += 256) a.logits[(size_t)r * a.V + v] = logits[v];
+    if (tid >= 64) return;
+    // ---- emitter, one wave
+    const int lane = tid, V = a.V;
+    const float* l = a.lm_add ? a.lm_add + (size_t)r * V : nullptr;
+    float lse_a = 0.f, lse_l = 0.f, lse_t = 0.f, mx0 = 0.f;
+    if (!l) {
+        // SoftmaxEmitter: the same arithmetic as softmax_nll_kernel ((x - max) - log(sum))
+        mx0 = -3.0e38f;
+        for (int v = lane; v < V; v += 64) mx0 = fmaxf(mx0, logits[v]);
+        mx0 = wave_max(mx0);
+        float s0 = 0.f;
+        for (int v = lane; v < V; v += 64) s0 += expf(logits[v] - mx0);
+        lse_a = logf(wave_sum(s0));
+    } else {
+        // ShallowFusionReadout: the same arithmetic as shallow_fusion_kernel
+        lse_a = a.norm_am ? row_lse(logits, V, a.am_beta, lane) : 0.f;
+        lse_l = a.norm_lm ? row_lse(l, V, -1.f, lane) : 0.f;
+        if (a.norm_tot) {
+            float mx = -3.0e38f;
+            for (int v = lane; v < V; v += 64) mx = fmaxf(mx, (a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l));
+            mx = wave_max(mx);
+            float s = 0.f;
+            for (int v = lane; v < V; v += 64) s += expf(((a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l)) - mx);
+            s = wave_sum(s);
+            lse_t = mx + logf(s);
+        }
+    }
+    // log-probabilities of the step in xin (free again), costs = their negation
+    for (int v = lane; v < V; v += 64) {
+        const float lp = l ? ((a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l)) - lse_t : (logits[v] - mx0) - lse_a;
+        xin[v] = lp;
+        if (a.neglogp) a.neglogp[(size_t)r * V + v] = -lp;
+    }
+    if (a.uniforms) {
+        // SoftmaxEmitter.emit: multinomial by inverse CDF over the class order (MultinomialFromUniform: the first class whose
+        // running float32 sum of probabilities exceeds the uniform; none -> class 0 as argmax of an all-zero row)
+        if (lane == 0) {
+            const float u = a.uniforms[r];
+            float cum = 0.f;
+            int pick = 0;
+            bool hit = false;
+            for (int v = 0; v < V; ++v) {
+                cum += expf(xin[v]);
+                if (!hit && cum > u) { pick = v; hit = true; }
+            }
+            a.outputs[r] = pick;
+            if (a.costs) a.costs[r] = -xin[pick];
+        }
+    }
+}
+
 extern "C" {
+
+int lvsr_readout_step(void* stream, const lvsr_readout_step_args* args) {
+    LVSR_REQUIRE(args != nullptr, "lvsr_readout_step: null args");
+    const lvsr_readout_step_args& a = *args;
+    LVSR_REQUIRE(a.n > 0 && a.E > 0 && a.P > 0 && a.V > 0 && a.WA && a.Wmw, "lvsr_readout_step: bad arguments");
+    LVSR_REQUIRE(a.D + a.E <= RS_MAX_IN && a.P <= RS_MAX_P && a.V <= RS_MAX_V && (!a.Wms || a.P <= RS_MAX_V),
+                 "lvsr_readout_step: sizes exceed the LDS budget (D+E <= %d, P <= %d, V <= %d)", RS_MAX_IN, RS_MAX_P, RS_MAX_V);
+    LVSR_REQUIRE(a.Wout != nullptr || a.P == a.V, "lvsr_readout_step: without a post-merge layer the merge width must be V");
+    LVSR_REQUIRE(a.act >= 0 && a.act <= 3 && (a.act != 1 || a.P % 2 == 0), "lvsr_readout_step: bad activation");
+    LVSR_REQUIRE(!a.uniforms || a.outputs, "lvsr_readout_step: emit needs an output buffer");
+    hipLaunchKernelGGL(readout_step_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a);
+    return lvsr_check_launch("lvsr_readout_step");
+}
 
 int lvsr_gather_rows(void* stream, const float* table, int ldt, const long long* idx, int n, int nrows, int width,
                      const float* bias, float* out, int ldo) {

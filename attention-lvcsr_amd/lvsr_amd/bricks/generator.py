@@ -414,3 +414,167 @@ def _generation_methods():
 for _k, _v in _generation_methods().items():
     setattr(SequenceGenerator, _k, _v)
 SequenceGenerator.language_model = None
+
+
+# ---- device-resident beam search (csrc/beam.hip): state of one search + the launches of one position ------------------
+CTL = dict(nlive=0, pos=1, done=2, nfin=3, patience=4, nsel=5, err=6, steps=7)
+
+
+def _beam_methods():
+    def beam_begin(self, K, eol, max_length, ignore_first_eol=False, char_discount=0.0, round_to_inf=1e9, stop_on="patience"):
+        """Allocate (once per (K, T', max_length)) and reset the device state of a beam search over the contexts set by
+        `init_generation`: hypothesis 0 = initial state / initial glimpses (search.py:287-299), every other row a copy."""
+        d, p, n_, lib, ws, g = self.d, self.store.p, self.n, self.lib, self.ws, self._gen
+        Tp, dev = g["Tp"], g["A"].device
+        lm = self.language_model
+        on_dev_lm = lm is not None and getattr(lm, "on_device", False)
+        tag = ".K%d" % K
+        i32, i64, f64 = torch.int32, torch.int64, torch.float64
+        fin_cap = 2 * K if stop_on == "patience" else K * (max_length + 1)
+        Kc = max(d.K, 1)
+        pos_needed = d.conv and self._prior()[0] != 0
+
+        def attbufs(which, phases):
+            t = tag + which
+            return dict(xg=ws.get("bs.xg" + t, (K, 3 * d.D)) if phases & 2 else None, ymask=None,
+                        S=ws.get("bs.S" + t, (2, K, d.D)), W=ws.get("bs.W" + t, (2, K, Tp)),
+                        pos=ws.get("bs.pos" + t, (2, K)) if pos_needed else None,
+                        WA=ws.get("bs.WA" + t, (1, K, d.E)), EN=ws.get("bs.EN" + t, (1, K, Tp)), ZB=None,
+                        sW=ws.get("bs.sW" + t, (1, K, d.M)), CV=ws.get("bs.CV" + t, (1, K, Kc, Tp)) if d.conv else None,
+                        U=ws.get("bs.U" + t, (1, K, d.D)), R=ws.get("bs.R" + t, (1, K, d.D)),
+                        C=ws.get("bs.C" + t, (1, K, d.D)), RH=ws.get("bs.RH" + t, (1, K, d.D)),
+                        sg=ws.get("bs.sg" + t, (K, 2 * d.D)), xin=ws.get("bs.xin" + t, (K, d.D)),
+                        ep=ws.get("bs.ep" + t, (K, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
+        A_, B_ = attbufs("a", 1), attbufs("b", 3)
+        st = dict(K=K, Tp=Tp, max_length=int(max_length), fin_cap=fin_cap, A=A_, B=B_,
+                  ctl=ws.get("bs.ctl" + tag, (16,), i32), fctl=ws.get("bs.fctl" + tag, (4,)),
+                  neglogp=ws.get("bs.neglogp" + tag, (K, d.V)), running=ws.get("bs.running" + tag, (K,)),
+                  live_col=ws.get("bs.live_col" + tag, (K,), i32),
+                  hist_parent=ws.get("bs.hist_parent" + tag, (max_length, K), i32),
+                  hist_char=ws.get("bs.hist_char" + tag, (max_length, K), i32),
+                  hist_cost=ws.get("bs.hist_cost" + tag, (max_length, K)),
+                  fin_pos=ws.get("bs.fin_pos" + tag, (fin_cap,), i32), fin_col=ws.get("bs.fin_col" + tag, (fin_cap,), i32),
+                  fin_cost=ws.get("bs.fin_cost" + tag, (fin_cap,)), fin_score=ws.get("bs.fin_score" + tag, (fin_cap,)),
+                  keep=ws.get("bs.keep" + tag, (K,), i32), chars=ws.get("bs.chars" + tag, (K,), i64),
+                  parents=ws.get("bs.parents" + tag, (K,), i32),
+                  fb=ws.get("bs.fb" + tag, (K, d.FB)) if d.embed else None, lm=None)
+        if lm is not None:
+            st["lm"] = dict(add_live=ws.get("bs.lm_add_live" + tag, (K, d.V)))
+            if on_dev_lm:
+                st["lm"].update(states_live=ws.get("bs.lm_sl" + tag, (K, 7), i64), weights_live=ws.get("bs.lm_wl" + tag, (K, 7), f64),
+                                states_sel=ws.get("bs.lm_ss" + tag, (K, 7), i64), weights_sel=ws.get("bs.lm_ws" + tag, (K, 7), f64),
+                                states_new=ws.get("bs.lm_sn" + tag, (K, 7), i64), weights_new=ws.get("bs.lm_wn" + tag, (K, 7), f64),
+                                add_new=ws.get("bs.lm_add_new" + tag, (K, d.V)))
+        pk = self._packed()
+        # window centres travel with the rows (select / compact move them), so neither pass recomputes slot 0: phases bit 2
+        skip_pos = 4 if pos_needed else 0
+        fa = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, A_, phases=1 | skip_pos, step0=0, broadcast=True)
+        fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True)
+        pos_word = st["ctl"][CTL["pos"]:]
+        st["argsA"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fa)
+        st["argsB"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fb_)     # runs after the select kernel moved on: step0 = -1
+        L = st["lm"] or {}
+        st["args"] = lib.make(
+            "lvsr_beam_args", K=K, V=d.V, eol=int(eol), ignore_first_eol=int(bool(ignore_first_eol)),
+            stop_on={"patience": 0, "optimistic_future_cost": 1}[stop_on], max_length=int(max_length), fin_cap=fin_cap, D=d.D, Tp=Tp,
+            round_to_inf=float(numpy.float32(min(float(round_to_inf), 3.0e38))), char_discount=float(char_discount),
+            ctl=st["ctl"], fctl=st["fctl"], neglogp=st["neglogp"], running=st["running"], live_col=st["live_col"],
+            hist_parent=st["hist_parent"], hist_char=st["hist_char"], hist_cost=st["hist_cost"], fin_pos=st["fin_pos"],
+            fin_col=st["fin_col"], fin_cost=st["fin_cost"], fin_score=st["fin_score"], keep=st["keep"], chars=st["chars"],
+            parents=st["parents"], S_live=A_["S"][0], W_live=A_["W"][0], S_sel=B_["S"][0], W_sel=B_["W"][0],
+            lm_states_live=L.get("states_live"), lm_weights_live=L.get("weights_live"), lm_states_sel=L.get("states_sel"),
+            lm_weights_sel=L.get("weights_sel"), S_new=B_["S"][1], W_new=B_["W"][1], S_live_out=A_["S"][0], W_live_out=A_["W"][0],
+            lm_states_new=L.get("states_new"), lm_weights_new=L.get("weights_new"), lm_add_new=L.get("add_new"),
+            lm_states_live_out=L.get("states_live"), lm_weights_live_out=L.get("weights_live"),
+            lm_add_live_out=L.get("add_live") if on_dev_lm else None,
+            pos_live=A_["pos"][0] if pos_needed else None, pos_sel=B_["pos"][0] if pos_needed else None,
+            pos_new=B_["pos"][1] if pos_needed else None, pos_live_out=A_["pos"][0] if pos_needed else None,
+            # one-hot feedback: the fork of the chosen characters is a row gather the select launch does itself
+            fork_xg=None if d.embed else B_["xg"], fork_Wi=None if d.embed else p[n_["Wfi"]], fork_Wg=None if d.embed else p[n_["Wfg"]],
+            fork_bi=None if d.embed else p[n_["bfi"]], fork_bg=None if d.embed else p[n_["bfg"]], fork_rows=0 if d.embed else d.FB)
+        st["readout"] = self._readout_step_args(A_["S"][0], A_["WA"][0], K, neglogp=st["neglogp"],
+                                                lm_add=L.get("add_live") if lm is not None else None)
+        # ---- reset: one live hypothesis, replicated over the K rows
+        ctl0 = numpy.zeros(16, numpy.int32)
+        ctl0[CTL["nlive"]], ctl0[CTL["patience"]] = 1, -1
+        st["ctl"].copy_(torch.from_numpy(ctl0))
+        st["fctl"].copy_(torch.tensor([1000.0, 0.0, 0.0, 0.0]))
+        st["running"].zero_()
+        st["live_col"].zero_()
+        A_["S"][0].copy_(p[n_["h0"]].unsqueeze(0).expand(K, d.D))
+        A_["W"][0].zero_()
+        if d.conv:
+            A_["W"][0][:, 0] = 1.0
+        if pos_needed:
+            A_["pos"].zero_()         # centre of the initial glimpses [1, 0, ...]: mean 0, no median crossing -> 0
+        if on_dev_lm:
+            first = lm.initial_states(K)
+            L["states_live"].copy_(first["states"])
+            L["weights_live"].copy_(first["weights"])
+            L["add_live"].copy_(first["add"])
+        st["on_dev_lm"] = on_dev_lm
+        st["key"] = ("beam_step", K, Tp, int(max_length), stop_on, int(bool(ignore_first_eol)), int(eol), float(char_discount),
+                     float(round_to_inf), lm is not None, on_dev_lm)
+        st["volatile"] = (g["A"].data_ptr(), g["PA"].data_ptr(), g["Am"].data_ptr(), ws.generation, id(pk), self.store.version)
+        self._beam = st
+        return st
+
+    def _readout_step_args(self, S2, WA2, n, neglogp=None, lm_add=None, uniforms=None, outputs=None, costs=None, logits=None):
+        """Argument block of the fused generation-time readout + emitter (lvsr_readout_step)."""
+        d, p, n_ = self.d, self.store.p, self.n
+        lm = self.language_model
+        return self.lib.make(
+            "lvsr_readout_step_args", S=S2, WA=WA2, lds=int(S2.stride(0)), ldwa=int(WA2.stride(0)), n=n, D=d.D, E=d.E, P=d.P, V=d.V,
+            act=ACT_KIND[d.act] if d.post_merge else 0, Wms=p[n_["Wms"]] if d.use_states_for_readout else None, Wmw=p[n_["Wmw"]],
+            bias1=p[n_["bpm"]] if d.post_merge else p[n_["bro"]], Wout=p[n_["Wout"]] if d.post_merge else None,
+            bout=p[n_["bout"]] if d.post_merge else None, lm_add=lm_add,
+            am_beta=lm.am_beta if lm_add is not None else 1.0, lm_weight=lm.lm_weight if lm_add is not None else 0.0,
+            norm_am=int(lm.norm[0]) if lm_add is not None else 1, norm_lm=int(lm.norm[1]) if lm_add is not None else 0,
+            norm_tot=int(lm.norm[2]) if lm_add is not None else 0, neglogp=neglogp, logits=logits, uniforms=uniforms,
+            outputs=outputs, costs=costs)
+
+    def beam_costs(self):
+        """Pass A of a position: glimpses of the live hypotheses -> readout -> step costs `neglogp` (K,V)
+        (logprobs_computer, search.py:126-134; with a language model ShallowFusionReadout + LMEmitter)."""
+        d, lib, st = self.d, self.lib, self._beam
+        K, A_ = st["K"], st["A"]
+        lib.call("lvsr_attdec_fwd", lib.stream_for(A_["S"]), ctypes.byref(st["argsA"]), 0)
+        lib.call("lvsr_readout_step", lib.stream_for(st["neglogp"]), ctypes.byref(st["readout"]))
+
+    def beam_select(self):
+        """Stopping rules, the beam_size best continuations, finished hypotheses, back-pointers; gathers the rows of pass B."""
+        st = self._beam
+        self.lib.call("lvsr_beam_select", self.lib.stream_for(st["ctl"]), ctypes.byref(st["args"]))
+
+    def beam_advance(self):
+        """Pass B: glimpses AGAIN on the re-arranged hypotheses (the window of the location prior depends on the batch it is
+        computed for) + compute_states with the chosen characters (next_state_computer, search.py:112-124), language-model
+        transition, then the surviving rows become the new beam."""
+        d, lib, st = self.d, self.lib, self._beam
+        K, B_ = st["K"], st["B"]
+        if d.embed:          # lookup feedback needs the fork's GEMMs; one-hot feedback was gathered by the select launch
+            self._feedback_fork(st["chars"], K, B_["xg"], st["fb"])
+        lib.call("lvsr_attdec_fwd", lib.stream_for(B_["S"]), ctypes.byref(st["argsB"]), 0)
+        if st["on_dev_lm"]:
+            L, lm = st["lm"], self.language_model
+            lib.call("lvsr_fst_lm_step", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
+                     lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
+                     lib_ptr(L["add_new"]), lib_ptr(lm._err))
+        lib.call("lvsr_beam_compact", lib.stream_for(st["ctl"]), ctypes.byref(st["args"]))
+
+    def beam_step(self):
+        """All launches of one position as one replayed hipGraph (captured on the second step of a search shape)."""
+        st = self._beam
+
+        def enqueue():
+            self.beam_costs()
+            self.beam_select()
+            self.beam_advance()
+        self.lib.region(self, st["key"], st["ctl"], enabled=self.use_graph, volatile=st["volatile"], drain=False).run(enqueue)
+
+    return dict(beam_begin=beam_begin, beam_costs=beam_costs, beam_select=beam_select, beam_advance=beam_advance,
+                beam_step=beam_step, _readout_step_args=_readout_step_args)
+
+
+for _k, _v in _beam_methods().items():
+    setattr(SequenceGenerator, _k, _v)

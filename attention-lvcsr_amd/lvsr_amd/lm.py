@@ -262,6 +262,14 @@ class DeviceFSTLanguageModel(FSTLanguageModel):
                 raise ValueError(self._ERRORS.get(code, "lvsr_fst_lm_step error %d" % code))
         return dict(states=ns, weights=nw, add=add)
 
+    def check_error(self):
+        """Raise what the device walk flagged since the last check (the beam-search driver looks once per search: the error
+        word is sticky and the kernels of a flagged row keep producing finite numbers)."""
+        code = int(self._err.item())
+        if code:
+            self._err.zero_()
+            raise ValueError(self._ERRORS.get(code, "lvsr_fst_lm_step error %d" % code))
+
     def initial_states(self, n):
         st = torch.from_numpy(numpy.tile(self._start[0][None, :], (n, 1))).to(self.device)
         wt = torch.from_numpy(numpy.tile(self._start[1][None, :], (n, 1))).to(self.device)

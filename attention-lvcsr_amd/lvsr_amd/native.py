@@ -270,10 +270,10 @@ class Lib(object):
         if _SYNC_AFTER_GRAPH and ref_tensor.is_cuda and steps >= 16 and not self.capturing:
             torch.cuda.current_stream(ref_tensor.device).synchronize()
 
-    def region(self, owner, key, ref_tensor, enabled=True, volatile=()):
+    def region(self, owner, key, ref_tensor, enabled=True, volatile=(), drain=True):
         """`owner`: the object whose buffers the region's launches reference (it carries the bookkeeping, so it dies with
         it, and a process-unique token, so a later object at a recycled address can never hit its graphs)."""
-        return Region(self, owner, key, ref_tensor, enabled, volatile)
+        return Region(self, owner, key, ref_tensor, enabled, volatile, drain)
 
     _uid = [0]
 
@@ -296,8 +296,9 @@ class Region(object):
     `volatile` part (workspace generation: buffers were re-allocated) re-captures without another eager pass.  A capture during
     which the caching allocator handed out memory is dropped (a replay would write to memory it does not own) and the key
     is enqueued again eagerly, and stays eager.  Disabled on the emulator / CPU tensors, with LVSR_STEP_GRAPH=0, and inside another region."""
-    def __init__(self, lib, owner, key, ref, enabled, volatile=()):
+    def __init__(self, lib, owner, key, ref, enabled, volatile=(), drain=True):
         self.lib, self.ref = lib, ref
+        self.drain = drain          # block the host until a replay has drained (long time-loop regions); False: short regions
         if not hasattr(owner, "_region_token"):
             owner._region_token, owner._regions = lib.unique_token(), {}
         soft = repr((owner._region_token, key)).encode()
@@ -335,7 +336,8 @@ class Region(object):
             raise NativeError("lvsr_region_begin failed (%d): %s" % (rc, lib.last_error()))
         if rc == 1:
             self.state = "replayed"
-            lib.after_graph(self.ref, 1 << 20)
+            if self.drain:
+                lib.after_graph(self.ref, 1 << 20)
             return False
         if rc == 2:
             self.slot["bad"] = True
@@ -363,7 +365,8 @@ class Region(object):
         if not clean:
             self.slot["bad"] = True
             return False
-        lib.after_graph(self.ref, 1 << 20)
+        if self.drain:
+            lib.after_graph(self.ref, 1 << 20)
         return True
 
     def run(self, fn):

@@ -1,21 +1,22 @@
-"""Beam search over the HIP generation step.
+"""Beam search driver over the device-resident beam step (csrc/beam.hip, `SequenceGenerator.beam_*`).
 
-What must agree with the reference's (modified) `blocks.search.BeamSearch` (libs/blocks/blocks/search.py:19-407) is the
-RESULT — the hypotheses and their costs, bit for bit — so the selection rules are kept exactly:
-  * candidates = cumulative cost + step cost over (live hypothesis, character); the `beam_size` smallest are taken with
-    `argpartition` then `argsort` (numpy's tie order is part of parity, search.py:221-242);
-  * a hypothesis ending in `<eol>` is finished when its last step cost is below `round_to_inf` (and the optional
-    `validate_solution_function` accepts it); finished hypotheses leave the beam, so the beam shrinks;
-  * ranking of finished hypotheses: final cumulative cost minus `char_discount` per emitted position;
-  * `stop_on='patience'`: stop after 30 consecutive steps without a better best finished hypothesis;
-    `stop_on='optimistic_future_cost'`: stop once the `beam_size`-th finished hypothesis (in order of completion — the
-    reference does not sort in this mode) beats min(live cumulative cost) - `char_discount` * `max_length`;
-  * no finished hypothesis at all -> CandidateNotFoundError.
-The two compiled Theano functions the reference calls per step are `SequenceGenerator.generation_logprobs` /
-`generation_next_states` on the device; everything else here is host bookkeeping in float32 like the reference's.
+The reference's `BeamSearch.search` (libs/blocks/blocks/search.py:244-407, as modified by lvsr) is a host loop around two
+compiled functions; here the whole position — step costs of every continuation, choice of the `beam_size` best, finished
+hypotheses, stopping rules, next states, language-model transition — is device work replayed as one hipGraph, and the
+host's part shrinks to: start the search, replay steps, look at the `done` word every few steps, and at the end follow the
+back-pointers of the finished hypotheses.  The RESULT (hypotheses, costs, the CandidateNotFoundError contract) is what has
+to agree with the reference, bit for bit on its golden fixtures; the rules that produce it are listed in csrc/beam.hip.
+
+Two things need the host inside the loop and switch the driver to one synchronisation per position: a
+`validate_solution_function` (a Python callback that may veto a finished hypothesis, search.py:372-374) and a language
+model whose walk runs on the host (`FSTLanguageModel` without the device tables).
 """
 import numpy
 import torch
+
+from .bricks.generator import CTL
+
+POLL_EVERY = 8          # positions between two looks at the `done` word (a look is the only host<->device round trip)
 
 
 class CandidateNotFoundError(Exception):
@@ -23,32 +24,26 @@ class CandidateNotFoundError(Exception):
     pass
 
 
-class _Finished(object):
-    """A completed hypothesis: the token column and the running-cost column of the beam at the step it ended."""
-    __slots__ = ("tokens", "running")
-
-    def __init__(self, tokens, running):
-        self.tokens, self.running = tokens, running
-
-    def score(self, char_discount):
-        return self.running[-1] - char_discount * len(self.running)
-
-
 class BeamSearch(object):
-    PATIENCE = 30
-
     def __init__(self, beam_size, recognizer):
         self.beam_size = beam_size
         self.rec = recognizer
+        self.last_stats = {}
 
-    @staticmethod
-    def _smallest(matrix, k):
-        """Indices (row, column) and values of the k smallest entries, ascending; ties as numpy breaks them."""
-        flat = matrix.reshape(-1)
-        pick = numpy.argpartition(flat, k)[:k] if flat.size > k else numpy.arange(flat.size)
-        pick = pick[numpy.argsort(flat[pick])]
-        return numpy.unravel_index(pick, matrix.shape), flat[pick]
+    # ---- the reference's `_smallest` on the device (kept for callers / tests of the selection rule) -----------------
+    def _smallest(self, matrix, k):
+        """Indices (row, column) and values of the k smallest entries of a 2-D array, ascending, equal values in flat-index
+        order (lvsr_topk_smallest)."""
+        from .native import ptr
+        lib, dev = self.rec.lib, self.rec.device
+        m = torch.as_tensor(numpy.ascontiguousarray(matrix, dtype=numpy.float32)).to(dev).contiguous()
+        n, k = int(m.numel()), int(min(k, m.numel()))
+        idx = torch.empty(k, dtype=torch.int64, device=dev)
+        val = torch.empty(k, dtype=torch.float32, device=dev)
+        lib.call("lvsr_topk_smallest", lib.stream_for(m), ptr(m), n, k, ptr(idx), ptr(val))
+        return numpy.unravel_index(idx.cpu().numpy(), matrix.shape), val.cpu().numpy()
 
+    # ---- driver ---------------------------------------------------------------------------------------------------
     def search(self, input_values, eol_symbol, max_length, ignore_first_eol=False, as_arrays=False, char_discount=0,
                round_to_inf=1e9, stop_on="patience", validate_solution_function=None):
         """`input_values` = {'recordings': (T,F) ndarray}.  Returns (outputs, costs) lists, best first, or the padded
@@ -57,92 +52,134 @@ class BeamSearch(object):
             raise ValueError("Unknown stopping criterion {}".format(stop_on))
         rec, gen = self.rec, self.rec.generator
         lm = gen.language_model
-        dev = rec.device
-        lm_on_device = getattr(lm, "on_device", False)
-
-        def to_dev(idx):
-            return torch.as_tensor(numpy.ascontiguousarray(idx), dtype=torch.int64).to(dev)
-
+        host_lm = lm is not None and not getattr(lm, "on_device", False)
+        stepping = host_lm or validate_solution_function is not None
+        max_length = int(max_length)
+        first_token = 0 if lm is not None else gen.d.V            # LMEmitter / SoftmaxEmitter initial outputs
+        if max_length <= 0:
+            raise CandidateNotFoundError()
         with rec._on_stream():
             rec.compute_contexts(input_values["recordings"])
-            start = gen.generation_initial_states(1)
-            lm_states = rec.lm_initial_states(1) if lm is not None else None
-        S, W, step = start["states"], start["weights"], start["step"]
-        tokens = start["outputs"][None, :]                          # (positions so far + 1, live hypotheses)
-        running = numpy.zeros(tokens.shape, dtype=numpy.float32)     # cumulative costs, same layout
-        finished = []
-        best_seen, patience = 1000, None
-
-        for position in range(max_length):
-            if S.shape[0] == 0:
-                break
-            # ---- stopping rules
-            if stop_on == "patience":
-                finished.sort(key=lambda f: f.score(char_discount))
-                del finished[self.beam_size:]
-                if finished:
-                    leader = finished[0].score(char_discount)
-                    if leader < best_seen:
-                        best_seen, patience = leader, self.PATIENCE
-                    else:
-                        if patience is None:      # the reference decrements before it ever assigns (first cost >= 1000)
-                            raise UnboundLocalError("local variable 'patience' referenced before assignment")
-                        patience -= 1
-                        if patience == 0:
+            st = gen.beam_begin(self.beam_size, eol_symbol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
+            ctl = None
+            if not stepping:
+                for position in range(max_length):
+                    gen.beam_step()
+                    if (position + 1) % POLL_EVERY == 0 or position + 1 == max_length:
+                        ctl = st["ctl"].cpu().numpy()
+                        if ctl[CTL["done"]]:
                             break
-            elif len(finished) >= self.beam_size:
-                bound = running[-1].min() - char_discount * max_length
-                if finished[self.beam_size - 1].score(char_discount) < bound:
-                    break
-            # ---- expand: cost of every continuation of every live hypothesis
-            with rec._on_stream():
-                if lm_states is not None:
-                    lm.stage(lm_states, dev)
-                neglogp = gen.generation_logprobs(S, W, step)
-            step_costs = neglogp.cpu().numpy().astype(numpy.float32)
-            assert numpy.isfinite(step_costs).all()
-            (parents, chars), chosen = self._smallest(running[-1][:, None] + step_costs, self.beam_size)
-            # ---- re-arrange the beam along the chosen parents and advance it by the chosen characters
-            with rec._on_stream():
-                parents_t = to_dev(parents)
-                S, W = S.index_select(0, parents_t), W.index_select(0, parents_t)
-                if lm_states is not None:
-                    lm_states = lm.take(lm_states, parents_t if lm_on_device else parents)
-                nxt = gen.generation_next_states(S, W, step, chars)
-                if lm_states is not None:
-                    lm_states = lm.transition(lm_states, chars)
-            S, W, step = nxt["states"], nxt["weights"], nxt["step"]
-            tokens = numpy.concatenate([tokens[:, parents], chars[None, :]], axis=0)
-            running = numpy.concatenate([running[:, parents], chosen[None, :]], axis=0)
-            # ---- hypotheses that just emitted <eol> finish (unless the step was "infinitely" expensive) and leave the beam
-            ended = chars == eol_symbol
-            affordable = (running[-1] - running[-2]) < round_to_inf
-            for col in numpy.flatnonzero(ended & affordable):
-                if validate_solution_function is None or validate_solution_function(input_values, tokens[:, col]):
-                    finished.append(_Finished(tokens[:, col], running[:, col]))
-            alive = numpy.ones_like(ended) if (ignore_first_eol and position == 0) else ~ended
-            if not alive.all():
-                keep = numpy.flatnonzero(alive)
-                with rec._on_stream():
-                    keep_t = to_dev(keep)
-                    S, W = S.index_select(0, keep_t), W.index_select(0, keep_t)
-                    if lm_states is not None:
-                        lm_states = lm.take(lm_states, keep_t if lm_on_device else keep)
-                tokens, running = tokens[:, keep], running[:, keep]
+            else:
+                ctl = self._search_stepping(st, input_values, lm if host_lm else None, validate_solution_function, first_token)
+            if lm is not None and getattr(lm, "on_device", False):
+                lm.check_error()
+        if ctl is None:
+            ctl = st["ctl"].cpu().numpy()
+        self._raise_device_errors(ctl)
+        self.last_stats = dict(positions=int(ctl[CTL["steps"]]), finished=int(ctl[CTL["nfin"]]), done=int(ctl[CTL["done"]]))
+        return self._collect(st, ctl, first_token, char_discount, as_arrays)
 
-        if not finished:
+    @staticmethod
+    def _raise_device_errors(ctl):
+        err = int(ctl[CTL["err"]])
+        if err == 1:
+            raise AssertionError("non-finite step costs in beam search")             # search.py:345 `assert numpy.isfinite`
+        if err == 2:
+            raise RuntimeError("beam search: the finished-hypothesis list overflowed its device buffer")
+        if err == 3:       # the reference decrements `patience` before it ever assigns it (first finished score >= 1000)
+            raise UnboundLocalError("local variable 'patience' referenced before assignment")
+
+    def _search_stepping(self, st, input_values, host_lm, validate, first_token):
+        """One synchronisation per position: the host language-model walk feeds the fusion costs of the live hypotheses,
+        and/or a Python callback vetoes finished hypotheses (search.py:372-374)."""
+        gen, dev = self.rec.generator, self.rec.device
+        K = st["K"]
+        lm_states = host_lm.initial_states(1) if host_lm is not None else None
+        hist_p, hist_c = [], []
+        ctl = st["ctl"].cpu().numpy()
+        for position in range(st["max_length"]):
+            if host_lm is not None:
+                n = int(ctl[CTL["nlive"]])
+                add = numpy.zeros((K, gen.d.V), numpy.float32)
+                if n:
+                    add[:n] = lm_states["add"][:n]
+                    add[n:] = add[0]
+                st["lm"]["add_live"].copy_(torch.from_numpy(add))
+            nfin_before = int(ctl[CTL["nfin"]])
+            gen.beam_costs()
+            gen.beam_select()
+            ctl = st["ctl"].cpu().numpy()
+            if ctl[CTL["done"]] in (1, 2):
+                break                                         # a stopping rule fired: nothing was selected at this position
+            nsel, nlive = int(ctl[CTL["nsel"]]), int(ctl[CTL["nlive"]])
+            parents = st["parents"].cpu().numpy()[:nsel]
+            chars = st["chars"].cpu().numpy()[:nsel]
+            keep = st["keep"].cpu().numpy()[:nlive]
+            if validate is not None:
+                hist_p.append(st["hist_parent"][position].cpu().numpy().copy())
+                hist_c.append(st["hist_char"][position].cpu().numpy().copy())
+                nfin = int(ctl[CTL["nfin"]])
+                if nfin > nfin_before:
+                    cols = st["fin_col"].cpu().numpy()
+                    ok = [i for i in range(nfin_before, nfin)
+                          if validate(input_values, self._tokens_of(hist_p, hist_c, position, int(cols[i]), first_token))]
+                    if len(ok) != nfin - nfin_before:
+                        for name in ("fin_pos", "fin_col", "fin_cost", "fin_score"):
+                            t = st[name]
+                            kept = t[torch.as_tensor(ok, dtype=torch.int64, device=dev)].clone() if ok else t[:0]
+                            t[nfin_before: nfin_before + len(ok)] = kept
+                        st["ctl"][CTL["nfin"]] = nfin_before + len(ok)
+                        ctl[CTL["nfin"]] = nfin_before + len(ok)
+            if host_lm is not None:
+                lm_states = host_lm.take(lm_states, parents)
+                lm_states = host_lm.transition(lm_states, chars)
+                lm_states = host_lm.take(lm_states, keep)
+            gen.beam_advance()
+            if ctl[CTL["done"]]:
+                break
+        return st["ctl"].cpu().numpy()
+
+    @staticmethod
+    def _tokens_of(hist_p, hist_c, position, col, first_token):
+        toks = []
+        for p in range(position, -1, -1):
+            toks.append(int(hist_c[p][col]))
+            col = int(hist_p[p][col])
+        return numpy.array([first_token] + toks[::-1])
+
+    def _collect(self, st, ctl, first_token, char_discount, as_arrays):
+        """Follow the back-pointers of the finished hypotheses and rank them (search.py:378-407)."""
+        nfin, npos = int(ctl[CTL["nfin"]]), int(ctl[CTL["steps"]])
+        if nfin == 0:
             raise CandidateNotFoundError()
-        finished.sort(key=lambda f: f.score(char_discount))
-        longest = max(len(f.tokens) for f in finished)
-        out_tokens = numpy.zeros((longest, len(finished)))
-        out_mask = numpy.zeros((longest, len(finished)))
-        out_running = numpy.zeros((longest, len(finished)))
-        for col, f in enumerate(finished):
-            n = len(f.tokens)
-            out_tokens[:n, col] = f.tokens
+        fin_pos = st["fin_pos"][:nfin].cpu().numpy()
+        fin_col = st["fin_col"][:nfin].cpu().numpy()
+        hp = st["hist_parent"][:npos].cpu().numpy()
+        hc = st["hist_char"][:npos].cpu().numpy()
+        hcost = st["hist_cost"][:npos].cpu().numpy()
+        hyps = []
+        for p, col in zip(fin_pos, fin_col):
+            toks, run = [], []
+            for q in range(int(p), -1, -1):
+                toks.append(hc[q, col])
+                run.append(hcost[q, col])
+                col = hp[q, col]
+            tokens = numpy.array([first_token] + toks[::-1], dtype=numpy.int64)
+            running = numpy.array([numpy.float32(0)] + run[::-1], dtype=numpy.float32)
+            hyps.append((tokens, running))
+        # final ranking: cumulative cost minus the discount per row of the cost column; Python's sort is stable, so equal
+        # scores keep the order of completion (patience mode: of the truncated, sorted list)
+        hyps.sort(key=lambda h: h[1][-1] - char_discount * len(h[1]))
+        longest = max(len(t) for t, _ in hyps)
+        out_tokens = numpy.zeros((longest, len(hyps)))
+        out_mask = numpy.zeros((longest, len(hyps)))
+        out_running = numpy.zeros((longest, len(hyps)))
+        for col, (tokens, running) in enumerate(hyps):
+            n = len(tokens)
+            out_tokens[:n, col] = tokens
             out_mask[:n, col] = 1
-            out_running[:n, col] = f.running
-            out_running[n:, col] = f.running[-1]
+            out_running[:n, col] = running
+            out_running[n:, col] = running[-1]
         # drop the initial pseudo-token; step costs = differences of the running costs
         result = out_tokens[1:], out_mask[1:], out_running[1:] - out_running[:-1]
         return result if as_arrays else self.result_to_lists(result)

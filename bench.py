@@ -205,7 +205,7 @@ def main():
         raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d" % (args.gpus, world))
     if args.workload == "wsj_decode":
         from tools.bench_decode import decode_bench
-        return decode_bench(args, rank, world, local_rank)
+        return decode_bench(args, rank, world, local_rank, json_out)
     if EMULATED:
         sys.path.insert(0, os.path.join(REPO, "tests"))
         from emu import emu_lib

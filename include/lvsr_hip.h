@@ -126,7 +126,8 @@ typedef struct lvsr_attdec_args {
     int Tp, B, L, E, D, M, K, c;          /* K = conv_num_filters (0: content-only attention), c = conv_n */
     int prior_type;                       /* 0 expanding, 1 window_around_mean, 2 window_around_median */
     int step0;                            /* value of the reference's `step` state at slot 0 */
-    int phases;                           /* bit0: attention (glimpse) part, bit1: GRU part, of every step */
+    int phases;                           /* bit0: attention (glimpse) part, bit1: GRU part, of every step; bit2: pos slot 0 is
+                                             already filled by the caller (window_around_* priors) */
     int normalizer;                       /* energy_normalizer: 0 softmax, 1 logistic, 2 relu (lvsr/bricks/attention.py:191-213) */
     double p0, p1, p2, p3;                /* expanding: initial_begin, initial_end, f32(min_speed), f32(max_speed); window_around_*: before, after */
     /* contexts; element (t,b,x) at base[t*ts + b*bs + x]; bs = 0 broadcasts one utterance (beam search) */
@@ -162,6 +163,8 @@ typedef struct lvsr_attdec_args {
     float* sg;                            /* (B,2D) state part of the gate pre-activations */
     float* xin;                           /* (B,D) candidate input */
     float* ep;                            /* (B,ceil(M/32),Tp) partial energies of the match-dim slices */
+    const int* step_dev;                  /* optional device word added to step0 (graph-replayed generation: the position
+                                             counter of lvsr_beam_select), else NULL */
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
@@ -242,6 +245,71 @@ typedef struct lvsr_opt_args {
     float adaptive_decay, pad1;
 } lvsr_opt_args;
 int lvsr_opt_step(void* stream, const lvsr_opt_args* a);
+
+/* Generation-time readout + emitter of n rows in one launch (one work-group per row):
+ * Readout.readout (libs/blocks/blocks/bricks/sequence_generators.py:614-619) with the post-merge stack of
+ * lvsr/bricks/recognizer.py:298-320, then SoftmaxEmitter.costs (:788-791) or, with lm_add, ShallowFusionReadout + LMEmitter
+ * (lvsr/bricks/language_models.py:92-184), and optionally SoftmaxEmitter.emit (:770-776): the class drawn by inverse CDF
+ * from uniforms[r] (Theano's MultinomialFromUniform rule) and its cost. */
+typedef struct lvsr_readout_step_args {
+    const float* S; const float* WA;      /* (n,D) states (row stride lds), (n,E) weighted averages (row stride ldwa) */
+    int lds, ldwa, n, D, E, P, V, act;    /* P = merge width; act: 0 identity, 1 Maxout(2), 2 Rectifier, 3 Tanh */
+    const float* Wms;                     /* merge/transform_states.W (D,P) or NULL (use_states_for_readout = False) */
+    const float* Wmw;                     /* merge/transform_weighted_averages.W (E,P) */
+    const float* bias1;                   /* post_merge/bias.b (P), or readout/bias.b when there is no post-merge layer */
+    const float* Wout; const float* bout; /* post_merge/mlp/linear_0.{W (P or P/2,V), b (V)} or NULL (then P == V) */
+    const float* lm_add;                  /* (n,V) language-model look-ahead costs or NULL */
+    float am_beta, lm_weight;
+    int norm_am, norm_lm, norm_tot;
+    float* neglogp;                       /* (n,V) out: step costs of every class, or NULL */
+    float* logits;                        /* (n,V) out, or NULL */
+    const float* uniforms;                /* (n) in [0,1): emit, or NULL */
+    long long* outputs; float* costs;     /* (n) out: emitted class and its cost (with uniforms) */
+} lvsr_readout_step_args;
+int lvsr_readout_step(void* stream, const lvsr_readout_step_args* a);
+
+/* ---- beam search on the device ------------------------------------------------------------------------
+ * The candidate selection, stopping rules and bookkeeping of BeamSearch.search (libs/blocks/blocks/search.py:244-407)
+ * as one launch per emitted character; see csrc/beam.hip for the rules that are kept.  State words:
+ *   ctl[0] live hypotheses, [1] position, [2] done (0 running, 1 stopping rule, 2 beam empty, 3 max_length), [3] finished
+ *   hypotheses, [4] patience left (-1 = unassigned), [5] rows selected by the last step, [6] error (1 non-finite step cost,
+ *   2 finished list full, 3 patience used before assignment = the reference's UnboundLocalError), [7] steps executed;
+ *   fctl[0] best finished score seen (patience rule; the caller initialises it to 1000).
+ * The caller zeroes ctl (ctl[0] = 1, ctl[4] = -1), running[0] = 0, live_col[0] = 0 and fills row 0 of the live buffers. */
+typedef struct lvsr_beam_args {
+    int K, V, eol, ignore_first_eol;      /* beam size, characters, <eol> label, keep <eol> hypotheses alive at position 0 */
+    int stop_on;                          /* 0 patience, 1 optimistic_future_cost */
+    int max_length, fin_cap, D, Tp;       /* positions, capacity of the finished list (>= 2K), state / alignment widths */
+    float round_to_inf;
+    double char_discount;
+    int* ctl; float* fctl;
+    const float* neglogp;                 /* (K,V) step costs of the live hypotheses (rows >= ctl[0] ignored) */
+    float* running; int* live_col;        /* (K) cumulative cost / history column of live hypothesis i */
+    int* hist_parent; int* hist_char; float* hist_cost;     /* (max_length,K) back-pointers: parent column, character, cost */
+    int* fin_pos; int* fin_col; float* fin_cost; float* fin_score;     /* (fin_cap) finished hypotheses */
+    int* keep;                            /* (K) out: selected row that becomes live row i (rows >= new ctl[0]: keep[0]) */
+    long long* chars;                     /* (K) out: chosen characters = feedback labels of the next-state pass */
+    int* parents;                         /* (K) out: live row each chosen candidate extends */
+    /* rows of the next-state pass: sel[k] = live[parent of candidate k] (rows >= ctl[5] replicate candidate 0) */
+    const float* S_live; const float* W_live; float* S_sel; float* W_sel;          /* (K,D) / (K,Tp) */
+    const long long* lm_states_live; const double* lm_weights_live;                /* (K,7) or NULL */
+    long long* lm_states_sel; double* lm_weights_sel;
+    const float* pos_live; float* pos_sel;                                         /* (K) window centres or NULL */
+    /* one-hot feedback (embed_outputs = False): fork inputs of the chosen characters, xg[k] = [Wi[c]+bi | Wg[c]+bg];
+     * fork_xg = NULL when the caller computes them itself (lookup feedback) */
+    float* fork_xg; const float* fork_Wi; const float* fork_Wg; const float* fork_bi; const float* fork_bg; int fork_rows;
+    /* lvsr_beam_compact: live row i <- row keep[i] of the next-state pass */
+    const float* pos_new; float* pos_live_out;
+    const float* S_new; const float* W_new; float* S_live_out; float* W_live_out;
+    const long long* lm_states_new; const double* lm_weights_new; const float* lm_add_new;      /* or NULL */
+    long long* lm_states_live_out; double* lm_weights_live_out; float* lm_add_live_out;
+} lvsr_beam_args;
+/* two launches: the selection kernel (one work-group) and the row gather / feedback fork of the K chosen candidates */
+int lvsr_beam_select(void* stream, const lvsr_beam_args* a);
+int lvsr_beam_compact(void* stream, const lvsr_beam_args* a);
+/* `_smallest` (libs/blocks/blocks/search.py:221-242) alone: the k smallest of costs[0..n) ascending, equal values in index
+ * order; idx (k) / val (k) on the device.  n <= 8192, k <= 256. */
+int lvsr_topk_smallest(void* stream, const float* costs, int n, int k, long long* idx, float* val);
 
 /* ShallowFusionReadout.readout (lvsr/bricks/language_models.py:92-104):
  * out = [logsoftmax](am_beta*am) + lm_weight*[logsoftmax](-lm_add) [-> logsoftmax]; with an LM the emitter is

@@ -254,6 +254,22 @@ inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
     return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
 }
 #define __builtin_amdgcn_mov_dpp hipemu_mov_dpp
+// v_readlane_b32: the value lane `src` holds, for every lane (all lanes of the wave must reach the call)
+inline int hipemu_readlane(int v, int src) { return (int)hipemu::shfl_generic<long long, long long>(v, src); }
+#define __builtin_amdgcn_readlane hipemu_readlane
+inline unsigned long long __ballot(int pred) {
+    unsigned long long m = 0;
+    for (int src = 0; src < hipemu::wave_size_here(); ++src)
+        if (hipemu::shfl_generic<long long, long long>(pred ? 1 : 0, src) != 0) m |= 1ull << src;
+    return m;
+}
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __shfl_up(int v, unsigned d, int width = 64) {
+    int l = hipemu::lane_id();
+    int src = l - (int)d;
+    if (src < 0 || src / width != l / width) src = l;
+    return (int)hipemu::shfl_generic<long long, long long>(v, src);
+}
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 

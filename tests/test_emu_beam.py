@@ -65,3 +65,72 @@ def test_generation_states_are_not_overwritten_by_the_next_step():
         keepS, keepW = S.clone(), W.clone()
         gen.generation_logprobs(S, W, step + 1)
         assert torch.equal(S, keepS) and torch.equal(W, keepW)
+
+
+# ---- the selection rule alone (lvsr_topk_smallest) against the reference's `_smallest` (search.py:221-242) -------------
+def _reference_smallest(matrix, k):
+    flat = matrix.ravel()
+    k = min(k, flat.size)
+    args = numpy.argpartition(flat, k)[:k] if flat.size > k else numpy.arange(flat.size)
+    args = args[numpy.argsort(flat[args])]
+    return numpy.unravel_index(args, matrix.shape), flat[args]
+
+
+def check_smallest(bs):
+    rng = numpy.random.RandomState(0)
+    cases = [rng.normal(size=(5, 7)), rng.normal(size=(1, 33)), rng.normal(size=(16, 33)), rng.normal(size=(3, 2)),
+             numpy.abs(rng.normal(size=(40, 33))) * 50, -numpy.abs(rng.normal(size=(9, 11)))]
+    for m in cases:
+        m = m.astype(numpy.float32)
+        for k in (1, 4, 16, min(m.size, 200), min(m.size + 5, 256)):          # k <= 256 (kernel capacity)
+            (r, c), v = bs._smallest(m, k)
+            (rr, rc), rv = _reference_smallest(m, k)
+            assert numpy.array_equal(v, rv) and numpy.array_equal(r, rr) and numpy.array_equal(c, rc)     # no ties: identical
+    # adversarial ties: many equal values around (and inside) the cut.  The reference's order among EQUAL values is whatever
+    # introselect + quicksort leave (not portable across numpy builds); the device rule is stable: equal values in flat-index
+    # order.  What both must agree on is the multiset of values, and every device pick must be a smallest-possible index.
+    for trial in range(20):
+        m = rng.randint(0, 4, size=(rng.randint(1, 17), 33)).astype(numpy.float32) * 0.5
+        if trial % 3 == 0:
+            m[:, ::2] = -0.0                              # negative zero sorts before +0.0 only in the bit pattern
+            m[:, 1::2] = 0.0
+        k = int(rng.randint(1, 40))
+        (r, c), v = bs._smallest(m, k)
+        (_, _), rv = _reference_smallest(m, k)
+        assert numpy.array_equal(numpy.sort(v), numpy.sort(rv)) if trial % 3 else numpy.allclose(v, rv)
+        flat = r * m.shape[1] + c
+        order = numpy.lexsort((flat, v)) if trial % 3 else numpy.arange(len(v))
+        assert numpy.array_equal(order, numpy.arange(len(v)))                      # ascending values, then ascending index
+        if trial % 3:
+            kth = v[-1]
+            ties_taken = flat[v == kth]
+            all_ties = numpy.flatnonzero(m.ravel() == kth)
+            assert numpy.array_equal(ties_taken, all_ties[: len(ties_taken)])     # the lowest indices of the tied value
+
+
+def test_smallest_on_the_device_matches_the_reference_rule():
+    from lvsr_amd.search import BeamSearch
+    z, meta = load_golden("tiny_conv_median")
+    rec = SpeechRecognizer(device="cpu", params=synthetic.make_params(meta["cfg"], seed=5), lib=emu_lib(), net_config=meta["cfg"])
+    check_smallest(BeamSearch(4, rec))
+
+
+def test_validate_solution_function_vetoes_finished_hypotheses():
+    """search.py:372-374: a rejected hypothesis leaves the beam but is not recorded; with a validator the driver steps with the
+    host in the loop and must give the same result as the free-running device loop when nothing is rejected."""
+    z, meta = load_golden("tiny_conv_nowindow")
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=meta["cfg"])
+    b = meta["beam"][0]
+    s = dict(b["settings"])
+    s.pop("utt", 0)
+    rec.init_beam_search(s.pop("beam_size"))
+    x = batch["recordings"][: int(batch["recordings_mask"][:, 0].sum()), 0]
+    seen = []
+    outs, costs = rec.beam_search({"recordings": x}, validate_solution_function=lambda inp, toks: seen.append(list(toks)) or True, **s)
+    assert outs == b["outputs"] and len(seen) >= len(outs)
+    assert all(t[0] == meta["cfg"]["num_phonemes"] for t in seen)                 # the validator sees the initial pseudo-token too
+    best = outs[0]
+    outs2, _ = rec.beam_search({"recordings": x}, validate_solution_function=lambda inp, toks: list(toks[1:]) != best, **s)
+    assert best not in outs2 and len(outs2) > 0                 # the search goes on without it (other hypotheses may appear)

@@ -140,8 +140,35 @@ def test_full_size_configs_vs_reference_golden(gpu_device, case):
 @pytest.mark.parametrize("case", ["tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_logistic", "tiny_conv_relu",
                                   "tiny_conv_bottom", "tiny_content_embed", "tiny_content_relu", "small_conv_median"])
 def test_beam_search_vs_reference_golden(gpu_device, case):
+    """Twice: the first search of a shape runs its positions eagerly / captures the step graph, the second replays it."""
     from test_emu_beam import run_beam_case
     run_beam_case(case, gpu_device, None)
+    run_beam_case(case, gpu_device, None)
+
+
+def test_topk_smallest_on_the_gpu(gpu_device):
+    from test_emu_beam import check_smallest
+    from lvsr_amd.search import BeamSearch
+    z, meta = load_golden("tiny_conv_median")
+    rec = SpeechRecognizer(device=gpu_device, params=synthetic.make_params(meta["cfg"], seed=5), net_config=meta["cfg"])
+    check_smallest(BeamSearch(4, rec))
+
+
+def test_beam_step_graph_replay_equals_eager_steps(gpu_device):
+    """The same search three times on one recognizer (eager positions, capture, pure replay) and once on a recognizer without
+    graphs: identical hypotheses and costs; the device loop leaves no host synchronisation but the polls."""
+    z, meta = load_golden("small_conv_median")
+    params, batch = _setup(meta)
+    x = batch["recordings"][: int(batch["recordings_mask"][:, 1].sum()), 1]
+    kw = dict(char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost")
+    results = []
+    for use_graph in (True, True, True, False):
+        if not results or not use_graph:
+            rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"], use_graph=use_graph)
+            rec.init_beam_search(6)
+        results.append(rec.beam_search({"recordings": x}, **kw))
+    for outs, costs in results[1:]:
+        assert outs == results[0][0] and costs == results[0][1]
 
 
 def test_wsj_deep_shapes_vs_oracle(gpu_device):

@@ -1,45 +1,122 @@
-"""Decode benchmark (BASELINE.json configs[4], reported in DESIGN.md; not the bench.py metric): beam search width 16 with a
-synthetic character FST language model (shallow fusion) over synthetic WSJ-shape utterances, WSJ-base weights, window_around_median
-prior (exp/wsj/decode.sh settings: lm.weight 0.5, no_transition_cost 20, char_discount 1.0, before 10 / after 100)."""
-import argparse, json, os, sys, time
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "attention-lvcsr_amd"))
-import numpy, torch
-from lvsr_amd import spec, synthetic, lm as LM
-from lvsr_amd.bricks.recognizer import SpeechRecognizer
-from lvsr_amd.search import CandidateNotFoundError
+"""Decode benchmark (BASELINE.json configs[4]; `python bench.py --workload wsj_decode`): beam search width 16 with a synthetic
+character-trigram FST language model (shallow fusion) over synthetic WSJ-shape utterances (T = 800 frames), WSJ-base weights
+(random init, seed 10), window_around_median prior and the settings of exp/wsj/decode.sh:12-25 (lm.weight 0.5,
+no_transition_cost 20, char_discount 1.0, before 10 / after 100, max length T/3, stop_on optimistic_future_cost).
+Decoding has no exchange step: with N GPUs rank r decodes utterances r::N ("replicas only").
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--utts", type=int, default=8)
-ap.add_argument("--frames", type=int, default=800)
-ap.add_argument("--beam", type=int, default=16)
-ap.add_argument("--no-lm", action="store_true")
-ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
-args = ap.parse_args()
-cfg = spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100))
-cfg["max_decoded_length_scale"] = 3.0
-rec = SpeechRecognizer(device="cuda:0", params=synthetic.make_params(cfg, seed=10, scale=1.0), net_config=cfg)
-if not args.no_lm:
-    fst, cmap = LM.char_ngram_fst(33, seed=7)
-    if args.host_lm:
-        rec.set_language_model(LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
-    else:
-        rec.set_language_model(LM.DeviceFSTLanguageModel(fst, "cuda:0", nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
-rec.init_beam_search(args.beam)
-rng = numpy.random.RandomState(1234)
-done, steps, t0 = 0, 0, None
-for i in range(args.utts + 1):
-    x = rng.normal(size=(args.frames, 40)).astype(numpy.float32)
-    if i == 1:
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-    try:
-        outs, costs = rec.beam_search({"recordings": x}, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")
-        n = len(outs[0])
-    except CandidateNotFoundError:
-        n = 0
-    if i >= 1:
-        done += 1; steps += n
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(json.dumps(dict(metric="beam-search decode", utterances=done, beam=args.beam, lm=not args.no_lm, frames_per_utt=args.frames,
-                      sec_per_utt=dt / done, frames_per_sec=done * args.frames / dt, mean_best_len=steps / done)))
+    python bench.py --workload wsj_decode [--utterances 1000] [--gpus N]
+    python tools/bench_decode.py [--utts 8] [--frames 800] [--beam 16] [--no-lm] [--host-lm]      (stand-alone, one GPU)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (REPO, os.path.join(REPO, "attention-lvcsr_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy
+import torch
+
+
+def build(device, beam=16, lm="device"):
+    from lvsr_amd import spec, synthetic, lm as LM
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    cfg = spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100))
+    cfg["max_decoded_length_scale"] = 3.0
+    rec = SpeechRecognizer(device=device, params=synthetic.make_params(cfg, seed=10, scale=1.0), net_config=cfg)
+    if lm != "none":
+        fst, cmap = LM.char_ngram_fst(33, seed=7)
+        if lm == "host":
+            rec.set_language_model(LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
+        else:
+            rec.set_language_model(LM.DeviceFSTLanguageModel(fst, device, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
+    rec.init_beam_search(beam)
+    return rec, cfg
+
+
+def run(rec, utterances, frames, rank=0, world=1, warm=1):
+    """Decode utterances rank::world of the seeded synthetic set; returns (seconds, utterances, frames, characters, steps)."""
+    from lvsr_amd.search import CandidateNotFoundError
+    done = chars = steps = 0
+    t0 = None
+    ids = list(range(rank, utterances, world))
+    for j, i in enumerate([ids[0]] * warm + ids):
+        x = numpy.random.RandomState(1234 + i).normal(size=(frames, 40)).astype(numpy.float32)
+        if j == warm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+        try:
+            outs, costs = rec.beam_search({"recordings": x}, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")
+            n = len(outs[0])
+        except CandidateNotFoundError:
+            n = 0
+        if j >= warm:
+            done += 1
+            chars += n
+            steps += rec._beam_search.last_stats.get("positions", 0)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, done, done * frames, chars, steps
+
+
+def decode_bench(args, rank, world, local_rank, json_out=None):
+    """The bench.py line of configs[4]."""
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = world > 1
+    if dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    json_out = json_out or sys.stdout
+    utterances = args.utterances or 1000
+    frames, beam = 800, 16
+    rec, cfg = build(dev, beam)
+    if dist:
+        torch.distributed.barrier()
+    sec, done, nframes, chars, steps = run(rec, utterances, frames, rank, world)
+    tot = torch.tensor([sec, done, nframes, chars, steps], dtype=torch.float64, device=dev)
+    if dist:
+        mx = tot[:1].clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(tot)
+        tot[0] = mx[0]
+    sec, done, nframes, chars, steps = [float(v) for v in tot]
+    if rank == 0:
+        d = rec.d
+        out = dict(metric="WSJ decode frames/sec: beam search width 16 + FST language model shallow fusion (whole node)",
+                   value=nframes / sec, unit="frames/s", n_gpus=world, steps=int(done), warmup=1, ms_per_step=sec / max(done / world, 1) * 1e3,
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="wsj_decode: %d synthetic utterances x %d frames, WSJ-base weights (random init), beam %d, "
+                                        "window_around_median(before=10, after=100), char-trigram FST LM on the device (weight 0.5, "
+                                        "no_transition_cost 20), char_discount 1.0, max length T/3, stop_on optimistic_future_cost"
+                                        % (int(done), frames, beam),
+                               utterances_per_sec=done / sec, sec_per_utterance=sec / max(done / world, 1), parallelism="replicas%d" % world,
+                               mean_best_hypothesis_length=chars / max(done, 1), positions_per_utterance=steps / max(done, 1),
+                               us_per_position=(sec * 1e6 * world / steps if steps else None),
+                               launches_per_position="one hipGraph replay (21 kernel nodes: 2 x attention pass, readout, fusion, "
+                                                     "select, feedback fork, GRU, FST walk, compaction); no device->host "
+                                                     "synchronisation except one look at the `done` word every 8 positions",
+                               encoder="persistent clusters, batch 1 (8 work-groups)"))
+        print(json.dumps(out), file=json_out, flush=True)
+    if dist:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--utts", type=int, default=8)
+    ap.add_argument("--frames", type=int, default=800)
+    ap.add_argument("--beam", type=int, default=16)
+    ap.add_argument("--no-lm", action="store_true")
+    ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
+    a = ap.parse_args()
+    rec, _ = build("cuda:0", a.beam, "none" if a.no_lm else ("host" if a.host_lm else "device"))
+    sec, done, nframes, chars, steps = run(rec, a.utts, a.frames)
+    print(json.dumps(dict(metric="beam-search decode", utterances=done, beam=a.beam, lm=not a.no_lm, frames_per_utt=a.frames,
+                          sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,
+                          positions_per_utt=steps / done, us_per_position=sec * 1e6 / max(steps, 1))))
