@@ -257,58 +257,95 @@ __global__ __launch_bounds__(256) void readout_step_kernel(lvsr_readout_step_arg
         logits = lg;
     }
     if (a.logits) for (int v = tid; v < a.V; v += 256) a.logits[(size_t)r * a.V + v] = logits[v];
-    if (tid >= 64) return;
-    // ---- emitter, one wave
-    const int lane = tid, V = a.V;
+    // ---- emitter: wave 0 (the others only keep the barriers company)
+    const int lane = tid & 63, V = a.V;
+    const bool w0 = tid < 64;
     const float* l = a.lm_add ? a.lm_add + (size_t)r * V : nullptr;
-    float lse_a = 0.f, lse_l = 0.f, lse_t = 0.f, mx0 = 0.f;
-    if (!l) {
-        // SoftmaxEmitter: the same arithmetic as softmax_nll_kernel ((x - max) - log(sum))
-        mx0 = -3.0e38f;
-        for (int v = lane; v < V; v += 64) mx0 = fmaxf(mx0, logits[v]);
-        mx0 = wave_max(mx0);
-        float s0 = 0.f;
-        for (int v = lane; v < V; v += 64) s0 += expf(logits[v] - mx0);
-        lse_a = logf(wave_sum(s0));
-    } else {
-        // ShallowFusionReadout: the same arithmetic as shallow_fusion_kernel
-        lse_a = a.norm_am ? row_lse(logits, V, a.am_beta, lane) : 0.f;
-        lse_l = a.norm_lm ? row_lse(l, V, -1.f, lane) : 0.f;
-        if (a.norm_tot) {
-            float mx = -3.0e38f;
-            for (int v = lane; v < V; v += 64) mx = fmaxf(mx, (a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l));
-            mx = wave_max(mx);
-            float s = 0.f;
-            for (int v = lane; v < V; v += 64) s += expf(((a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l)) - mx);
-            s = wave_sum(s);
-            lse_t = mx + logf(s);
+    if (w0) {
+        float lse_a = 0.f, lse_l = 0.f, lse_t = 0.f, mx0 = 0.f;
+        if (!l) {
+            // SoftmaxEmitter: the same arithmetic as softmax_nll_kernel ((x - max) - log(sum))
+            mx0 = -3.0e38f;
+            for (int v = lane; v < V; v += 64) mx0 = fmaxf(mx0, logits[v]);
+            mx0 = wave_max(mx0);
+            float s0 = 0.f;
+            for (int v = lane; v < V; v += 64) s0 += expf(logits[v] - mx0);
+            lse_a = logf(wave_sum(s0));
+        } else {
+            // ShallowFusionReadout: the same arithmetic as shallow_fusion_kernel
+            lse_a = a.norm_am ? row_lse(logits, V, a.am_beta, lane) : 0.f;
+            lse_l = a.norm_lm ? row_lse(l, V, -1.f, lane) : 0.f;
+            if (a.norm_tot) {
+                float mx = -3.0e38f;
+                for (int v = lane; v < V; v += 64) mx = fmaxf(mx, (a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l));
+                mx = wave_max(mx);
+                float s = 0.f;
+                for (int v = lane; v < V; v += 64) s += expf(((a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l)) - mx);
+                s = wave_sum(s);
+                lse_t = mx + logf(s);
+            }
+        }
+        // log-probabilities of the step in xin (free again), costs = their negation
+        for (int v = lane; v < V; v += 64) {
+            const float lp = l ? ((a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l)) - lse_t : (logits[v] - mx0) - lse_a;
+            xin[v] = lp;
+            if (a.neglogp) a.neglogp[(size_t)r * V + v] = -lp;
         }
     }
-    // log-probabilities of the step in xin (free again), costs = their negation
-    for (int v = lane; v < V; v += 64) {
-        const float lp = l ? ((a.am_beta * logits[v] - lse_a) + a.lm_weight * (-l[v] - lse_l)) - lse_t : (logits[v] - mx0) - lse_a;
-        xin[v] = lp;
-        if (a.neglogp) a.neglogp[(size_t)r * V + v] = -lp;
-    }
-    if (a.uniforms) {
+    __syncthreads();
+    if (a.uniforms && tid == 0) {
         // SoftmaxEmitter.emit: multinomial by inverse CDF over the class order (MultinomialFromUniform: the first class whose
         // running float32 sum of probabilities exceeds the uniform; none -> class 0 as argmax of an all-zero row)
-        if (lane == 0) {
-            const float u = a.uniforms[r];
-            float cum = 0.f;
-            int pick = 0;
-            bool hit = false;
-            for (int v = 0; v < V; ++v) {
-                cum += expf(xin[v]);
-                if (!hit && cum > u) { pick = v; hit = true; }
-            }
-            a.outputs[r] = pick;
-            if (a.costs) a.costs[r] = -xin[pick];
+        const float u = a.uniforms[r];
+        float cum = 0.f;
+        int pick = 0;
+        bool hit = false;
+        for (int v = 0; v < V; ++v) {
+            cum += expf(xin[v]);
+            if (!hit && cum > u) { pick = v; hit = true; }
         }
+        a.outputs[r] = pick;
+        if (a.costs) a.costs[r] = -xin[pick];
+    }
+}
+
+// SoftmaxEmitter.emit alone (sequence_generators.py:770-776): class by inverse CDF of softmax(logits[r]) at uniforms[r]
+// (MultinomialFromUniform: first class whose running float32 sum exceeds the uniform), and its cost; one wave per row.
+__global__ __launch_bounds__(256) void softmax_emit_kernel(const float* logits, int ld, const float* uniforms, int n, int V,
+                                                           long long* outputs, float* costs) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const float* x = logits + (size_t)r * ld;
+    float mx = -3.0e38f;
+    for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int v = lane; v < V; v += 64) s += expf(x[v] - mx);
+    const float lse = logf(wave_sum(s));
+    if (lane == 0) {
+        const float u = uniforms[r];
+        float cum = 0.f;
+        int pick = 0;
+        bool hit = false;
+        for (int v = 0; v < V; ++v) {
+            cum += expf((x[v] - mx) - lse);
+            if (!hit && cum > u) { pick = v; hit = true; }
+        }
+        outputs[r] = pick;
+        if (costs) costs[r] = -((x[pick] - mx) - lse);
     }
 }
 
 extern "C" {
+
+int lvsr_softmax_emit(void* stream, const float* logits, int ld, const float* uniforms, int n, int V, long long* outputs,
+                      float* costs) {
+    LVSR_REQUIRE(logits && uniforms && outputs && V > 0, "lvsr_softmax_emit: bad arguments");
+    if (n <= 0) return LVSR_OK;
+    hipLaunchKernelGGL(softmax_emit_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, uniforms, n, V, outputs,
+                       costs);
+    return lvsr_check_launch("lvsr_softmax_emit");
+}
 
 int lvsr_readout_step(void* stream, const lvsr_readout_step_args* args) {
     LVSR_REQUIRE(args != nullptr, "lvsr_readout_step: null args");

@@ -416,6 +416,110 @@ for _k, _v in _generation_methods().items():
 SequenceGenerator.language_model = None
 
 
+# ---- free-running generation: SequenceGenerator.generate / initial_states, SoftmaxEmitter.emit ---------------------------
+def _sampling_methods():
+    def initial_states(self, batch_size, attended=None, attended_mask=None):
+        """BaseSequenceGenerator.initial_states (sequence_generators.py:404-422): initial values of the `generate` states:
+        states = tiled initial_state (recurrent.py:622-624), outputs = SoftmaxEmitter.initial_outputs (num_phonemes,
+        recognizer.py:286), glimpses = initial_glimpses (lvsr/bricks/attention.py:215-222)."""
+        d, p, n_ = self.d, self.store.p, self.n
+        dev = p[n_["h0"]].device
+        B = int(batch_size)
+        Tp = int(attended.shape[0]) if attended is not None else 0
+        out = dict(states=p[n_["h0"]].unsqueeze(0).expand(B, d.D).clone(),
+                   outputs=torch.full((B,), d.V, dtype=torch.int64, device=dev),
+                   weighted_averages=torch.zeros(B, d.E, device=dev), weights=torch.zeros(B, Tp, device=dev))
+        if d.conv:
+            if Tp:
+                out["weights"][:, 0] = 1.0
+            out["energies"] = out["weights"].clone()
+            out["step"] = torch.zeros(B, dtype=torch.int64, device=dev)
+        return out
+
+    def emit(self, readouts, uniforms=None, seed=None):
+        """SoftmaxEmitter.emit (sequence_generators.py:770-776) on readouts (n,V): one class per row by inverse CDF of the
+        softmax at a uniform number per row.  `uniforms` (n) in [0,1) or None = drawn from torch's Philox generator
+        (`seed`; the reference draws from Theano's MRG31k3p: another stream of the same distribution).  -> (outputs, costs)."""
+        d, lib = self.d, self.lib
+        x = readouts.contiguous()
+        n = int(x.shape[0])
+        u = self._uniforms((n,), uniforms, seed, x.device)
+        out = torch.empty(n, dtype=torch.int64, device=x.device)
+        cost = torch.empty(n, dtype=torch.float32, device=x.device)
+        lib.call("lvsr_softmax_emit", lib.stream_for(x), lib_ptr(x), int(x.stride(0)), lib_ptr(u), n, int(x.shape[1]), lib_ptr(out),
+                 lib_ptr(cost))
+        return out, cost
+
+    def _uniforms(self, shape, uniforms, seed, dev):
+        if uniforms is not None:
+            u = torch.as_tensor(numpy.ascontiguousarray(uniforms, dtype=numpy.float32)) if not torch.is_tensor(uniforms) else uniforms
+            u = u.to(dev).to(torch.float32).contiguous()
+            assert tuple(u.shape) == tuple(shape), "uniforms must have shape %s" % (tuple(shape),)
+            return u
+        if dev.type == "cuda":
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(int(seed if seed is not None else 1))
+            return torch.rand(shape, generator=gen, device=dev, dtype=torch.float32)
+        gen = torch.Generator()
+        gen.manual_seed(int(seed if seed is not None else 1))
+        return torch.rand(shape, generator=gen, dtype=torch.float32)
+
+    def generate(self, n_steps=None, batch_size=None, attended=None, attended_mask=None, uniforms=None, seed=None):
+        """BaseSequenceGenerator.generate under its `recurrent` wrapper (sequence_generators.py:328-377): per step
+        take_glimpses(previous states and glimpses) -> readout -> emit -> cost -> feedback/fork -> compute_states, all on the
+        device with no host synchronisation.  attended (T',B,E), attended_mask (T',B); `uniforms` (n_steps,B) fixes the
+        draws (see `emit`).  -> dict(states (n,B,D), outputs (n,B) int64, weighted_averages (n,B,E), weights (n,B,T'),
+        energies (n,B,T'), costs (n,B))."""
+        d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
+        if self.language_model is not None:
+            raise NotImplementedError("generate() with a language model is not built (beam search is)")
+        N = int(n_steps)
+        Tp, B = int(attended.shape[0]), int(attended.shape[1])
+        assert batch_size is None or int(batch_size) == B
+        pk = self._packed()
+        A, Am = attended.contiguous(), attended_mask.contiguous()
+        PA = self.preprocess(A)
+        dev = A.device
+        u = self._uniforms((N, B), uniforms, seed, dev)
+        Kc = max(d.K, 1)
+        pos_needed = d.conv and self._prior()[0] != 0
+        S = ws.get("sg.S", (N + 1, B, d.D))
+        W = ws.get("sg.W", (N + 1, B, Tp))
+        first = self.initial_states(B, attended=A)
+        S[0].copy_(first["states"])
+        W[0].copy_(first["weights"])
+        full = dict(xg=ws.get("sg.xg", (N, B, 3 * d.D)), S=S, W=W, pos=ws.get("sg.pos", (N + 1, B)) if pos_needed else None,
+                    WA=ws.get("sg.WA", (N, B, d.E)), EN=ws.get("sg.EN", (N, B, Tp)), sW=ws.get("sg.sW", (N, B, d.M)),
+                    CV=ws.get("sg.CV", (N, B, Kc, Tp)) if d.conv else None, U=ws.get("sg.U", (N, B, d.D)),
+                    R=ws.get("sg.R", (N, B, d.D)), C=ws.get("sg.C", (N, B, d.D)), RH=ws.get("sg.RH", (N, B, d.D)))
+        shared = dict(ymask=None, ZB=None, sg=ws.get("sg.sg", (B, 2 * d.D)), xin=ws.get("sg.xin", (B, d.D)),
+                      ep=ws.get("sg.ep", (B, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
+        outputs = ws.get("sg.outputs", (N, B), torch.int64)
+        costs = ws.get("sg.costs", (N, B))
+        fb = ws.get("sg.fb", (B, d.FB)) if d.embed else None
+        if pos_needed:
+            full["pos"][0].zero_()
+        st = lib.stream_for(S)
+        for t in range(N):
+            bufs = {k: (None if v is None else v[t:]) for k, v in full.items()}
+            bufs.update(shared)
+            skip = 4 if pos_needed else 0
+            fa = self._attdec_fields(pk, A, PA, Am, 1, B, bufs, phases=1 | skip, step0=t, broadcast=False)
+            lib.call("lvsr_attdec_fwd", st, ctypes.byref(lib.make("lvsr_attdec_args", **fa)), 0)
+            ra = self._readout_step_args(S[t], full["WA"][t], B, uniforms=u[t], outputs=outputs[t], costs=costs[t])
+            lib.call("lvsr_readout_step", st, ctypes.byref(ra))
+            self._feedback_fork(outputs[t], B, full["xg"][t], fb)
+            fg = self._attdec_fields(pk, A, PA, Am, 1, B, bufs, phases=2, step0=t, broadcast=False)
+            lib.call("lvsr_attdec_fwd", st, ctypes.byref(lib.make("lvsr_attdec_args", **fg)), 0)
+        return dict(states=S[1:], outputs=outputs, weighted_averages=full["WA"], weights=W[1:], energies=full["EN"], costs=costs)
+
+    return dict(initial_states=initial_states, emit=emit, _uniforms=_uniforms, generate=generate)
+
+
+for _k, _v in _sampling_methods().items():
+    setattr(SequenceGenerator, _k, _v)
+
+
 # ---- device-resident beam search (csrc/beam.hip): state of one search + the launches of one position ------------------
 CTL = dict(nlive=0, pos=1, done=2, nfin=3, patience=4, nsel=5, err=6, steps=7)
 

@@ -150,6 +150,31 @@ class SpeechRecognizer(object):
         return self.generator.cost_matrix(y, ym, attended=encoded, attended_mask=encoded_mask,
                                           save_for_backward=save_for_backward)
 
+    # ---- free-running generation (recognizer.py:393-406, 535-547) ------------------------------------------------------
+    def generate(self, n_steps=None, inputs_mask=None, recordings=None, uniforms=None, seed=None, **kw):
+        """SpeechRecognizer.generate: encoder, then SequenceGenerator.generate for `n_steps` steps on the whole batch.
+        -> dict(states, outputs, weighted_averages, weights, energies, costs) of device tensors, time-major."""
+        if "recordings_mask" in kw:
+            inputs_mask = kw.pop("recordings_mask")
+        if kw:
+            raise TypeError("unknown inputs: %s" % sorted(kw))
+        with self._on_stream():
+            x = self._t(recordings, torch.float32, "recordings")
+            xm = self._t(inputs_mask, torch.float32, "recordings_mask")
+            encoded, encoded_mask = self.encoder.apply(self.bottom.apply(x, False), xm, save_for_backward=False)
+            return self.generator.generate(n_steps=n_steps, batch_size=int(encoded.shape[1]), attended=encoded,
+                                           attended_mask=encoded_mask, uniforms=uniforms, seed=seed)
+
+    def sample(self, inputs, n_steps=None, uniforms=None, seed=None):
+        """SpeechRecognizer.sample (recognizer.py:540-547): one utterance, no input mask, n_steps defaults to
+        frames / max_decoded_length_scale; -> the sampled label sequence (n_steps, 1) as a numpy array."""
+        x = numpy.asarray(dict(inputs)["recordings"], dtype=numpy.float32)
+        if n_steps is None:
+            n_steps = int(x.shape[0] / self.max_decoded_length_scale)
+        out = self.generate(n_steps=n_steps, inputs_mask=None, recordings=x[:, None, :],
+                            uniforms=None if uniforms is None else numpy.asarray(uniforms, numpy.float32).reshape(n_steps, 1), seed=seed)
+        return out["outputs"].cpu().numpy()
+
     def backward(self):
         """Gradient of cost.sum() wrt all parameters -> self.store.grad (flat) / self.store.g (named views)."""
         with self._on_stream():

@@ -1,9 +1,8 @@
 """FST language model + shallow fusion for beam-search decoding (A17 of SURVEY.md §8a).
 
-Host-side state-set walk exactly as the reference's Theano host Ops do it (lvsr/ops.py:37-225: `FST.transition`,
-`FST.expand` = epsilon closure in the log semiring with a toposorted relaxation, `FSTTransitionOp`, `FSTCostsOp`;
-MAX_STATES = 7 padded state sets) wrapped like `FSTTransition` / `LanguageModel` (lvsr/bricks/language_models.py:14-72,
-107-137).  The fusion itself (`ShallowFusionReadout.readout`, language_models.py:92-104) is the device kernel
+What the reference's Theano host Ops compute (lvsr/ops.py:37-225: `FST.transition`, `FST.expand` = epsilon closure in the log
+semiring, `FSTTransitionOp`, `FSTCostsOp`; MAX_STATES = 7 padded state sets) is computed here by `CsrWalk` over the same CSR arc
+tables the device kernel walks, wrapped like `FSTTransition` / `LanguageModel` (lvsr/bricks/language_models.py:14-72, 107-137).  The fusion itself (`ShallowFusionReadout.readout`, language_models.py:92-104) is the device kernel
 `lvsr_shallow_fusion`.  The reference reads OpenFST binaries through PyFST; here the automaton is an in-memory arc list
 with an AT&T text reader and a reader/writer for OpenFST's binary `vector` / `standard` container (`read_openfst_binary`).
 
@@ -12,7 +11,7 @@ HIP kernel `lvsr_fst_lm_step` over a CSR arc table, with the same interface, so 
 """
 import math
 import struct
-from collections import defaultdict, deque
+from collections import defaultdict
 
 import numpy
 import torch
@@ -85,41 +84,81 @@ class ArcFST(object):
             f.isyms = dict(isyms)
         return f
 
-    # ---- lvsr/ops.py:51-97 --------------------------------------------------------------------------
-    @staticmethod
-    def combine_weights(*args):
-        m = max(a for a in args if a is not None) if any(a is not None for a in args) else None
-        return m - math.log(sum(math.exp(m - x) for x in args if x is not None))
-
-    def get_arcs(self, state, character):
-        return [(state, nxt, il, w) for (il, nxt, w) in self.arcs.get(state, ()) if il == character]
+    # ---- the state-set walk (what lvsr/ops.py:51-97 computes), over the CSR tables the device kernel uses ---------------
+    def walker(self):
+        """The host walk over this automaton's CSR arc tables (built once; invalidated when an arc is added)."""
+        sig = sum(len(v) for v in self.arcs.values())
+        if getattr(self, "_walker", None) is None or self._walker_sig != sig:
+            self._walker, self._walker_sig = CsrWalk(build_fst_table(self, {}, 0)), sig
+        return self._walker
 
     def transition(self, states, character):
-        arcs = [a for state in states for a in self.get_arcs(state, character)]
-        next_states = {}
-        for next_state in {arc[1] for arc in arcs}:
-            next_states[next_state] = self.combine_weights(*[states[arc[0]] + arc[3] for arc in arcs if arc[1] == next_state])
-        return next_states
+        """{state: -log weight} -> the set reached by arcs labelled `character` (no epsilon closure); parallel arcs and
+        several sources of one target are combined in the log semiring."""
+        return self.walker().advance(states, character)
 
     def expand(self, states):
-        seen, depends, queue = set(), defaultdict(list), deque()
-        for state in states:
-            queue.append(state)
-            seen.add(state)
-        while len(queue):
-            state = queue.popleft()
-            for arc in self.get_arcs(state, EPSILON):
-                depends[arc[1]].append((arc[0], arc[3]))
-                if arc[1] in seen:
-                    continue
-                queue.append(arc[1])
-                seen.add(arc[1])
-        order = _toposort_flatten({key: {s for s, _ in value} for key, value in depends.items()})
-        next_states = states
-        for next_state in order:
-            next_states[next_state] = self.combine_weights(
-                *([next_states.get(next_state)] + [next_states[prev] + weight for prev, weight in depends[next_state]]))
-        return next_states
+        """Epsilon closure of a weighted state set in the log semiring."""
+        return self.walker().close(states)
+
+
+def log_add(terms):
+    """-log(sum_i exp(-x_i)) of a non-empty list of -log weights, shifted by the largest term like the reference's
+    combine_weights (lvsr/ops.py:51-54) so that equal inputs give equal float64 results."""
+    m = max(terms)
+    return m - math.log(sum(math.exp(m - x) for x in terms))
+
+
+class CsrWalk(object):
+    """Host-side walk of a weighted state set over the CSR arc tables of `build_fst_table` — the same tables, topological
+    ranks and order of operations as the device kernel `lvsr_fst_lm_step` (csrc/fst_lm.hip), so the two are each other's
+    check; both are pinned to the reference's own dict walk through tests/golden/fst_walk.npz.
+      advance: labelled arcs of a state are sorted by label, so the arcs of one character are a contiguous run found by
+               bisection; contributions to one target are collected in (source order, arc order) and log-added;
+      close:   states reachable over epsilon arcs are relaxed in increasing topological rank; a state's weight is final when
+               it is visited (all its epsilon predecessors rank lower), then pushed along its epsilon arcs."""
+    def __init__(self, table):
+        self.t = table
+        self.arc_off, self.arc_lab = table["arc_off"].tolist(), table["arc_lab"].tolist()
+        self.arc_dst, self.arc_w = table["arc_dst"].tolist(), table["arc_w"].tolist()
+        self.eps_off, self.eps_dst, self.eps_w = table["eps_off"].tolist(), table["eps_dst"].tolist(), table["eps_w"].tolist()
+        self.rank = table["topo"].tolist()
+        self.num_states = table["num_states"]
+
+    def advance(self, states, label):
+        import bisect
+        into = {}
+        for q, w in states.items():
+            if q < 0 or q >= self.num_states:
+                continue
+            lo, hi = self.arc_off[q], self.arc_off[q + 1]
+            i = bisect.bisect_left(self.arc_lab, label, lo, hi)
+            while i < hi and self.arc_lab[i] == label:
+                into.setdefault(self.arc_dst[i], []).append(w + self.arc_w[i])
+                i += 1
+        return {d: log_add(terms) for d, terms in into.items()}
+
+    def close(self, states):
+        out = dict(states)
+        reach, stack = set(out), list(out)
+        while stack:                                   # everything reachable over epsilon arcs
+            q = stack.pop()
+            if q < 0 or q >= self.num_states:
+                continue
+            for i in range(self.eps_off[q], self.eps_off[q + 1]):
+                d = self.eps_dst[i]
+                if d not in reach:
+                    reach.add(d)
+                    stack.append(d)
+        pending = {}
+        for q in sorted((q for q in reach if 0 <= q < self.num_states), key=lambda q_: self.rank[q_]):
+            terms = pending.pop(q, None)
+            if terms:
+                out[q] = log_add(([out[q]] if q in out else []) + terms)
+            w = out[q]
+            for i in range(self.eps_off[q], self.eps_off[q + 1]):
+                pending.setdefault(self.eps_dst[i], []).append(w + self.eps_w[i])
+        return out
 
 
 def _pad(arr, value):
@@ -147,19 +186,14 @@ class FSTLanguageModel(object):
         self.norm = (bool(normalize_am_weights), bool(normalize_lm_weights), bool(normalize_tot_weights))
         self.out_dim = len(self.remap_table)
         self.device_add = None
-        # The walk is a pure function of the state set and of the weights RELATIVE to their minimum (costs are differences
-        # of log-sums, so a common offset cancels; transitions carry the offset through).  Hypotheses of a beam share LM
-        # states all the time, so memoising on that key removes almost all of the Python dict walking.
+        # memo of the walk on EXACT keys (state ids and float64 weights as they are): a hit returns precisely what the walk
+        # would compute again, so decoding stays a pure function of its inputs (bit-for-bit reproducible beams)
         self._cost_cache = {}
         self._trans_cache = {}
 
     @staticmethod
     def _key(sd):
-        if not sd:
-            return (), 0.0
-        items = sorted(sd.items())
-        base = min(w for _, w in items)
-        return tuple((s, round(w - base, 10)) for s, w in items), base
+        return tuple(sorted(sd.items()))
 
     # FSTCostsOp.perform, lvsr/ops.py:206-225
     def costs(self, states, weights):
@@ -167,16 +201,18 @@ class FSTLanguageModel(object):
         for st, wt in zip(states, weights):
             sd = dict(zip(st.tolist(), wt.tolist()))
             sd.pop(NOT_STATE, None)
-            key, _ = self._key(sd)
+            key = self._key(sd)
             c = self._cost_cache.get(key)
             if c is None:
                 c = numpy.ones(self.out_dim, dtype=numpy.float32) * self.no_transition_cost
                 if sd:
-                    total = self.fst.combine_weights(*sd.values())
+                    total = log_add(list(sd.values()))
                     for nn_ch, fst_ch in self.remap_table.items():
                         nxt = self.fst.expand(self.fst.transition(sd, fst_ch))
                         if nxt:
-                            c[nn_ch] = self.fst.combine_weights(*nxt.values()) - total
+                            c[nn_ch] = log_add(list(nxt.values())) - total
+                if len(self._cost_cache) > 100000:
+                    self._cost_cache.clear()
                 self._cost_cache[key] = c
             out.append(c)
         return numpy.array(out, dtype=numpy.float32).reshape(len(states), self.out_dim)
@@ -194,16 +230,16 @@ class FSTLanguageModel(object):
         for st, wt, ch in zip(lm_states["states"], lm_states["weights"], outputs):
             sd = dict(zip(st.tolist(), wt.tolist()))
             sd.pop(NOT_STATE, None)
-            key, base = self._key(sd)
-            ck = (key, int(ch))
+            ck = (self._key(sd), int(ch))
             hit = self._trans_cache.get(ck)
             if hit is None:
-                rel = {s_: w_ - base for s_, w_ in sd.items()}
-                nxt = self.fst.expand(self.fst.transition(rel, self.remap_table[int(ch)]))
+                nxt = self.fst.expand(self.fst.transition(sd, self.remap_table[int(ch)]))
                 hit = (list(nxt.keys()), list(nxt.values()))
+                if len(self._trans_cache) > 100000:
+                    self._trans_cache.clear()
                 self._trans_cache[ck] = hit
             ns.append(_pad(hit[0], NOT_STATE))
-            nw.append(_pad([w_ + base for w_ in hit[1]], 0))
+            nw.append(_pad(hit[1], 0))
         states = numpy.array(ns, dtype=numpy.int64).reshape(len(outputs), MAX_STATES)
         weights = numpy.array(nw, dtype=numpy.float64).reshape(len(outputs), MAX_STATES)
         return dict(states=states, weights=weights, add=self.costs(states, weights))

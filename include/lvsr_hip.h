@@ -267,6 +267,9 @@ typedef struct lvsr_readout_step_args {
     long long* outputs; float* costs;     /* (n) out: emitted class and its cost (with uniforms) */
 } lvsr_readout_step_args;
 int lvsr_readout_step(void* stream, const lvsr_readout_step_args* a);
+/* SoftmaxEmitter.emit + cost on given readouts (n,V): outputs[r] = class drawn at uniforms[r], costs[r] = -log p (or NULL) */
+int lvsr_softmax_emit(void* stream, const float* logits, int ld, const float* uniforms, int n, int V, long long* outputs,
+                      float* costs);
 
 /* ---- beam search on the device ------------------------------------------------------------------------
  * The candidate selection, stopping rules and bookkeeping of BeamSearch.search (libs/blocks/blocks/search.py:244-407)

@@ -208,6 +208,79 @@ def run_lm_case(name, cfg, T, param_seed, fst_seed, beams, lm_kwargs, scale=1.0,
     sys.stdout.flush()
 
 
+def run_generate_case(name, cfg, B, T, n_steps, param_seed, batch_seed, scale=1.0):
+    """SpeechRecognizer.generate (lvsr/bricks/recognizer.py:393-406 -> SequenceGenerator.generate,
+    libs/blocks/blocks/bricks/sequence_generators.py:328-377) with its own Theano random stream.  The fixture records what
+    the reference produced (outputs, costs, states, weights, weighted averages) and, per step and utterance, a uniform number
+    that reproduces the emitted class under MultinomialFromUniform's rule (first class whose running float32 sum of
+    probabilities exceeds the uniform): the midpoint of that class's interval, computed from the reference's own readout +
+    softmax evaluated on the returned states / glimpses.  The MRG31k3p stream itself is not reproduced."""
+    t0 = time.time()
+    rec = build_reference(cfg)
+    cgc = rec.get_cost_graph(batch=True)
+    params = Model(cgc.outputs[0].sum()).get_parameter_dict()
+    values = synthetic.make_params(cfg, seed=param_seed, scale=scale)
+    for k, v in params.items():
+        v.set_value(values[k])
+    batch = synthetic.make_batch(cfg, B, T, 4, seed=batch_seed, ragged=True)
+    generated = rec.get_generate_graph(use_mask=True, n_steps=n_steps)
+    keys = [k for k in ("states", "outputs", "weighted_averages", "weights", "costs") if k in generated]
+    cg = ComputationGraph([generated[k] for k in keys])
+    f = theano.function([rec.inputs["recordings"], rec.inputs_mask], cg.outputs, updates=cg.updates)
+    res = f(batch["recordings"], batch["recordings_mask"])
+    out = dict(zip(keys, res))
+    # the reference's readout on (previous states, current glimpses) -> class probabilities of every step
+    gen = rec.generator
+    st = tensor.tensor3("st")
+    wa = tensor.tensor3("wa")
+    fb = tensor.lmatrix("prev_outputs")
+    readouts = gen.readout.readout(feedback=gen.readout.feedback(fb), states=st, weighted_averages=wa)
+    probs_fn = theano.function([fb, st, wa], gen.readout.emitter.probs(readouts), on_unused_input="ignore")
+    states, outputs = out["states"], out["outputs"]
+    init_state = params["/recognizer/generator/att_trans/transition.initial_state"].get_value()
+    prev_states = numpy.concatenate([numpy.tile(init_state[None, None, :], (1, B, 1)), states[:-1]], axis=0).astype("float32")
+    prev_outputs = numpy.concatenate([numpy.full((1, B), cfg["num_phonemes"], dtype="int64"), outputs[:-1]], axis=0)
+    probs = probs_fn(prev_outputs, prev_states, out["weighted_averages"].astype("float32"))
+    uniforms = numpy.zeros(outputs.shape, dtype=numpy.float32)
+    for t in range(outputs.shape[0]):
+        for b in range(B):
+            cum = numpy.float32(0)
+            lo = numpy.float32(0)
+            m = int(outputs[t, b])
+            for c in range(probs.shape[2]):
+                lo = cum
+                cum = numpy.float32(cum + probs[t, b, c])
+                if c == m:
+                    break
+            u = numpy.float32((numpy.float64(lo) + numpy.float64(cum)) / 2)
+            # check: the rule applied to the reference's probabilities with this uniform returns the emitted class
+            cc, pick = numpy.float32(0), 0
+            for c in range(probs.shape[2]):
+                cc = numpy.float32(cc + probs[t, b, c])
+                if cc > u:
+                    pick = c
+                    break
+            assert pick == m, (t, b, pick, m)
+            uniforms[t, b] = u
+    meta = dict(name=name, cfg=cfg, B=B, T=T, n_steps=n_steps, param_seed=param_seed, batch_seed=batch_seed, scale=scale,
+                theano_flags=os.environ.get("THEANO_FLAGS", ""))
+    save = {k: v for k, v in out.items()}
+    save.update(uniforms=uniforms, probs=probs.astype(numpy.float32), meta=numpy.array(json.dumps(meta)))
+    numpy.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+    print("[golden] %s: %.1fs outputs %s cost sum %.5f" % (name, time.time() - t0, outputs[:, 0].tolist(), float(out["costs"].sum())))
+    sys.stdout.flush()
+
+
+def mid_cfg(prior, **kw):
+    """A mid-size WSJ-like network for the decode fixture: 33 characters, one-hot feedback, maxout readout, 5 location filters."""
+    cfg = dict(input_dim=40, num_phonemes=33, dims_bidir=[48, 48], subsample=[1, 2], dim_dec=64, dim_matcher=80,
+               attention_type="content_and_conv", conv_n=40, conv_num_filters=5, prior=prior,
+               post_merge_dims=[64], post_merge_activation="maxout2", embed_outputs=False,
+               data_prepend_eos=False, max_decoded_length_scale=3.0)
+    cfg.update(kw)
+    return cfg
+
+
 def tiny_cfg(prior, **kw):
     cfg = dict(input_dim=5, num_phonemes=6, dims_bidir=[3, 3], subsample=[1, 2], dim_dec=4, dim_matcher=7,
                attention_type="content_and_conv", conv_n=2, conv_num_filters=3, prior=prior,
@@ -283,6 +356,24 @@ CASES = {
         param_seed=41, fst_seed=5, scale=6.0, utterances=4, lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
         beams=[dict(beam_size=4, char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost"),
                dict(beam_size=3, char_discount=1.0, round_to_inf=15.0, stop_on="patience")]),
+    # configs[4] in miniature: beam 16, window_around_median(before 10, after 100), FST LM with the settings of
+    # exp/wsj/decode.sh:12-25 (lm.weight 0.5, no_transition_cost 20, char_discount 1.0, max length T/3), T' = 150
+    "mid_conv_lm_decode": lambda: run_lm_case(
+        "mid_conv_lm_decode", mid_cfg(dict(type="window_around_median", before=10, after=100)), T=300,
+        # scale 2.0: peaked alignments, and still well conditioned (at 4.0 the float32 and float64 oracles part ways: saturated
+        # tanh units make energies of distant positions tie, and rounding picks the winner)
+        param_seed=51, fst_seed=9, scale=2.0, utterances=3, lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
+        beams=[dict(beam_size=16, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")]),
+    # the same network, teacher forced (cost matrix, alignments, gradients): long attended sequence (T' = 150), wide location
+    # filters (81 taps), 5 filters, window of 110 positions — none of which the tiny / small cases reach
+    "mid_conv_median": lambda: run_case(
+        "mid_conv_median", mid_cfg(dict(type="window_around_median", before=10, after=100)),
+        B=3, T=300, L=20, ragged=True, param_seed=51, batch_seed=52, scale=2.0),
+    "tiny_conv_generate": lambda: run_generate_case(
+        "tiny_conv_generate", tiny_cfg(dict(type="window_around_median", before=1, after=2)), B=3, T=13, n_steps=7,
+        param_seed=3, batch_seed=13, scale=2.0),
+    "small_conv_generate": lambda: run_generate_case(
+        "small_conv_generate", small_cfg(None), B=4, T=40, n_steps=12, param_seed=7, batch_seed=17, scale=2.0),
     "timit_tiny": lambda: run_case(
         "timit_tiny", spec.timit_tiny(), B=2, T=200, L=40, ragged=False, param_seed=9, batch_seed=1234,
         store_full=False),
@@ -295,6 +386,6 @@ CASES = {
 }
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep")]
+    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "mid_conv_lm_decode")]
     for k in which:
         CASES[k]()

@@ -24,13 +24,12 @@ def test_alignment_diagnostics():
     assert_allclose(ER.entropy(w, numpy.ones((3, 1))), 3 * numpy.log(1 + 1e-7), atol=1e-9)
 
 
-def test_decode_driver_emulated():
-    from emu import emu_lib
+def _decode_driver(device, lib):
     from lvsr_amd import synthetic, decode
     from lvsr_amd.bricks.recognizer import SpeechRecognizer
     cfg = dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",
                post_merge_dims=None, embed_outputs=True, data_prepend_eos=False)
-    rec = SpeechRecognizer(device="cpu", params=synthetic.make_params(cfg, seed=5), lib=emu_lib(), net_config=cfg)
+    rec = SpeechRecognizer(device=device, params=synthetic.make_params(cfg, seed=5), lib=lib, net_config=cfg)
     rng = numpy.random.RandomState(0)
     utts = [(rng.normal(size=(9, 5)).astype(numpy.float32), [1, 2, 5]), (rng.normal(size=(7, 5)).astype(numpy.float32), [3, 5])]
     rep = decode.search(rec, utts, beam_size=3, char_discount=0.3, to_words=lambda ls: ["w%d" % l for l in ls if l != 5])
@@ -38,6 +37,28 @@ def test_decode_driver_emulated():
     for row in rep["per_utterance"]:
         assert numpy.isfinite(row["groundtruth_cost"])
         assert row["char_errors"] == ER.edit_distance(row["groundtruth"], row["recognized"])
+    return rep
+
+
+def test_decode_driver_emulated():
+    from emu import emu_lib
+    _decode_driver("cpu", emu_lib())
+
+
+import pytest        # noqa: E402
+
+
+@pytest.mark.gpu
+def test_decode_driver_gpu(gpu_device):
+    """lvsr_amd.decode.search on the MI355X: the same report as through the emulated kernels (beam search, analyze of the
+    ground truth and of the best hypothesis, error counts)."""
+    from emu import emu_lib
+    got, ref = _decode_driver(gpu_device, None), _decode_driver("cpu", emu_lib())
+    for a, b in zip(got["per_utterance"], ref["per_utterance"]):
+        assert a["recognized"] == b["recognized"] and a["char_errors"] == b["char_errors"]
+        assert_allclose(a["groundtruth_cost"], b["groundtruth_cost"], rtol=1e-4)
+        assert_allclose(a["search_cost"], b["search_cost"], rtol=1e-4)
+    assert got["cer"] == ref["cer"] and got["wer"] == ref["wer"]
 
 
 def test_host_side_pieces_match_the_reference_functions():

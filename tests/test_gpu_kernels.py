@@ -81,7 +81,7 @@ from lvsr_amd.bricks.recognizer import SpeechRecognizer            # noqa: E402
 
 SMALL = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_conv_logistic",
          "tiny_conv_relu", "tiny_conv_bottom", "tiny_content_embed",
-         "tiny_content_relu", "small_conv_median", "small_conv_expanding"]
+         "tiny_content_relu", "small_conv", "small_conv_median", "small_conv_expanding", "mid_conv_median"]
 
 
 def _setup(meta):
@@ -98,21 +98,25 @@ def test_recognizer_vs_reference_golden(gpu_device, case, use_graph):
     z, meta = load_golden(case)
     params, batch = _setup(meta)
     rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"], use_graph=use_graph)
+    # element-wise tolerances: the long case (300 frames, 150 attended positions, 20 labels) accumulates more float32 rounding
+    # per element than the tiny ones (the reference's own arithmetic in float64 differs from its float32 run by as much,
+    # tests/test_oracle_golden.py TOL); the north-star bar below (cost sum 1e-4, identical argmax) is the same for all
+    long_case = case.startswith("mid_")
     for rep in range(2):
         cm = rec.cost_and_gradients(batch)
         torch.cuda.synchronize()
         cmn = cm.cpu().numpy()
-        assert_allclose(cmn, z["cost_matrix"], rtol=2e-4, atol=2e-5)
+        assert_allclose(cmn, z["cost_matrix"], rtol=5e-4 if long_case else 2e-4, atol=2e-5)
         assert abs(cmn.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-4              # north_star: 1e-4 relative
         w = rec.generator.last["weights"].cpu().numpy()
-        assert_allclose(w, z["weights"], rtol=2e-4, atol=2e-6)
+        assert_allclose(w, z["weights"], rtol=1e-2 if long_case else 2e-4, atol=2e-5 if long_case else 2e-6)
         assert (w.argmax(axis=2) == z["weights_argmax"]).all()                          # bit-exact alignment indices
         assert_allclose(rec.encoded.cpu().numpy(), z["encoded"], rtol=1e-4, atol=2e-6)
         got = rec.store.get_grads()
         for name in z["grad_names"]:
             ref = z["grad:" + str(name)]
             scale = max(1e-3, numpy.abs(ref).max())
-            assert_allclose(got[str(name)] / scale, ref / scale, rtol=0, atol=2e-4, err_msg=str(name))
+            assert_allclose(got[str(name)] / scale, ref / scale, rtol=0, atol=1e-3 if long_case else 2e-4, err_msg=str(name))
 
 
 @pytest.mark.parametrize("case", ["timit_tiny", "wsj_base", "wsj_deep"])

@@ -14,7 +14,7 @@ from lvsr_amd import synthetic
 SMALL_CASES = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_conv_logistic",
                "tiny_conv_relu", "tiny_conv_bottom",
                "tiny_content_embed", "tiny_content_relu", "small_conv", "small_conv_median",
-               "small_conv_expanding"]
+               "small_conv_expanding", "mid_conv_median"]
 
 
 def test_conv1d_reference_golden():
@@ -82,26 +82,32 @@ def _oracle_for(meta, dtype):
     return O.OracleRecognizer(meta["cfg"], params, dtype=dtype), batch
 
 
+# element-wise tolerances; the long case (300 frames, 150 attended positions, 20 labels, float32 reference) accumulates more
+# rounding per element than the tiny ones — the north-star bar (cost sum within 1e-4, identical argmax) is the same for all
+TOL = {"mid_conv_median": dict(cost=3e-4, weights=1e-2, watol=2e-5, grad=1e-3, energies=2e-2)}      # grad: SURVEY 8(d) bar
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
 @pytest.mark.parametrize("case", SMALL_CASES)
 def test_cost_alignment_gradients_vs_reference(case, dtype):
     z, meta = load_golden(case)
+    tol = dict(dict(cost=2e-5, weights=1e-4, watol=2e-6, grad=5e-5, energies=5e-5), **TOL.get(case, {}))
     orc, batch = _oracle_for(meta, dtype)
     out, grads = orc.cost_and_grads(batch)
     cm = out["cost_matrix"].detach().numpy()
-    assert_allclose(cm, z["cost_matrix"], rtol=2e-5, atol=2e-6)
+    assert_allclose(cm, z["cost_matrix"], rtol=tol["cost"], atol=2e-6)
     assert abs(cm.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-5          # north_star: 1e-4 relative
     w = out["weights"].detach().numpy()
-    assert_allclose(w, z["weights"], rtol=1e-4, atol=2e-6)
+    assert_allclose(w, z["weights"], rtol=tol["weights"], atol=tol["watol"])
     assert (w.argmax(axis=2) == z["weights_argmax"]).all()                      # bit-exact alignment indices
     assert_allclose(out["encoded"].detach().numpy(), z["encoded"], rtol=1e-4, atol=2e-6)
     if "energies" in z.files:
-        assert_allclose(out["energies"].detach().numpy(), z["energies"], rtol=1e-4, atol=5e-6)
+        assert_allclose(out["energies"].detach().numpy(), z["energies"], rtol=1e-4, atol=tol["energies"])   # float32 sums of M tanh terms
     for name in z["grad_names"]:
         name = str(name)
         ref = z["grad:" + name]
         scale = max(1e-3, numpy.abs(ref).max())
-        assert_allclose(grads[name] / scale, ref / scale, rtol=0, atol=5e-5, err_msg=name)
+        assert_allclose(grads[name] / scale, ref / scale, rtol=0, atol=tol["grad"], err_msg=name)
 
 
 @pytest.mark.parametrize("case", SMALL_CASES)
@@ -147,3 +153,22 @@ def test_full_size_config_vs_reference(case):
     for name, fp in zip(z["grad_names"], z["grad_fp"]):
         got = synthetic.fingerprint(str(name), grads[str(name)])
         assert_allclose(got, fp, rtol=2e-3, atol=2e-4 * max(1.0, fp[0]), err_msg=str(name))
+
+
+@pytest.mark.slow
+def test_oracle_reproduces_the_full_size_wsj_deep_reference_step():
+    """BASELINE.json configs[3] at full size (6x512 BiGRU, 8 x 1500 frames): the torch restatement against the reference's own
+    output (tests/golden/wsj_deep.npz).  ~2 minutes per pass on 8 cores, hence `--runslow`; observed: cost 6e-8 relative,
+    identical alignment argmax, gradient fingerprints within 6e-6."""
+    z, meta = load_golden("wsj_deep")
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float32)
+    out, grads = orc.cost_and_grads(batch)
+    cm = out["cost_matrix"].detach().numpy()
+    assert abs(cm.astype(numpy.float64).sum() - float(z["cost_sum"])) / float(z["cost_sum"]) < 1e-5
+    assert (out["weights"].detach().numpy().argmax(axis=2) == z["weights_argmax"]).all()
+    for i, name in enumerate(z["grad_names"]):
+        fp = z["grad_fp"][i]
+        mine = synthetic.fingerprint(str(name), grads[str(name)])
+        assert_allclose(mine, fp, rtol=2e-3, atol=2e-4 * max(1.0, fp[0]), err_msg=str(name))
