@@ -85,9 +85,9 @@ class SpeechRecognizer(object):
         from ..checkpoint import load_parameters
         self.store.set_values(load_parameters(path))
 
-    def save_params(self, path):
+    def save_params(self, path, extra=None):
         from ..checkpoint import save_parameters
-        save_parameters(path, self.store.get_values())
+        save_parameters(path, self.store.get_values(), extra=extra)
 
     def initialize(self, initialization, seed=1):
         """Apply the reference's `initialization:` config section (lvsr/main.py:225-232): brick paths mapped to

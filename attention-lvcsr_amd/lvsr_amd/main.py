@@ -30,12 +30,17 @@ def _dist_state(distributed):
     return torch.distributed.get_rank(), torch.distributed.get_world_size(), torch.distributed.barrier
 
 
-def _save_atomically(recognizer, path):
+def _save_atomically(recognizer, path, trainer=None, counters=None):
     """Checkpoints are written to a temporary name and renamed: a reader (the next stage, another rank) never sees a
-    half-written tar."""
+    half-written tar.  With a trainer the optimiser state and the loop counters ride along as `_training_state`."""
     root, ext = os.path.splitext(path)
     tmp = "%s.tmp%d%s" % (root, os.getpid(), ext)
-    recognizer.save_params(tmp)
+    extra = None
+    if trainer is not None:
+        state = trainer.state_dict()
+        state.update({k: numpy.asarray(v) for k, v in (counters or {}).items()})
+        extra = {"_training_state": state}
+    recognizer.save_params(tmp, extra=extra)
     os.replace(tmp, path)
 
 
@@ -50,9 +55,13 @@ def validate(recognizer, data, part="valid"):
     return total / max(1, count)
 
 
-def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=None, distributed=None, search_subset=10):
+def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=None, distributed=None, search_subset=10,
+          resume=False):
     """One stage.  `config`: a (stage) configuration mapping with `net`, `training`, optional `regularization`,
-    `monitoring`, `initialization`; `data`: lvsr_amd.data.Data.  Returns (recognizer, log)."""
+    `monitoring`, `initialization`; `data`: lvsr_amd.data.Data.  Returns (recognizer, log).
+    `resume=True`: `params` is a checkpoint of THIS stage written by an earlier call: besides the parameters, the optimiser
+    accumulators, the adaptive-clipping statistics and the epoch / iteration / best-cost counters are restored from its
+    `_training_state` member, so the recipe continues where it stopped (the reference resumes from its pickled main loop)."""
     from .config import Configuration
     log = [] if log is None else log
     reg = dict(config.get("regularization") or {})
@@ -81,6 +90,14 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
     num_batches, num_epochs = train_conf.get("num_batches"), train_conf.get("num_epochs")
     patience = train_conf.get("patience")
     iterations, epoch, done = 0, 0, False
+    if resume:
+        from .checkpoint import load_member
+        state = load_member(params, "_training_state") if params else None
+        if state is None:
+            raise ValueError("resume=True needs a checkpoint with a `_training_state` member (written by this driver)")
+        trainer.load_state_dict(state)
+        iterations, epoch = int(state["iterations_done"]), int(state["epochs_done"])
+        best_ll, best_per, best_epoch = float(state["best_ll"]), float(state["best_per"]), int(state["best_epoch"])
     has_valid = "valid" in data.datasets
     while not done:
         costs = []
@@ -124,7 +141,8 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                     if rank == 0:
                         _save_atomically(rec, root + "_best" + ext)
         if rank == 0:
-            _save_atomically(rec, save_path)
+            _save_atomically(rec, save_path, trainer, dict(iterations_done=iterations, epochs_done=epoch, best_ll=best_ll,
+                                                           best_per=best_per, best_epoch=best_epoch))
         barrier()                 # the next stage (any rank) may read the checkpoint as soon as its training returns
         log.append(row)
         if num_epochs and epoch >= num_epochs:

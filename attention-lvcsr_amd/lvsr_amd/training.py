@@ -85,6 +85,28 @@ class Trainer(object):
                    burn_in_steps=training.get("burn_in_steps", 0),
                    adaptive_clipping=adaptive_clipping and bool(training.get("gradient_threshold")), **kw)
 
+    # ---- what a restart needs besides the parameters (the reference pickles the whole main loop, serialization.py:145-262) --
+    def state_dict(self):
+        """AdaDelta / momentum accumulators (flat, in parameter order), the adaptive-clipping statistics and burn-in counter."""
+        out = {}
+        for name in ("velocity", "ms_step", "ms_dx"):
+            t = getattr(self, name)
+            if t is not None:
+                out[name] = t.detach().cpu().numpy()
+        if self.clip_state is not None:
+            out["clip_state"] = self.clip_state.detach().cpu().numpy()
+        out["layout"] = numpy.array(["%s:%d:%d" % (n, o, c) for n, (o, c) in self.rec.store.offsets.items()])
+        return out
+
+    def load_state_dict(self, state):
+        layout = ["%s:%d:%d" % (n, o, c) for n, (o, c) in self.rec.store.offsets.items()]
+        if "layout" in state and [str(x) for x in state["layout"]] != layout:
+            raise ValueError("training state was saved for another parameter layout")
+        for name in ("velocity", "ms_step", "ms_dx", "clip_state"):
+            t = getattr(self, name)
+            if t is not None and name in state:
+                t.copy_(torch.as_tensor(numpy.asarray(state[name])).to(t.dtype))
+
     def gradient_threshold(self):
         """The StepClipping threshold in force for the next step (moves when adaptive clipping is on)."""
         return float(self.clip_state[0]) if self.clip_state is not None else self.conf["clip_threshold"]

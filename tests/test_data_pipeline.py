@@ -195,3 +195,34 @@ stages:
     a, b = load_parameters(save + "/pretraining_best_ll.zip"), load_parameters(save + "/main.zip")
     name = "/recognizer/generator/readout/bias.b" if "/recognizer/generator/readout/bias.b" in a else sorted(a)[0]
     assert numpy.abs(a[name] - b[name]).max() < 0.2 and set(a) == set(b)
+
+
+def test_training_state_survives_a_restart(tmp_path):
+    """A stage interrupted after one epoch and resumed from its checkpoint (parameters + `_training_state`: AdaDelta
+    accumulators, adaptive-clipping statistics, counters) ends exactly where the uninterrupted run ends; a Blocks-style
+    checkpoint without that member still loads as plain parameters."""
+    from emu import emu_lib
+    from lvsr_amd import main
+    from lvsr_amd.checkpoint import load_member, load_parameters
+    from lvsr_amd import blocks_compat as BC
+    cfg = dict(net=dict(dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content", embed_outputs=True),
+               initialization={"/recognizer": dict(weights_init=BC.IsotropicGaussian(0.3), biases_init=BC.Constant(0.0),
+                                                   rec_weights_init=BC.Orthogonal(), initial_states_init=BC.IsotropicGaussian(0.001))},
+               training=dict(gradient_threshold=10.0, scale=0.05, momentum=0.0, rules=["momentum", "adadelta"], num_epochs=2))
+    data = Data({"train": _dataset(n=6), "valid": _dataset(n=6)}, batch_size=3)
+    full, _ = main.train(cfg, data, str(tmp_path / "full.zip"), device="cpu", lib=emu_lib(), distributed=False)
+    one = dict(cfg, training=dict(cfg["training"], num_epochs=1))
+    first, _ = main.train(one, data, str(tmp_path / "part.zip"), device="cpu", lib=emu_lib(), distributed=False)
+    state = load_member(str(tmp_path / "part.zip"), "_training_state")
+    assert int(state["epochs_done"]) == 1 and int(state["iterations_done"]) == 2 and "ms_step" in state and "clip_state" in state
+    resumed, log = main.train(cfg, data, str(tmp_path / "part.zip"), params=str(tmp_path / "part.zip"), device="cpu", lib=emu_lib(),
+                              distributed=False, resume=True)
+    a, b = full.store.get_values(), resumed.store.get_values()
+    for k in a:
+        assert numpy.array_equal(a[k], b[k]), k
+    assert [r["iterations_done"] for r in log if "train_cost" in r] == [3, 4]
+    assert set(load_parameters(str(tmp_path / "full.zip"))) == set(a)
+    with pytest.raises(ValueError):
+        bare = str(tmp_path / "bare.zip")
+        full.save_params(bare)
+        main.train(cfg, data, str(tmp_path / "x.zip"), params=bare, device="cpu", lib=emu_lib(), distributed=False, resume=True)
