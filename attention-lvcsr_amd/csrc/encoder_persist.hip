@@ -20,7 +20,7 @@
 //     gate / the dpre_u contraction run in the shadow of the hand-off;
 //   * epoch = step + 1, planes zeroed by a memset node before every launch (graph-replay safe); a plane is overwritten only
 //     after every consumer has read it (the producer needs all consumers' next-phase granules first), so single buffering
-//     is enough — except dpre_u, which is gathered off the critical path and is double buffered;
+//     is enough;
 //   * every spin is bounded: a work-group that waits too long raises the abort word and all work-groups leave.
 // Saved tensors (u, r, c, rh, y / dxg) go out with plain stores off the critical path; the per-step operands that do not
 // depend on the recurrence are prefetched one step ahead.
@@ -102,8 +102,11 @@ struct Sweep {                       // one sweep of granule loads of a lane: NG
 // sweep issued right after the own publish) makes the step SLOWER, 3.8 instead of 2.5 us — every outstanding sc1 load sits in
 // the consumer CU's own memory queue in front of the one that will carry the new epoch (MI355X_MICROARCH.md: "the price sits in
 // the CONSUMER CU's own memory queue").
-template <int NG, int HP, int KS, int LDH, int KSPLIT, bool PRIV>
+// NPL > 1: NPL planes that were published together and lie back to back are swept as one vector; plane p lands in the LDS
+// buffer dst + p * DSTRIDE.
+template <int NG1, int HP, int KS, int LDH, int KSPLIT, bool PRIV, int NPL = 1, int DSTRIDE = 0>
 __device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float* dst, int* abort_word, int flags = 0) {
+    constexpr int NG = NG1 * NPL;
     typedef Sweep<NG, PRIV> S;
     constexpr int NT = S::NT;
     const int tid = PRIV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
@@ -125,12 +128,19 @@ __device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float
     for (int i = 0; i < S::N; ++i) {
         const int idx = tid + NT * i;
         if (NG % NT == 0 || idx < NG) {
-            const int row = idx / HP, k = idx % HP;
-            dst[(row * KSPLIT + k / KS) * LDH + (k % KS)] = __uint_as_float((unsigned)a.w[i]);
+            const int pl = idx / NG1, rem = idx % NG1, row = rem / HP, k = rem % HP;
+            dst[pl * DSTRIDE + (row * KSPLIT + k / KS) * LDH + (k % KS)] = __uint_as_float((unsigned)a.w[i]);
         }
     }
     return true;
 }
+// A cluster of ONE work-group (H <= 128) has nobody to hand anything to: the phase vector goes straight into the LDS operand
+// buffer and the hand-off is a work-group barrier.
+template <int KS, int LDH, int KSPLIT>
+__device__ __forceinline__ void lds_publish(float* dst, int row, int k, float v) {
+    dst[(row * KSPLIT + k / KS) * LDH + (k % KS)] = v;
+}
+
 // what follows a gather: the work-group barrier for a shared buffer; for wave-private buffers only the wave's own LDS order
 // matters (lanes of a wave run in lock step; the builtin keeps the compiler from moving the reads above the writes)
 template <bool PRIV>
@@ -202,7 +212,7 @@ template <int KS, int KSPLIT, int RB, bool PRIVOK>
 __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
-    constexpr bool PRIV = PRIVOK && NG <= 512;              // wave-private operand buffers, see gather_plane
+    constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1;     // wave-private operand buffers, see gather_plane
     constexpr int NBUF = PRIV ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float hbuf_all[2][NBUF][RB * KSPLIT * LDH];
     float* const hbuf[2] = {hbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], hbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0]};
@@ -264,7 +274,7 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
         float xin[NR], gu[NR], gr[NR], m[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xin[i] = n_xin[i]; gu[i] = n_gu[i]; gr[i] = n_gr[i]; m[i] = n_m[i]; }
-        if (n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
+        if (P > 1 && n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
         gather_fence<PRIV>();
         // ---- reset gate: the only thing the next exchange waits for
         float s[RB], rr[NR], uu[NR];
@@ -275,7 +285,8 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
             if (r < RB) {
                 rr[i] = sigmoid_fast(pick_row<RB, KSPLIT>(s, q, i) + gr[i]);
                 const float rh = rvalid[i] ? rr[i] * hown[i] : 0.f;
-                granule_store(grh + (size_t)r * HP + j, (unsigned)(n + 1), rh, flags);
+                if (P == 1) lds_publish<KS, LDH, KSPLIT>(hbuf[1], r, j, rh);
+                else granule_store(grh + (size_t)r * HP + j, (unsigned)(n + 1), rh, flags);
                 if (rvalid[i] && save) {
                     const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
                     a.r[o] = rr[i]; a.rh[o] = rh;
@@ -292,7 +303,7 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
                 if (rvalid[i] && save) a.u[((size_t)t * B + b0 + r) * 2 * H + dir * H + j] = uu[i];
             }
         }
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
         gather_fence<PRIV>();
         // ---- candidate, state update, mask blend
         slice_dot<KS, RB, LDH, KSPLIT>(wc, hbuf[1], q, s, flags);
@@ -304,7 +315,8 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
                 float hn = cand * uu[i] + hown[i] * (1.f - uu[i]);
                 hn = m[i] * hn + (1.f - m[i]) * hown[i];
                 if (!rvalid[i]) hn = 0.f;
-                if (n + 1 < T) granule_store(gh + (size_t)r * HP + j, (unsigned)(n + 1), hn, flags);
+                if (P == 1) lds_publish<KS, LDH, KSPLIT>(hbuf[0], r, j, hn);
+                else if (n + 1 < T) granule_store(gh + (size_t)r * HP + j, (unsigned)(n + 1), hn, flags);
                 if (rvalid[i]) {
                     const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
                     if (save) a.c[o] = cand;
@@ -347,7 +359,7 @@ template <int KS, int KSPLIT, int RB, bool PRIVOK>
 __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
-    constexpr bool PRIV = PRIVOK && NG <= 512;
+    constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1;
     constexpr int NBUF = PRIV ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float vbuf_all[3][NBUF][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
     float* const vbuf[3] = {vbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], vbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0],
@@ -380,9 +392,9 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
             wa[x] = (f32x2){v[0], v[1]}; wbu[x] = (f32x2){v[2], v[3]}; wbr[x] = (f32x2){v[4], v[5]};
         }
     }
-    u64* gc = planes + (size_t)cl * 4 * NG;        // dpre_c
-    u64* gr = gc + NG;                             // dpre_r
-    u64* gu0 = gc + 2 * NG;                        // dpre_u, two planes by step parity
+    u64* gc = planes + (size_t)cl * 4 * NG;        // dpre_c, then dpre_u right behind it: published together, swept together
+    u64* gu = gc + NG;
+    u64* gr = gc + 2 * NG;                         // dpre_r
     const int t_first = dir == 0 ? T - 1 : 0;
     float dh[NR], n_u[NR], n_c[NR], n_r[NR], n_hp[NR], n_m[NR], n_dy[NR];
     bool rvalid[NR];
@@ -406,7 +418,6 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
     for (int n = 0; n < T; ++n) {
         const int t = dir == 0 ? T - 1 - n : n;
         float uu[NR], cc[NR], rr[NR], hp[NR], part[NR];
-        u64* gu = gu0 + (size_t)(n & 1) * NG;
         // ---- everything of this step that depends on dh elementwise only; publish dpre_c and dpre_u
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -416,8 +427,13 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
                 const float dhn = n_m[i] * dh[i];
                 const float dpc = rvalid[i] ? dhn * uu[i] * (1.f - cc[i] * cc[i]) : 0.f;
                 const float dpu = rvalid[i] ? dhn * (cc[i] - hp[i]) * uu[i] * (1.f - uu[i]) : 0.f;
-                granule_store(gc + (size_t)r * HP + j, (unsigned)(n + 1), dpc, flags);
-                granule_store(gu + (size_t)r * HP + j, (unsigned)(n + 1), dpu, flags);
+                if (P == 1) {
+                    lds_publish<KS, LDH, KSPLIT>(vbuf[0], r, j, dpc);
+                    lds_publish<KS, LDH, KSPLIT>(vbuf[1], r, j, dpu);
+                } else {
+                    granule_store(gc + (size_t)r * HP + j, (unsigned)(n + 1), dpc, flags);
+                    granule_store(gu + (size_t)r * HP + j, (unsigned)(n + 1), dpu, flags);
+                }
                 part[i] = dhn * (1.f - uu[i]) + (1.f - n_m[i]) * dh[i] + n_dy[i];
                 if (rvalid[i] && save) {
                     float* dx = a.dxg + ((size_t)t * B + b0 + r) * 6 * H + dir * 3 * H;
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
             for (int i = 0; i < NR; ++i)
                 if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
         }
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 2, NBUF * RB * KSPLIT * LDH>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
         gather_fence<PRIV>();
         float s[RB], vu[RB];
         slice_dot<KS, RB, LDH, KSPLIT>(wa, vbuf[0], q, s);                     // d(r*h)
@@ -441,16 +457,15 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
             if (r < RB) {
                 const float drh = pick_row<RB, KSPLIT>(s, q, i);
                 const float dpr = rvalid[i] ? drh * hp[i] * rr[i] * (1.f - rr[i]) : 0.f;
-                granule_store(gr + (size_t)r * HP + j, (unsigned)(n + 1), dpr, flags);
+                if (P == 1) lds_publish<KS, LDH, KSPLIT>(vbuf[2], r, j, dpr);
+                else granule_store(gr + (size_t)r * HP + j, (unsigned)(n + 1), dpr, flags);
                 part[i] += drh * rr[i];
                 if (rvalid[i] && save) a.dxg[((size_t)t * B + b0 + r) * 6 * H + dir * 3 * H + 2 * H + j] = dpr;
             }
         }
-        // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off (dpre_u was published a phase ago: its sweep completes at once)
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gu, (unsigned)(n + 1), vbuf[1], abort_word)) return;
-        gather_fence<PRIV>();
+        // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off (dpre_u came in with dpre_c's sweep)
         slice_dot<KS, RB, LDH, KSPLIT>(wbu, vbuf[1], q, vu);
-        if (!gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
         gather_fence<PRIV>();
         slice_dot<KS, RB, LDH, KSPLIT>(wbr, vbuf[2], q, s);
 #pragma unroll
