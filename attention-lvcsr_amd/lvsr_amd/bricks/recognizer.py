@@ -8,6 +8,7 @@ What Theano derived symbolically is explicit here: `cost(...)` is the forward pa
 size afterwards; `cost_and_gradients` does the same).
 """
 import contextlib
+import os
 
 import numpy
 import torch
@@ -201,7 +202,7 @@ class SpeechRecognizer(object):
             key = ("train_step", tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
             volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
                         self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
-            plain = region and self.use_graph and not self.encoder.overlap
+            plain = region and self.use_graph and (not self.encoder.overlap or os.environ.get('LVSR_OVERLAP_REGION', '0') == '1')
             return self.lib.region(self, key, x, enabled=plain, volatile=volatile).run(enqueue)
 
     # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------

@@ -283,7 +283,11 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
     if not bidir:
         raise NotImplementedError("bidir=False is not built")
     if dims_top:
-        raise NotImplementedError("dims_top (MLP on top of the encoder) is not built")
+        # The reference cannot run this option either: it builds MLP([Tanh()], [dim_encoded] + dims_top + [dim_encoded])
+        # (lvsr/bricks/recognizer.py:244-246) — ONE activation for len(dims_top) + 1 linear layers — and Blocks' MLP raises
+        # ValueError when the two counts differ (libs/blocks/blocks/bricks/sequences.py:153-155).  Same error here.
+        raise ValueError("dims_top: MLP with 1 activation and %d layers (the reference's own construction fails the same way)"
+                         % (len(dims_top) + 1))
     if dec_stack != 1:
         raise NotImplementedError("dec_stack > 1 is not built")
     bottom_dims, bottom_act = None, "tanh"

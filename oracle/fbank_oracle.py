@@ -9,6 +9,16 @@ zero-padding to 512, power spectrum, triangular filters equally spaced on mel(f)
 Nyquist, log with floor FLT_EPSILON; deltas = regression over +-2 frames applied once / twice with edge replication.
 It checks the HIP kernel against an independent formulation (numpy rfft vs the kernel's table DFT); it does not prove
 Kaldi parity.
+
+Kaldi options ASSUMED (the recipe passes only --use-energy=true --num-mel-bins=40, so everything else is Kaldi's documented
+default — except dither): --sample-frequency=16000 --frame-length=25 --frame-shift=10 --snip-edges=true
+--remove-dc-offset=true --preemphasis-coefficient=0.97 --window-type=povey --round-to-power-of-two=true (512-point FFT)
+--raw-energy=true (log energy BEFORE pre-emphasis and windowing) --energy-floor=0 (floored at FLT_EPSILON instead of -inf)
+--low-freq=20 --high-freq=0 (Nyquist) --use-log-fbank=true --use-power=true --htk-compat=false (energy is column 0) --vtln-warp=1;
+**--dither=0** (Kaldi's default 1.0 adds Gaussian noise per sample: not reproducible, switched off here, SURVEY.md A0');
+add-deltas: --delta-order=2 --delta-window=2 with edge replication.  Pinned without Kaldi: a frozen vector of this oracle
+(tests/golden/fbank_frozen.npz, oracle/gen_fbank_frozen.py), a naive O(N^2) third formulation and closed forms
+(tests/test_fbank.py).
 """
 import numpy
 

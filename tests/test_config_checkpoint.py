@@ -46,7 +46,7 @@ def test_unsupported_bricks_raise_not_silently_fall_back():
     ok = spec.from_reference_kwargs(bottom={"bottom_class": blocks_compat.SpeechBottom, "dims": [100],
                                             "activation": blocks_compat.Rectifier()}, **base)
     assert ok["bottom_dims"] == [100] and ok["bottom_activation"] == "rectifier"
-    for bad in (dict(enc_transition=blocks_compat.SimpleRecurrent), dict(dims_top=[5]), dict(dec_stack=2),
+    for bad in (dict(enc_transition=blocks_compat.SimpleRecurrent), dict(dec_stack=2),
                 dict(bottom={"bottom_class": blocks_compat.LookupBottom}), dict(bidir=False)):
         kw = dict(base)
         kw.update(bad)
@@ -54,6 +54,8 @@ def test_unsupported_bricks_raise_not_silently_fall_back():
             spec.from_reference_kwargs(**kw)
     with pytest.raises(ValueError):
         spec.from_reference_kwargs(attention_type="nope", **base)                        # recognizer.py:275-277
+    with pytest.raises(ValueError):                # the reference's own MLP(1 activation, 2+ layers) raises ValueError, too
+        spec.from_reference_kwargs(dims_top=[5], **base)
 
 
 def test_blocks_checkpoint_round_trip(tmp_path):

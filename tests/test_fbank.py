@@ -37,6 +37,63 @@ def test_oracle_self_consistency():
     assert_allclose(const[:, 3:], 0, atol=1e-12)                               # deltas of a constant are zero
 
 
+def _direct_fbank_frame(x, num_mel=40):
+    """A third, deliberately naive formulation of ONE frame (O(N^2) DFT by its definition, mel filters from their defining
+    triangle in mel space sampled per bin) sharing no code with the oracle or the kernel."""
+    import math
+    x = [float(v) for v in x]
+    mean = sum(x) / len(x)
+    x = [v - mean for v in x]
+    energy = math.log(max(sum(v * v for v in x), 1.1920929e-07))
+    y = [x[0] - 0.97 * x[0]] + [x[i] - 0.97 * x[i - 1] for i in range(1, len(x))]
+    y = [v * (0.5 - 0.5 * math.cos(2 * math.pi * i / (len(x) - 1))) ** 0.85 for i, v in enumerate(y)] + [0.0] * (512 - len(x))
+    power = []
+    for k in range(256):
+        re = sum(v * math.cos(2 * math.pi * k * i / 512) for i, v in enumerate(y))
+        im = sum(v * math.sin(2 * math.pi * k * i / 512) for i, v in enumerate(y))
+        power.append(re * re + im * im)
+    mel = lambda f: 1127.0 * math.log(1.0 + f / 700.0)
+    lo, hi = mel(20.0), mel(8000.0)
+    step = (hi - lo) / (num_mel + 1)
+    out = [energy]
+    for b in range(num_mel):
+        left, center, right = lo + b * step, lo + (b + 1) * step, lo + (b + 2) * step
+        acc = 0.0
+        for k in range(256):
+            m = mel(16000.0 / 512 * k)
+            if left < m < right:
+                acc += power[k] * ((m - left) / (center - left) if m <= center else (right - m) / (right - center))
+        out.append(math.log(max(acc, 1.1920929e-07)))
+    return out
+
+
+def test_oracle_against_a_frozen_vector_a_naive_formulation_and_closed_forms():
+    """What can be pinned without Kaldi: (a) the oracle has not drifted (frozen vector, oracle/gen_fbank_frozen.py);
+    (b) a naive O(N^2) restatement of the documented algorithm agrees frame by frame; (c) closed forms: a pure tone peaks in
+    the mel bin whose triangle contains it, the raw log-energy of a constant-amplitude tone is log(N A^2 / 2), the delta of
+    a linear ramp is its slope away from the edges and the delta-delta is zero."""
+    from conftest import golden_path
+    z = numpy.load(golden_path("fbank_frozen"))
+    f = FO.fbank(z["wav"])
+    assert_allclose(f, z["fbank"], rtol=1e-10, atol=1e-10)
+    assert_allclose(FO.add_deltas(f), z["full"], rtol=1e-10, atol=1e-10)
+    for frame in (0, 5):
+        naive = _direct_fbank_frame(z["wav"][frame * 160: frame * 160 + 400])
+        assert_allclose(f[frame], naive, rtol=1e-8, atol=1e-8)
+    t = numpy.arange(400 + 160 * 3) / 16000.0
+    tone = (8000 * numpy.sin(2 * numpy.pi * 1000.0 * t)).astype(numpy.int16)
+    ft = FO.fbank(tone)
+    mel = FO.mel
+    edges = mel(20.0) + (mel(8000.0) - mel(20.0)) / 41 * numpy.arange(42)
+    expect = int(numpy.searchsorted(edges, mel(1000.0))) - 1          # triangle b spans edges[b]..edges[b+2], centre edges[b+1]
+    assert ft[1, 1:].argmax() in (expect - 1, expect)
+    assert_allclose(ft[1, 0], numpy.log(400 * 8000.0 ** 2 / 2), rtol=2e-3)
+    ramp = numpy.arange(12, dtype=numpy.float64)[:, None] * numpy.array([[1.0, -2.5]])
+    d = FO.add_deltas(ramp)
+    assert_allclose(d[2:-2, 2:4], numpy.tile([[1.0, -2.5]], (8, 1)), atol=1e-12)
+    assert_allclose(d[4:-4, 4:6], 0.0, atol=1e-12)
+
+
 def test_fbank_emulated():
     from emu import emu_lib
     run_fbank("cpu", emu_lib(), 400 + 160 * 5)
