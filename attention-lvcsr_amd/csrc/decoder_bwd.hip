@@ -173,6 +173,27 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     const float sw_m = mok ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
     const float* al = a.W + ((size_t)(i + 1) * B + b) * Tp;       // alignment produced by step i
     const float* qr = g.Q + (size_t)b * Tp;
+    // more independent loads, issued before the first barrier so that their latency hides behind the block reduction: the
+    // convolution features of this tile, and the running sums this work-group will add to at the very end
+    float cvr[(ATT_KMAX * ATT_TT + 255) / 256];
+#pragma unroll
+    for (int c = 0; c < (ATT_KMAX * ATT_TT + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
+        cvr[c] = (x < K * ATT_TT && t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+    }
+    float oldacc[((2 + ATT_KMAX) * ATT_MS + 255) / 256];
+#pragma unroll
+    for (int c = 0; c < ((2 + ATT_KMAX) * ATT_MS + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        const int v = x / ATT_MS, j = x % ATT_MS, mm = slice * ATT_MS + j;
+        float o = 0.f;
+        if (x < (2 + K) * ATT_MS && mm < M) {
+            if (v == 1) o = g.accWe[bt * M + mm];
+            else if (v >= 2) o = g.accH[(bt * K + (v - 2)) * M + mm];
+        }
+        oldacc[c] = o;
+    }
     float sd = 0.f;
     for (int t = w.begin + threadIdx.x; t < w.end; t += 256) sd += al[t] * qr[t];
     sd = block_sum(sd, red);
@@ -192,9 +213,10 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
         }
         des[threadIdx.x] = de;
     }
-    for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
-        const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
-        cvs[k][tl] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+#pragma unroll
+    for (int c = 0; c < (ATT_KMAX * ATT_TT + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        if (x < K * ATT_TT) cvs[x / ATT_TT][x % ATT_TT] = cvr[c];
     }
     if (tg == 0) {
 #pragma unroll
@@ -211,7 +233,7 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
 #pragma unroll
             for (int k = 0; k < KC; ++k)
                 if (KC == K || k < K) x += cvs[k][tl] * Hk[k];
-            const float th = tanhf(x);
+            const float th = tanh_fast(x);
             const float de = des[tl];
             d = de * we_m * (1.f - th * th);
             dpab[(size_t)t * dpa_ts] = dpv[r] + d;
@@ -243,15 +265,17 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
             dcvp[(size_t)k * Tp + t] = p;
         }
     }
-    for (int x = threadIdx.x; x < (2 + K) * ATT_MS; x += 256) {
+#pragma unroll
+    for (int c = 0; c < ((2 + ATT_KMAX) * ATT_MS + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
         const int v = x / ATT_MS, j = x % ATT_MS, mm = slice * ATT_MS + j;
-        if (mm < M) {
+        if (x < (2 + K) * ATT_MS && mm < M) {
             float r = 0.f;
 #pragma unroll
             for (int q = 0; q < 8; ++q) r += racc[q][v][j];
             if (v == 0) g.dswp[bt * M + mm] = r;
-            else if (v == 1) g.accWe[bt * M + mm] += r;
-            else g.accH[(bt * K + (v - 2)) * M + mm] += r;
+            else if (v == 1) g.accWe[bt * M + mm] = oldacc[c] + r;
+            else g.accH[(bt * K + (v - 2)) * M + mm] = oldacc[c] + r;
         }
     }
 }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
 #pragma unroll
             for (int k = 0; k < KC; ++k)
                 if (KC == K || k < K) x += cvs[k][tl] * Hk[k];
-            c = we_m * tanhf(x);
+            c = we_m * tanh_fast(x);
         }
         cs[tl][ml] = c;
     }
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void attdec_gru1_kernel(AttDec a, int i) {
         rb_mm(acc0, acc1, row_src(wa, E, B - b0, E), a.Wdg_p, E, tile);
         const float v = rb_reduce(acc0, acc1);
         if (ok) {
-            const float g = sigmoidf_(v + fg);
+            const float g = sigmoid_fast(v + fg);
             if (j < D) a.U[row * D + j] = g;
             else { a.R[row * D + (j - D)] = g; a.RH[row * D + (j - D)] = g * sp; }
         }
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void attdec_gru2_kernel(AttDec a, int i) {
     rb_mm(acc0, acc1, row_src(a.RH + ((size_t)i * B + b0) * D, D, B - b0, D), a.Whh_p, D, tile);
     const float v = rb_reduce(acc0, acc1);
     if (ok) {
-        const float cand = tanhf(v + xin);
+        const float cand = tanh_fast(v + xin);
         float sn = cand * uu + sp * (1.f - uu);
         sn = m * sn + (1.f - m) * sp;
         a.C[row * D + j] = cand;

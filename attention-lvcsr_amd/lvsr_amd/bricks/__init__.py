@@ -219,7 +219,8 @@ class Encoder(object):
                 Whh, Whg = [p[nf["Whh"]], p[nb["Whh"]]], [p[nf["Whg"]], p[nb["Whg"]]]
             else:
                 Whh, Whg = [pk["Whh"][0], pk["Whh"][1]], [pk["Whg"][0], pk["Whg"][1]]
-            lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", y, self.use_graph, xg=xg, mask=m, Whh_p=Whh, Whg_p=Whg, h0=h0s,
+            # (a persistent layer is a memset + one launch: no graph to build, and no host wait for a time-loop graph to drain)
+            lib.run("lvsr_bigru_fwd", "lvsr_bigru_fwd_args", y, self.use_graph and sync is None, xg=xg, mask=m, Whh_p=Whh, Whg_p=Whg, h0=h0s,
                     y=y, ysub=(ysub if s > 1 else None), u=u, r=r, c=c, rh=rh, sub=s, T=T, B=B, H=H,
                     persistent=int(sync is not None), sync_ws=sync)
             saved.append(dict(x=x, mask=m, T=T, y=y, u=u, r=r, c=c, rh=rh))
@@ -258,7 +259,7 @@ class Encoder(object):
                 WhhT, WhgT = [p[nf["Whh"]], p[nb["Whh"]]], [p[nf["Whg"]], p[nb["Whg"]]]
             else:
                 WhhT, WhgT = [pk["WhhT"][0], pk["WhhT"][1]], [pk["WhgT"][0], pk["WhgT"][1]]
-            lib.run("lvsr_bigru_bwd", "lvsr_bigru_bwd_args", dxg, self.use_graph, mask=sv["mask"], y=sv["y"],
+            lib.run("lvsr_bigru_bwd", "lvsr_bigru_bwd_args", dxg, self.use_graph and sync is None, mask=sv["mask"], y=sv["y"],
                     u=sv["u"], r=sv["r"], c=sv["c"], WhhT_p=WhhT, WhgT_p=WhgT, h0=[p[nf["h0"]], p[nb["h0"]]], dy=dy,
                     dxg=dxg, dh_ws=dh_ws, dh0=[g[nf["h0"]], g[nb["h0"]]], sub=s, T=T, B=B, H=H,
                     persistent=int(sync is not None), sync_ws=sync)

@@ -272,6 +272,7 @@ class DeviceFSTLanguageModel(FSTLanguageModel):
                                   topo=d["topo"], remap=d["remap"], num_states=self.table["num_states"], V=self.out_dim,
                                   no_transition_cost=float(self.no_transition_cost))
         self._err = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._initial = {}
         start = self.fst.expand({self.fst.start: 0.0})
         self._start = (_pad(start.keys(), NOT_STATE).astype(numpy.int64), _pad(start.values(), 0).astype(numpy.float64))
 
@@ -307,9 +308,14 @@ class DeviceFSTLanguageModel(FSTLanguageModel):
             raise ValueError(self._ERRORS.get(code, "lvsr_fst_lm_step error %d" % code))
 
     def initial_states(self, n):
-        st = torch.from_numpy(numpy.tile(self._start[0][None, :], (n, 1))).to(self.device)
-        wt = torch.from_numpy(numpy.tile(self._start[1][None, :], (n, 1))).to(self.device)
-        return self._step(st, wt, None)
+        """State sets / look-ahead costs of n fresh hypotheses.  Computed once per n and kept (callers copy them into their own
+        buffers): starting a search then costs no launch and, unlike `_step`, no look at the error word."""
+        hit = self._initial.get(n)
+        if hit is None:
+            st = torch.from_numpy(numpy.tile(self._start[0][None, :], (n, 1))).to(self.device)
+            wt = torch.from_numpy(numpy.tile(self._start[1][None, :], (n, 1))).to(self.device)
+            hit = self._initial[n] = self._step(st, wt, None)
+        return {k: v.clone() for k, v in hit.items()}
 
     def transition(self, lm_states, outputs):
         out = torch.as_tensor(numpy.ascontiguousarray(outputs), dtype=torch.int64).to(self.device).contiguous()

@@ -58,26 +58,87 @@ class BeamSearch(object):
         first_token = 0 if lm is not None else gen.d.V            # LMEmitter / SoftmaxEmitter initial outputs
         if max_length <= 0:
             raise CandidateNotFoundError()
+        if stepping:
+            with rec._on_stream():
+                rec.compute_contexts(input_values["recordings"])
+                st = gen.beam_begin(self.beam_size, eol_symbol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
+                ctl = self._search_stepping(st, input_values, lm if host_lm else None, validate_solution_function, first_token)
+            return self._finish(st, ctl, first_token, char_discount, as_arrays)
+        run = self.begin(input_values, eol_symbol, max_length, ignore_first_eol=ignore_first_eol, char_discount=char_discount,
+                         round_to_inf=round_to_inf, stop_on=stop_on)
+        while not run["done"]:
+            self.advance(run, POLL_EVERY, wait=True)
+        return self.finish(run, as_arrays=as_arrays)
+
+    # ---- the same search in pieces that never block the host: several searches (one recognizer + stream each) can be kept in
+    #      flight from one thread (tools/bench_decode.py: decoding is "replicas only", also within a GPU) -----------------------
+    def begin(self, input_values, eol_symbol, max_length, ignore_first_eol=False, char_discount=0, round_to_inf=1e9,
+              stop_on="patience"):
+        """Enqueue the encoder pass and the reset of the beam state; returns the handle of the running search."""
+        rec, gen = self.rec, self.rec.generator
+        if stop_on not in ("patience", "optimistic_future_cost"):
+            raise ValueError("Unknown stopping criterion {}".format(stop_on))
+        lm = gen.language_model
+        assert lm is None or getattr(lm, "on_device", False), "the free-running search needs the device language model"
         with rec._on_stream():
             rec.compute_contexts(input_values["recordings"])
-            st = gen.beam_begin(self.beam_size, eol_symbol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
-            ctl = None
-            if not stepping:
-                for position in range(max_length):
-                    gen.beam_step()
-                    if (position + 1) % POLL_EVERY == 0 or position + 1 == max_length:
-                        ctl = st["ctl"].cpu().numpy()
-                        if ctl[CTL["done"]]:
-                            break
-            else:
-                ctl = self._search_stepping(st, input_values, lm if host_lm else None, validate_solution_function, first_token)
+            st = gen.beam_begin(self.beam_size, eol_symbol, int(max_length), ignore_first_eol, char_discount, round_to_inf, stop_on)
+        host = None
+        if rec.device.type == "cuda":
+            host = torch.empty(16, dtype=torch.int32).pin_memory()
+        return dict(st=st, positions=0, max_length=int(max_length), done=False, ctl=None, host=host, event=None,
+                    first_token=0 if lm is not None else gen.d.V, char_discount=char_discount)
+
+    def advance(self, run, positions=POLL_EVERY, wait=False):
+        """Enqueue up to `positions` more positions and a look at the control block.  wait=False returns at once; the look is
+        picked up by the next call (or by `ready`)."""
+        rec, gen, st = self.rec, self.rec.generator, run["st"]
+        if run["done"]:
+            return True
+        if run["event"] is not None:                       # a look is in flight
+            if not wait and not run["event"].query():
+                return False
+            run["event"].synchronize()
+            run["event"] = None
+            run["ctl"] = run["host"].numpy().copy()
+            if run["ctl"][CTL["done"]] or run["positions"] >= run["max_length"]:
+                run["done"] = True
+                return True
+        if positions <= 0:
+            return False
+        with rec._on_stream():
+            n = min(int(positions), run["max_length"] - run["positions"])
+            for _ in range(n):
+                gen.beam_step()
+            run["positions"] += n
+            if run["host"] is None:                        # CPU emulator: plain synchronous look
+                run["ctl"] = st["ctl"].cpu().numpy()
+                run["done"] = bool(run["ctl"][CTL["done"]]) or run["positions"] >= run["max_length"]
+                return run["done"]
+            run["host"].copy_(st["ctl"], non_blocking=True)
+            run["event"] = torch.cuda.Event()
+            run["event"].record(torch.cuda.current_stream(rec.device))
+        if wait:
+            return self.advance(run, 0, wait=True) if run["event"] is not None else run["done"]
+        return False
+
+    def finish(self, run, as_arrays=False):
+        """Collect the result of a search whose `advance` reported done."""
+        rec, gen = self.rec, self.rec.generator
+        assert run["done"]
+        lm = gen.language_model
+        with rec._on_stream():
             if lm is not None and getattr(lm, "on_device", False):
                 lm.check_error()
-        if ctl is None:
-            ctl = st["ctl"].cpu().numpy()
-        self._raise_device_errors(ctl)
-        self.last_stats = dict(positions=int(ctl[CTL["steps"]]), finished=int(ctl[CTL["nfin"]]), done=int(ctl[CTL["done"]]))
-        return self._collect(st, ctl, first_token, char_discount, as_arrays)
+            ctl = run["st"]["ctl"].cpu().numpy()
+            return self._finish(run["st"], ctl, run["first_token"], run["char_discount"], as_arrays)
+
+    def _finish(self, st, ctl, first_token, char_discount, as_arrays):
+        with self.rec._on_stream():
+            self.rec.encoder.check_persistent()
+            self._raise_device_errors(ctl)
+            self.last_stats = dict(positions=int(ctl[CTL["steps"]]), finished=int(ctl[CTL["nfin"]]), done=int(ctl[CTL["done"]]))
+            return self._collect(st, ctl, first_token, char_discount, as_arrays)
 
     @staticmethod
     def _raise_device_errors(ctl):

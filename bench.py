@@ -189,6 +189,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="secondary run of SURVEY.md 8(d): utterance lengths ~U{T/2..T}, zero padded; counts real frames only")
     ap.add_argument("--utterances", type=int, default=None, help="wsj_decode: number of utterances (default 1000 = configs[4])")
+    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: beam searches in flight per GPU (default 4)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -293,6 +294,7 @@ def main():
         elapsed = float(t[0])
     last_cost = float(cm.sum())
     assert numpy.isfinite(last_cost), "training diverged in the benchmark"
+    rec.encoder.check_persistent()          # raises if a persistent cluster kernel gave up waiting (results would be invalid)
     ms = elapsed / args.steps * 1e3
     value = frames_per_step * args.steps / elapsed
 

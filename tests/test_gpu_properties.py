@@ -99,3 +99,46 @@ def test_cost_at_near_zero_weights_is_n_labels_ln_v(gpu_device):
     cm = rec.cost(recordings=batch["recordings"], inputs_mask=batch["recordings_mask"], labels=batch["labels"],
                   labels_mask=batch["labels_mask"], save_for_backward=False)
     assert abs(float(cm.sum()) - B * L * numpy.log(33.0)) / (B * L * numpy.log(33.0)) < 1e-4
+
+
+def test_concurrent_searches_equal_sequential_ones(gpu_device):
+    """Several beam searches kept in flight from one host thread (one recognizer + stream each, begin / advance / finish never
+    blocking) return exactly what the same searches return one after the other."""
+    from conftest import load_golden
+    from lvsr_amd.search import CandidateNotFoundError
+    z, meta = load_golden("small_conv_median")
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    rng = numpy.random.RandomState(3)
+    utts = [rng.normal(size=(int(rng.randint(30, 60)), meta["cfg"]["input_dim"])).astype(numpy.float32) for _ in range(7)]
+    kw = dict(char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost")
+    recs = [SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"]) for _ in range(3)]
+    for r in recs:
+        r.init_beam_search(6)
+
+    def one(rec, x):
+        try:
+            return rec.beam_search({"recordings": x}, **kw)
+        except CandidateNotFoundError:
+            return None
+    want = [one(recs[0], x) for x in utts]
+    got, pending, slots = {}, list(range(len(utts))), [None] * len(recs)
+    while pending or any(s is not None for s in slots):
+        for k, rec in enumerate(recs):
+            bs = rec._beam_search
+            with torch.cuda.stream(rec.stream):
+                if slots[k] is None:
+                    if not pending:
+                        continue
+                    i = pending.pop(0)
+                    x = utts[i]
+                    slots[k] = (i, bs.begin({"recordings": x[:, None, :]}, rec.eos_label, int(x.shape[0] / rec.max_decoded_length_scale),
+                                            ignore_first_eol=rec.data_prepend_eos, **kw))
+                i, run = slots[k]
+                if bs.advance(run, 3, wait=False):
+                    try:
+                        got[i] = bs.finish(run)
+                    except CandidateNotFoundError:
+                        got[i] = None
+                    slots[k] = None
+    for i in range(len(utts)):
+        assert got[i] == want[i], i

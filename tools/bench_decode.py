@@ -62,6 +62,54 @@ def run(rec, utterances, frames, rank=0, world=1, warm=1):
     return time.perf_counter() - t0, done, done * frames, chars, steps
 
 
+def run_concurrent(recs, utterances, frames, rank=0, world=1, warm=None):
+    """The same set decoded with len(recs) searches in flight, one recognizer (own stream and workspaces, same parameters)
+    each, driven round-robin from this thread: begin / advance / finish never block the host, the GPU overlaps the small
+    kernels of different utterances.  Returns what `run` returns."""
+    from lvsr_amd.search import CandidateNotFoundError
+    kw = dict(char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")
+    ids = list(range(rank, utterances, world))
+
+    def wav(i):
+        return numpy.random.RandomState(1234 + i).normal(size=(frames, 40)).astype(numpy.float32)
+
+    for rec in recs:                                    # warm-up: workspaces, graph capture of the step
+        for _ in range(2):
+            try:
+                rec.beam_search({"recordings": wav(ids[0])}, **kw)
+            except CandidateNotFoundError:
+                pass
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pending = list(ids)
+    slots = [None] * len(recs)
+    done = chars = steps = 0
+    while pending or any(s is not None for s in slots):
+        for k, rec in enumerate(recs):
+            bs = rec._beam_search
+            # the recognizer's own stream is made current for the calls: SpeechRecognizer then neither forks from nor joins
+            # the caller's stream (which would chain the searches one behind the other through the default stream)
+            with torch.cuda.stream(rec.stream):
+                if slots[k] is None:
+                    if not pending:
+                        continue
+                    x = wav(pending.pop(0))
+                    slots[k] = bs.begin({"recordings": x[:, None, :]}, rec.eos_label, int(x.shape[0] / rec.max_decoded_length_scale),
+                                        ignore_first_eol=rec.data_prepend_eos, **kw)
+                run_ = slots[k]
+                if bs.advance(run_, 8, wait=False):
+                    try:
+                        outs, _ = bs.finish(run_)
+                        chars += len(outs[0])
+                    except CandidateNotFoundError:
+                        pass
+                    steps += bs.last_stats.get("positions", 0)
+                    done += 1
+                    slots[k] = None
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, done, done * frames, chars, steps
+
+
 def decode_bench(args, rank, world, local_rank, json_out=None):
     """The bench.py line of configs[4]."""
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -74,10 +122,15 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
     json_out = json_out or sys.stdout
     utterances = args.utterances or 1000
     frames, beam = 800, 16
-    rec, cfg = build(dev, beam)
+    streams = max(1, int(getattr(args, "streams", None) or 4))
+    recs = [build(dev, beam)[0] for _ in range(streams)]
+    rec = recs[0]
     if dist:
         torch.distributed.barrier()
-    sec, done, nframes, chars, steps = run(rec, utterances, frames, rank, world)
+    if streams == 1:
+        sec, done, nframes, chars, steps = run(rec, utterances, frames, rank, world)
+    else:
+        sec, done, nframes, chars, steps = run_concurrent(recs, utterances, frames, rank, world)
     tot = torch.tensor([sec, done, nframes, chars, steps], dtype=torch.float64, device=dev)
     if dist:
         mx = tot[:1].clone()
@@ -95,6 +148,7 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
                                         "no_transition_cost 20), char_discount 1.0, max length T/3, stop_on optimistic_future_cost"
                                         % (int(done), frames, beam),
                                utterances_per_sec=done / sec, sec_per_utterance=sec / max(done / world, 1), parallelism="replicas%d" % world,
+                               searches_in_flight_per_gpu=streams,
                                mean_best_hypothesis_length=chars / max(done, 1), positions_per_utterance=steps / max(done, 1),
                                us_per_position=(sec * 1e6 * world / steps if steps else None),
                                launches_per_position="one hipGraph replay (21 kernel nodes: 2 x attention pass, readout, fusion, "
@@ -114,9 +168,15 @@ if __name__ == "__main__":
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
+    ap.add_argument("--streams", type=int, default=1, help="searches in flight (one recognizer + stream each)")
     a = ap.parse_args()
-    rec, _ = build("cuda:0", a.beam, "none" if a.no_lm else ("host" if a.host_lm else "device"))
-    sec, done, nframes, chars, steps = run(rec, a.utts, a.frames)
+    kind = "none" if a.no_lm else ("host" if a.host_lm else "device")
+    if a.streams > 1:
+        recs = [build("cuda:0", a.beam, kind)[0] for _ in range(a.streams)]
+        sec, done, nframes, chars, steps = run_concurrent(recs, a.utts, a.frames)
+    else:
+        rec, _ = build("cuda:0", a.beam, kind)
+        sec, done, nframes, chars, steps = run(rec, a.utts, a.frames)
     print(json.dumps(dict(metric="beam-search decode", utterances=done, beam=a.beam, lm=not a.no_lm, frames_per_utt=a.frames,
-                          sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,
+                          streams=a.streams, sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,
                           positions_per_utt=steps / done, us_per_position=sec * 1e6 / max(steps, 1))))
