@@ -13,52 +13,6 @@
 //                                                        libs/blocks/blocks/bricks/recurrent.py:608-620
 #include "decoder.h"
 
-// Window centre of one alignment row (lvsr/bricks/attention.py:133-144).  The order of the float32 additions decides where
-// the median crossing lands (cumsum), so the sum stays sequential — but it is run by a whole wave: the row is fetched 64
-// positions at a time with one coalesced load, every lane then walks the same chain of adds with v_readlane broadcasts
-// (~10 cycles per position instead of one dependent memory access per position: 30 us -> 1 us at T' = 200).
-// Call with all 64 lanes of a wave; `w` may be global or LDS; the result is wave-uniform.
-__device__ __forceinline__ float attdec_pos_of_row_wave(const AttDec& a, const float* w) {
-    const int lane = threadIdx.x & 63, Tp = a.Tp;
-    float v = lane < Tp ? w[lane] : 0.f;
-    if (a.prior_type == 1) {               // window_around_mean: sum_t alpha[t] * t
-        float p = 0.f;
-        for (int t0 = 0; t0 < Tp; t0 += 64) {
-            const float cur = v;
-            if (t0 + 64 < Tp) v = (t0 + 64 + lane < Tp) ? w[t0 + 64 + lane] : 0.f;       // next chunk in flight
-#pragma unroll
-            for (int l = 0; l < 64; ++l)          // positions beyond T' add 0.0
-                p += __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cur), l)) * (float)(t0 + l);
-        }
-        return p;
-    }
-    // window_around_median: first crossing of cumsum(alpha) - 0.5 >= 0.  Only the additions are a chain; every lane keeps the
-    // running sum of ITS position and the crossing is found with one ballot per 64 positions.
-    float c = 0.f, res = 0.f;
-    bool found = false, carry = false;     // carry: (c - 0.5 >= 0) at the last position of the previous chunk
-    for (int t0 = 0; t0 < Tp; t0 += 64) {
-        const float cur = v;
-        if (t0 + 64 < Tp) v = (t0 + 64 + lane < Tp) ? w[t0 + 64 + lane] : 0.f;
-        float xs[64];
-#pragma unroll
-        for (int l = 0; l < 64; ++l) xs[l] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cur), l));
-        float mine = 0.f;
-#pragma unroll
-        for (int l = 0; l < 64; ++l) {             // positions beyond T' add 0.0: neither sum nor crossing changes
-            c += xs[l];
-            mine = lane == l ? c : mine;
-        }
-        const bool ge = (mine - 0.5f) >= 0.f;
-        const int below = __shfl_up((int)ge, 1, 64);
-        const bool prev = lane == 0 ? carry : below != 0;
-        const bool cross = ge && !prev && (t0 + lane) > 0;
-        const unsigned long long m = __ballot(cross);
-        if (!found && m != 0ull) { res = (float)(t0 + (__ffsll((long long)m) - 1) - 1); found = true; }
-        carry = (c - 0.5f) >= 0.f;
-    }
-    return res;
-}
-
 __global__ __launch_bounds__(64) void attdec_pos_kernel(AttDec a, int slot) {
     const int b = blockIdx.x;          // one wave per alignment row
     const float r = attdec_pos_of_row_wave(a, a.W + ((size_t)slot * a.B + b) * a.Tp);

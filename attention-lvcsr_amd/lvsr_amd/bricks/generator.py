@@ -25,12 +25,13 @@ def _f32(x):
 
 
 class SequenceGenerator(object):
-    def __init__(self, dims, store, lib, workspace, use_graph=True):
+    def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=None):
         self.d = dims
         self.store = store
         self.lib = lib
         self.ws = workspace
         self.use_graph = use_graph
+        self.use_persistent = use_persistent      # None: LVSR_DEC_PERSISTENT / auto (persistent label loop when available)
         self._packs = None
         self._pack_cache = {}
         self._gen_cache = {}
@@ -144,6 +145,31 @@ class SequenceGenerator(object):
         lib.sgemm(R2, p[n["Wout"]], logits, bias=p[n["bout"]])
         return R1, R2, logits
 
+    # ---- persistent label loop -------------------------------------------------------------------
+    def _persistent_ws(self, fields):
+        """Workspace of the persistent decoder kernel for this argument block, or None when the step kernels run: the
+        configuration is outside the kernel's limits (lvsr_attdec_persist_ws_bytes == 0), LVSR_DEC_PERSISTENT=0, or — on the
+        CPU emulator — its work-groups are not run concurrently."""
+        mode = os.environ.get("LVSR_DEC_PERSISTENT", "auto") if self.use_persistent is None else ("1" if self.use_persistent else "0")
+        if mode == "0":
+            return None
+        import ctypes as _ct
+        a = self.lib.make("lvsr_attdec_args", **fields)
+        nbytes = int(self.lib._lvsr_attdec_persist_ws_bytes(_ct.byref(a)))
+        if self.lib.is_emulator and not self.lib.emulates_concurrency():
+            nbytes = 0
+        if nbytes == 0:
+            if mode == "1":
+                raise ValueError("persistent decoder kernel requested but not available for this configuration")
+            return None
+        return self.ws.get("gen.sync", ((nbytes + 3) // 4,), torch.int32)
+
+    def check_persistent(self):
+        """After a synchronisation point: raise if the persistent decoder kernel gave up waiting for its cluster."""
+        for k, buf in self.ws._bufs.items():
+            if k[0] == "gen.sync" and int(buf[0]) != 0:
+                raise RuntimeError("persistent decoder kernel aborted (a work-group of a cluster was not scheduled)")
+
     # ---- teacher-forced cost ---------------------------------------------------------------------
     def cost_matrix(self, outputs, mask=None, attended=None, attended_mask=None, save_for_backward=True):
         """outputs (L,B) int64 labels, mask (L,B) or None, attended (T',B,E), attended_mask (T',B) -> costs (L,B).
@@ -177,7 +203,19 @@ class SequenceGenerator(object):
                     RH=ws.get("gen.RH", (L, B, d.D)), sg=ws.get("gen.sg", (B, 2 * d.D)), xin=ws.get("gen.xin", (B, d.D)),
                     ep=ws.get("gen.ep", (B, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
         fields = self._attdec_fields(pk, A, PA, Am, L, B, bufs, phases=3, step0=0, broadcast=False)
-        if os.environ.get("LVSR_SYNC_DEC_FWD", "1") == "1":
+        sync = self._persistent_ws(fields)
+        if sync is not None:
+            # one persistent launch for the whole label loop (csrc/decoder_persist.hip): a memset and a kernel, no graph needed
+            import ctypes as _ct
+            fwd_args = lib.make("lvsr_attdec_args", **fields)
+            # gate inputs of the glimpse, reassociated: AW = attended @ [fork_inputs.W | fork_gate_inputs.W] once per batch
+            wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
+            AW = ws.get("gen.AW", (Tp * B, 3 * d.D))
+            lib.sgemm(A.view(Tp * B, d.E), wd, AW)
+            plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
+            lib.call("lvsr_attdec_fwd_persistent", lib.stream_for(S), _ct.byref(fwd_args), _ct.byref(plain), lib_ptr(sync), 0)
+            lib.call("lvsr_attdec_glimpses", lib.stream_for(S), _ct.byref(fwd_args))
+        elif os.environ.get("LVSR_SYNC_DEC_FWD", "1") == "1":
             fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
         else:
             import ctypes as _ct

@@ -294,6 +294,7 @@ def main():
         elapsed = float(t[0])
     last_cost = float(cm.sum())
     assert numpy.isfinite(last_cost), "training diverged in the benchmark"
+    rec.generator.check_persistent()
     rec.encoder.check_persistent()          # raises if a persistent cluster kernel gave up waiting (results would be invalid)
     ms = elapsed / args.steps * 1e3
     value = frames_per_step * args.steps / elapsed

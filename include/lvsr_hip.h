@@ -168,6 +168,27 @@ typedef struct lvsr_attdec_args {
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
+/* The same label loop as ONE persistent launch (csrc/decoder_persist.hip): a cluster of ceil(D/32) work-groups per utterance
+ * keeps the decoder's state weights in registers and the utterance's contexts in LDS for the whole sequence and exchanges four
+ * phase vectors per label through {epoch,value} granules.  Same semantics, inputs and saved tensors as lvsr_attdec_fwd with
+ * phases = 3 (the scratch fields sg / xin / ep are not used), except that
+ *   - it takes the PLAIN row-major state weights instead of the packed ones, and AW = attended @ [fork_inputs.W |
+ *     fork_gate_inputs.W] (T',B,3D) computed by the caller: the gate inputs are formed as sum_t alpha_t AW[t] (the glimpse
+ *     contraction reassociated; equal up to float32 rounding);
+ *   - it does NOT write WA: call lvsr_attdec_glimpses afterwards (all labels' weighted averages in one launch).
+ * lvsr_attdec_persist_ws_bytes returns the workspace size, or 0 when the configuration is outside the kernel's limits (then
+ * call lvsr_attdec_fwd). */
+typedef struct lvsr_attdec_plain {
+    const float* Ws;                      /* transform_states.W (D,M) */
+    const float* Whg;                     /* transition.state_to_gates (D,2D) */
+    const float* Whh;                     /* transition.state_to_state (D,D) */
+    const float* AW;                      /* (T',B,3D) attended @ [distribute/fork_inputs.W | distribute/fork_gate_inputs.W] */
+} lvsr_attdec_plain;
+long long lvsr_attdec_persist_ws_bytes(const lvsr_attdec_args* a);
+int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* a, const lvsr_attdec_plain* w, void* ws, int use_graph);
+/* WA[l,b,:] = sum_t W[l+1,b,t] * A[t,b,:] for l in [0,L) (compute_weighted_averages, libs/blocks/blocks/bricks/attention.py:236-256) */
+int lvsr_attdec_glimpses(void* stream, const lvsr_attdec_args* a);
+
 /* Backward of lvsr_attdec_fwd (what theano.grad derives through the decoder scan,
  * libs/blocks/blocks/algorithms/__init__.py:216-224).  Walks the steps in reverse; per-step tensors needed
  * for the weight gradients (DXG, DWA, DSW, DCV) are left for batched GEMMs by the caller. */

@@ -1,0 +1,58 @@
+"""The persistent attention-decoder forward (csrc/decoder_persist.hip: one launch for the whole label loop, a cluster of
+work-groups per utterance exchanging five phase vectors per label through {epoch,value} granules) on the emulator with
+concurrent work-groups, against the float64 oracle, the reference goldens and the step kernels (whose saved tensors the
+backward pass reads: the gradients are checked through the persistent forward)."""
+import os
+
+import numpy
+import pytest
+import torch
+from numpy.testing import assert_allclose
+
+from conftest import load_golden
+from emu import emu_lib
+from oracle import lvsr_oracle as O
+from lvsr_amd import synthetic
+from lvsr_amd.bricks.recognizer import SpeechRecognizer
+from test_emu_recognizer import check_against
+
+
+@pytest.fixture
+def concurrent_lib():
+    lib = emu_lib()
+    lib._dll.hipemu_set_concurrent(1)
+    old = os.environ.get("LVSR_DEC_PERSISTENT")
+    os.environ["LVSR_DEC_PERSISTENT"] = "1"
+    try:
+        yield lib
+    finally:
+        lib._dll.hipemu_set_concurrent(0)
+        if old is None:
+            os.environ.pop("LVSR_DEC_PERSISTENT", None)
+        else:
+            os.environ["LVSR_DEC_PERSISTENT"] = old
+
+
+def engaged(rec):
+    return any(k[0] == "gen.sync" for k in rec.generator.ws._bufs)
+
+
+# every prior / normaliser / attention type of the goldens; small_conv and mid_conv_median run clusters of two work-groups
+@pytest.mark.parametrize("case", ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean",
+                                  "tiny_conv_logistic", "tiny_conv_relu", "tiny_conv_bottom", "tiny_content_embed",
+                                  "tiny_content_relu", "small_conv", "mid_conv_median"])
+def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
+    z, meta = load_golden(case)
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float64)
+    out, grads = orc.cost_and_grads(batch)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=meta["cfg"])
+    cm = rec.cost_and_gradients(batch)
+    assert engaged(rec), "persistent decoder did not engage"
+    rec.generator.check_persistent()
+    # the long case accumulates more float32 rounding per element (tests/test_oracle_golden.py TOL); the north-star bars inside
+    # check_against (cost sum 1e-4 relative, identical alignment argmax against the reference golden) are the same for all
+    check_against(rec, cm, z, out, grads, tol=50.0 if case.startswith("mid_") else 1.0)
+
+
