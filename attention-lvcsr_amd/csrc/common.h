@@ -37,6 +37,36 @@ __device__ __forceinline__ float lvsr_dpp_quad_xor2(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
 }
 
+__device__ __forceinline__ float lvsr_dpp_row_ror4(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x124, 0xf, 0xf, true));   // row_ror:4
+}
+__device__ __forceinline__ float lvsr_dpp_row_ror8(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x128, 0xf, 0xf, true));   // row_ror:8
+}
+// Wave-wide sum / max without the LDS crossbar: four DPP moves fold each row of 16 lanes (every lane of the row gets the row's
+// total), four v_readlane fetch the rows' totals as scalars.  ~12 instructions instead of six ds_bpermute round trips; the
+// result is wave-uniform.  (Order of the float additions differs from wave_sum's xor tree.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += lvsr_dpp_quad_xor1(v);
+    v += lvsr_dpp_quad_xor2(v);
+    v += lvsr_dpp_row_ror4(v);
+    v += lvsr_dpp_row_ror8(v);
+    const int b = (int)__float_as_uint(v);
+    const float r0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 0)), r1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 32)), r3 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, lvsr_dpp_quad_xor1(v));
+    v = fmaxf(v, lvsr_dpp_quad_xor2(v));
+    v = fmaxf(v, lvsr_dpp_row_ror4(v));
+    v = fmaxf(v, lvsr_dpp_row_ror8(v));
+    const int b = (int)__float_as_uint(v);
+    const float r0 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 0)), r1 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 16));
+    const float r2 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 32)), r3 = __uint_as_float((unsigned)__builtin_amdgcn_readlane(b, 48));
+    return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

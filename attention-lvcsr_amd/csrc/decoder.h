@@ -92,14 +92,17 @@ __device__ __forceinline__ float attdec_pos_of_row_wave(const AttDec& a, const f
     for (int t0 = 0; t0 < Tp; t0 += 64) {
         const float cur = v;
         if (t0 + 64 < Tp) v = (t0 + 64 + lane < Tp) ? w[t0 + 64 + lane] : 0.f;
-        float xs[64];
-#pragma unroll
-        for (int l = 0; l < 64; ++l) xs[l] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cur), l));
         float mine = 0.f;
 #pragma unroll
-        for (int l = 0; l < 64; ++l) {             // positions beyond T' add 0.0: neither sum nor crossing changes
-            c += xs[l];
-            mine = lane == l ? c : mine;
+        for (int l0 = 0; l0 < 64; l0 += 8) {       // 8 broadcasts ahead of the adds that consume them (64 would need 64 SGPRs)
+            float xs[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) xs[l] = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(cur), l0 + l));
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {          // positions beyond T' add 0.0: neither sum nor crossing changes
+                c += xs[l];
+                mine = lane == l0 + l ? c : mine;
+            }
         }
         const bool ge = (mine - 0.5f) >= 0.f;
         const int below = __shfl_up((int)ge, 1, 64);

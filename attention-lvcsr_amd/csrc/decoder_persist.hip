@@ -32,13 +32,15 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define PD_THREADS 256       // one wave per SIMD: 512 registers per lane (VGPR + AGPR), the weights' home
-#define PD_KSPLIT 8
+#define PD_THREADS 512       // two waves per SIMD: with one, every LDS / transcendental latency of the energy phase is exposed
+#define PD_KSPLIT 16
 #define PD_UNITS 32          // decoder units per work-group
-#define PD_KD 32             // state rows per thread
+#define PD_KD 16             // state rows per thread
 #define PD_MC 2              // transform_states columns per lane group
 #define PD_AWS (3 * PD_UNITS + 4)   // LDS row stride of the AW slice: +4 words spreads the 8 position lanes of a unit over the banks
-#define PD_CH 16             // attended positions per butterfly round
+#define PD_CH 16             // attended positions per energy round (8 per half of the work-group)
+#define PD_EG 2              // positions whose chains are written interleaved in the energy phase (registers: 12 per position)
+#define PD_MP 256            // match-column pairs (m, m + 256): one per thread of a half
 #define PD_MAXV 512          // longest exchanged vector
 #define PD_NV (PD_MAXV / PD_THREADS)     // granules per thread and sweep
 #define PD_NW (PD_THREADS / 64)
@@ -47,8 +49,8 @@
 #define PD_NPROF 16
 
 struct PdGeom {
-    int P, nown, nownp, KC, KCP, FW;
-    int o_pa, o_a, o_f, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, Bp, total;
+    int P, nown, nownp, KC, KCP, FW, prof;
+    int o_pa, o_a, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, o_sw, Bp, total;
 };
 
 __host__ __device__ __forceinline__ int pd_slot(int k, int KX) { return (k / KX) * (KX + 4) + (k % KX); }
@@ -71,22 +73,26 @@ static bool pd_geom(const AttDec& a, PdGeom& g) {
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
     g.FW = 2 * a.c + 1;
+    if (a.K > 0 && g.FW > 4 * 8 * PD_NW) return false;          // tap groups of the convolution: 8 per wave
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 3) / 4 * 4; return at; };
     g.o_pa = take(g.nown * a.M);
     g.o_a = take(a.Tp * PD_AWS);
-    g.o_f = take(a.K * g.FW);
     g.o_cv = take(g.nownp * (g.KCP > 0 ? g.KCP : 4));
+    take(256);                               // the convolution reads up to 255 floats below `al` (and c + 16 P above) unclamped
     g.o_al = take(a.Tp);
     g.o_sv = take(PD_KSPLIT * (PD_KD + 4));
     g.o_rs = take(PD_KSPLIT * (PD_KD + 4));
-    g.o_xw = take(PD_NW * PD_CH);
-    g.o_red = take(16);
+    g.o_xw = take(PD_NW * 8);
+    g.o_sw = take(PD_THREADS);
+    g.o_red = take(3 * PD_NW);
     g.Bp = (a.B + 3) / 4 * 4;
     g.o_pos = take(2 * g.Bp);
     g.o_clk = take(2 * (PD_NPROF + 1));
     g.o_cp = take(PD_NW * 16 * 17);
     g.total = o;
+    const char* env = getenv("LVSR_PD_PROF");          // phase clock of work-group 0 (tools/probe_decoder_persist.py); costs ~1 us per label
+    g.prof = env ? atoi(env) : 0;
     return o <= PD_LDS_FLOATS;
 }
 
@@ -106,22 +112,6 @@ __device__ __forceinline__ Win pd_window(const AttDec& a, int i, const float* po
     w.end = (int)fminf((float)a.Tp, mx);
     if (w.end < w.begin) w.end = w.begin;
     return w;
-}
-
-// sum / max over the waves of the work-group (all threads call; `red` has PD_NW floats)
-__device__ __forceinline__ float pd_wg_sum(float v, float* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-__device__ __forceinline__ float pd_wg_max(float v, float* red) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 // One sweep over a plane of n <= 512 granules until every granule carries `epoch`; thread tid gets granules tid and tid + 256.
@@ -169,16 +159,16 @@ __device__ __forceinline__ float pd_dot(const f32x2 (&w)[KX / 2], const float* b
     return group_sum<PD_KSPLIT>((a0.x + a1.x) + (a0.y + a1.y));
 }
 
-// v[x] (x < 16) -> sum over the 64 lanes of the wave; lane l ends with the total of value index
-// 8*bit5(l) + 4*bit4(l) + 2*bit3(l) + bit2(l): every stage halves the values a lane carries (17 shuffles instead of 16 x 6)
-__device__ __forceinline__ float pd_butterfly16(float (&v)[PD_CH]) {
+// v[x] (x < 8) -> sum over the 64 lanes of the wave; lane l ends with the total of value index 4*bit5(l) + 2*bit4(l) + bit3(l):
+// every stage halves the values a lane carries (10 shuffles instead of 8 x 6)
+__device__ __forceinline__ float pd_butterfly8(float (&v)[8]) {
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        const int half = 8 >> s, off = 32 >> s;
+    for (int s = 0; s < 3; ++s) {
+        const int half = 4 >> s, off = 32 >> s;
         const bool up = (lane & off) != 0;
 #pragma unroll
-        for (int x = 0; x < 8; ++x) {
+        for (int x = 0; x < 4; ++x) {
             if (x < half) {
                 const float keep = up ? v[x + half] : v[x];
                 const float send = up ? v[x] : v[x + half];
@@ -187,16 +177,16 @@ __device__ __forceinline__ float pd_butterfly16(float (&v)[PD_CH]) {
         }
     }
     float r = v[0];
+    r += __shfl_xor(r, 4, 64);
     r += lvsr_dpp_quad_xor1(r);
     r += lvsr_dpp_quad_xor2(r);
     return r;
 }
-__device__ __forceinline__ int pd_butterfly_index(int lane) {
-    return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
-}
+__device__ __forceinline__ int pd_butterfly_index(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
 
 // Phase clock of work-group 0 (thread 0): accumulated s_memrealtime ticks (100 MHz) per phase of the label loop, left in the
-// workspace header (bytes 64..255) for tools/probe_decoder_persist.py.  A dozen scalar clock reads per label in one wave.
+// workspace header (bytes 64..255) for tools/probe_decoder_persist.py (LVSR_PD_PROF=1).  Every read drains the wave's
+// outstanding LDS traffic, so the clock itself costs about a microsecond per label: off by default.
 struct PdClock {          // accumulators in LDS (2 floats each), touched by thread 0 of work-group 0 only
     long long* acc;
     bool on;
@@ -223,19 +213,20 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     __shared__ __attribute__((aligned(16))) float lds[PD_LDS_FLOATS];
     float* const PAs = lds + g.o_pa;      // [nown][M]   own positions (t = tl*P + p) of the preprocessed attended
     float* const AWs = lds + g.o_a;       // [T'][PD_AWS] own gate columns of AW: [x | u | r][32 units]
-    float* const Fs = lds + g.o_f;        // [K][FW]     convolution filters
     float* const cvs = lds + g.o_cv;      // [nownp][KCP] convolution features of the own positions
     float* const al = lds + g.o_al;       // [T']        current alignment
     float* const sv = lds + g.o_sv;       // state, sliced by PD_KD
     float* const rsv = lds + g.o_rs;      // r*s, sliced by PD_KD
-    float* const xw = lds + g.o_xw;       // [PD_NW][PD_CH]
+    float* const xw = lds + g.o_xw;       // [PD_NW][8] energy partials
+    float* const swst = lds + g.o_sw;     // [512] transformed state, staged between the sweep's and the energy phase's thread layout
     float* const red = lds + g.o_red;
     float* const posv = lds + g.o_pos;    // [2][Bp] window centres of all utterances, by label parity
     float* const cp = lds + g.o_cp;       // [PD_NW][16][17] convolution partial tiles
     const int P = g.P, nown = g.nown;
     int b, p;
     cluster_of_block(P, 0, b, p);
-    const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: conditions on it become scalar branches
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L;
     const int j = p * PD_UNITS + jl;
     const bool junit = j < D;
@@ -265,35 +256,40 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
             for (int c = 0; c < PD_MC; ++c) wsw[c][x] = (f32x2){s2[c][0], s2[c][1]};
         }
     }
-    // energy phase: thread tid holds match columns m = tid and tid + 256 (handler column pair per filter, energy vector pair)
-    f32x2 Hk[KC > 0 ? KC : 1], we2;
-    float am[PD_NV];
+    // energy phase: thread (pair mp = tid % 256, half = tid / 256) holds match columns mp and mp + 256 (handler column pair per
+    // filter, energy vector pair) and takes 8 of a round's 16 positions.  tanh(x) = 1 - 2 / (1 + 2^(c x)), c = 2 log2(e): the
+    // operands are pre-scaled by c (preprocessed attended and handler once, the transformed state per label), and
+    // w_e . tanh = sum(w_e) - 2 w_e . (1 / (1 + 2^y)) with the -2 folded into the vector
+    const float C2 = 2.885390081777927f;
+    const int mp = tid & (PD_MP - 1), ehalf = wave / (PD_MP / 64);
+    f32x2 Hk[KC > 0 ? KC : 1], wem2;
+    float wsum, am;
     {
         float h[2][KC > 0 ? KC : 1], wv[2];
 #pragma unroll
-        for (int x = 0; x < PD_NV; ++x) {
-            const int m = tid + x * PD_THREADS, t = m;
+        for (int x = 0; x < 2; ++x) {
+            const int m = mp + x * PD_MP;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) h[x][k] = (k < K && m < M) ? a.handler[(size_t)k * M + m] : 0.f;
+            for (int k = 0; k < KC; ++k) h[x][k] = (k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
             wv[x] = m < M ? a.w_e[m] : 0.f;
-            am[x] = t < Tp ? a.Am[(size_t)t * a.Am_ts + (size_t)b * a.Am_bs] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < KC; ++k) Hk[k] = (f32x2){h[0][k], h[1][k]};
-        we2 = (f32x2){wv[0], wv[1]};
+        wem2 = (f32x2){-2.f * wv[0], -2.f * wv[1]};
+        wsum = wv[0] + wv[1];
+        am = tid < Tp ? a.Am[(size_t)tid * a.Am_ts + (size_t)b * a.Am_bs] : 0.f;
     }
     const float eb = a.e_bias ? a.e_bias[0] : 0.f;
     // ---- LDS residents
     for (int x = tid; x < g.total - g.o_cv; x += PD_THREADS) lds[g.o_cv + x] = 0.f;      // everything behind the big tables
     for (int x = tid; x < nown * M; x += PD_THREADS) {
         const int tl = x / M, m = x % M, t = tl * P + p;
-        PAs[x] = t < Tp ? a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m] : 0.f;
+        PAs[x] = t < Tp ? C2 * a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m] : 0.f;
     }
     for (int x = tid; x < Tp * 3 * PD_UNITS; x += PD_THREADS) {
         const int t = x / (3 * PD_UNITS), gcol = x % (3 * PD_UNITS), gate = gcol / PD_UNITS, unit = p * PD_UNITS + gcol % PD_UNITS;
         AWs[t * PD_AWS + gcol] = unit < D ? w.AW[((size_t)t * B + b) * 3 * D + (size_t)gate * D + unit] : 0.f;
     }
-    for (int x = tid; x < K * g.FW; x += PD_THREADS) Fs[x] = a.filters[x];
     __syncthreads();
     for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[(size_t)b * Tp + t];
     for (int k = tid; k < D; k += PD_THREADS) sv[pd_slot(k, PD_KD)] = a.S[(size_t)b * D + k];
@@ -321,46 +317,57 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         }
     }
 
+    PdClock clk;
+    clk.start(g.prof != 0 && blockIdx.x == 0 && tid == 0, lds + g.o_clk);
+
     // Location convolution of the alignment in `al` for the own positions with the window of label i (lvsr/expressions.py:28-54:
     // true convolution of the cut alignment): cv[k][t] = sum_d f[k][c+d] * al[t-d].  On the matrix cores: per block of 16 own
     // positions a 16(filters) x 16(positions) tile accumulates over the 2c+1 taps four at a time (v_mfma_f32_16x16x4_f32: A =
     // filter taps, B = shifted, window-masked alignment values); the four waves split the tap groups and fold through LDS.
-    auto conv = [&](int i, const Win wi) {
-        const int cn = a.c, FW = g.FW, ng4 = (FW + 3) / 4;
+    // A operands (filter taps) of this lane's MFMAs: wave w takes the tap groups w, w + 8, ...; the same for every label and block
+    float cfa[8];
+    {
         const int r16 = lane & 15, kk = lane >> 4;
-        const int frow = min(r16, K - 1) * FW;
-        auto operands = [&](int g4, int tx, bool colok, float& fa, float& fb) {
-            const int u = 4 * g4 + kk, idx = tx - (u - cn);
-            fa = Fs[frow + min(u, FW - 1)];
-            fa = (r16 < K && u < FW) ? fa : 0.f;
-            fb = al[min(max(idx, 0), Tp - 1)];
-            fb = (colok && idx >= wi.begin && idx < wi.end) ? fb : 0.f;
-        };
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int u = 4 * (wave + n * PD_NW) + kk;
+            cfa[n] = (KC > 0 && r16 < K && u < g.FW) ? a.filters[(size_t)min(r16, K - 1) * g.FW + min(u, g.FW - 1)] : 0.f;
+        }
+    }
+    auto conv = [&](int i, const Win wi) {
+        const int cn = a.c, ng4 = (g.FW + 3) / 4;
+        const int r16 = lane & 15, kk = lane >> 4;
         for (int bl = 0; bl * 16 < nown; ++bl) {
             const int tlx = bl * 16 + r16, tx = tlx * P + p;          // B operand: this lane's position column
             const bool colok = tlx < nown && tx < Tp;
+            // alignment index of tap group n: idx0 - 32 n; in the window <=> (unsigned)(idx - begin) < width.  The reads are
+            // not clamped: +-(c + 16 P) around `al` stays inside this work-group's LDS block (pd_geom), the select drops them
+            const int idx0 = tx + cn - kk - 4 * wave;
+            const unsigned width = colok ? (unsigned)(wi.end - wi.begin) : 0u;
+            const float* ap = al + idx0;
+            float fb[8];
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                const float v = ap[-32 * n];
+                fb[n] = ((unsigned)(idx0 - 32 * n - wi.begin) < width) ? v : 0.f;
+            }
             f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
-            int g4 = wave;
-            for (; g4 + PD_NW < ng4; g4 += 2 * PD_NW) {
-                float fa0, fb0, fa1, fb1;
-                operands(g4, tx, colok, fa0, fb0);
-                operands(g4 + PD_NW, tx, colok, fa1, fb1);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0, fb0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1, fb1, acc1, 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 8; n += 2) {
+                if (wave + n * PD_NW < ng4) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cfa[n], fb[n], acc0, 0, 0, 0);
+                if (wave + (n + 1) * PD_NW < ng4) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cfa[n + 1], fb[n + 1], acc1, 0, 0, 0);
             }
-            if (g4 < ng4) {
-                float fa0, fb0;
-                operands(g4, tx, colok, fa0, fb0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0, fb0, acc0, 0, 0, 0);
-            }
+            clk.mark(12);
 #pragma unroll
             for (int r = 0; r < 4; ++r) cp[(wave * 16 + kk * 4 + r) * 17 + r16] = acc0[r] + acc1[r];
             __syncthreads();
-            {
+            clk.mark(13);
+            if (tid < 256) {
                 const int k = tid >> 4, x = tid & 15, tl = bl * 16 + x, t = tl * P + p;
-                float sum = 0.f;
+                float pv[PD_NW];
 #pragma unroll
-                for (int wv = 0; wv < PD_NW; ++wv) sum += cp[(wv * 16 + k) * 17 + x];
+                for (int wv = 0; wv < PD_NW; ++wv) pv[wv] = cp[(wv * 16 + k) * 17 + x];          // all loads in flight
+                const float sum = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
                 if (k < K && tl < nown && t < Tp) {
                     const float val = (t >= wi.begin && t < wi.end) ? sum : 0.f;
                     cvs[tl * KCP + k] = val;
@@ -368,11 +375,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 }
             }
             if ((bl + 1) * 16 < nown) __syncthreads();
+            clk.mark(14);
         }
     };
-    PdClock clk;
-    clk.start(blockIdx.x == 0 && tid == 0, lds + g.o_clk);
 
+    Win wnext = attdec_window(a, 0);          // not used with the window_around_* priors
+    if (KC > 0 && !winprior) conv(0, wnext);
     for (int i = 0; i < L; ++i) {
         const unsigned epoch = (unsigned)(i + 1);
         const size_t row = (size_t)i * B + b;
@@ -417,10 +425,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 if (tid + x * PD_THREADS < B) posv[(i & 1) * g.Bp + tid + x * PD_THREADS] = v[x];
             __syncthreads();
         }
-        const Win wi = pd_window(a, i, posv + (i & 1) * g.Bp);
+        // window of this label: known without the centres for the expanding prior (computed, with the convolution, in the shadow
+        // of the previous label's r*s exchange: wnext)
+        const Win wi = winprior ? pd_window(a, i, posv + (i & 1) * g.Bp) : wnext;
         float amk[PD_NV];                    // attended mask x window-around mask of this utterance (attdec_mask)
 #pragma unroll
-        for (int x = 0; x < PD_NV; ++x) amk[x] = am[x];
+        for (int x = 0; x < PD_NV; ++x) amk[x] = am;
         if (winprior) {
             const float pb = posv[(i & 1) * g.Bp + b];
             const float lo = floorf(pb - (float)a.p0), hi = ceilf(pb + (float)a.p1);
@@ -430,65 +440,74 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 amk[x] *= (tf > lo && tf < hi) ? 1.f : 0.f;
             }
         }
-        if (KC > 0) conv(i, wi);
+        clk.mark(9);
+        if (KC > 0 && winprior) conv(i, wi);
         clk.mark(7);
         float swv[PD_NV];
         if (!pd_gather(gSW, M, epoch, abort_word, swv)) return;
-        __syncthreads();                     // the convolution features are in place for everybody
+        // thread tid received granule tid; the energy phase wants columns mp and mp + 256 in one thread: through LDS.  The
+        // barrier also publishes the convolution features
+        swst[tid] = swv[0];
+        __syncthreads();
         clk.mark(2);
-        // ---- phase B: energies of the own positions, 16 per round; thread tid holds columns tid and tid + 256.  Branch-free
-        // (clamped addresses, results masked afterwards): with one wave per SIMD the 16 positions' chains are the only ILP
-        const int m0c = min(tid, M - 1), m1c = min(tid + PD_THREADS, M - 1);       // columns beyond M carry w_e = 0
+        // ---- phase B: energies of the own positions, 16 per round (alternate positions per half of the work-group, PD_EG at a time written
+        // operand-first / filter-major so that the four chains interleave); branch-free inside a group (clamped addresses,
+        // results masked afterwards)
+        const int m0c = min(mp, M - 1), m1c = min(mp + PD_MP, M - 1);              // columns beyond M carry w_e = 0
+        const f32x2 swp = {C2 * swst[mp], C2 * swst[mp + PD_MP]};                   // pre-scaled, see C2
         for (int tl0 = 0; tl0 < nown; tl0 += PD_CH) {
-            float v[PD_CH];
+            float v[8];
 #pragma unroll
-            for (int x0 = 0; x0 < PD_CH; x0 += 4) {
-                // four positions at a time, written operand-first / filter-major so that the four chains interleave
-                f32x2 xx[4];
-                float4 c4[4][KCP > 0 ? KCP / 4 : 1];
+            for (int x = 0; x < 8; ++x) v[x] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tlc = min(tl0 + x0 + e, nown - 1);
-                    xx[e] = (f32x2){swv[0] + PAs[tlc * M + m0c], swv[1] + PAs[tlc * M + m1c]};
-                    const float4* cr = (const float4*)(cvs + tlc * KCP);
+            for (int x0 = 0; x0 < 8; x0 += PD_EG) {
+                const int tlb = tl0 + 2 * x0 + ehalf;          // the halves take alternate positions: balanced for any T'
+                if (tlb < nown) {                              // wave-uniform: padded groups of the last round are skipped
+                    f32x2 xx[PD_EG];
+                    float4 c4[PD_EG][KCP > 0 ? KCP / 4 : 1];
 #pragma unroll
-                    for (int k4 = 0; k4 < KCP / 4; ++k4) c4[e][k4] = cr[k4];
-                }
+                    for (int e = 0; e < PD_EG; ++e) {
+                        const int tlc = min(tlb + 2 * e, nown - 1);
+                        xx[e] = (f32x2){swp.x + PAs[tlc * M + m0c], swp.y + PAs[tlc * M + m1c]};
+                        const float4* cr = (const float4*)(cvs + tlc * KCP);
 #pragma unroll
-                for (int k4 = 0; k4 < KCP / 4; ++k4) {
+                        for (int k4 = 0; k4 < KCP / 4; ++k4) c4[e][k4] = cr[k4];
+                    }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float4 c = c4[e][k4];
-                        if (4 * k4 < KC) xx[e] = Hk[4 * k4] * (f32x2){c.x, c.x} + xx[e];
-                        if (4 * k4 + 1 < KC) xx[e] = Hk[4 * k4 + 1 < KC ? 4 * k4 + 1 : 0] * (f32x2){c.y, c.y} + xx[e];
-                        if (4 * k4 + 2 < KC) xx[e] = Hk[4 * k4 + 2 < KC ? 4 * k4 + 2 : 0] * (f32x2){c.z, c.z} + xx[e];
-                        if (4 * k4 + 3 < KC) xx[e] = Hk[4 * k4 + 3 < KC ? 4 * k4 + 3 : 0] * (f32x2){c.w, c.w} + xx[e];
+                    for (int k4 = 0; k4 < KCP / 4; ++k4) {
+#pragma unroll
+                        for (int e = 0; e < PD_EG; ++e) {
+                            const float4 c = c4[e][k4];
+                            if (4 * k4 < KC) xx[e] = Hk[4 * k4] * (f32x2){c.x, c.x} + xx[e];
+                            if (4 * k4 + 1 < KC) xx[e] = Hk[4 * k4 + 1 < KC ? 4 * k4 + 1 : 0] * (f32x2){c.y, c.y} + xx[e];
+                            if (4 * k4 + 2 < KC) xx[e] = Hk[4 * k4 + 2 < KC ? 4 * k4 + 2 : 0] * (f32x2){c.z, c.z} + xx[e];
+                            if (4 * k4 + 3 < KC) xx[e] = Hk[4 * k4 + 3 < KC ? 4 * k4 + 3 : 0] * (f32x2){c.w, c.w} + xx[e];
+                        }
+                    }
+                    float ex[PD_EG][2];
+#pragma unroll
+                    for (int e = 0; e < PD_EG; ++e) { ex[e][0] = __builtin_amdgcn_exp2f(xx[e].x); ex[e][1] = __builtin_amdgcn_exp2f(xx[e].y); }
+#pragma unroll
+                    for (int e = 0; e < PD_EG; ++e) {
+                        ex[e][0] = __builtin_amdgcn_rcpf(1.0f + ex[e][0]);
+                        ex[e][1] = __builtin_amdgcn_rcpf(1.0f + ex[e][1]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < PD_EG; ++e) {
+                        const int tl = tlb + 2 * e, t = tl * P + p;
+                        const float val = wem2.y * ex[e][1] + (wem2.x * ex[e][0] + wsum);
+                        v[x0 + e] = (tl < nown && t >= wi.begin && t < wi.end) ? val : 0.f;
                     }
                 }
-                float ex[4][2];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ex[e][0] = __expf(2.0f * xx[e].x); ex[e][1] = __expf(2.0f * xx[e].y); }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    ex[e][0] = __builtin_amdgcn_rcpf(1.0f + ex[e][0]);
-                    ex[e][1] = __builtin_amdgcn_rcpf(1.0f + ex[e][1]);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int tl = tl0 + x0 + e, t = tl * P + p;
-                    const float val = we2.x * (1.0f - 2.0f * ex[e][0]) + we2.y * (1.0f - 2.0f * ex[e][1]);      // w_e . tanh_fast
-                    v[x0 + e] = (tl < nown && t >= wi.begin && t < wi.end) ? val : 0.f;
-                }
             }
-            const float tot = pd_butterfly16(v);
-            if ((lane & 3) == 0) xw[wave * PD_CH + pd_butterfly_index(lane)] = tot;
+            const float tot = pd_butterfly8(v);
+            if ((lane & 7) == 0) xw[wave * 8 + pd_butterfly_index(lane)] = tot;
             __syncthreads();
             if (tid < PD_CH) {
                 const int tl = tl0 + tid, t = tl * P + p;
                 if (tl < nown && t < Tp) {
-                    float e = 0.f;
-#pragma unroll
-                    for (int wv = 0; wv < PD_NW; ++wv) e += xw[wv * PD_CH + tid];
+                    const float* xr = xw + (tid & 1) * 4 * 8 + (tid >> 1);       // the four waves of this position's half
+                    const float e = (xr[0] + xr[8]) + (xr[16] + xr[24]);
                     granule_store(gEN + t, epoch, (t >= wi.begin && t < wi.end) ? e : 0.f);
                 }
             }
@@ -498,42 +517,36 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         float eg[PD_NV];
         if (!pd_gather(gEN, Tp, epoch, abort_word, eg)) return;
         clk.mark(4);
-        // ---- phase C: normalisation over the window (every work-group, redundantly), glimpse of the own columns
+        // ---- phase C: normalisation over the window (every work-group, redundantly; one position per thread, three barriers)
         {
-            bool inw[PD_NV];
-            float e[PD_NV], u[PD_NV], mxl = -3.0e38f, anyl = 0.f;
+            const int t = tid;
+            const bool inw = t < Tp && t >= wi.begin && t < wi.end;
+            const float e = inw ? eg[0] + eb : 0.f;
+            if (p == 0 && t < Tp) a.EN[row * Tp + t] = e;                  // pasted into zeros
+            const float wmx = wave_max_dpp(inw ? e : -3.0e38f);
+            const float wany = wave_max_dpp((inw && 1.f - amk[0] == 0.f) ? 1.f : 0.f);
+            if (lane == 0) { red[wave] = wmx; red[PD_NW + wave] = wany; }
+            __syncthreads();
+            float mx = red[0], anyone = red[PD_NW];
 #pragma unroll
-            for (int x = 0; x < PD_NV; ++x) {
-                const int t = tid + x * PD_THREADS;
-                inw[x] = t < Tp && t >= wi.begin && t < wi.end;
-                e[x] = inw[x] ? eg[x] + eb : 0.f;
-                if (p == 0 && t < Tp) a.EN[row * Tp + t] = e[x];          // pasted into zeros
-                if (inw[x]) mxl = fmaxf(mxl, e[x]);
-                if (inw[x] && 1.f - amk[x] == 0.f) anyl = 1.f;
+            for (int x = 1; x < PD_NW; ++x) { mx = fmaxf(mx, red[x]); anyone = fmaxf(anyone, red[PD_NW + x]); }
+            float u = 0.f;
+            if (inw) {
+                if (a.normalizer == 0) u = __expf(e - mx) * amk[0];
+                else if (a.normalizer == 1) u = sigmoidf_(e) * amk[0];
+                else u = fmaxf(e / 1000.f, 0.f) * amk[0];
             }
-            const float mx = pd_wg_max(mxl, red);
-            float sl = 0.f;
+            const float wsm = wave_sum_dpp(u);
+            if (lane == 0) red[2 * PD_NW + wave] = wsm;
+            __syncthreads();
+            float ssum = 0.f;
 #pragma unroll
-            for (int x = 0; x < PD_NV; ++x) {
-                u[x] = 0.f;
-                if (inw[x]) {
-                    if (a.normalizer == 0) u[x] = __expf(e[x] - mx) * amk[x];
-                    else if (a.normalizer == 1) u[x] = sigmoidf_(e[x]) * amk[x];
-                    else u[x] = fmaxf(e[x] / 1000.f, 0.f) * amk[x];
-                }
-                sl += u[x];
-            }
-            const float ssum = pd_wg_sum(sl, red);
-            const float anyone = pd_wg_max(anyl, red);
+            for (int x = 0; x < PD_NW; ++x) ssum += red[2 * PD_NW + x];
             const float Z = ssum + (anyone > 0.f ? 0.f : 1.f);
-#pragma unroll
-            for (int x = 0; x < PD_NV; ++x) {
-                const int t = tid + x * PD_THREADS;
-                const float alpha = inw[x] ? u[x] / Z : 0.f;
-                if (t < Tp) {
-                    al[t] = alpha;
-                    if (p == 0) a.W[((size_t)(i + 1) * B + b) * Tp + t] = alpha;
-                }
+            const float alpha = inw ? u / Z : 0.f;
+            if (t < Tp) {
+                al[t] = alpha;
+                if (p == 0) a.W[((size_t)(i + 1) * B + b) * Tp + t] = alpha;
             }
             if (p == 0 && tid == 0 && a.ZB) a.ZB[row] = Z;
         }
@@ -572,7 +585,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         const float xin = fx + group_sum<PD_KSPLIT>(gx);
         if (q == 0 && junit) a.U[row * D + j] = uu;
         clk.mark(6);
-        // the next label's window centre of this utterance: a sequential scan of the alignment by one wave, behind the r*s exchange
+        // behind the r*s exchange: the next label's window and convolution features (expanding prior / content-only attention),
+        // or the next window centre of this utterance (a sequential scan of the alignment by one wave)
+        if (!winprior && i + 1 < L) {
+            wnext = attdec_window(a, i + 1);
+            if (KC > 0) conv(i + 1, wnext);
+        }
         if (winprior && pos_wave && i + 1 < L) {            // next window centre
             const float r = attdec_pos_of_row_wave(a, al);
             if (lane == 0) {
@@ -696,5 +714,6 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     key.add(&a, sizeof(a));
     key.add(&w, sizeof(w));
     key.add(&ws, sizeof(ws));
+    key.add(&g.prof, sizeof(g.prof));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd_persistent");
 }

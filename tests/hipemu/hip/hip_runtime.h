@@ -248,16 +248,20 @@ inline int __all(int pred) {
     (void)l;
     return acc;
 }
-// v_mov_b32 with a DPP quad_perm control (ctrl < 0x100): lane l reads lane (l & ~3) + ((ctrl >> 2*(l&3)) & 3)
+// v_mov_b32 with a DPP control: quad_perm (ctrl < 0x100): lane l reads lane (l & ~3) + ((ctrl >> 2*(l&3)) & 3);
+// row_ror:n (ctrl 0x121..0x12F): rotation by n lanes inside each row of 16
 inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
     int l = hipemu::lane_id();
-    if (ctrl >= 0x100) { fprintf(stderr, "hipemu: only quad_perm DPP controls are emulated\n"); abort(); }
+    if (ctrl >= 0x121 && ctrl <= 0x12F) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | ((l - (ctrl - 0x120)) & 15));
+    if (ctrl >= 0x100) { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
     return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
 }
 #define __builtin_amdgcn_mov_dpp hipemu_mov_dpp
 // v_readlane_b32: the value lane `src` holds, for every lane (all lanes of the wave must reach the call)
 inline int hipemu_readlane(int v, int src) { return (int)hipemu::shfl_generic<long long, long long>(v, src); }
 #define __builtin_amdgcn_readlane hipemu_readlane
+// v_readfirstlane_b32: only used on values that are already wave-uniform, so the lane's own value is the answer
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
 inline unsigned long long __ballot(int pred) {
     unsigned long long m = 0;
     for (int src = 0; src < hipemu::wave_size_here(); ++src)
@@ -336,6 +340,7 @@ inline long long wall_clock64() { return 0; }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.0f / a; }
 inline float __builtin_amdgcn_rcpf(float a) { return 1.0f / a; }
+inline float __builtin_amdgcn_exp2f(float a) { return std::exp2(a); }
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                         \
     do {                                                                                      \

@@ -18,10 +18,11 @@ if prior == "median":
 params = synthetic.make_params(cfg, seed=1)
 batch = synthetic.make_batch(cfg, B, T, L, seed=2, ragged=False)
 PH = ["S gather", "A: sW/sg dots + publish", "SW gather", "B: energies", "EN gather", "C: softmax", "D: gate sums + publish",
-      "centres + conv (SW shadow)", "centre scan (RS shadow)", "-", "RS gather", "E: candidate"]
+      "conv (SW shadow)", "centre scan (RS shadow)", "centres + window", "RS gather", "E: candidate", "  conv: operands + MFMA", "  conv: partials + barrier", "  conv: fold + store"]
 ref = None
-for mode in ("0", "1"):
+for mode, prof in (("0", "0"), ("1", "0"), ("1", "1")):
     os.environ["LVSR_DEC_PERSISTENT"] = mode
+    os.environ["LVSR_PD_PROF"] = prof
     rec = SpeechRecognizer(device="cuda:0", params=params, net_config=cfg)
     gen = rec.generator
     x = torch.from_numpy(batch["recordings"]).cuda(); xm = torch.from_numpy(batch["recordings_mask"]).cuda()
@@ -38,12 +39,13 @@ for mode in ("0", "1"):
     gen.check_persistent()
     tot = float(cm.sum())
     print("%s decoder cost_matrix forward, %s: %.3f ms (%.2f us/label), cost sum %.6f" % (
-        name, "persistent" if mode == "1" else "step kernels", best, best * 1e3 / L, tot), flush=True)
-    if mode == "1":
+        name, ("persistent + phase clock" if prof == "1" else "persistent") if mode == "1" else "step kernels", best, best * 1e3 / L, tot), flush=True)
+    if prof == "1":
         sync = [b for k, b in gen.ws._bufs.items() if k[0] == "gen.sync"][0]
         clk = sync[16:16 + 2 * len(PH)].cpu().numpy().view(numpy.int64)
         for nm, c in zip(PH, clk):
             print("    %-28s %7.3f us/label" % (nm, c * 0.01 / L))
         print("    %-28s %7.3f us/label" % ("sum", clk.sum() * 0.01 / L))
         print("    rel. cost difference vs step kernels %.2e" % (abs(tot - ref) / abs(ref)))
-    ref = tot
+    if mode == "0":
+        ref = tot
