@@ -280,6 +280,195 @@ __global__ __launch_bounds__(256) void attbwd_energy_kernel(AttBwd g, int i) {
     }
 }
 
+// B4 on the matrix cores (K > 0): the three handler contractions of the kernel above — the forward recomputation
+// match += cv^T handler, dcv = dm handler^T and the handler gradient cv dm — as v_mfma_f32_16x16x4_f32 tiles instead of K
+// FMAs per element and phase.  Same grid, same inputs / outputs, same per-tile / per-slice partials.
+// Work-group = 64 positions x 32 match columns; wave w owns positions [16w, 16w+16): MFMA output lane (c16 = lane%16, g4 =
+// lane/16) holds positions 16w + 4 g4 + r (r < 4) x columns ct*16 + c16 (ct < 2), so the elementwise part (tanh, softmax /
+// energy backward, dPA) runs directly on the accumulators.  KP = K rounded up to a multiple of 4 (zero filters beyond K).
+template <int KP>
+__global__ __launch_bounds__(256) void attbwd_energy_mfma_kernel(AttBwd g, int i) {
+    constexpr int NS = KP / 4;
+    __shared__ float cvs[KP][ATT_TT + 1];
+    __shared__ float des[ATT_TT];
+    __shared__ float dms[ATT_TT][ATT_MS + 1];
+    __shared__ float racc[4][KP + 2][ATT_MS + 1];
+    __shared__ float red[4];
+    const AttDec& a = g.f;
+    const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x, tile = blockIdx.z, ntile = gridDim.z;
+    const int B = a.B, Tp = a.Tp, M = a.M, K = a.K, t0 = tile * ATT_TT;
+    const Win w = attdec_window(a, i);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
+    const size_t bt = (size_t)b * ntile + tile;
+    if (t0 >= w.end || t0 + ATT_TT <= w.begin) {                   // tile outside the window: zero partial
+        if (threadIdx.x < ATT_MS && slice * ATT_MS + threadIdx.x < M) g.dswp[bt * M + slice * ATT_MS + threadIdx.x] = 0.f;
+        return;
+    }
+    // ---- independent loads first: this lane's 4 positions x 2 columns of PA and of the running dPA, its operand registers
+    float pav[2][4], dpv[2][4], we_m[2], sw_m[2];
+    bool mok[2];
+    const size_t dpa_ts = (size_t)B * M;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int m = slice * ATT_MS + ct * 16 + c16;
+        mok[ct] = m < M;
+        const float* pab = a.PA + (size_t)b * a.PA_bs + m;
+        const float* dpab = g.dPA + (size_t)b * M + m;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * wv + 4 * g4 + r;
+            const bool ok = t >= w.begin && t < w.end && mok[ct];
+            pav[ct][r] = ok ? pab[(size_t)t * a.PA_ts] : 0.f;
+            dpv[ct][r] = ok ? dpab[(size_t)t * dpa_ts] : 0.f;
+        }
+        we_m[ct] = mok[ct] ? a.w_e[m] : 0.f;
+        sw_m[ct] = mok[ct] ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
+    }
+    float Hb[NS][2];        // B operand of the forward contraction: handler[4s + g4][column ct*16 + c16]
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            const int k = 4 * s + g4;
+            Hb[s][ct] = (k < K && mok[ct]) ? a.handler[(size_t)k * M + slice * ATT_MS + ct * 16 + c16] : 0.f;
+        }
+    float Ht[ATT_MS / 4];   // B operand of dcv = dm handler^T: handler[filter c16][column 4 s + g4]
+#pragma unroll
+    for (int s = 0; s < ATT_MS / 4; ++s) {
+        const int m = slice * ATT_MS + 4 * s + g4;
+        Ht[s] = (c16 < K && m < M) ? a.handler[(size_t)c16 * M + m] : 0.f;
+    }
+    const float* al = a.W + ((size_t)(i + 1) * B + b) * Tp;       // alignment produced by step i
+    const float* qr = g.Q + (size_t)b * Tp;
+    float cvr[(KP * ATT_TT + 255) / 256];
+#pragma unroll
+    for (int c = 0; c < (KP * ATT_TT + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
+        cvr[c] = (x < K * ATT_TT && t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
+    }
+    float oldacc[((2 + KP) * ATT_MS + 255) / 256];
+#pragma unroll
+    for (int c = 0; c < ((2 + KP) * ATT_MS + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        const int v = x / ATT_MS, j = x % ATT_MS, mm = slice * ATT_MS + j;
+        float o = 0.f;
+        if (x < (2 + K) * ATT_MS && mm < M) {
+            if (v == 1) o = g.accWe[bt * M + mm];
+            else if (v >= 2) o = g.accH[(bt * K + (v - 2)) * M + mm];
+        }
+        oldacc[c] = o;
+    }
+    float sd = 0.f;
+    for (int t = w.begin + threadIdx.x; t < w.end; t += 256) sd += al[t] * qr[t];
+    sd = block_sum(sd, red);
+    if (threadIdx.x < ATT_TT) {
+        const int t = t0 + threadIdx.x;
+        float de = 0.f;
+        if (t >= w.begin && t < w.end) {
+            if (a.normalizer == 0) {
+                de = al[t] * (qr[t] - sd);
+            } else {
+                const float e = a.EN[((size_t)i * B + b) * Tp + t], Z = a.ZB[(size_t)i * B + b];
+                const float gq = (qr[t] - sd) / Z * attdec_mask(a, i, b, t);
+                if (a.normalizer == 1) { const float sg = sigmoidf_(e); de = gq * sg * (1.f - sg); }
+                else de = e > 0.f ? gq / 1000.f : 0.f;
+            }
+        }
+        des[threadIdx.x] = de;
+    }
+#pragma unroll
+    for (int c = 0; c < (KP * ATT_TT + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        if (x < KP * ATT_TT) cvs[x / ATT_TT][x % ATT_TT] = cvr[c];
+    }
+    __syncthreads();
+    // ---- match = PA + sW + cv^T handler on this wave's 16 positions x 32 columns
+    f32x4 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+        acc[ct] = (f32x4){pav[ct][0] + sw_m[ct], pav[ct][1] + sw_m[ct], pav[ct][2] + sw_m[ct], pav[ct][3] + sw_m[ct]};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float av = cvs[4 * s + g4][16 * wv + c16];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Hb[s][0], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Hb[s][1], acc[1], 0, 0, 0);
+    }
+    // ---- elementwise: dm = de * w_e * (1 - tanh^2); dPA += dm; partial sums over this lane's 4 positions
+    float swacc[2] = {0.f, 0.f}, weacc[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int tl = 16 * wv + 4 * g4 + r, t = t0 + tl;
+        const bool tin = t >= w.begin && t < w.end;
+        const float de = des[tl];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+            float d = 0.f;
+            if (tin && mok[ct]) {
+                const float th = tanh_fast(acc[ct][r]);
+                d = de * we_m[ct] * (1.f - th * th);
+                g.dPA[(size_t)t * dpa_ts + (size_t)b * M + slice * ATT_MS + ct * 16 + c16] = dpv[ct][r] + d;
+                swacc[ct] += d;
+                weacc[ct] += de * th;
+            }
+            dms[tl][ct * 16 + c16] = d;
+        }
+    }
+    if (a.e_bias && slice == 0 && threadIdx.x == 0) {           // d energy bias = sum of de (des is complete: barrier above)
+        float sb = 0.f;
+        for (int x = 0; x < ATT_TT; ++x) sb += des[x];
+        g.accEb[bt] += sb;
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {                             // fold the four position groups of the wave
+        swacc[ct] += __shfl_xor(swacc[ct], 16, 64); swacc[ct] += __shfl_xor(swacc[ct], 32, 64);
+        weacc[ct] += __shfl_xor(weacc[ct], 16, 64); weacc[ct] += __shfl_xor(weacc[ct], 32, 64);
+        if (g4 == 0) { racc[wv][0][ct * 16 + c16] = swacc[ct]; racc[wv][1][ct * 16 + c16] = weacc[ct]; }
+    }
+    __syncthreads();
+    // ---- dcv[t][k] = sum_m dm[t][m] handler[k][m] for this wave's 16 positions (rows) x 16 filters (columns)
+    if (K > 0) {
+        f32x4 dc = F32X4_ZERO;
+#pragma unroll
+        for (int s = 0; s < ATT_MS / 4; ++s)
+            dc = __builtin_amdgcn_mfma_f32_16x16x4f32(dms[16 * wv + c16][4 * s + g4], Ht[s], dc, 0, 0, 0);
+        float* dcvp = g.dcvp + ((size_t)b * nslice + slice) * K * Tp;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * wv + 4 * g4 + r;
+            if (c16 < K && t >= w.begin && t < w.end) dcvp[(size_t)c16 * Tp + t] = dc[r];
+        }
+    }
+    // ---- handler gradient partial: dH[k][m] = sum_t cv[k][t] dm[t][m]; wave w takes positions [16w, 16w+16) of the sum
+    {
+        f32x4 dh[2] = {F32X4_ZERO, F32X4_ZERO};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int tl = 16 * wv + 4 * s + g4;
+            const float av = c16 < KP ? cvs[c16 < KP ? c16 : 0][tl] : 0.f;
+            dh[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dms[tl][c16], dh[0], 0, 0, 0);
+            dh[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dms[tl][16 + c16], dh[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g4 + r;
+            if (k < KP) { racc[wv][2 + k][c16] = dh[0][r]; racc[wv][2 + k][16 + c16] = dh[1][r]; }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ((2 + KP) * ATT_MS + 255) / 256; ++c) {
+        const int x = threadIdx.x + 256 * c;
+        const int v = x / ATT_MS, j = x % ATT_MS, mm = slice * ATT_MS + j;
+        if (x < (2 + K) * ATT_MS && mm < M) {
+            const float r = (racc[0][v][j] + racc[1][v][j]) + (racc[2][v][j] + racc[3][v][j]);
+            if (v == 0) g.dswp[bt * M + mm] = r;
+            else if (v == 1) g.accWe[bt * M + mm] = oldacc[c] + r;
+            else g.accH[(bt * K + (v - 2)) * M + mm] = oldacc[c] + r;
+        }
+    }
+}
+
 struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of the per-work-group partials (read only:
                      // a store inside the functor would order every later operand load behind it)
     const float* __restrict__ dswp; int ntile, M, nrows; bool vec, fast;
@@ -385,37 +574,63 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
 }
 
 // gradient wrt conv1d.filters: df[k][j] = sum_{i,b,t in win_i} dcv_i[b,k,t] * alpha_i[b, t-(j-c)]  (alpha index in win_i).
-// Block (chunk of R rows (i,b), filter k): the R rows of dcv and alpha are staged in LDS once, thread j owns lag j and
-// walks them; per-chunk partials are folded by lvsr_colsum in a fixed order.
+// A product (filters x positions) . (positions x lags) per row (i,b), on the matrix cores: A = the row's dcv (zero outside the
+// window), B = a Toeplitz view of the row's alignment (zero outside the window, c zeros either side in LDS, so no operand is
+// masked), four positions per v_mfma_f32_16x16x4_f32.  Block = a chunk of R rows; wave w owns the lag tiles w, w+4, ...
+// (NTW of them) for ALL filters, so an A operand is fetched once per four positions and reused by the wave's tiles.  Per-chunk
+// partials are folded by lvsr_colsum in a fixed order.  (Was: one thread per lag walking rows and positions with two LDS reads
+// per multiply-add, one block per filter — 165 us per call on WSJ-base.)
 #define FG_LDS 8192
+#define FG_PADF 16
+template <int NTW>
 __global__ __launch_bounds__(256) void attdec_filter_grad_kernel(AttDec a, const float* DCV, float* part, int R) {
-    __shared__ float X[FG_LDS];
-    __shared__ float Wr[FG_LDS];
+    __shared__ float X[FG_LDS];                    // [R][K][Tp] dcv rows, zero outside the row's window
+    __shared__ float Wp[FG_LDS];                   // [R][FG_PADF + Tp + 2c + 4] alignment rows, zero outside the window / in the pads
     __shared__ int wb[16], we[16];
-    const int chunk = blockIdx.x, k = blockIdx.y, FW = 2 * a.c + 1, Tp = a.Tp, nrow = a.L * a.B;
-    const int r0 = chunk * R, nr = min(R, nrow - r0);
+    const int chunk = blockIdx.x, FW = 2 * a.c + 1, Tp = a.Tp, K = a.K, nrow = a.L * a.B;
+    const int r0 = chunk * R, nr = min(R, nrow - r0), wlen = FG_PADF + Tp + 2 * a.c + 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
     if (threadIdx.x < nr) {
         const Win w = attdec_window(a, (r0 + threadIdx.x) / a.B);
         wb[threadIdx.x] = w.begin; we[threadIdx.x] = w.end;
     }
-    for (int x = threadIdx.x; x < nr * Tp; x += 256) {
-        const int r = x / Tp, t = x % Tp, row = r0 + r;          // row = i*B + b
-        X[x] = DCV[((size_t)row * a.K + k) * Tp + t];
-        Wr[x] = a.W[(size_t)row * Tp + t];                        // alignment slot i = alpha_{i-1}
+    __syncthreads();
+    for (int x = threadIdx.x; x < nr * K * Tp; x += 256) {
+        const int r = x / (K * Tp), t = x % Tp;
+        X[x] = (t >= wb[r] && t < we[r]) ? DCV[(size_t)(r0 + r) * K * Tp + (x - r * K * Tp)] : 0.f;
+    }
+    for (int x = threadIdx.x; x < nr * wlen; x += 256) {
+        const int r = x / wlen, t = x % wlen - FG_PADF - a.c;             // alignment slot i = alpha_{i-1}
+        Wp[x] = (t >= wb[r] && t < we[r]) ? a.W[(size_t)(r0 + r) * Tp + t] : 0.f;
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < FW; j += 256) {
-        const int d = j - a.c;
-        float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < nr; ++r) {
-            const int lo = max(wb[r], wb[r] + d), hi = min(we[r], we[r] + d);     // t and t-d inside [begin,end)
-            const float* xr = X + r * Tp;
-            const float* ar = Wr + r * Tp - d;
-            int t = lo;
-            for (; t + 1 < hi; t += 2) { s0 += xr[t] * ar[t]; s1 += xr[t + 1] * ar[t + 1]; }
-            if (t < hi) s0 += xr[t] * ar[t];
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[n] = F32X4_ZERO;
+    const int kc = min(c16, K - 1);
+    for (int r = 0; r < nr; ++r) {
+        const float* xr = X + ((size_t)r * K + kc) * Tp;
+        // B[kk][lag j] = alpha[t - (j - c)], t = 4 s + kk: index FG_PADF + c + t - (j - c) - ... = FG_PADF + 2c + t - j in the padded row
+        const float* wr = Wp + (size_t)r * wlen + FG_PADF + 2 * a.c - c16;
+        const int s0 = wb[r] / 4, s1 = (we[r] + 3) / 4;                    // positions outside the window contribute zeros
+        for (int s = s0; s < s1; ++s) {
+            const int t = 4 * s + g4;
+            const float av = (c16 < K && t < Tp) ? xr[min(t, Tp - 1)] : 0.f;
+#pragma unroll
+            for (int n = 0; n < NTW; ++n) {
+                const int j0 = (wv + 4 * n) * 16;
+                if (j0 < FW) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wr[t - j0], acc[n], 0, 0, 0);
+            }
         }
-        part[((size_t)chunk * a.K + k) * FW + j] = s0 + s1;
+    }
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int j = (wv + 4 * n) * 16 + c16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * g4 + r;
+            if (k < K && j < FW) part[((size_t)chunk * K + k) * FW + j] = acc[n][r];
+        }
     }
 }
 
@@ -437,14 +652,13 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
             hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
             hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
             hipLaunchKernelGGL(attbwd_q_kernel, dim3((a.Tp + 3) / 4, a.B), dim3(256), 0, s, g, i);
-            switch (att_kc(a.K)) {
-                case 0: hipLaunchKernelGGL(attbwd_energy_kernel<0>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
-                case 1: hipLaunchKernelGGL(attbwd_energy_kernel<1>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
-                case 2: hipLaunchKernelGGL(attbwd_energy_kernel<2>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
-                case 4: hipLaunchKernelGGL(attbwd_energy_kernel<4>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
-                case 8: hipLaunchKernelGGL(attbwd_energy_kernel<8>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
-                case 10: hipLaunchKernelGGL(attbwd_energy_kernel<10>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
-                default: hipLaunchKernelGGL(attbwd_energy_kernel<16>, dim3(nslice, a.B, ntile), dim3(256), 0, s, g, i); break;
+            const dim3 eg(nslice, a.B, ntile);
+            switch ((a.K + 3) / 4) {             // K > 0: handler contractions on the matrix cores, filters padded to a multiple of 4
+                case 0: hipLaunchKernelGGL(attbwd_energy_kernel<0>, eg, dim3(256), 0, s, g, i); break;
+                case 1: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<4>, eg, dim3(256), 0, s, g, i); break;
+                case 2: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<8>, eg, dim3(256), 0, s, g, i); break;
+                case 3: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<12>, eg, dim3(256), 0, s, g, i); break;
+                default: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<16>, eg, dim3(256), 0, s, g, i); break;
             }
             hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.B * a.M + 255) / 256 + a.B * a.K), dim3(256), 0, s, g, i);
         }
@@ -461,14 +675,21 @@ int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float
     memcpy(&a, f, sizeof(a));
     if (int rc = attdec_check(a, "lvsr_attdec_filter_grad")) return rc;
     if (a.K == 0) return LVSR_OK;
-    int R = FG_LDS / a.Tp;
-    if (R > 16) R = 16;
-    if (R < 1) R = 1;
-    LVSR_REQUIRE(a.Tp <= FG_LDS, "lvsr_attdec_filter_grad: attended length %d > %d", a.Tp, FG_LDS);
-    const int nrow = a.L * a.B, nchunk = (nrow + R - 1) / R, FW = 2 * a.c + 1;
+    const int FW = 2 * a.c + 1, wlen = FG_PADF + a.Tp + 2 * a.c + 4;
+    int R = FG_LDS / (a.K * a.Tp);
+    if (R > 4) R = 4;
+    LVSR_REQUIRE(R >= 1 && wlen <= FG_LDS, "lvsr_attdec_filter_grad: conv_num_filters * attended length %d > %d", a.K * a.Tp, FG_LDS);
+    while (R > 1 && R * wlen > FG_LDS) --R;
+    const int nrow = a.L * a.B, nchunk = (nrow + R - 1) / R, ntile = (FW + 15) / 16, ntw = (ntile + 3) / 4;
     const long long need = (long long)nchunk * a.K * FW * 4;
     LVSR_REQUIRE(ws && ws_bytes >= need, "lvsr_attdec_filter_grad: workspace of %lld bytes needed", need);
-    hipLaunchKernelGGL(attdec_filter_grad_kernel, dim3(nchunk, a.K), dim3(256), 0, (hipStream_t)stream, a, DCV, ws, R);
+    LVSR_REQUIRE(ntw <= 16, "lvsr_attdec_filter_grad: conv filter too wide");
+    hipStream_t s = (hipStream_t)stream;
+    if (ntw <= 1) hipLaunchKernelGGL(attdec_filter_grad_kernel<1>, dim3(nchunk), dim3(256), 0, s, a, DCV, ws, R);
+    else if (ntw <= 2) hipLaunchKernelGGL(attdec_filter_grad_kernel<2>, dim3(nchunk), dim3(256), 0, s, a, DCV, ws, R);
+    else if (ntw <= 4) hipLaunchKernelGGL(attdec_filter_grad_kernel<4>, dim3(nchunk), dim3(256), 0, s, a, DCV, ws, R);
+    else if (ntw <= 8) hipLaunchKernelGGL(attdec_filter_grad_kernel<8>, dim3(nchunk), dim3(256), 0, s, a, DCV, ws, R);
+    else hipLaunchKernelGGL(attdec_filter_grad_kernel<16>, dim3(nchunk), dim3(256), 0, s, a, DCV, ws, R);
     if (int rc = lvsr_check_launch("lvsr_attdec_filter_grad")) return rc;
     return lvsr_colsum(stream, ws, nchunk, a.K * FW, a.K * FW, dfilters, 0.f, nullptr, 0);
 }

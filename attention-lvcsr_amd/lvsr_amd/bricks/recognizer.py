@@ -21,9 +21,11 @@ from .generator import SequenceGenerator
 
 class SpeechRecognizer(object):
     def __init__(self, device="cuda:0", params=None, lib=None, use_graph=True, use_persistent=None, net_config=None,
-                 **net_kwargs):
+                 use_persistent_decoder=None, **net_kwargs):
         """`net_kwargs` = the reference's constructor keywords (recognizer.py:176-204), or pass an
-        already-normalised `net_config` (lvsr_amd.spec).  `params` = dict name -> ndarray (Blocks names)."""
+        already-normalised `net_config` (lvsr_amd.spec).  `params` = dict name -> ndarray (Blocks names).
+        `use_persistent` / `use_persistent_decoder`: force (True) or forbid (False) the persistent cluster kernels of the
+        encoder / of the decoder's teacher-forced label loop; None = use them where they are available and faster."""
         from .. import native
         lm_config = dict(net_kwargs.get("lm") or {})
         cfg = net_config if net_config is not None else spec.from_reference_kwargs(**net_kwargs)
@@ -41,7 +43,8 @@ class SpeechRecognizer(object):
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self.bottom = SpeechBottom(self.d, self.store, self.lib, self.ws)
         self.encoder = Encoder(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph, use_persistent=use_persistent)
-        self.generator = SequenceGenerator(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph)
+        self.generator = SequenceGenerator(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph,
+                                           use_persistent=use_persistent_decoder)
         # hipGraph capture cannot run on the legacy null stream: the hot path owns a side stream
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.beam_size = None

@@ -217,7 +217,7 @@ typedef struct lvsr_attdec_bwd_args {
 } lvsr_attdec_bwd_args;
 int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
 /* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block; ws: scratch of at least
- * ceil(L*B / min(16, 8192/Tp)) * K * (2c+1) floats */
+ * ceil(L*B / R) * K * (2c+1) floats with R = min(4, 8192 / (K*Tp)) rows per work-group (L*B*K*(2c+1) floats always suffice) */
 int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters, float* ws,
                             long long ws_bytes);
 

@@ -58,10 +58,10 @@ def test_persistent_cluster_kernels_agree_with_step_kernels(gpu_device, setup):
     cm = per.cost_and_gradients(s["batch"]).cpu().numpy()
     torch.cuda.synchronize()
     per.encoder.check_persistent()
-    assert any(k[0].endswith(".sync") for k in per.ws._bufs), "persistent mode did not engage"
+    assert any(k[0].startswith("enc") and k[0].endswith(".sync") for k in per.ws._bufs), "persistent mode did not engage"
     stp = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_persistent=False)
     cm_s = stp.cost_and_gradients(s["batch"]).cpu().numpy()
-    assert not any(k[0].endswith(".sync") for k in stp.ws._bufs)
+    assert not any(k[0].startswith("enc") and k[0].endswith(".sync") for k in stp.ws._bufs)
     assert_allclose(cm, cm_s, rtol=1e-3, atol=1e-3)
     assert abs(cm.sum() - s["cm"].sum()) / abs(s["cm"].sum()) < 1e-5
     assert_allclose(cm, s["cm"], rtol=1e-3, atol=1e-3)
@@ -69,6 +69,36 @@ def test_persistent_cluster_kernels_agree_with_step_kernels(gpu_device, setup):
     for k in g:
         scale = max(1e-3, numpy.abs(s["grads"][k]).max())
         assert numpy.abs(g[k] - s["grads"][k]).max() / scale < 2e-3, k
+
+
+@pytest.mark.parametrize("prior", [None, dict(type="window_around_median", before=20, after=60),
+                                   dict(type="window_around_mean", before=30, after=40)])
+def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
+    """The persistent label loop (csrc/decoder_persist.hip) against the five-launches-per-label forward, full WSJ-base size,
+    expanding and window_around_* priors: costs, alignments and — through the tensors it saves for the backward pass — every
+    gradient.  The two differ by float32 rounding only (order of additions, the reassociated glimpse)."""
+    s = setup
+    cfg = dict(s["cfg"])
+    if prior is not None:
+        cfg["prior"] = prior
+    out = {}
+    for persistent in (True, False):
+        rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=cfg, use_persistent_decoder=persistent)
+        cm = rec.cost_and_gradients(s["batch"]).cpu().numpy()
+        torch.cuda.synchronize()
+        rec.generator.check_persistent()
+        assert any(k[0] == "gen.sync" for k in rec.ws._bufs) == persistent, "persistent decoder engaged / did not engage"
+        out[persistent] = (cm, rec.generator.last["weights"].cpu().numpy(), rec.generator.last["weighted_averages"].cpu().numpy(),
+                           rec.store.get_grads())
+    (cm_p, w_p, wa_p, g_p), (cm_s, w_s, wa_s, g_s) = out[True], out[False]
+    assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
+    assert_allclose(cm_p, cm_s, rtol=1e-3, atol=1e-3)
+    assert (w_p.argmax(axis=2) == w_s.argmax(axis=2)).all()
+    assert_allclose(w_p, w_s, rtol=1e-3, atol=1e-6)
+    assert_allclose(wa_p, wa_s, rtol=1e-3, atol=1e-5)
+    for k in g_s:
+        scale = max(1e-3, numpy.abs(g_s[k]).max())
+        assert numpy.abs(g_p[k] - g_s[k]).max() / scale < 2e-3, k
 
 
 def test_shard_gradients_add_up_to_the_batch_gradient(gpu_device, setup):
