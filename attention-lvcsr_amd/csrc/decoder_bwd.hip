@@ -492,8 +492,9 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of 
 // for the filter gradient) and correlate with filter k inside the window:
 //   dalp[b,k,t] = sum_d f[k,c+d] * dcv[k,t+d];   the q kernel of the next (earlier) step adds the K rows up.
 __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
-    __shared__ float row[ATT_MAX_T];
-    __shared__ float fl[ATT_MAX_FW];
+    __shared__ float row[ATT_MAX_T + ATT_MAX_FW + 272];
+    __shared__ float fl[ATT_MAX_FW + 496];
+    __shared__ float cpart[4][16][17];
     const AttDec& a = g.f;
     const int D = a.D, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
     const int rt = (B + 15) / 16, ntD = (D + 15) / 16, nmm = ntD * rt;
@@ -531,10 +532,12 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
     blk -= nfold;
     const int k = blk % K, b = blk / K, nslice = (M + ATT_MS - 1) / ATT_MS;
     const Win w = attdec_window(a, i);
-    const int FW = 2 * a.c + 1;
+    const int FW = 2 * a.c + 1, cn = a.c;
     const float* pp = g.dcvp + ((size_t)b * nslice * K + k) * Tp;
     float* dcv = g.DCV + (((size_t)i * B + b) * K + k) * Tp;
-    for (int t = threadIdx.x; t < Tp; t += 256) {
+    // the folded dcv row, zero outside the window, with cn zeros in front and cn + 272 behind (the correlation reads them unmasked)
+    for (int x = threadIdx.x; x < Tp + 2 * cn + 272; x += 256) {
+        const int t = x - cn;
         float s = 0.f;
         if (t >= w.begin && t < w.end) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -548,28 +551,40 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
             for (; sl < nslice; ++sl) s0 += pp[(size_t)sl * K * Tp + t];
             s = (s0 + s1) + (s2 + s3);
         }
-        row[t] = s;
-        dcv[t] = s;
+        row[x] = s;
+        if (t >= 0 && t < Tp) dcv[t] = s;
     }
-    for (int x = threadIdx.x; x < FW; x += 256) fl[x] = a.filters[(size_t)k * FW + x];
+    // filter k with 240 (256) zeros either side: tile column j reads it shifted by 16 j
+    for (int x = threadIdx.x; x < FW + 496; x += 256) fl[x] = (x >= 240 && x < 240 + FW) ? a.filters[(size_t)k * FW + (x - 240)] : 0.f;
     __syncthreads();
+    // dalp[t] = sum_d f[cn+d] * dcv[t+d] on the matrix cores: a 16 x 16 tile holds 256 consecutive outputs, D[i][j] = out[T + i + 16 j]
+    // = sum_u dcv[T + i + u] * f[cn + u - 16 j] over the shifted taps u in [-cn, cn + 240]: A is a Hankel view of the row, B a
+    // Toeplitz view of the filter, four taps per v_mfma_f32_16x16x4_f32; the waves split the tap groups and fold through LDS.
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
+    const int ng = (2 * cn + 241 + 3) / 4;
     float* out = g.dalp + ((size_t)b * K + k) * Tp;
-    for (int t = threadIdx.x; t < Tp; t += 256) {
-        float s = 0.f;
-        if (t >= w.begin && t < w.end) {
-            const int dlo = max(-a.c, w.begin - t), dhi = min(a.c, w.end - 1 - t);
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int d = dlo;
-            for (; d + 3 <= dhi; d += 4) {
-                s0 += fl[a.c + d] * row[t + d];
-                s1 += fl[a.c + d + 1] * row[t + d + 1];
-                s2 += fl[a.c + d + 2] * row[t + d + 2];
-                s3 += fl[a.c + d + 3] * row[t + d + 3];
-            }
-            for (; d <= dhi; ++d) s0 += fl[a.c + d] * row[t + d];
-            s = (s0 + s1) + (s2 + s3);
+    for (int T0 = 0; T0 < Tp; T0 += 256) {
+        f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+        const float* xa = row + T0 + c16 + g4;                  // row[] index of position t is t + cn; tap u = -cn + 4 gq + kk
+        const float* fb = fl + 240 + g4 - 16 * c16;             // fl[] index of filter tap f[cn + u] is 240 + cn + u
+        int gq = wv;
+        for (; gq + 4 < ng; gq += 8) {
+            const float a0 = xa[4 * gq], b0 = fb[4 * gq], a1 = xa[4 * gq + 16], b1 = fb[4 * gq + 16];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
         }
-        out[t] = s;
+        if (gq < ng) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[4 * gq], fb[4 * gq], acc0, 0, 0, 0);
+        __syncthreads();                                         // (protects cpart against the previous block's readers)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cpart[wv][4 * g4 + r][c16] = acc0[r] + acc1[r];
+        __syncthreads();
+        {
+            const int ii = threadIdx.x & 15, jj = threadIdx.x >> 4, t = T0 + ii + 16 * jj;
+            if (t < Tp) {
+                const float v = (cpart[0][ii][jj] + cpart[1][ii][jj]) + (cpart[2][ii][jj] + cpart[3][ii][jj]);
+                out[t] = (t >= w.begin && t < w.end) ? v : 0.f;
+            }
+        }
     }
 }
 
