@@ -8,6 +8,7 @@
 //          dalpha'[b,t'] = sum_k sum_d f[k,c+d] * dcv[b,k,t'+d]   (correlation, inside the step's window)
 // Window positions carry no gradient (disconnected_grad / floor, lvsr/bricks/attention.py:141-147).
 #include "decoder.h"
+#include <stdlib.h>
 
 typedef lvsr_attdec_bwd_args AttBwd;
 
@@ -475,6 +476,24 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of 
     template <bool FAST>
     __device__ __forceinline__ float4 get(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FAST) {
+            // unguarded: rows beyond nrows re-read the last valid one (discarded by the epilogue).  No branch between the
+            // loads: the guarded path below serialised its ntile x 8 loads per lane behind their bounds checks — 13 us per
+            // label for this product alone (tools/r2p.sh ablation)
+            const float4* p = (const float4*)(dswp + (size_t)min(i, nrows - 1) * ntile * M + k);
+            const int stride = M / 4;
+            float4 x0 = p[0], x1 = make_float4(0.f, 0.f, 0.f, 0.f), x2 = x1, x3 = x1;
+            if (ntile > 1) x1 = p[stride];
+            if (ntile > 2) x2 = p[2 * stride];
+            if (ntile > 3) x3 = p[3 * stride];
+            v.x = (x0.x + x1.x) + (x2.x + x3.x); v.y = (x0.y + x1.y) + (x2.y + x3.y);
+            v.z = (x0.z + x1.z) + (x2.z + x3.z); v.w = (x0.w + x1.w) + (x2.w + x3.w);
+            for (int c = 4; c < ntile; ++c) {
+                const float4 x = p[(size_t)c * stride];
+                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+            }
+            return v;
+        }
         if (i >= nrows || k >= M) return v;
         const float* p = dswp + (size_t)i * ntile * M + k;
 #pragma unroll 4
@@ -491,7 +510,7 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of 
 // remaining blocks, one per (utterance b, filter k): fold the per-slice dcv partials of row k (stored as DCV[i]
 // for the filter gradient) and correlate with filter k inside the window:
 //   dalp[b,k,t] = sum_d f[k,c+d] * dcv[k,t+d];   the q kernel of the next (earlier) step adds the K rows up.
-__global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
+__global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i, int ablate) {
     __shared__ float row[ATT_MAX_T + ATT_MAX_FW + 272];
     __shared__ float fl[ATT_MAX_FW + 496];
     __shared__ float cpart[4][16][17];
@@ -500,6 +519,9 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
     const int rt = (B + 15) / 16, ntD = (D + 15) / 16, nmm = ntD * rt;
     const int ntile = (Tp + ATT_TT - 1) / ATT_TT;
     int blk = blockIdx.x;
+    // ablation switch of tools/r2p.sh (LVSR_ATTBWD_POST_ABLATE: 1 skip the state product, 2 the folds, 4 the correlations; wrong results)
+    if (ablate && (((ablate & 1) && blk < nmm) || ((ablate & 2) && blk >= nmm && blk < nmm + (B * M + 255) / 256) ||
+                   ((ablate & 4) && blk >= nmm + (B * M + 255) / 256))) return;
     if (blk < nmm) {
         const int tile = blk % ntD, b0 = (blk / ntD) * 16;
         const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
         src.dswp = g.dswp + (size_t)b0 * ntile * M;
         src.ntile = ntile; src.M = M; src.nrows = B - b0;
         src.vec = ((M & 3) == 0) && ((((size_t)src.dswp) & 15) == 0);
-        src.fast = false;
+        src.fast = src.vec && src.nrows > 0 && rb_no_kpad(M);
         f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
         rb_mm(acc0, acc1, src, g.WsT_p, M, tile);
         const float v = rb_reduce(acc0, acc1);
@@ -662,6 +684,8 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     hipStream_t s = (hipStream_t)stream;
     const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;
     const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, ntile = (a.Tp + ATT_TT - 1) / ATT_TT, nslice = (a.M + ATT_MS - 1) / ATT_MS;
+    const char* abl = getenv("LVSR_ATTBWD_POST_ABLATE");
+    const int ablate = abl ? atoi(abl) : 0;
     auto enqueue = [&]() {
         for (int i = a.L - 1; i >= 0; --i) {
             hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
@@ -675,11 +699,12 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
                 case 3: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<12>, eg, dim3(256), 0, s, g, i); break;
                 default: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<16>, eg, dim3(256), 0, s, g, i); break;
             }
-            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.B * a.M + 255) / 256 + a.B * a.K), dim3(256), 0, s, g, i);
+            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.B * a.M + 255) / 256 + a.B * a.K), dim3(256), 0, s, g, i, ablate);
         }
     };
     GraphKey key("attdec_bwd");
     key.add(&g, sizeof(g));
+    key.add(&ablate, sizeof(ablate));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_bwd");
 }
 
