@@ -128,6 +128,63 @@ __global__ __launch_bounds__(256) void attbwd_q_kernel(AttBwd g, int i) {
     if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
 }
 
+// B2+B3 merged (reassociated glimpse): with AW = attended @ [Wdi|Wdg] and QR[i,b,t] = dWA_readout[i,b,:] . A[t,b,:] supplied by the
+// caller, q[b,t] = DXG[i][b,:] . AW[t,b,:] + QR[i,b,t] + sum_k dalp[b,k,t] needs no dwa, so the D tiles of B2 and the rows of B3
+// are independent and share ONE launch (a kernel boundary less per label); DWA for all labels is one GEMM after the loop.
+// Blocks [0, ntD*rt): dsacc = dspart + [dpu|dpr] @ Whg^T; the rest: one wave per (b,t), 4 per work-group.
+__global__ __launch_bounds__(256) void attbwd_gru_bq_kernel(AttBwd g, int i) {
+    const AttDec& a = g.f;
+    const int D = a.D, B = a.B, Tp = a.Tp;
+    const int rt = (B + 15) / 16, ntD = (D + 15) / 16, nmm = ntD * rt;
+    int blk = blockIdx.x;
+    if (blk < nmm) {
+        const int tile = blk % ntD, b0 = (blk / ntD) * 16;
+        const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
+        const bool ok = b < B && j < D;
+        const float* dx = g.DXG + ((size_t)i * B + b0) * 3 * D;
+        const float part = ok ? g.dspart[(size_t)b * D + j] : 0.f;
+        f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+        rb_mm(acc0, acc1, row_src(dx + D, 3 * D, B - b0, 2 * D), g.WhgT_p, 2 * D, tile);
+        const float v = rb_reduce(acc0, acc1);
+        if (ok) g.dsacc[(size_t)b * D + j] = part + v;
+        return;
+    }
+    blk -= nmm;
+    const int nchunk = (Tp + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blk / nchunk, t = (blk % nchunk) * 4 + wave, G = 3 * D;
+    if (t >= Tp) return;
+    const Win w = attdec_window(a, i);
+    float q = 0.f;
+    if (t >= w.begin && t < w.end) {
+        const float* dx = g.DXG + ((size_t)i * B + b) * G;
+        const float* ar = g.AW + ((size_t)t * B + b) * G;
+        const bool vec = ((G & 3) == 0) && ((((size_t)ar | (size_t)dx) & 15) == 0);
+        float4 x[4], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = lane * 4 + r * 256;
+            x[r] = ld4g(ar + e, G - e, vec);
+            y[r] = ld4g(dx + e, G - e, vec);
+        }
+        const float dal = lane < a.K ? g.dalp[((size_t)b * a.K + lane) * Tp + t] : 0.f;
+        const float qr = lane == 0 ? g.QR[((size_t)i * B + b) * Tp + t] : 0.f;
+        float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+            q0 += x[r].x * y[r].x + x[r].y * y[r].y + x[r].z * y[r].z + x[r].w * y[r].w;
+            q1 += x[r + 1].x * y[r + 1].x + x[r + 1].y * y[r + 1].y + x[r + 1].z * y[r + 1].z + x[r + 1].w * y[r + 1].w;
+        }
+        q = q0 + q1;
+        for (int e = lane * 4 + 1024; e < G; e += 256) {          // 3D > 1024: remaining columns
+            const float4 xx = ld4g(ar + e, G - e, vec), yy = ld4g(dx + e, G - e, vec);
+            q += xx.x * yy.x + xx.y * yy.y + xx.z * yy.z + xx.w * yy.w;
+        }
+        q = wave_sum(q + dal + qr);
+    }
+    if (lane == 0) g.Q[(size_t)b * Tp + t] = q;
+}
+
 // B4: softmax backward + energy backward.  Grid (ceil(M/32), B, ceil(T'/64)), same decomposition as the forward
 // energy kernel.  Sums over positions (dsW, handler / energy-vector gradients) leave as per-tile partials, sums
 // over the match dimension (dcv) as per-slice partials; both are folded in a fixed order by their consumers.
@@ -689,8 +746,12 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     auto enqueue = [&]() {
         for (int i = a.L - 1; i >= 0; --i) {
             hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
-            hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
-            hipLaunchKernelGGL(attbwd_q_kernel, dim3((a.Tp + 3) / 4, a.B), dim3(256), 0, s, g, i);
+            if (g.AW && g.QR) {
+                hipLaunchKernelGGL(attbwd_gru_bq_kernel, dim3(ntD * rt + ((a.Tp + 3) / 4) * a.B), dim3(256), 0, s, g, i);
+            } else {
+                hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
+                hipLaunchKernelGGL(attbwd_q_kernel, dim3((a.Tp + 3) / 4, a.B), dim3(256), 0, s, g, i);
+            }
             const dim3 eg(nslice, a.B, ntile);
             switch ((a.K + 3) / 4) {             // K > 0: handler contractions on the matrix cores, filters padded to a multiple of 4
                 case 0: hipLaunchKernelGGL(attbwd_energy_kernel<0>, eg, dim3(256), 0, s, g, i); break;

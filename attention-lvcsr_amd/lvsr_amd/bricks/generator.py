@@ -231,7 +231,7 @@ class SequenceGenerator(object):
         self.last = dict(weights=W[1:], energies=bufs["EN"], states=S[:L], weighted_averages=WA)
         if save_for_backward:
             self._saved = dict(L=L, B=B, Tp=Tp, A=A, Am=Am, PA=PA, labels=labels, ym=ym, xg=xg, fb=fb, bufs=bufs,
-                               fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk)
+                               fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk, AW_valid=sync is not None)
         return cost
 
     def backward(self):
@@ -289,7 +289,22 @@ class SequenceGenerator(object):
                       dswp=ws.get("gen.dswp", (B, ntile, d.M)))
         bw.f = lib.make("lvsr_attdec_args", **sv["fields"])
         import ctypes
+        reassoc = os.environ.get("LVSR_DEC_BWD_REASSOC", "1") == "1"
+        if reassoc:
+            # the glimpse contraction reassociated (as in the persistent forward): q = DXG . AW + QR, one launch less per label
+            wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
+            AW = ws.get("gen.AW", (Tp * B, 3 * d.D))
+            if not sv.get("AW_valid"):
+                lib.sgemm(sv["A"].view(Tp * B, d.E), wd, AW)
+            QR = ws.get("gen.QR", (L, B, Tp))
+            lib.call("lvsr_sgemm_batched", lib.stream_for(QR), 0, 1, L, Tp, d.E, 1.0, lib_ptr(dWA_r), B * d.E, d.E,
+                     lib_ptr(sv["A"]), B * d.E, d.E, 0.0, lib_ptr(QR), B * Tp, Tp, B)
+            bw.AW, bw.QR = AW.data_ptr(), QR.data_ptr()
         lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
+        if reassoc:
+            DWA2 = DWA.view(nrows, d.E)
+            DWA2.copy_(dWA_r)
+            lib.sgemm(DXG, wd, DWA2, transB=True, beta=1.0)
         if self.use_graph and os.environ.get("LVSR_SYNC_DEC_BWD", "0") == "1":
             lib.after_graph(ds, L)
         # ---- weight gradients as batched GEMMs over all steps

@@ -214,6 +214,10 @@ typedef struct lvsr_attdec_bwd_args {
     float* Q;                             /* (B,Tp) scratch */
     float* dcvp;                          /* (B,ceil(M/32),K,Tp) scratch: per-slice partials of DCV */
     float* dswp;                          /* (B,ntile,M) scratch: per-tile partials of DSW */
+    /* optional (both or neither): the reassociated glimpse — q[b,t] = DXG[i][b,:] . AW[t,b,:] + QR[i,b,t] + ..., one launch less
+     * per label; DWA is then NOT written: the caller forms DWA = DXG @ [Wdi|Wdg]^T + dWA_r for all labels after the call */
+    const float* AW;                      /* (Tp,B,3D) attended @ [fork_inputs.W | fork_gate_inputs.W] */
+    const float* QR;                      /* (L,B,Tp) dWA_r[i,b,:] . A[t,b,:] (zeros if dWA_r is NULL) */
 } lvsr_attdec_bwd_args;
 int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
 /* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block; ws: scratch of at least
