@@ -341,6 +341,18 @@ __global__ __launch_bounds__(256) void lvsr_colsum_finish(const float* part, int
 }
 
 // out[c*rows + r] = in[r*cols + c]
+#define COPY_MANY_MAX 32
+struct CopyPack { lvsr_copy_desc d[COPY_MANY_MAX]; int n; };
+// blockIdx.y = descriptor; the 16 blocks of a descriptor stride over its elements
+__global__ __launch_bounds__(256) void lvsr_copy2d_many_kernel(CopyPack pk) {
+    const lvsr_copy_desc& d = pk.d[blockIdx.y];
+    const long long total = (long long)d.rows * d.cols;
+    for (long long x = (long long)blockIdx.x * 256 + threadIdx.x; x < total; x += (long long)gridDim.x * 256) {
+        const int r = (int)(x / d.cols), c = (int)(x % d.cols);
+        d.dst[(size_t)r * d.ldd + c] = d.src[(size_t)r * d.lds + c];
+    }
+}
+
 __global__ __launch_bounds__(256) void lvsr_transpose_kernel(const float* in, int rows, int cols, float* out) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
@@ -462,6 +474,19 @@ int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out,
     if (S > 1)
         hipLaunchKernelGGL(lvsr_colsum_finish, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, S, N, out, beta);
     return lvsr_check_launch("lvsr_colsum");
+}
+
+int lvsr_copy2d_many(void* stream, const lvsr_copy_desc* descs, int n) {
+    LVSR_REQUIRE(n >= 0 && (n == 0 || descs), "lvsr_copy2d_many: bad arguments");
+    for (int i = 0; i < n; ++i)
+        LVSR_REQUIRE(descs[i].rows >= 0 && descs[i].cols >= 0 && descs[i].src && descs[i].dst, "lvsr_copy2d_many: bad descriptor %d", i);
+    for (int i0 = 0; i0 < n; i0 += COPY_MANY_MAX) {
+        CopyPack pk;
+        pk.n = n - i0 < COPY_MANY_MAX ? n - i0 : COPY_MANY_MAX;
+        for (int i = 0; i < pk.n; ++i) pk.d[i] = descs[i0 + i];
+        hipLaunchKernelGGL(lvsr_copy2d_many_kernel, dim3(16, pk.n), dim3(256), 0, (hipStream_t)stream, pk);
+    }
+    return lvsr_check_launch("lvsr_copy2d_many");
 }
 
 int lvsr_transpose(void* stream, const float* in, int rows, int cols, float* out) {

@@ -140,13 +140,13 @@ class Encoder(object):
             H, I = self.d.Hs[i], self.d.layer_input_dim(i)
             W = ws.get("enc%d.Wcat" % i, (I, 6 * H))
             b = ws.get("enc%d.bcat" % i, (6 * H,))
+            pairs = []
             for di, direction in enumerate(("forward", "backward")):
                 n = self._names(i, direction)
                 o = di * 3 * H
-                W[:, o: o + H].copy_(p[n["Wi"]])
-                W[:, o + H: o + 3 * H].copy_(p[n["Wg"]])
-                b[o: o + H].copy_(p[n["bi"]])
-                b[o + H: o + 3 * H].copy_(p[n["bg"]])
+                pairs += [(p[n["Wi"]], W[:, o: o + H]), (p[n["Wg"]], W[:, o + H: o + 3 * H]),
+                          (p[n["bi"]], b[o: o + H]), (p[n["bg"]], b[o + H: o + 3 * H])]
+            self.lib.copy_many(pairs)                      # one launch instead of eight copy kernels
             ent = dict(version=self.store.version, W=W, b=b)
             self._cats[i] = ent
         return ent["W"], ent["b"]
@@ -298,13 +298,13 @@ class Encoder(object):
                 gb = ws.get("enc%d.gbcat" % i, (6 * H,))
                 lib.sgemm(x2, dxg2, gW, transA=True, ws=side_ws)
                 lib.colsum(dxg2, gb, ws=side_ws)
+                pairs = []
                 for di, direction in enumerate(("forward", "backward")):
                     n = self._names(i, direction)
                     o = di * 3 * H
-                    g[n["Wi"]].copy_(gW[:, o: o + H])
-                    g[n["Wg"]].copy_(gW[:, o + H: o + 3 * H])
-                    g[n["bi"]].copy_(gb[o: o + H])
-                    g[n["bg"]].copy_(gb[o + H: o + 3 * H])
+                    pairs += [(gW[:, o: o + H], g[n["Wi"]]), (gW[:, o + H: o + 3 * H], g[n["Wg"]]),
+                              (gb[o: o + H], g[n["bi"]]), (gb[o + H: o + 3 * H], g[n["bg"]])]
+                lib.copy_many(pairs)
             dy = dx
         self.join_side_stream()
         return dy

@@ -69,8 +69,7 @@ class SequenceGenerator(object):
         pack("Whh", p[n["Whh"]]); pack("WhhT", p[n["Whh"]], True)
         pack("Wdi", p[n["Wdi"]]); pack("Wdg", p[n["Wdg"]])
         wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
-        wd[:, : d.D].copy_(p[n["Wdi"]])
-        wd[:, d.D:].copy_(p[n["Wdg"]])
+        lib.copy_many([(p[n["Wdi"]], wd[:, : d.D]), (p[n["Wdg"]], wd[:, d.D:])])
         pack("WdT", wd, True)
         lib.pack_many(jobs, use_graph=self.use_graph, cache=self._pack_cache)
         self._packs = ent

@@ -212,6 +212,21 @@ class Lib(object):
         self.call("lvsr_colsum", self.stream_for(out), ptr(X), M, N, X.stride(0) if ldx is None else ldx, ptr(out), beta,
                   ptr(ws), (ws.numel() * 4 if ws is not None else 0))
 
+    def copy_many(self, pairs):
+        """pairs: [(src, dst)] of equally shaped 1-D / 2-D fp32 tensors with unit inner stride -> one lvsr_copy2d_many launch
+        (per 32 pairs)."""
+        if not pairs:
+            return
+        cls = self.structs["lvsr_copy_desc"]
+        arr = (cls * len(pairs))()
+        for d, (src, dst) in zip(arr, pairs):
+            assert src.shape == dst.shape and src.dim() in (1, 2) and src.stride(-1) == 1 and dst.stride(-1) == 1
+            rows, cols = (1, src.shape[0]) if src.dim() == 1 else (src.shape[0], src.shape[1])
+            d.src, d.dst, d.rows, d.cols = src.data_ptr(), dst.data_ptr(), rows, cols
+            d.lds = src.stride(0) if src.dim() == 2 else cols
+            d.ldd = dst.stride(0) if dst.dim() == 2 else cols
+        self.call("lvsr_copy2d_many", self.stream_for(pairs[0][1]), arr, len(pairs))
+
     def transpose(self, x, out):
         self.call("lvsr_transpose", self.stream_for(out), ptr(x), x.shape[0], x.shape[1], ptr(out))
 

@@ -50,6 +50,14 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
 int lvsr_sgemm_batched(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                        long long strideA, const float* B, int ldb, long long strideB, float beta, float* C, int ldc,
                        long long strideC, int batch);
+/* n independent strided 2-D copies (dst[r*ldd + c] = src[r*lds + c]) in ONE launch per 32 descriptors: the concatenated
+ * fork weights of the encoder layers ((I,6H) = [Wi_f | Wg_f | Wi_b | Wg_b], refreshed per step) and the scatter of their
+ * gradient back into the four parameters were 8 copy kernels of ~5 us per layer and pass. */
+typedef struct lvsr_copy_desc {
+    const float* src; float* dst;
+    int rows, cols, lds, ldd;
+} lvsr_copy_desc;
+int lvsr_copy2d_many(void* stream, const lvsr_copy_desc* descs, int n);
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]  (bias gradients); ws: optional workspace for the row-split partials */
 int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,
                 long long ws_bytes);
