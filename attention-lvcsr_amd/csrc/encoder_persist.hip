@@ -38,9 +38,9 @@ typedef lvsr_bigru_bwd_args EncBwd0;
 // PRIV = true (experiment, LVSR_PERSIST_FLAGS & 32): every wave sweeps the WHOLE vector (NG/64 loads per lane) into a buffer of
 // its own, so no work-group barrier sits between the hand-off and the contraction — measured slower (see PF_PRIVATE).
 // Returns false when the cluster gave up.
-template <int NG, bool PRIV>
+template <int NG, bool PRIV, int NTH = 256>
 struct Sweep {                       // one sweep of granule loads of a lane: NG/64 (wave-private) or NG/256 (shared) of them
-    static constexpr int NT = PRIV ? 64 : 256;
+    static constexpr int NT = PRIV ? 64 : NTH;
     static constexpr int N = (NG + NT - 1) / NT;
     u64 w[N];
     __device__ __forceinline__ void issue(const u64* g, unsigned epoch) {
@@ -66,10 +66,10 @@ struct Sweep {                       // one sweep of granule loads of a lane: NG
 // the CONSUMER CU's own memory queue").
 // NPL > 1: NPL planes that were published together and lie back to back are swept as one vector; plane p lands in the LDS
 // buffer dst + p * DSTRIDE.
-template <int NG1, int HP, int KS, int LDH, int KSPLIT, bool PRIV, int NPL = 1, int DSTRIDE = 0>
+template <int NG1, int HP, int KS, int LDH, int KSPLIT, bool PRIV, int NPL = 1, int DSTRIDE = 0, int NTH = 256>
 __device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float* dst, int* abort_word, int flags = 0) {
     constexpr int NG = NG1 * NPL;
-    typedef Sweep<NG, PRIV> S;
+    typedef Sweep<NG, PRIV, NTH> S;
     constexpr int NT = S::NT;
     const int tid = PRIV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     S a;
@@ -144,7 +144,7 @@ __device__ __forceinline__ float pick_row(const float (&s)[RB], int q, int i) {
     return v;
 }
 
-struct PersistGeom { int KS, KSPLIT, HP, UNITS, P, RB, rt, grid; long long plane; };
+struct PersistGeom { int KS, KSPLIT, HP, UNITS, P, RB, rt, grid, NTH; long long plane; };
 // Variant for a hidden size: the smallest padded size HP = KS*KSPLIT >= H among the built ones; RB = the smallest number of
 // utterances per cluster (1, 2, 4, 8) whose grid fits the chip with one work-group per CU.
 static bool persist_geom(int B, int H, PersistGeom& g) {
@@ -152,7 +152,8 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
     else if (H <= 256) { g.KS = 64; g.KSPLIT = 4; }
     else if (H <= 512) { g.KS = 64; g.KSPLIT = 8; }
     else return false;
-    g.HP = g.KS * g.KSPLIT; g.UNITS = 256 / g.KSPLIT; g.P = g.HP / g.UNITS;
+    g.NTH = 256;
+    g.HP = g.KS * g.KSPLIT; g.UNITS = g.NTH / g.KSPLIT; g.P = g.HP / g.UNITS;
     const char* env = getenv("LVSR_PERSIST_ROWS");
     const int want = env ? min(8, atoi(env)) : 0;
     g.RB = 0;
@@ -161,6 +162,13 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
         if (2 * rt * g.P <= PERSIST_MAX_WG && rb >= want) { g.RB = rb; break; }
     }
     if (!g.RB) return false;
+    // One utterance per cluster (the default): 512-thread work-groups, two waves per SIMD — half the k-slice per thread (96
+    // instead of 192 weight registers), twice the lanes per unit, the same number of work-groups per cluster; 2.03 instead of
+    // 2.12 us per step on WSJ-base (the second wave hides the first one's LDS and hand-off latencies; WSJ-base step 21.42 ->
+    // 20.79 ms).  1024 threads (four waves, 48 weight registers) were measured too: 26.4 ms — the sweeps and barriers of 16
+    // waves cost more than their latency hiding buys.  LVSR_PERSIST_THREADS=256 brings the one-wave version back.
+    const char* envt = getenv("LVSR_PERSIST_THREADS");
+    if (g.RB == 1 && !(envt && atoi(envt) == 256)) { g.NTH = 512; g.KS /= 2; g.KSPLIT *= 2; g.UNITS = g.NTH / g.KSPLIT; }
     g.rt = (B + g.RB - 1) / g.RB;
     g.grid = 2 * g.rt * g.P;
     g.plane = (long long)g.RB * g.HP;
@@ -170,11 +178,11 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int KSPLIT, int RB, bool PRIVOK>
-__global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
-    constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
+template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
+__global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
+    constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
-    constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1;     // wave-private operand buffers, see gather_plane
+    constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;     // wave-private operand buffers, see gather_plane
     constexpr int NBUF = PRIV ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float hbuf_all[2][NBUF][RB * KSPLIT * LDH];
     float* const hbuf[2] = {hbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], hbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0]};
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
         }
     }
     // h_{-1} = initial state, broadcast over the rows (every wave fills its own buffer when they are private)
-    for (int idx = PRIV ? (tid & 63) : tid; idx < RB * HP; idx += PRIV ? 64 : 256) {
+    for (int idx = PRIV ? (tid & 63) : tid; idx < RB * HP; idx += PRIV ? 64 : NTH) {
         const int row = idx / HP, k = idx % HP;
         hbuf[0][(row * KSPLIT + k / KS) * LDH + (k % KS)] = k < H ? a.h0[dir][k] : 0.f;
     }
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
         float xin[NR], gu[NR], gr[NR], m[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xin[i] = n_xin[i]; gu[i] = n_gu[i]; gr[i] = n_gr[i]; m[i] = n_m[i]; }
-        if (P > 1 && n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
+        if (P > 1 && n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
         gather_fence<PRIV>();
         // ---- reset gate: the only thing the next exchange waits for
         float s[RB], rr[NR], uu[NR];
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void enc_pfwd_kernel(EncFwd a, u64* planes, in
                 if (rvalid[i] && save) a.u[((size_t)t * B + b0 + r) * 2 * H + dir * H + j] = uu[i];
             }
         }
-        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
         gather_fence<PRIV>();
         // ---- candidate, state update, mask blend
         slice_dot<KS, RB, LDH, KSPLIT>(wc, hbuf[1], q, s, flags);
@@ -317,11 +325,11 @@ __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int di
     return a.dy[((size_t)(t / a.sub) * a.B + b) * 2 * a.H + dir * a.H + j];
 }
 
-template <int KS, int KSPLIT, int RB, bool PRIVOK>
-__global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
-    constexpr int HP = KS * KSPLIT, UNITS = 256 / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
+template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
+__global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
+    constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
-    constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1;
+    constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;
     constexpr int NBUF = PRIV ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float vbuf_all[3][NBUF][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
     float* const vbuf[3] = {vbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], vbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0],
@@ -409,7 +417,7 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
             for (int i = 0; i < NR; ++i)
                 if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
         }
-        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 2, NBUF * RB * KSPLIT * LDH>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 2, NBUF * RB * KSPLIT * LDH, NTH>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
         gather_fence<PRIV>();
         float s[RB], vu[RB];
         slice_dot<KS, RB, LDH, KSPLIT>(wa, vbuf[0], q, s);                     // d(r*h)
@@ -427,7 +435,7 @@ __global__ __launch_bounds__(256) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
         }
         // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off (dpre_u came in with dpre_c's sweep)
         slice_dot<KS, RB, LDH, KSPLIT>(wbu, vbuf[1], q, vu);
-        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
         gather_fence<PRIV>();
         slice_dot<KS, RB, LDH, KSPLIT>(wbr, vbuf[2], q, s);
 #pragma unroll
@@ -473,6 +481,10 @@ extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
 
 template <int KS, int KSPLIT>
 static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, int* ab, int flags) {
+    if (g.NTH == 512 && g.RB == 1) {           // two waves per SIMD: half the k-slice per thread
+        hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, flags);
+        return;
+    }
     switch (g.RB) {
         case 1:
             if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags);
@@ -485,6 +497,10 @@ static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64
 }
 template <int KS, int KSPLIT>
 static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, int* ab, float* dh, int Bp, int flags) {
+    if (g.NTH == 512 && g.RB == 1) {
+        hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, dh, Bp, flags);
+        return;
+    }
     switch (g.RB) {
         case 1:
             if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags);
@@ -507,7 +523,7 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     const int flags = persist_flags();
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
-        switch (g.KSPLIT) {
+        switch (g.KSPLIT / (g.NTH / 256)) {
             case 2: launch_fwd<64, 2>(s, a, g, planes, ab, flags); break;
             case 4: launch_fwd<64, 4>(s, a, g, planes, ab, flags); break;
             default: launch_fwd<64, 8>(s, a, g, planes, ab, flags); break;
@@ -516,6 +532,7 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     GraphKey key("bigru_pfwd");
     key.add(&a, sizeof(a));
     key.add(&g.RB, sizeof(g.RB));
+    key.add(&g.NTH, sizeof(g.NTH));
     key.add(&flags, sizeof(flags));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_fwd(persistent)");
 }
@@ -531,7 +548,7 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     const int flags = persist_flags();
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
-        switch (g.KSPLIT) {
+        switch (g.KSPLIT / (g.NTH / 256)) {
             case 2: launch_bwd<64, 2>(s, a, g, planes, ab, dh, Bp, flags); break;
             case 4: launch_bwd<64, 4>(s, a, g, planes, ab, dh, Bp, flags); break;
             default: launch_bwd<64, 8>(s, a, g, planes, ab, dh, Bp, flags); break;
@@ -541,6 +558,7 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     GraphKey key("bigru_pbwd");
     key.add(&a, sizeof(a));
     key.add(&g.RB, sizeof(g.RB));
+    key.add(&g.NTH, sizeof(g.NTH));
     key.add(&flags, sizeof(flags));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_bwd(persistent)");
 }
