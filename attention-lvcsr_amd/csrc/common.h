@@ -37,6 +37,14 @@ __device__ __forceinline__ float lvsr_dpp_quad_xor2(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x4E, 0xf, 0xf, true));   // quad_perm:[2,3,0,1]
 }
 
+// lane i <- lane 7-i of its half row (8 lanes) / lane 15-i of its row (16 lanes): after the two quad exchanges every lane of
+// a quad holds the quad's sum, so one mirror folds two quads (8 lanes), a second one two half rows (16 lanes) — no LDS crossbar
+__device__ __forceinline__ float lvsr_dpp_half_mirror(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+}
+__device__ __forceinline__ float lvsr_dpp_mirror(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x140, 0xf, 0xf, true));   // row_mirror
+}
 __device__ __forceinline__ float lvsr_dpp_row_ror4(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x124, 0xf, 0xf, true));   // row_ror:4
 }

@@ -177,9 +177,9 @@ __device__ __forceinline__ float pd_butterfly8(float (&v)[8]) {
         }
     }
     float r = v[0];
-    r += __shfl_xor(r, 4, 64);
     r += lvsr_dpp_quad_xor1(r);
     r += lvsr_dpp_quad_xor2(r);
+    r += lvsr_dpp_half_mirror(r);
     return r;
 }
 __device__ __forceinline__ int pd_butterfly_index(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }

@@ -38,8 +38,7 @@ template <int KSPLIT>
 __device__ __forceinline__ float group_sum(float v) {
     if (KSPLIT >= 2) v += lvsr_dpp_quad_xor1(v);
     if (KSPLIT >= 4) v += lvsr_dpp_quad_xor2(v);
-    if (KSPLIT >= 8) v += __shfl_xor(v, 4, 64);
-    if (KSPLIT >= 16) v += __shfl_xor(v, 8, 64);
+    if (KSPLIT >= 8) v += lvsr_dpp_half_mirror(v);          // all DPP: the lane groups are aligned to their size
+    if (KSPLIT >= 16) v += lvsr_dpp_mirror(v);
     return v;
 }
-

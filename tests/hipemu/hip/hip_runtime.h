@@ -249,9 +249,11 @@ inline int __all(int pred) {
     return acc;
 }
 // v_mov_b32 with a DPP control: quad_perm (ctrl < 0x100): lane l reads lane (l & ~3) + ((ctrl >> 2*(l&3)) & 3);
-// row_ror:n (ctrl 0x121..0x12F): rotation by n lanes inside each row of 16
+// row_ror:n (ctrl 0x121..0x12F): rotation by n lanes inside each row of 16; row_mirror / row_half_mirror (0x140 / 0x141)
 inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
     int l = hipemu::lane_id();
+    if (ctrl == 0x140) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | (15 - (l & 15)));      // row_mirror
+    if (ctrl == 0x141) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~7) | (7 - (l & 7)));        // row_half_mirror
     if (ctrl >= 0x121 && ctrl <= 0x12F) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | ((l - (ctrl - 0x120)) & 15));
     if (ctrl >= 0x100) { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
     return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
