@@ -343,13 +343,22 @@ __global__ __launch_bounds__(256) void lvsr_colsum_finish(const float* part, int
 // out[c*rows + r] = in[r*cols + c]
 #define COPY_MANY_MAX 32
 struct CopyPack { lvsr_copy_desc d[COPY_MANY_MAX]; int n; };
-// blockIdx.y = descriptor; the 16 blocks of a descriptor stride over its elements
+// blockIdx.y = descriptor; the blocks of a descriptor stride over its rows, the threads over 16-byte pieces of a row
 __global__ __launch_bounds__(256) void lvsr_copy2d_many_kernel(CopyPack pk) {
     const lvsr_copy_desc& d = pk.d[blockIdx.y];
-    const long long total = (long long)d.rows * d.cols;
-    for (long long x = (long long)blockIdx.x * 256 + threadIdx.x; x < total; x += (long long)gridDim.x * 256) {
-        const int r = (int)(x / d.cols), c = (int)(x % d.cols);
-        d.dst[(size_t)r * d.ldd + c] = d.src[(size_t)r * d.lds + c];
+    const bool vec = ((d.cols | d.lds | d.ldd) & 3) == 0 && ((((size_t)d.src) | ((size_t)d.dst)) & 15) == 0;
+    if (d.rows == 1) {                                       // vectors: all blocks share the one row
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < d.cols; c += gridDim.x * 256) d.dst[c] = d.src[c];
+        return;
+    }
+    for (int r = blockIdx.x; r < d.rows; r += gridDim.x) {
+        const float* s = d.src + (size_t)r * d.lds;
+        float* o = d.dst + (size_t)r * d.ldd;
+        if (vec) {
+            for (int c = threadIdx.x * 4; c < d.cols; c += 1024) *(float4*)(o + c) = *(const float4*)(s + c);
+        } else {
+            for (int c = threadIdx.x; c < d.cols; c += 256) o[c] = s[c];
+        }
     }
 }
 
@@ -484,7 +493,7 @@ int lvsr_copy2d_many(void* stream, const lvsr_copy_desc* descs, int n) {
         CopyPack pk;
         pk.n = n - i0 < COPY_MANY_MAX ? n - i0 : COPY_MANY_MAX;
         for (int i = 0; i < pk.n; ++i) pk.d[i] = descs[i0 + i];
-        hipLaunchKernelGGL(lvsr_copy2d_many_kernel, dim3(16, pk.n), dim3(256), 0, (hipStream_t)stream, pk);
+        hipLaunchKernelGGL(lvsr_copy2d_many_kernel, dim3(128, pk.n), dim3(256), 0, (hipStream_t)stream, pk);
     }
     return lvsr_check_launch("lvsr_copy2d_many");
 }
