@@ -181,23 +181,19 @@ __device__ __forceinline__ void gemm_tile_store(float (*S)[GLD], const float4 (&
 
 // FAST (host-selected): operands 16-B aligned with ld % 4 == 0.  Blocks whose 128x128 tile lies inside the matrix then take
 // the unguarded loads for every complete k-tile; edge blocks and a ragged last k-tile of a chunk take the guarded ones.
+// launch-linear block L of `total` -> position t in the tile sequence: block L runs on XCD L % 8; every XCD gets one contiguous
+// run of the sequence, so tiles sharing an operand panel / a k-chunk meet in one L2
+__device__ __forceinline__ int gemm_xcd_order(int L, int total) {
+    const int xcd = L & 7, per = total >> 3, rem = total & 7;
+    return xcd * per + min(xcd, rem) + (L >> 3);
+}
+
+// one 128x128 output tile (bx, by) of k-chunk / batch member bz
 template <bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
+__device__ __forceinline__ void sgemm128_tile(GemmArgs g, int bx, int by, int bz) {
     __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // XCD-aware tile order: launch-linear block L runs on XCD L % 8; give every XCD one contiguous run of the
-    // (k-split, m-tile, n-tile) sequence, n fastest, so tiles sharing an A panel / a k-chunk meet in one L2
-    int bx, by, bz;
-    {
-        const int total = gridDim.x * gridDim.y * gridDim.z;
-        const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = L & 7, per = total >> 3, rem = total & 7;
-        const int t = xcd * per + min(xcd, rem) + (L >> 3);
-        bx = t % gridDim.x;
-        by = (t / gridDim.x) % gridDim.y;
-        bz = t / (gridDim.x * gridDim.y);
-    }
     if (g.batch > 1) {
         g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
         bz = 0;
@@ -287,6 +283,60 @@ __global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
                     }
                 }
             }
+}
+
+template <bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(256) void lvsr_sgemm128_kernel(GemmArgs g) {
+    // (k-split, m-tile, n-tile) sequence, n fastest
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    const int t = gemm_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total);
+    sgemm128_tile<TA, TB, FAST>(g, t % gridDim.x, (t / gridDim.x) % gridDim.y, t / (gridDim.x * gridDim.y));
+}
+
+// ---- grouped launch of transposed-A products (weight gradients): C_p = A_p^T B_p (+ beta_p C_p) for up to GROUP_MAX problems.
+// The recurrent weight gradients of the encoder (H x H / H x 2H outputs, K = T*B) and the decoder's (K = L*B) are each too small
+// to fill the chip: alone they were split 50-fold over K (256-deep chunks: prologue-bound, 13 MB of partials per product) or ran
+// on a handful of work-groups at 26 us per launch.  Together their (problem, tile, k-chunk) units fill the chip with ~1 000-deep
+// chunks in ONE launch, and one more launch folds all partials in a fixed order (deterministic).
+#define GROUP_MAX 40
+struct GroupDesc {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    float beta;
+    int ksplit, kchunk, gx, gy, unit0;      // tiles gx x gy, ksplit chunks; unit0 = first unit of this problem in the launch
+    long long part_off;                     // offset (floats) of this problem's partials in the workspace
+};
+struct GroupPack { GroupDesc d[GROUP_MAX]; int n, total; float* part; };
+
+template <bool FAST>
+__global__ __launch_bounds__(256) void lvsr_sgemm128_grouped_tn_kernel(GroupPack pk) {
+    const int t = gemm_xcd_order(blockIdx.x, pk.total);
+    int p = 0;
+    for (int x = 1; x < pk.n; ++x)
+        if (t >= pk.d[x].unit0) p = x;
+    const GroupDesc& d = pk.d[p];
+    const int local = t - d.unit0;
+    GemmArgs g;
+    g.A = d.A; g.B = d.B; g.C = d.C; g.bias = nullptr;
+    g.M = d.M; g.N = d.N; g.K = d.K; g.lda = d.lda; g.ldb = d.ldb; g.ldc = d.ldc; g.transA = 1; g.transB = 0;
+    g.alpha = 1.f; g.beta = d.beta; g.ksplit = d.ksplit; g.kchunk = d.kchunk; g.part = pk.part + d.part_off;
+    g.batch = 1; g.sA = g.sB = g.sC = 0;
+    sgemm128_tile<true, false, FAST>(g, local % d.gx, (local / d.gx) % d.gy, local / (d.gx * d.gy));
+}
+
+// blockIdx.y = problem; its blocks stride over the output elements and fold the k-chunks in order
+__global__ __launch_bounds__(256) void lvsr_sgemm_grouped_reduce(GroupPack pk) {
+    const GroupDesc& d = pk.d[blockIdx.y];
+    if (d.ksplit <= 1) return;
+    const size_t total = (size_t)d.M * d.N;
+    const float* part = pk.part + d.part_off;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int m = (int)(idx / d.N), n = (int)(idx % d.N);
+        float s = 0.f;
+        for (int z = 0; z < d.ksplit; ++z) s += part[(size_t)z * total + idx];
+        if (d.beta != 0.f) s += d.beta * d.C[(size_t)m * d.ldc + n];
+        d.C[(size_t)m * d.ldc + n] = s;
+    }
 }
 
 __global__ __launch_bounds__(256) void lvsr_sgemm_splitk_reduce(GemmArgs g) {
@@ -464,6 +514,44 @@ int lvsr_sgemm_batched(void* stream, int transA, int transB, int M, int N, int K
     if (batch == 0) return LVSR_OK;
     return sgemm_launch(stream, transA, transB, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, nullptr, nullptr, 0, batch,
                         strideA, strideB, strideC);
+}
+
+int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, float* ws, long long ws_bytes) {
+    LVSR_REQUIRE(n >= 0 && (n == 0 || descs), "lvsr_sgemm_tn_grouped: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += GROUP_MAX) {
+        GroupPack pk;
+        pk.n = n - i0 < GROUP_MAX ? n - i0 : GROUP_MAX;
+        pk.part = ws;
+        bool fast = true;
+        int units = 0;
+        long long off = 0;
+        for (int i = 0; i < pk.n; ++i) {
+            const lvsr_gemm_desc& s = descs[i0 + i];
+            LVSR_REQUIRE(s.A && s.B && s.C && s.M > 0 && s.N > 0 && s.K > 0, "lvsr_sgemm_tn_grouped: bad descriptor %d", i0 + i);
+            GroupDesc& d = pk.d[i];
+            d.A = s.A; d.B = s.B; d.C = s.C; d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.beta = s.beta;
+            fast = fast && (s.lda & 3) == 0 && (s.ldb & 3) == 0 && (((size_t)s.A) & 15) == 0 && (((size_t)s.B) & 15) == 0;
+            d.gx = (s.N + GN - 1) / GN; d.gy = (s.M + GM - 1) / GM;
+            // k-chunks of about 1024 (a multiple of the k-tile), as long as the partials fit the workspace
+            int want = (s.K + 1023) / 1024;
+            if (!ws) want = 1;
+            while (want > 1 && (off + (long long)want * s.M * s.N) * 4 > ws_bytes) --want;
+            int chunk = (s.K + want - 1) / want;
+            chunk = ((chunk + GK - 1) / GK) * GK;
+            d.kchunk = chunk;
+            d.ksplit = (s.K + chunk - 1) / chunk;
+            d.part_off = off;
+            if (d.ksplit > 1) off += (long long)d.ksplit * s.M * s.N;
+            d.unit0 = units;
+            units += d.gx * d.gy * d.ksplit;
+        }
+        pk.total = units;
+        if (fast) hipLaunchKernelGGL(lvsr_sgemm128_grouped_tn_kernel<true>, dim3(units), dim3(256), 0, st, pk);
+        else hipLaunchKernelGGL(lvsr_sgemm128_grouped_tn_kernel<false>, dim3(units), dim3(256), 0, st, pk);
+        if (off > 0) hipLaunchKernelGGL(lvsr_sgemm_grouped_reduce, dim3(32, pk.n), dim3(256), 0, st, pk);
+    }
+    return lvsr_check_launch("lvsr_sgemm_tn_grouped");
 }
 
 int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,

@@ -281,18 +281,18 @@ class Encoder(object):
                     dc = dxg2[:, di * 3 * H: di * 3 * H + H]
                     dg = dxg2[:, di * 3 * H + H: di * 3 * H + 3 * H]
                     hcol = slice(di * H, (di + 1) * H)
-                    lib.sgemm(rh2[:, hcol], dc, g[n["Whh"]], transA=True, ws=side_ws)
+                    lib.sgemm(rh2[:, hcol], dc, g[n["Whh"]], transA=True, ws=side_ws, group=True)
                     if T > 1:
                         if di == 0:     # h_{t-1} = y[t-1]
-                            lib.sgemm(y2[: (T - 1) * B, hcol], dg[B:], g[n["Whg"]], transA=True, ws=side_ws)
+                            lib.sgemm(y2[: (T - 1) * B, hcol], dg[B:], g[n["Whg"]], transA=True, ws=side_ws, group=True)
                         else:           # backward direction: previous state in scan order is y[t+1]
-                            lib.sgemm(y2[B:, hcol], dg[: (T - 1) * B], g[n["Whg"]], transA=True, ws=side_ws)
+                            lib.sgemm(y2[B:, hcol], dg[: (T - 1) * B], g[n["Whg"]], transA=True, ws=side_ws, group=True)
                         beta = 1.0
                     else:
                         beta = 0.0
                     # the first scan step starts from the (broadcast) initial state: rank-B update with lda = 0
                     first = dg[:B] if di == 0 else dg[(T - 1) * B:]
-                    lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0)
+                    lib.sgemm(p[n["h0"]], first, g[n["Whg"]], transA=True, beta=beta, M=H, K=B, lda=0, group=True)
                 # fork gradients of both directions: one (I, 6H) product and one column sum, scattered into the four matrices
                 gW = ws.get("enc%d.gWcat" % i, (I, 6 * H))
                 gb = ws.get("enc%d.gbcat" % i, (6 * H,))

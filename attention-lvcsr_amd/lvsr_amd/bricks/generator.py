@@ -247,7 +247,7 @@ class SequenceGenerator(object):
         dlogits, R1, R2 = sv["dlogits"], sv["R1"], sv["R2"]
         # ---- readout backward
         if d.post_merge:
-            lib.sgemm(R2, dlogits, g[n["Wout"]], transA=True, ws=gws)
+            lib.sgemm(R2, dlogits, g[n["Wout"]], transA=True, ws=gws, group=True)
             lib.colsum(dlogits, g[n["bout"]], ws=gws)
             dR2 = ws.get("gen.dR2", (nrows, d.Pout))
             lib.sgemm(dlogits, p[n["Wout"]], dR2, transB=True)
@@ -258,12 +258,12 @@ class SequenceGenerator(object):
         else:
             dR1 = dlogits
             lib.colsum(dR1, g[n["bro"]], ws=gws)
-        lib.sgemm(WA2, dR1, g[n["Wmw"]], transA=True, ws=gws)
+        lib.sgemm(WA2, dR1, g[n["Wmw"]], transA=True, ws=gws, group=True)
         dWA_r = ws.get("gen.dWA_r", (nrows, d.E))
         lib.sgemm(dR1, p[n["Wmw"]], dWA_r, transB=True)
         dS_r = None
         if d.use_states_for_readout:
-            lib.sgemm(S2, dR1, g[n["Wms"]], transA=True, ws=gws)
+            lib.sgemm(S2, dR1, g[n["Wms"]], transA=True, ws=gws, group=True)
             dS_r = ws.get("gen.dS_r", (nrows, d.D))
             lib.sgemm(dR1, p[n["Wms"]], dS_r, transB=True)
         # ---- recurrent part
@@ -309,11 +309,11 @@ class SequenceGenerator(object):
         # ---- weight gradients as batched GEMMs over all steps
         dpc, dg = DXG[:, : d.D], DXG[:, d.D:]
         RH2 = bufs["RH"].view(nrows, d.D)
-        lib.sgemm(RH2, dpc, g[n["Whh"]], transA=True, ws=gws)
-        lib.sgemm(S2, dg, g[n["Whg"]], transA=True, ws=gws)
-        lib.sgemm(WA2, dpc, g[n["Wdi"]], transA=True, ws=gws)
-        lib.sgemm(WA2, dg, g[n["Wdg"]], transA=True, ws=gws)
-        lib.sgemm(S2, DSW, g[n["Ws"]], transA=True, ws=gws)
+        lib.sgemm(RH2, dpc, g[n["Whh"]], transA=True, ws=gws, group=True)
+        lib.sgemm(S2, dg, g[n["Whg"]], transA=True, ws=gws, group=True)
+        lib.sgemm(WA2, dpc, g[n["Wdi"]], transA=True, ws=gws, group=True)
+        lib.sgemm(WA2, dg, g[n["Wdg"]], transA=True, ws=gws, group=True)
+        lib.sgemm(S2, DSW, g[n["Ws"]], transA=True, ws=gws, group=True)
         lib.colsum(ds, g[n["h0"]], ws=gws)
         lib.colsum(dpc, g[n["bfi"]], ws=gws)
         lib.colsum(dg, g[n["bfg"]], ws=gws)
@@ -321,8 +321,8 @@ class SequenceGenerator(object):
         labels_flat = sv["labels"].view(-1)
         if d.embed:
             fb = sv["fb"]
-            lib.sgemm(fb, dpc, g[n["Wfi"]], transA=True, ws=gws)
-            lib.sgemm(fb, dg, g[n["Wfg"]], transA=True, ws=gws)
+            lib.sgemm(fb, dpc, g[n["Wfi"]], transA=True, ws=gws, group=True)
+            lib.sgemm(fb, dg, g[n["Wfg"]], transA=True, ws=gws, group=True)
             dfb = ws.get("gen.dfb", (nrows, d.FB))
             lib.sgemm(dpc, p[n["Wfi"]], dfb, transB=True)
             lib.sgemm(dg, p[n["Wfg"]], dfb, transB=True, beta=1.0)
@@ -342,7 +342,7 @@ class SequenceGenerator(object):
                      gws.numel() * 4)
         # ---- attended: preprocess backward + glimpse backward
         A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
-        lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws)
+        lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws, group=True)
         lib.colsum(dPA2, g[n["bpre"]], ws=gws)
         dA = ws.get("gen.dA", (Tp, B, d.E))
         lib.sgemm(dPA2, p[n["Wpre"]], dA.view(Tp * B, d.E), transB=True)

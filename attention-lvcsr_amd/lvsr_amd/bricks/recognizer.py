@@ -182,8 +182,15 @@ class SpeechRecognizer(object):
     def backward(self):
         """Gradient of cost.sum() wrt all parameters -> self.store.grad (flat) / self.store.g (named views)."""
         with self._on_stream():
+            # the small weight-gradient products of decoder and encoder (recurrent matrices, readout, ...) are collected and
+            # run as ONE grouped launch at the end: alone none of them fills the chip (LVSR_GROUP_GEMM=0: one launch each)
+            grouped = os.environ.get("LVSR_GROUP_GEMM", "1") == "1"
+            if grouped:
+                self.lib.begin_group()
             d_encoded = self.generator.backward()
             d_bottom = self.encoder.backward(d_encoded, need_input_grad=bool(self.d.bottom_dims))
+            if grouped:
+                self.lib.flush_group(self.ws.get("gemm_ws.grouped", (1 << 25,)))
             if self.d.bottom_dims:
                 self.bottom.backward(d_bottom)
 

@@ -191,9 +191,39 @@ class Lib(object):
         return self._lvsr_last_error().decode()
 
     # ---- thin typed wrappers -----------------------------------------------------------------
+    # ---- grouped weight-gradient products ---------------------------------------------------------
+    def begin_group(self):
+        """Until flush_group(): sgemm(..., transA=True, group=True) calls are collected instead of launched."""
+        self._group, self._group_after = [], []
+
+    def flush_group(self, ws):
+        """One lvsr_sgemm_tn_grouped launch for everything collected since begin_group() (then the deferred follow-ups, in
+        order).  The operands must still hold what they held when the products were requested."""
+        jobs, after = getattr(self, "_group", None), getattr(self, "_group_after", None)
+        self._group = self._group_after = None
+        if jobs:
+            cls = self.structs["lvsr_gemm_desc"]
+            arr = (cls * len(jobs))()
+            for d, (A, B, C, beta) in zip(arr, jobs):
+                d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+                d.M, d.N, d.K = A.shape[1], B.shape[1], A.shape[0]
+                d.lda, d.ldb, d.ldc, d.beta = A.stride(0), B.stride(0), C.stride(0), beta
+            self.call("lvsr_sgemm_tn_grouped", self.stream_for(jobs[0][2]), arr, len(jobs), ptr(ws), ws.numel() * 4)
+        for kw in after or ():
+            self.sgemm(**kw)
+
     def sgemm(self, A, B, C, transA=False, transB=False, alpha=1.0, beta=0.0, bias=None, ws=None,
-              M=None, N=None, K=None, lda=None, ldb=None, ldc=None):
-        """C = alpha*op(A)@op(B) + beta*C + bias.  A,B,C are 2-D (possibly strided-row) fp32 tensors."""
+              M=None, N=None, K=None, lda=None, ldb=None, ldc=None, group=False):
+        """C = alpha*op(A)@op(B) + beta*C + bias.  A,B,C are 2-D (possibly strided-row) fp32 tensors.
+        group=True (weight gradients, transA only): join the pending grouped launch if one is open (begin_group)."""
+        if group and getattr(self, "_group", None) is not None:
+            plain = transA and not transB and alpha == 1.0 and bias is None and M is None and K is None and lda is None
+            if plain and A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1:
+                self._group.append((A, B, C, float(beta)))
+            else:       # depends on a collected product (e.g. a rank-B update with beta = 1): after the grouped launch, in order
+                self._group_after.append(dict(A=A, B=B, C=C, transA=transA, transB=transB, alpha=alpha, beta=beta, bias=bias, ws=ws,
+                                              M=M, N=N, K=K, lda=lda, ldb=ldb, ldc=ldc))
+            return
         if M is None:
             M = A.shape[1] if transA else A.shape[0]
         if K is None:

@@ -50,6 +50,16 @@ int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float 
 int lvsr_sgemm_batched(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                        long long strideA, const float* B, int ldb, long long strideB, float beta, float* C, int ldc,
                        long long strideC, int batch);
+/* n transposed-A products C_i = A_i^T B_i + beta_i C_i (A_i: K x M with leading dimension lda, B_i: K x N) in ONE launch (+ one
+ * that folds the k-chunk partials in a fixed order): the weight gradients of a training step (`tensor.grad` of the Linear /
+ * recurrent bricks, K = T*B or L*B rows), each too small to fill the chip alone.  ws: workspace for the partials (the more,
+ * the finer the k-chunks: sum_i ceil(K_i/1024) * M_i * N_i floats is enough); outputs must not overlap. */
+typedef struct lvsr_gemm_desc {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc;
+    float beta;
+} lvsr_gemm_desc;
+int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, float* ws, long long ws_bytes);
 /* n independent strided 2-D copies (dst[r*ldd + c] = src[r*lds + c]) in ONE launch per 32 descriptors: the concatenated
  * fork weights of the encoder layers ((I,6H) = [Wi_f | Wg_f | Wi_b | Wg_b], refreshed per step) and the scatter of their
  * gradient back into the four parameters were 8 copy kernels of ~5 us per layer and pass. */
