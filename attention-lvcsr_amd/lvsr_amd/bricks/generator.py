@@ -728,8 +728,22 @@ def _beam_methods():
             self.beam_advance()
         self.lib.region(self, st["key"], st["ctl"], enabled=self.use_graph, volatile=st["volatile"], drain=False).run(enqueue)
 
+    def beam_steps(self, n):
+        """n consecutive positions as ONE replayed hipGraph (the position counter lives on the device, so the graph does not
+        depend on where the search stands): the driver looks at the control block every n positions anyway."""
+        st = self._beam
+        if n == 1:
+            return self.beam_step()
+
+        def enqueue():
+            for _ in range(n):
+                self.beam_costs()
+                self.beam_select()
+                self.beam_advance()
+        self.lib.region(self, (st["key"], "x%d" % n), st["ctl"], enabled=self.use_graph, volatile=st["volatile"], drain=False).run(enqueue)
+
     return dict(beam_begin=beam_begin, beam_costs=beam_costs, beam_select=beam_select, beam_advance=beam_advance,
-                beam_step=beam_step, _readout_step_args=_readout_step_args)
+                beam_step=beam_step, beam_steps=beam_steps, _readout_step_args=_readout_step_args)
 
 
 for _k, _v in _beam_methods().items():

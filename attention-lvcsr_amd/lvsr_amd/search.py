@@ -11,6 +11,8 @@ Two things need the host inside the loop and switch the driver to one synchronis
 `validate_solution_function` (a Python callback that may veto a finished hypothesis, search.py:372-374) and a language
 model whose walk runs on the host (`FSTLanguageModel` without the device tables).
 """
+import os
+
 import numpy
 import torch
 
@@ -108,8 +110,11 @@ class BeamSearch(object):
             return False
         with rec._on_stream():
             n = min(int(positions), run["max_length"] - run["positions"])
-            for _ in range(n):
-                gen.beam_step()
+            if n == POLL_EVERY and os.environ.get("LVSR_BEAM_MULTI", "1") == "1":
+                gen.beam_steps(n)                          # one graph launch for the whole stretch between two looks
+            else:
+                for _ in range(n):
+                    gen.beam_step()
             run["positions"] += n
             if run["host"] is None:                        # CPU emulator: plain synchronous look
                 run["ctl"] = st["ctl"].cpu().numpy()

@@ -151,9 +151,9 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
                                searches_in_flight_per_gpu=streams,
                                mean_best_hypothesis_length=chars / max(done, 1), positions_per_utterance=steps / max(done, 1),
                                us_per_position=(sec * 1e6 * world / steps if steps else None),
-                               launches_per_position="one hipGraph replay (21 kernel nodes: 2 x attention pass, readout, fusion, "
-                                                     "select, feedback fork, GRU, FST walk, compaction); no device->host "
-                                                     "synchronisation except one look at the `done` word every 8 positions",
+                               launches_per_position="one hipGraph replay per 8 positions (21 kernel nodes each: 2 x attention pass, "
+                                                     "readout, fusion, select, feedback fork, GRU, FST walk, compaction); no "
+                                                     "device->host synchronisation except one look at the `done` word per replay",
                                encoder="persistent clusters, batch 1 (8 work-groups)"))
         print(json.dumps(out), file=json_out, flush=True)
     if dist:
