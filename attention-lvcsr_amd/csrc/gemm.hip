@@ -519,19 +519,34 @@ int lvsr_sgemm_batched(void* stream, int transA, int transB, int M, int N, int K
 int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, float* ws, long long ws_bytes) {
     LVSR_REQUIRE(n >= 0 && (n == 0 || descs), "lvsr_sgemm_tn_grouped: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    for (int i0 = 0; i0 < n; i0 += GROUP_MAX) {
+    for (int i = 0; i < n; ++i)
+        LVSR_REQUIRE(descs[i].A && descs[i].B && descs[i].C && descs[i].M > 0 && descs[i].N > 0 && descs[i].K > 0,
+                     "lvsr_sgemm_tn_grouped: bad descriptor %d", i);
+    auto aligned = [](const lvsr_gemm_desc& s) {
+        return (s.lda & 3) == 0 && (s.ldb & 3) == 0 && (((size_t)s.A) & 15) == 0 && (((size_t)s.B) & 15) == 0;
+    };
+    // two passes: the problems whose operands allow unguarded 16-byte loads share the fast kernel, the others the guarded one
+    // (one misaligned member — the V-wide output-layer gradient — would otherwise put the whole group on the guarded loads)
+    long long off = 0;
+    for (int pass = 0; pass < 2; ++pass) {
         GroupPack pk;
-        pk.n = n - i0 < GROUP_MAX ? n - i0 : GROUP_MAX;
-        pk.part = ws;
-        bool fast = true;
+        pk.n = 0; pk.part = ws;
         int units = 0;
-        long long off = 0;
-        for (int i = 0; i < pk.n; ++i) {
-            const lvsr_gemm_desc& s = descs[i0 + i];
-            LVSR_REQUIRE(s.A && s.B && s.C && s.M > 0 && s.N > 0 && s.K > 0, "lvsr_sgemm_tn_grouped: bad descriptor %d", i0 + i);
-            GroupDesc& d = pk.d[i];
+        bool any_split = false;
+        auto launch = [&]() {
+            if (pk.n == 0) return;
+            pk.total = units;
+            if (pass == 0) hipLaunchKernelGGL(lvsr_sgemm128_grouped_tn_kernel<true>, dim3(units), dim3(256), 0, st, pk);
+            else hipLaunchKernelGGL(lvsr_sgemm128_grouped_tn_kernel<false>, dim3(units), dim3(256), 0, st, pk);
+            if (any_split) hipLaunchKernelGGL(lvsr_sgemm_grouped_reduce, dim3(32, pk.n), dim3(256), 0, st, pk);
+            pk.n = 0; units = 0; any_split = false;
+        };
+        for (int i = 0; i < n; ++i) {
+            const lvsr_gemm_desc& s = descs[i];
+            if (aligned(s) != (pass == 0)) continue;
+            if (pk.n == GROUP_MAX) launch();
+            GroupDesc& d = pk.d[pk.n++];
             d.A = s.A; d.B = s.B; d.C = s.C; d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.beta = s.beta;
-            fast = fast && (s.lda & 3) == 0 && (s.ldb & 3) == 0 && (((size_t)s.A) & 15) == 0 && (((size_t)s.B) & 15) == 0;
             d.gx = (s.N + GN - 1) / GN; d.gy = (s.M + GM - 1) / GM;
             // k-chunks of about 1024 (a multiple of the k-tile), as long as the partials fit the workspace
             int want = (s.K + 1023) / 1024;
@@ -542,14 +557,11 @@ int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, floa
             d.kchunk = chunk;
             d.ksplit = (s.K + chunk - 1) / chunk;
             d.part_off = off;
-            if (d.ksplit > 1) off += (long long)d.ksplit * s.M * s.N;
+            if (d.ksplit > 1) { off += (long long)d.ksplit * s.M * s.N; any_split = true; }
             d.unit0 = units;
             units += d.gx * d.gy * d.ksplit;
         }
-        pk.total = units;
-        if (fast) hipLaunchKernelGGL(lvsr_sgemm128_grouped_tn_kernel<true>, dim3(units), dim3(256), 0, st, pk);
-        else hipLaunchKernelGGL(lvsr_sgemm128_grouped_tn_kernel<false>, dim3(units), dim3(256), 0, st, pk);
-        if (off > 0) hipLaunchKernelGGL(lvsr_sgemm_grouped_reduce, dim3(32, pk.n), dim3(256), 0, st, pk);
+        launch();
     }
     return lvsr_check_launch("lvsr_sgemm_tn_grouped");
 }

@@ -243,6 +243,7 @@ class Encoder(object):
         d, p, g, lib, ws = self.d, self.store.p, self.store.g, self.lib, self.ws
         assert self._saved is not None, "apply() must run first"
         gemm_ws = ws.get("gemm_ws", (1 << 22,))
+        self._scatter = []
         dy = d_encoded.contiguous()
         B = int(dy.shape[1])
         for i in reversed(range(d.n_layers)):
@@ -296,15 +297,23 @@ class Encoder(object):
                 # fork gradients of both directions: one (I, 6H) product and one column sum, scattered into the four matrices
                 gW = ws.get("enc%d.gWcat" % i, (I, 6 * H))
                 gb = ws.get("enc%d.gbcat" % i, (6 * H,))
+                # (not a member of the grouped launch: with 48 output tiles it fills the chip alone, and the group's one-size k-chunks
+                # would cost it 13 instead of 5 partial copies of its 3 MB output — measured slower)
                 lib.sgemm(x2, dxg2, gW, transA=True, ws=side_ws)
                 lib.colsum(dxg2, gb, ws=side_ws)
-                pairs = []
                 for di, direction in enumerate(("forward", "backward")):
                     n = self._names(i, direction)
                     o = di * 3 * H
-                    pairs += [(gW[:, o: o + H], g[n["Wi"]]), (gW[:, o + H: o + 3 * H], g[n["Wg"]]),
-                              (gb[o: o + H], g[n["bi"]]), (gb[o + H: o + 3 * H], g[n["bg"]])]
-                lib.copy_many(pairs)
+                    self._scatter += [(gW[:, o: o + H], g[n["Wi"]]), (gW[:, o + H: o + 3 * H], g[n["Wg"]]),
+                                      (gb[o: o + H], g[n["bi"]]), (gb[o + H: o + 3 * H], g[n["bg"]])]
             dy = dx
         self.join_side_stream()
+        if getattr(lib, "_group", None) is None:      # no grouped launch pending: the fork gradients are there
+            self.finish_backward()
         return dy
+
+    def finish_backward(self):
+        """Scatter the concatenated fork gradients of all layers into the four parameters each (one launch per 32 pieces).
+        Call after the grouped weight-gradient products have been flushed (the fork products are members of the group)."""
+        self.lib.copy_many(self._scatter)
+        self._scatter = []

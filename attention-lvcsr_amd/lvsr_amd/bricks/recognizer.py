@@ -190,7 +190,8 @@ class SpeechRecognizer(object):
             d_encoded = self.generator.backward()
             d_bottom = self.encoder.backward(d_encoded, need_input_grad=bool(self.d.bottom_dims))
             if grouped:
-                self.lib.flush_group(self.ws.get("gemm_ws.grouped", (1 << 25,)))
+                self.lib.flush_group(self.ws.get("gemm_ws.grouped", (1 << 26,)))
+            self.encoder.finish_backward()
             if self.d.bottom_dims:
                 self.bottom.backward(d_bottom)
 
