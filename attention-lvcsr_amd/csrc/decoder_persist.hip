@@ -49,7 +49,7 @@
 #define PD_NPROF 16
 
 struct PdGeom {
-    int P, nown, nownp, KC, KCP, FW, prof;
+    int P, nown, nownp, KC, KCP, FW, prof, RL;
     int o_pa, o_a, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, o_sw, Bp, total;
 };
 
@@ -76,14 +76,16 @@ static bool pd_geom(const AttDec& a, PdGeom& g) {
     if (a.K > 0 && g.FW > 4 * 8 * PD_NW) return false;          // tap groups of the convolution: 8 per wave
     int o = 0;
     auto take = [&](int n) { const int at = o; o += (n + 3) / 4 * 4; return at; };
-    g.o_pa = take(g.nown * a.M);
+    g.RL = (g.nown + 3) / 4 * 4;
+    if (g.RL % 32 == 0) g.RL += 4;          // transposed table [m][RL] of the MFMA energy path: row stride off the bank period
+    g.o_pa = take((g.KC > 0 ? g.RL : g.nown) * a.M + 64);
     g.o_a = take(a.Tp * PD_AWS);
     g.o_cv = take(g.nownp * (g.KCP > 0 ? g.KCP : 4));
     take(256);                               // the convolution reads up to 255 floats below `al` (and c + 16 P above) unclamped
     g.o_al = take(a.Tp);
     g.o_sv = take(PD_KSPLIT * (PD_KD + 4));
     g.o_rs = take(PD_KSPLIT * (PD_KD + 4));
-    g.o_xw = take(PD_NW * 8);
+    g.o_xw = take(PD_NW * PD_CH);
     g.o_sw = take(PD_THREADS);
     g.o_red = take(3 * PD_NW);
     g.Bp = (a.B + 3) / 4 * 4;
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     float* const al = lds + g.o_al;       // [T']        current alignment
     float* const sv = lds + g.o_sv;       // state, sliced by PD_KD
     float* const rsv = lds + g.o_rs;      // r*s, sliced by PD_KD
-    float* const xw = lds + g.o_xw;       // [PD_NW][8] energy partials
+    float* const xw = lds + g.o_xw;       // [PD_NW][16] energy partials (one per wave and position of a round)
     float* const swst = lds + g.o_sw;     // [512] transformed state, staged between the sweep's and the energy phase's thread layout
     float* const red = lds + g.o_red;
     float* const posv = lds + g.o_pos;    // [2][Bp] window centres of all utterances, by label parity
@@ -256,35 +258,58 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
             for (int c = 0; c < PD_MC; ++c) wsw[c][x] = (f32x2){s2[c][0], s2[c][1]};
         }
     }
-    // energy phase: thread (pair mp = tid % 256, half = tid / 256) holds match columns mp and mp + 256 (handler column pair per
-    // filter, energy vector pair) and takes 8 of a round's 16 positions.  tanh(x) = 1 - 2 / (1 + 2^(c x)), c = 2 log2(e): the
-    // operands are pre-scaled by c (preprocessed attended and handler once, the transformed state per label), and
-    // w_e . tanh = sum(w_e) - 2 w_e . (1 / (1 + 2^y)) with the -2 folded into the vector
+    // energy phase.  tanh(x) = 1 - 2 / (1 + 2^(c x)), c = 2 log2(e): the operands are pre-scaled by c (preprocessed attended and
+    // handler once, the transformed state per label), and w_e . tanh = sum(w_e) - 2 w_e . (1 / (1 + 2^y)) with the -2 folded in.
+    //  * location-aware attention (KC > 0): on the matrix cores.  Per round of 16 own positions wave w owns match columns
+    //    [64 w, 64 w + 64) as four 16 x 16 tiles: C = PA + sW (one 16-byte LDS read per tile from the TRANSPOSED table
+    //    PAs[m][RL]), A = convolution features (16 positions x 4 filters), B = handler (resident: Hb), three MFMAs per tile; the
+    //    accumulator lane (c16 = lane % 16, g4 = lane / 16) holds positions 4 g4 + r of column c16: exp2 / rcp / w_e on them, a
+    //    DPP fold over the 16 column lanes, one partial per (wave, position) through LDS;
+    //  * content-only attention (KC = 0): thread (pair mp, half) holds columns mp, mp + 256 on the VALU as before.
     const float C2 = 2.885390081777927f;
     const int mp = tid & (PD_MP - 1), ehalf = wave / (PD_MP / 64);
-    f32x2 Hk[KC > 0 ? KC : 1], wem2;
-    float wsum, am;
-    {
-        float h[2][KC > 0 ? KC : 1], wv[2];
+    const int c16 = lane & 15, g4 = lane >> 4;
+    float Hb[KC > 0 ? 4 : 1][KC > 0 ? KCP / 4 : 1], wet[4];          // MFMA path: B operands and -2 w_e of this lane's four columns
+    f32x2 wem2 = {0.f, 0.f};
+    float wsum = 0.f, am;
+    if (KC > 0) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const int m = mp + x * PD_MP;
+        for (int tile = 0; tile < 4; ++tile) {
+            const int m = (4 * wave + tile) * 16 + c16;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) h[x][k] = (k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
-            wv[x] = m < M ? a.w_e[m] : 0.f;
+            for (int sq = 0; sq < KCP / 4; ++sq) {
+                const int k = 4 * sq + g4;
+                Hb[tile][sq] = (k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
+            }
+            const float wv = m < M ? a.w_e[m] : 0.f;
+            wet[tile] = -2.f * wv;
+            wsum += wv;
         }
+    } else {
+        float wv[2];
 #pragma unroll
-        for (int k = 0; k < KC; ++k) Hk[k] = (f32x2){h[0][k], h[1][k]};
+        for (int x = 0; x < 2; ++x) wv[x] = (mp + x * PD_MP) < M ? a.w_e[mp + x * PD_MP] : 0.f;
         wem2 = (f32x2){-2.f * wv[0], -2.f * wv[1]};
         wsum = wv[0] + wv[1];
-        am = tid < Tp ? a.Am[(size_t)tid * a.Am_ts + (size_t)b * a.Am_bs] : 0.f;
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) wet[tile] = 0.f;
     }
+    am = tid < Tp ? a.Am[(size_t)tid * a.Am_ts + (size_t)b * a.Am_bs] : 0.f;
     const float eb = a.e_bias ? a.e_bias[0] : 0.f;
     // ---- LDS residents
     for (int x = tid; x < g.total - g.o_cv; x += PD_THREADS) lds[g.o_cv + x] = 0.f;      // everything behind the big tables
-    for (int x = tid; x < nown * M; x += PD_THREADS) {
-        const int tl = x / M, m = x % M, t = tl * P + p;
-        PAs[x] = t < Tp ? C2 * a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m] : 0.f;
+    if (KC > 0) {              // transposed: PAs[m * RL + tl]
+        for (int x = tid; x < g.RL * M + 64; x += PD_THREADS) PAs[x] = 0.f;
+        __syncthreads();
+        for (int x = tid; x < nown * M; x += PD_THREADS) {
+            const int tl = x / M, m = x % M, t = tl * P + p;
+            if (t < Tp) PAs[m * g.RL + tl] = C2 * a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m];
+        }
+    } else {
+        for (int x = tid; x < nown * M; x += PD_THREADS) {
+            const int tl = x / M, m = x % M, t = tl * P + p;
+            PAs[x] = t < Tp ? C2 * a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m] : 0.f;
+        }
     }
     for (int x = tid; x < Tp * 3 * PD_UNITS; x += PD_THREADS) {
         const int t = x / (3 * PD_UNITS), gcol = x % (3 * PD_UNITS), gate = gcol / PD_UNITS, unit = p * PD_UNITS + gcol % PD_UNITS;
@@ -450,9 +475,61 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         swst[tid] = swv[0];
         __syncthreads();
         clk.mark(2);
-        // ---- phase B: energies of the own positions, 16 per round (alternate positions per half of the work-group, PD_EG at a time written
-        // operand-first / filter-major so that the four chains interleave); branch-free inside a group (clamped addresses,
-        // results masked afterwards)
+        // ---- phase B: energies of the own positions, 16 per round
+        if (KC > 0) {
+            float swc[4];                      // transformed state of this lane's four columns, pre-scaled
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) swc[tile] = C2 * swst[(4 * wave + tile) * 16 + c16];
+            for (int tl0 = 0; tl0 < nown; tl0 += PD_CH) {
+                float av[KCP / 4 > 0 ? KCP / 4 : 1];
+                const int tla = min(tl0 + c16, nown - 1);           // A operand: convolution features of position row c16
+#pragma unroll
+                for (int sq = 0; sq < KCP / 4; ++sq) av[sq] = cvs[tla * KCP + 4 * sq + g4];
+                f32x4 acc[4];
+#pragma unroll
+                for (int tile = 0; tile < 4; ++tile) {
+                    const int m = min((4 * wave + tile) * 16 + c16, M - 1);
+                    const float4 pa = *(const float4*)(PAs + m * g.RL + tl0 + 4 * g4);      // positions tl0 + 4 g4 .. + 3
+                    acc[tile] = (f32x4){pa.x + swc[tile], pa.y + swc[tile], pa.z + swc[tile], pa.w + swc[tile]};
+                }
+#pragma unroll
+                for (int sq = 0; sq < KCP / 4; ++sq)
+#pragma unroll
+                    for (int tile = 0; tile < 4; ++tile)
+                        acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], Hb[tile][sq], acc[tile], 0, 0, 0);
+                float ra[4] = {wsum, wsum, wsum, wsum};
+#pragma unroll
+                for (int tile = 0; tile < 4; ++tile) {
+                    float ex[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(acc[tile][r]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_rcpf(1.0f + ex[r]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ra[r] += wet[tile] * ex[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {                      // fold the 16 column lanes of the row group
+                    ra[r] += lvsr_dpp_quad_xor1(ra[r]);
+                    ra[r] += lvsr_dpp_quad_xor2(ra[r]);
+                    ra[r] += lvsr_dpp_half_mirror(ra[r]);
+                    ra[r] += lvsr_dpp_mirror(ra[r]);
+                }
+                if (c16 == 0) *(float4*)(xw + wave * PD_CH + 4 * g4) = make_float4(ra[0], ra[1], ra[2], ra[3]);
+                __syncthreads();
+                if (tid < PD_CH) {
+                    const int tl = tl0 + tid, t = tl * P + p;
+                    if (tl < nown && t < Tp) {
+                        float e = 0.f;
+#pragma unroll
+                        for (int wv = 0; wv < PD_NW; ++wv) e += xw[wv * PD_CH + tid];
+                        granule_store(gEN + t, epoch, (t >= wi.begin && t < wi.end) ? e : 0.f);
+                    }
+                }
+                if (tl0 + PD_CH < nown) __syncthreads();
+            }
+        } else {
+        // content-only attention: alternate positions per half of the work-group, PD_EG at a time, two columns per thread
         const int m0c = min(mp, M - 1), m1c = min(mp + PD_MP, M - 1);              // columns beyond M carry w_e = 0
         const f32x2 swp = {C2 * swst[mp], C2 * swst[mp + PD_MP]};                   // pre-scaled, see C2
         for (int tl0 = 0; tl0 < nown; tl0 += PD_CH) {
@@ -463,30 +540,13 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
             for (int x0 = 0; x0 < 8; x0 += PD_EG) {
                 const int tlb = tl0 + 2 * x0 + ehalf;          // the halves take alternate positions: balanced for any T'
                 if (tlb < nown) {                              // wave-uniform: padded groups of the last round are skipped
-                    f32x2 xx[PD_EG];
-                    float4 c4[PD_EG][KCP > 0 ? KCP / 4 : 1];
+                    float ex[PD_EG][2];
 #pragma unroll
                     for (int e = 0; e < PD_EG; ++e) {
                         const int tlc = min(tlb + 2 * e, nown - 1);
-                        xx[e] = (f32x2){swp.x + PAs[tlc * M + m0c], swp.y + PAs[tlc * M + m1c]};
-                        const float4* cr = (const float4*)(cvs + tlc * KCP);
-#pragma unroll
-                        for (int k4 = 0; k4 < KCP / 4; ++k4) c4[e][k4] = cr[k4];
+                        ex[e][0] = __builtin_amdgcn_exp2f(swp.x + PAs[tlc * M + m0c]);
+                        ex[e][1] = __builtin_amdgcn_exp2f(swp.y + PAs[tlc * M + m1c]);
                     }
-#pragma unroll
-                    for (int k4 = 0; k4 < KCP / 4; ++k4) {
-#pragma unroll
-                        for (int e = 0; e < PD_EG; ++e) {
-                            const float4 c = c4[e][k4];
-                            if (4 * k4 < KC) xx[e] = Hk[4 * k4] * (f32x2){c.x, c.x} + xx[e];
-                            if (4 * k4 + 1 < KC) xx[e] = Hk[4 * k4 + 1 < KC ? 4 * k4 + 1 : 0] * (f32x2){c.y, c.y} + xx[e];
-                            if (4 * k4 + 2 < KC) xx[e] = Hk[4 * k4 + 2 < KC ? 4 * k4 + 2 : 0] * (f32x2){c.z, c.z} + xx[e];
-                            if (4 * k4 + 3 < KC) xx[e] = Hk[4 * k4 + 3 < KC ? 4 * k4 + 3 : 0] * (f32x2){c.w, c.w} + xx[e];
-                        }
-                    }
-                    float ex[PD_EG][2];
-#pragma unroll
-                    for (int e = 0; e < PD_EG; ++e) { ex[e][0] = __builtin_amdgcn_exp2f(xx[e].x); ex[e][1] = __builtin_amdgcn_exp2f(xx[e].y); }
 #pragma unroll
                     for (int e = 0; e < PD_EG; ++e) {
                         ex[e][0] = __builtin_amdgcn_rcpf(1.0f + ex[e][0]);
@@ -512,6 +572,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 }
             }
             if (tl0 + PD_CH < nown) __syncthreads();
+        }
         }
         clk.mark(3);
         float eg[PD_NV];
