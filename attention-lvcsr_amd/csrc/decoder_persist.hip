@@ -360,7 +360,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         }
     }
     auto conv = [&](int i, const Win wi) {
-        const int cn = a.c, ng4 = (g.FW + 3) / 4;
+        const int cn = a.c;
         const int r16 = lane & 15, kk = lane >> 4;
         for (int bl = 0; bl * 16 < nown; ++bl) {
             const int tlx = bl * 16 + r16, tx = tlx * P + p;          // B operand: this lane's position column
@@ -378,9 +378,9 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
             }
             f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
 #pragma unroll
-            for (int n = 0; n < 8; n += 2) {
-                if (wave + n * PD_NW < ng4) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cfa[n], fb[n], acc0, 0, 0, 0);
-                if (wave + (n + 1) * PD_NW < ng4) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cfa[n + 1], fb[n + 1], acc1, 0, 0, 0);
+            for (int n = 0; n < 8; n += 2) {               // tap groups beyond the filter carry zero A operands: no branches
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cfa[n], fb[n], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cfa[n + 1], fb[n + 1], acc1, 0, 0, 0);
             }
             clk.mark(12);
 #pragma unroll
