@@ -525,6 +525,20 @@ int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, floa
     auto aligned = [](const lvsr_gemm_desc& s) {
         return (s.lda & 3) == 0 && (s.ldb & 3) == 0 && (((size_t)s.A) & 15) == 0 && (((size_t)s.B) & 15) == 0;
     };
+    // k-chunk depth: ~1024 where the partials of ALL members fit the workspace, else the smallest common depth that fits (starving
+    // the members that come last of their splits instead left them as long serial tails: WSJ-deep 108 -> 113 ms)
+    int target = 1024;
+    if (ws) {
+        for (;; target += 512) {
+            long long need = 0;
+            bool splits = false;
+            for (int i = 0; i < n; ++i) {
+                const int want = (descs[i].K + target - 1) / target;
+                if (want > 1) { need += (long long)want * descs[i].M * descs[i].N; splits = true; }
+            }
+            if (!splits || need * 4 <= ws_bytes) break;
+        }
+    }
     // two passes: the problems whose operands allow unguarded 16-byte loads share the fast kernel, the others the guarded one
     // (one misaligned member — the V-wide output-layer gradient — would otherwise put the whole group on the guarded loads)
     long long off = 0;
@@ -548,10 +562,7 @@ int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, floa
             GroupDesc& d = pk.d[pk.n++];
             d.A = s.A; d.B = s.B; d.C = s.C; d.M = s.M; d.N = s.N; d.K = s.K; d.lda = s.lda; d.ldb = s.ldb; d.ldc = s.ldc; d.beta = s.beta;
             d.gx = (s.N + GN - 1) / GN; d.gy = (s.M + GM - 1) / GM;
-            // k-chunks of about 1024 (a multiple of the k-tile), as long as the partials fit the workspace
-            int want = (s.K + 1023) / 1024;
-            if (!ws) want = 1;
-            while (want > 1 && (off + (long long)want * s.M * s.N) * 4 > ws_bytes) --want;
+            int want = ws ? (s.K + target - 1) / target : 1;
             int chunk = (s.K + want - 1) / want;
             chunk = ((chunk + GK - 1) / GK) * GK;
             d.kchunk = chunk;
