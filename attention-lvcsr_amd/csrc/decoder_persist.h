@@ -1,0 +1,134 @@
+// Pieces shared by the persistent attention-decoder kernels (decoder_persist.hip: forward, decoder_persist_bwd.hip: backward).
+#pragma once
+#include "decoder.h"
+#include "persist.h"
+
+#define PD_THREADS 512       // two waves per SIMD: with one, every LDS / transcendental latency of the energy phase is exposed
+#define PD_KSPLIT 16
+#define PD_UNITS 32          // decoder units per work-group
+#define PD_KD 16             // state rows per thread
+#define PD_MC 2              // transform_states columns per lane group
+#define PD_AWS (3 * PD_UNITS + 4)   // LDS row stride of the AW slice: +4 words spreads the 8 position lanes of a unit over the banks
+#define PD_CH 16             // attended positions per energy round (8 per half of the work-group)
+#define PD_EG 2              // positions whose chains are written interleaved in the energy phase (registers: 12 per position)
+#define PD_MP 256            // match-column pairs (m, m + 256): one per thread of a half
+#define PD_MAXV 512          // longest exchanged vector
+#define PD_NV (PD_MAXV / PD_THREADS)     // granules per thread and sweep
+#define PD_NW (PD_THREADS / 64)
+#define PD_LDS_FLOATS (39 * 1024 + 512)
+#define PD_NPLANE 4          // SW | EN | RS | S
+#define PD_NPROF 16
+
+__host__ __device__ __forceinline__ int pd_slot(int k, int KX) { return (k / KX) * (KX + 4) + (k % KX); }
+
+// Window of label i (attdec_window) with the window centres taken from LDS: the centres of ALL utterances bound the window
+// (lvsr/bricks/attention.py:133-147), which is the one coupling between clusters
+__device__ __forceinline__ Win pd_window(const AttDec& a, int i, const float* posv) {
+    if (a.K == 0 || a.prior_type == 0) return attdec_window(a, i);
+    const float before = (float)a.p0, after = (float)a.p1;
+    float mn = 3.0e38f, mx = -3.0e38f;
+    for (int b = 0; b < a.B; ++b) {
+        const float pb = posv[b];
+        mn = fminf(mn, floorf(pb - before));
+        mx = fmaxf(mx, ceilf(pb + after));
+    }
+    Win w;
+    w.begin = (int)fmaxf(0.f, mn);
+    w.end = (int)fminf((float)a.Tp, mx);
+    if (w.end < w.begin) w.end = w.begin;
+    return w;
+}
+
+// One sweep over a plane of n <= 512 granules until every granule carries `epoch`; thread tid gets granules tid and tid + 256.
+// Returns false when the cluster gave up (spin limit / abort word).
+__device__ __forceinline__ bool pd_gather(const u64* g, int n, unsigned epoch, int* abort_word, float (&out)[PD_NV]) {
+    const int tid = threadIdx.x;
+    u64 wv[PD_NV];
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int x = 0; x < PD_NV; ++x) {
+            wv[x] = (u64)epoch << 32;
+            if (tid + x * PD_THREADS < n) wv[x] = __hip_atomic_load(g + tid + x * PD_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int x = 0; x < PD_NV; ++x) ok = ok && (unsigned)(wv[x] >> 32) == epoch;
+        if (__all(ok)) break;
+        ++spins;
+        if ((spins & 127u) == 0u) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spins > PERSIST_SPIN_LIMIT) {
+                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < PD_NV; ++x) out[x] = __uint_as_float((unsigned)wv[x]);
+    return true;
+}
+
+// sum_x w[x] * v[q][x] over this thread's row slice of a sliced LDS vector, folded over the lanes of the unit
+template <int KX>
+__device__ __forceinline__ float pd_dot(const f32x2 (&w)[KX / 2], const float* buf, int q) {
+    const float4* hv = (const float4*)(buf + q * (KX + 4));
+    f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < KX / 4; ++x) {
+        const float4 h4 = hv[x];
+        const f32x2 lo = {h4.x, h4.y}, hi = {h4.z, h4.w};
+        a0 = w[2 * x] * lo + a0;
+        a1 = w[2 * x + 1] * hi + a1;
+    }
+    return group_sum<PD_KSPLIT>((a0.x + a1.x) + (a0.y + a1.y));
+}
+
+// v[x] (x < 8) -> sum over the 64 lanes of the wave; lane l ends with the total of value index 4*bit5(l) + 2*bit4(l) + bit3(l):
+// every stage halves the values a lane carries (10 shuffles instead of 8 x 6)
+__device__ __forceinline__ float pd_butterfly8(float (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int half = 4 >> s, off = 32 >> s;
+        const bool up = (lane & off) != 0;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            if (x < half) {
+                const float keep = up ? v[x + half] : v[x];
+                const float send = up ? v[x] : v[x + half];
+                v[x] = keep + __shfl_xor(send, off, 64);
+            }
+        }
+    }
+    float r = v[0];
+    r += lvsr_dpp_quad_xor1(r);
+    r += lvsr_dpp_quad_xor2(r);
+    r += lvsr_dpp_half_mirror(r);
+    return r;
+}
+__device__ __forceinline__ int pd_butterfly_index(int lane) { return ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1); }
+
+// Phase clock of work-group 0 (thread 0): accumulated s_memrealtime ticks (100 MHz) per phase of the label loop, left in the
+// workspace header (bytes 64..255) for tools/probe_decoder_persist.py (LVSR_PD_PROF=1).  Every read drains the wave's
+// outstanding LDS traffic, so the clock itself costs about a microsecond per label: off by default.
+struct PdClock {          // accumulators in LDS (2 floats each), touched by thread 0 of work-group 0 only
+    long long* acc;
+    bool on;
+    __device__ __forceinline__ void start(bool enable, float* mem) {
+        on = enable;
+        acc = (long long*)mem;
+        if (on) {
+            for (int x = 1; x <= PD_NPROF; ++x) acc[x] = 0;
+            acc[0] = wall_clock64();
+        }
+    }
+    __device__ __forceinline__ void mark(int slot) {
+        if (on) {
+            const long long now = wall_clock64();
+            acc[1 + slot] += now - acc[0];
+            acc[0] = now;
+        }
+    }
+};
+

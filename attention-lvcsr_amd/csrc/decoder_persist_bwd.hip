@@ -1,0 +1,589 @@
+// Persistent attention-decoder BACKWARD for gfx950: one launch for the reverse walk over the labels instead of four per label.
+// Same cluster layout as the forward (decoder_persist.hip): P = ceil(D/32) work-groups of 512 threads serve ONE utterance,
+// work-group p owns decoder units [32p, 32p+32), attended positions t = p mod P and match columns [64p, 64p+64).
+//
+// Per label i = L-1 .. 0 (math as decoder_bwd.hip; AW / QR as its reassociated form):
+//   1. GRU:      dsn = ym ds; dpc = dsn u (1-c^2); dpu = dsn (c-s) u (1-u)                          (own units, elementwise)
+//                A: all-gather dpc;  drh = dpc @ Whh^T (own units: row of Whh in registers);  dpr = drh s r (1-r)
+//   2. gates:    B: all-gather [dpu | dpr];  dsacc = dsn(1-u) + (1-ym)ds + drh r + [dpu|dpr] @ Whg^T + dS_readout
+//      glimpse:  q[t] = [dpc|dpu|dpr] . AW[t] + QR[i,t] + dalpha[t]   for the OWN positions (AW rows streamed from L2, fetched
+//                behind exchange B);  C: all-gather q;  sd = sum_t alpha_t q_t;  de = alpha (q - sd)          (softmax backward)
+//   3. energies: own positions x all match columns on the matrix cores (as attbwd_energy_mfma_kernel): match = PA + sW + cv^T H,
+//                dm = de w_e (1 - tanh^2); dPA += dm; dcv = dm H^T (complete: all columns are local); handler / energy-vector
+//                gradients accumulate in REGISTERS over the whole label loop; dsW partial over the own positions
+//   4. state:    D: reduce-scatter dsW (every work-group publishes 512 partials, gathers the 8 x 64 of its column slice);
+//                its slice's contribution dsW[slice] @ Ws^T[slice] to ALL units;  E: reduce-scatter of those (8 x 32 gathered)
+//                ds' = dsacc + sum                                                                     -> next label
+//   5. alignment (off the chain, behind D / E): dalpha'[s] = sum_k sum_{own t} dcv[k][t] f[k][c+t-s] for all s;
+//                F: reduce-scatter, gathered by the owners of s at the start of the next label.
+// Five exchanges on the chain per label (A, B, C, D, E) instead of four kernel boundaries + four kernels.
+// Writes what the batched GEMMs after the loop need (DXG, DSW, DCV, dPA, ds) and per-work-group partials of the handler /
+// energy-vector / energy-bias gradients (accH, accWe, accEb: B*P rows, folded by lvsr_colsum).  Limits as the forward's.
+#include "decoder_persist.h"
+#include <stdlib.h>
+#include <string.h>
+
+typedef lvsr_attdec_bwd_args AttBwd;
+
+#define PB_NPLANE_SMALL 3           // A (dpc) | B (dpu, dpr: 2 x 256, packed as 512) | C (q)        : PD_MAXV granules each
+// per work-group planes: D (512) | E (256) | F (512)
+
+struct PbGeom {
+    int P, nown, nownp, KC, KCP, FW, RL;
+    int o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_red, o_clk, prof, total;
+};
+
+static int pb_kc(int K) {
+    const int inst[4] = {0, 4, 10, 16};
+    for (int i = 0; i < 4; ++i)
+        if (K <= inst[i]) return inst[i];
+    return -1;
+}
+
+static bool pb_geom(const AttDec& a, PbGeom& g) {
+    if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
+    if (a.D > PD_KSPLIT * PD_KD || a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
+    g.KC = pb_kc(a.K);
+    if (g.KC < 0) return false;
+    g.KCP = (g.KC + 3) / 4 * 4;
+    g.P = (a.D + PD_UNITS - 1) / PD_UNITS;
+    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > PERSIST_MAX_WG) return false;
+    g.nown = (a.Tp + g.P - 1) / g.P;
+    g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
+    if (g.nown > 32) return false;            // the q / alignment-gradient phases map one 16-lane group / one granule row per own position
+    g.FW = 2 * a.c + 1;
+    g.RL = (g.nown + 3) / 4 * 4;
+    if (g.RL % 32 == 0) g.RL += 4;
+    int o = 0;
+    auto take = [&](int n) { const int at = o; o += (n + 3) / 4 * 4; return at; };
+    g.o_pa = take(g.RL * a.M + 64);
+    g.o_cv = take(g.nownp * (g.KCP > 0 ? g.KCP : 4));
+    g.o_dcv = take(g.nownp * (g.KCP > 0 ? g.KCP : 4));
+    g.o_al = take(a.Tp);
+    g.o_q = take(a.Tp);
+    g.o_des = take(g.nownp);
+    g.o_dalp = take(32);                      // one slot per own position (nown <= 32)
+    g.o_dgl = take(3 * PD_KSPLIT * PD_KD);
+    g.o_dpc = take(PD_KSPLIT * (PD_KD + 4));
+    g.o_dpu = take(PD_KSPLIT * (PD_KD + 4));
+    g.o_dpr = take(PD_KSPLIT * (PD_KD + 4));
+    g.o_dms = take(PD_NW * 16 * 17);
+    g.o_r8 = take(8 * 64);
+    g.o_r8b = take(8 * 32);
+    g.o_dsw = take(64);
+    g.o_ws = take(256 * 68);                  // Ws[unit][own column slice] (+4 pad per row)
+    g.o_red = take(2 * PD_NW);
+    g.o_clk = take(2 * (PD_NPROF + 1));
+    g.total = o;
+    const char* env = getenv("LVSR_PD_PROF");
+    g.prof = env ? atoi(env) : 0;
+    return o <= PD_LDS_FLOATS;
+}
+
+template <int KC>
+__global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr_attdec_plain w, PbGeom g, u64* planes, int* abort_word) {
+    constexpr int KCP = (KC + 3) / 4 * 4;
+    constexpr int NS = KCP / 4 > 0 ? KCP / 4 : 1;
+    const AttDec& a = gb.f;
+    __shared__ __attribute__((aligned(16))) float lds[PD_LDS_FLOATS];
+    float* const PAs = lds + g.o_pa;      // [M][RL] own positions of the preprocessed attended, transposed, pre-scaled by C2
+    float* const cvs = lds + g.o_cv;      // [nownp][KCP] convolution features of the own positions (this label)
+    float* const dcvs = lds + g.o_dcv;    // [nownp][KCP] their gradient
+    float* const al = lds + g.o_al;       // [T'] alignment produced by this label
+    float* const qv = lds + g.o_q;        // [T'] q of all positions
+    float* const des = lds + g.o_des;     // [nownp] energy gradients of the own positions
+    float* const dalp = lds + g.o_dalp;   // [nownp] gradient wrt the alignment this label produced (from the next label's convolution)
+    float* const dgl = lds + g.o_dgl;     // [3][256] dpc | dpu | dpr, linear
+    float* const dpcs = lds + g.o_dpc;    // sliced copies for the register contractions
+    float* const dpus = lds + g.o_dpu;
+    float* const dprs = lds + g.o_dpr;
+    float* const dms = lds + g.o_dms;     // [PD_NW][16][17] dm tile of a wave; later the cross-wave dcv partials
+    float* const r8 = lds + g.o_r8;       // [8][64]
+    float* const r8b = lds + g.o_r8b;     // [8][32]
+    float* const dsws = lds + g.o_dsw;    // [64] dsW of the own column slice
+    float* const WsL = lds + g.o_ws;      // [256][68] transform_states rows x the own 64 match columns
+    float* const red = lds + g.o_red;
+    const int P = g.P, nown = g.nown;
+    int b, p;
+    cluster_of_block(P, 0, b, p);
+    const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c16 = lane & 15, g4 = lane >> 4;
+    const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L, G3 = 3 * a.D;
+    const int j = p * PD_UNITS + jl;
+    const bool junit = j < D;
+    const float C2 = 2.885390081777927f;
+    // ---- register-resident weights
+    f32x2 whh[PD_KD / 2], whu[PD_KD / 2], whr[PD_KD / 2];        // rows j of Whh, Whg[:, :D], Whg[:, D:], slice q of the columns
+    {
+        const size_t jc = (size_t)min(j, D - 1);
+#pragma unroll
+        for (int x = 0; x < PD_KD / 2; ++x) {
+            float v[3][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = q * PD_KD + 2 * x + e;
+                const size_t kc = (size_t)min(k, D - 1);
+                const float keep = (junit && k < D) ? 1.f : 0.f;
+                v[0][e] = w.Whh[jc * D + kc] * keep;
+                v[1][e] = w.Whg[jc * 2 * D + kc] * keep;
+                v[2][e] = w.Whg[jc * 2 * D + D + kc] * keep;
+            }
+            whh[x] = (f32x2){v[0][0], v[0][1]}; whu[x] = (f32x2){v[1][0], v[1][1]}; whr[x] = (f32x2){v[2][0], v[2][1]};
+        }
+    }
+    // MFMA operands of the energy phase: this wave's match columns [64 wave, 64 wave + 64) as four 16-column tiles
+    float Hb[4][NS], Ht[4][4], wet[4];
+    f32x4 dH[4];
+    float weacc[4], ebacc = 0.f;
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int m = (4 * wave + tile) * 16 + c16;
+#pragma unroll
+        for (int sq = 0; sq < NS; ++sq) {
+            const int k = 4 * sq + g4;
+            Hb[tile][sq] = (KC > 0 && k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
+        }
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+            const int mm = (4 * wave + tile) * 16 + 4 * sq + g4;
+            Ht[tile][sq] = (KC > 0 && c16 < K && mm < M) ? a.handler[(size_t)c16 * M + mm] : 0.f;
+        }
+        wet[tile] = m < M ? a.w_e[m] : 0.f;
+        dH[tile] = F32X4_ZERO;
+        weacc[tile] = 0.f;
+    }
+    // ---- LDS residents
+    for (int x = tid; x < g.total; x += PD_THREADS) lds[x] = 0.f;
+    __syncthreads();
+    for (int x = tid; x < nown * M; x += PD_THREADS) {
+        const int tl = x / M, m = x % M, t = tl * P + p;
+        if (t < Tp) PAs[m * g.RL + tl] = C2 * a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m];
+    }
+    for (int x = tid; x < 256 * 64; x += PD_THREADS) {
+        const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
+        WsL[kp * 68 + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
+    }
+    float dsj = junit ? gb.ds[(size_t)b * D + j] : 0.f;            // running gradient wrt the state (caller: zeros + readout part)
+    u64* const gA = planes + (size_t)b * (PB_NPLANE_SMALL * PD_MAXV + (size_t)P * (512 + 256 + 512));
+    u64* const gB = gA + PD_MAXV;
+    u64* const gC = gA + 2 * PD_MAXV;
+    u64* const gD = gA + 3 * PD_MAXV;                 // [P][512]
+    u64* const gE = gD + (size_t)P * 512;             // [P][256]
+    u64* const gF = gE + (size_t)P * 256;             // [P][512]
+    __syncthreads();
+    PdClock clk;
+    clk.start(g.prof != 0 && blockIdx.x == 0 && tid == 0, lds + g.o_clk);
+
+    for (int n = 0; n < L; ++n) {
+        const int i = L - 1 - n;
+        const unsigned epoch = (unsigned)(n + 1);
+        const size_t row = (size_t)i * B + b;
+        const Win wi = attdec_window(a, i);
+        // ---- this label's saved values
+        const float uu = junit ? a.U[row * D + j] : 0.f, rr = junit ? a.R[row * D + j] : 0.f, cc = junit ? a.C[row * D + j] : 0.f;
+        const float sp = junit ? a.S[row * D + j] : 0.f;
+        const float ym = a.ymask ? a.ymask[row] : 1.f;
+        const float dsr = (junit && gb.dS_r) ? gb.dS_r[row * D + j] : 0.f;
+        for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[((size_t)(i + 1) * B + b) * Tp + t];
+        if (KC > 0) {
+            for (int x = tid; x < nown * K; x += PD_THREADS) {
+                const int tl = x / K, k = x % K, t = tl * P + p;
+                cvs[tl * KCP + k] = t < Tp ? a.CV[((row * K) + k) * Tp + t] : 0.f;
+            }
+        }
+        // ---- 1. GRU
+        const float dsn = ym * dsj;
+        const float dpc = junit ? dsn * uu * (1.f - cc * cc) : 0.f;
+        const float dpu = junit ? dsn * (cc - sp) * uu * (1.f - uu) : 0.f;
+        float part = dsn * (1.f - uu) + (1.f - ym) * dsj + dsr;
+        if (q == 0 && junit) granule_store(gA + j, epoch, dpc);
+        // gradient wrt the alignment this label produced: gathered from the partial correlations of the previous iteration
+        if (n > 0 && KC > 0) {
+            float v[PD_NV];
+            const int src = tid >> 5, tl = tid & 31, t = tl * P + p;
+            const bool mine = tid < 8 * 32 && src < P && tl < nown && t < Tp;
+            // (granules of positions this work-group does not own are not waited for: sweep only the valid ones)
+            u64 wv = (u64)epoch << 32;
+            unsigned spins = 0;
+            for (;;) {
+                if (mine) wv = __hip_atomic_load(gF + (size_t)src * 512 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (unsigned)(wv >> 32) == (unsigned)n)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            (void)v;
+            if (tid < 8 * 32) r8b[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+        }
+        clk.mark(0);
+        {
+            float v[PD_NV];
+            if (!pd_gather(gA, D, epoch, abort_word, v)) return;
+            if (tid < D) { dpcs[pd_slot(tid, PD_KD)] = v[0]; dgl[tid] = v[0]; }
+        }
+        __syncthreads();
+        if (n > 0 && KC > 0 && tid < 32) {
+            float s = 0.f;
+#pragma unroll
+            for (int src = 0; src < 8; ++src) s += r8b[src * 32 + tid];
+            dalp[tid] = s;
+        }
+        clk.mark(1);
+        const float drh = pd_dot<PD_KD>(whh, dpcs, q);
+        const float dpr = junit ? drh * sp * rr * (1.f - rr) : 0.f;
+        part += drh * rr;
+        if (q == 0 && junit) {
+            granule_store(gB + j, epoch, dpu);
+            granule_store(gB + 256 + j, epoch, dpr);
+            float* dx = gb.DXG + row * G3;
+            dx[j] = dpc; dx[D + j] = dpu; dx[2 * D + j] = dpr;
+        }
+        clk.mark(2);
+        // ---- 2. gates
+        {
+            u64 wv = (u64)epoch << 32;
+            unsigned spins = 0;
+            const int src = tid < 256 ? tid : 256 + (tid - 256);
+            const bool mine = (tid < 256 ? tid : tid - 256) < D;
+            for (;;) {
+                if (mine) wv = __hip_atomic_load(gB + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            if (mine) {
+                const float v = __uint_as_float((unsigned)wv);
+                if (tid < 256) { dpus[pd_slot(tid, PD_KD)] = v; dgl[256 + tid] = v; }
+                else { dprs[pd_slot(tid - 256, PD_KD)] = v; dgl[512 + tid - 256] = v; }
+            }
+        }
+        __syncthreads();
+        clk.mark(3);
+        // AW rows of the own positions for q: thread (tl = tid / 16, l16): columns 4 l16 + 64 e.  Issued AFTER exchange B: a sweep of
+        // the exchange would queue behind them in this wave's memory pipeline (loads return in order) and the exchange would
+        // last as long as they do
+        const int qtl = tid >> 4, l16 = tid & 15, qt = qtl * P + p;
+        const bool qok = qtl < nown && qt < Tp && qt >= wi.begin && qt < wi.end;
+        float4 awv[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const int col = 4 * l16 + 64 * e;
+            awv[e] = (qok && col + 3 < G3) ? *(const float4*)(w.AW + ((size_t)qt * B + b) * G3 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float dsacc = part + pd_dot<PD_KD>(whu, dpus, q) + pd_dot<PD_KD>(whr, dprs, q);
+        clk.mark(11);
+        {
+            // q of the own positions
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int col = 4 * l16 + 64 * e;                 // columns [0,D) dpc, [D,2D) dpu, [2D,3D) dpr
+                const int blk = col / D, off = col - blk * D;     // (D is a multiple of 4 here: see pb_geom users)
+                const float4 dg = (col + 3 < G3) ? *(const float4*)(dgl + blk * 256 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s0 += awv[e].x * dg.x + awv[e].y * dg.y;
+                s1 += awv[e].z * dg.z + awv[e].w * dg.w;
+            }
+            clk.mark(12);
+            float qs = group_sum<16>(s0 + s1);
+            if (qok) qs += gb.QR[row * Tp + qt] + (KC > 0 ? dalp[qtl] : 0.f);
+            else qs = 0.f;
+            if (l16 == 0 && qtl < nown && qt < Tp) granule_store(gC + qt, epoch, qs);
+        }
+        clk.mark(4);
+        {
+            float v[PD_NV];
+            if (!pd_gather(gC, Tp, epoch, abort_word, v)) return;
+            if (tid < Tp) qv[tid] = v[0];
+            // sd = sum_t alpha_t q_t over the window
+            const bool inw = tid < Tp && tid >= wi.begin && tid < wi.end;
+            const float ws_ = wave_sum_dpp(inw ? al[tid] * v[0] : 0.f);
+            if (lane == 0) red[wave] = ws_;
+        }
+        __syncthreads();
+        float sd = 0.f;
+#pragma unroll
+        for (int x = 0; x < PD_NW; ++x) sd += red[x];
+        if (tid < g.nownp) {
+            const int t = tid * P + p;
+            float de = 0.f;
+            if (tid < nown && t >= wi.begin && t < wi.end) {
+                if (a.normalizer == 0) {
+                    de = al[t] * (qv[t] - sd);
+                } else {
+                    const float e = a.EN[row * Tp + t], Z = a.ZB[row];
+                    const float gq = (qv[t] - sd) / Z * attdec_mask(a, i, b, t);
+                    if (a.normalizer == 1) { const float sg = sigmoidf_(e); de = gq * sg * (1.f - sg); }
+                    else de = e > 0.f ? gq / 1000.f : 0.f;
+                }
+            }
+            des[tid] = de;
+        }
+        __syncthreads();
+        if (a.e_bias && tid == 0) {
+            float sb = 0.f;
+            for (int x = 0; x < nown; ++x) sb += des[x];
+            ebacc += sb;
+        }
+        clk.mark(5);
+        // ---- 3. energies backward on the matrix cores
+        float swc[4], dsw[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const int m = (4 * wave + tile) * 16 + c16;
+            swc[tile] = m < M ? C2 * a.sW[row * M + m] : 0.f;
+        }
+        float* const dmw = dms + wave * 16 * 17;
+        for (int tl0 = 0; tl0 < nown; tl0 += PD_CH) {
+            float av[NS];
+            const int tla = min(tl0 + c16, nown - 1);
+#pragma unroll
+            for (int sq = 0; sq < NS; ++sq) av[sq] = KC > 0 ? cvs[tla * KCP + 4 * sq + g4] : 0.f;
+            float derow[4];
+            bool rowok[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tl = tl0 + 4 * g4 + r, t = tl * P + p;
+                rowok[r] = tl < nown && t < Tp && t >= wi.begin && t < wi.end;
+                derow[r] = rowok[r] ? des[tl] : 0.f;
+            }
+            f32x4 dcva = F32X4_ZERO;
+            float dpo[4][4];                               // the running dPA of this lane's 16 elements: in flight during the MFMAs
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) {
+                const int m = (4 * wave + tile) * 16 + c16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int t = (tl0 + 4 * g4 + r) * P + p;
+                    dpo[tile][r] = (rowok[r] && m < M) ? gb.dPA[((size_t)t * B + b) * M + m] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) {
+                const int m = (4 * wave + tile) * 16 + c16, mc = min(m, M - 1);
+                const float4 pa = *(const float4*)(PAs + mc * g.RL + tl0 + 4 * g4);
+                f32x4 acc = (f32x4){pa.x + swc[tile], pa.y + swc[tile], pa.z + swc[tile], pa.w + swc[tile]};
+                if (KC > 0) {
+#pragma unroll
+                    for (int sq = 0; sq < NS; ++sq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], Hb[tile][sq], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
+                    const float th = 1.0f - 2.0f * rc;
+                    float d = 0.f;
+                    if (rowok[r] && m < M) {
+                        d = derow[r] * wet[tile] * (1.f - th * th);
+                        const int t = (tl0 + 4 * g4 + r) * P + p;
+                        gb.dPA[((size_t)t * B + b) * M + m] = dpo[tile][r] + d;
+                        weacc[tile] += derow[r] * th;
+                    }
+                    dsw[tile] += d;
+                    dmw[(4 * g4 + r) * 17 + c16] = d;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (KC > 0) {
+                    // dcv[pos][k] += dm[pos][m] handler[k][m];  dH[k][m] += cv[pos][k] dm[pos][m]
+#pragma unroll
+                    for (int sq = 0; sq < 4; ++sq) {
+                        dcva = __builtin_amdgcn_mfma_f32_16x16x4f32(dmw[c16 * 17 + 4 * sq + g4], Ht[tile][sq], dcva, 0, 0, 0);
+                        const int tlk = min(tl0 + 4 * sq + g4, nown - 1);
+                        const float cva = (c16 < KCP && tl0 + 4 * sq + g4 < nown) ? cvs[tlk * KCP + min(c16, KCP - 1)] : 0.f;
+                        dH[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(cva, dmw[(4 * sq + g4) * 17 + c16], dH[tile], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (KC > 0) {
+                __syncthreads();                                   // every wave is done with its dm tile: dms becomes the partial buffer
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dmw[(4 * g4 + r) * 17 + c16] = dcva[r];
+                __syncthreads();
+                if (tid < 256) {
+                    const int pos = tid >> 4, k = tid & 15, tl = tl0 + pos, t = tl * P + p;
+                    float s = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < PD_NW; ++wv) s += dms[(wv * 16 + pos) * 17 + k];
+                    if (k < K && tl < nown && t < Tp) {
+                        const float v = (t >= wi.begin && t < wi.end) ? s : 0.f;
+                        dcvs[tl * KCP + k] = v;
+                        gb.DCV[((row * K) + k) * Tp + t] = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const bool flt = KC > 0 && K * g.FW <= PD_NW * 16 * 17;
+        if (flt && i > 0)
+            for (int x = tid; x < K * g.FW; x += PD_THREADS) dms[x] = a.filters[x];      // (published by the barriers of exchange D)
+        clk.mark(6);
+        // ---- 4. dsW: fold the four position groups of the wave, publish the 512 partials, gather the own column slice
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            dsw[tile] += __shfl_xor(dsw[tile], 16, 64);
+            dsw[tile] += __shfl_xor(dsw[tile], 32, 64);
+            if (g4 == 0) granule_store(gD + (size_t)p * 512 + (4 * wave + tile) * 16 + c16, epoch, dsw[tile]);
+        }
+        {
+            const int src = tid >> 6, mm = tid & 63;
+            const bool mine = src < P && p * 64 + mm < M;
+            u64 wv = (u64)epoch << 32;
+            unsigned spins = 0;
+            for (;;) {
+                if (mine) wv = __hip_atomic_load(gD + (size_t)src * 512 + p * 64 + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int src = 0; src < 8; ++src) s += r8[src * 64 + tid];
+            dsws[tid] = s;
+            if (p * 64 + tid < M) gb.DSW[row * M + p * 64 + tid] = s;
+        }
+        __syncthreads();
+        clk.mark(7);
+        {
+            // contribution of the own column slice to ALL units: thread (k' = tid / 2, half) takes 32 of the 64 columns
+            const float4* dv = (const float4*)(dsws + (tid & 1) * 32);
+            const float4* wv4 = (const float4*)(WsL + (tid >> 1) * 68 + (tid & 1) * 32);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                const float4 d4 = dv[x], w4 = wv4[x];
+                s0 += d4.x * w4.x + d4.y * w4.y;
+                s1 += d4.z * w4.z + d4.w * w4.w;
+            }
+            float s = s0 + s1;
+            s += lvsr_dpp_quad_xor1(s);
+            if ((tid & 1) == 0 && (tid >> 1) < D) granule_store(gE + (size_t)p * 256 + (tid >> 1), epoch, s);
+        }
+        clk.mark(8);
+        // ---- 5. alignment gradient for the previous label, partial over the own positions: behind exchange E
+        if (KC > 0 && i > 0) {
+            // thread (s = tid % 256 [+256], half = tid / 256): the own positions tl = half, half + 2, ... whose taps reach s
+            const int cn = a.c, hsel = tid >> 8;
+            const float* fls = flt ? dms : a.filters;          // the filters: staged in the dm tile buffer when they fit
+            for (int s0 = 0; s0 < Tp; s0 += 256) {
+                const int sx = s0 + (tid & 255);
+                float acc = 0.f;
+                if (sx < Tp && sx >= wi.begin && sx < wi.end) {
+                    // t = tl P + p with |t - sx| <= c:  tl in [lo, hi]
+                    const int tmin = max(sx - cn, 0), tmax = min(sx + cn, Tp - 1);
+                    int lo = (tmin - p + P - 1) / P, hi = (tmax - p) / P;
+                    if (tmin < p) lo = 0;
+                    hi = tmax < p ? -1 : min(hi, nown - 1);
+                    lo += (lo & 1) != hsel;                     // this half's parity
+                    const float* fb = fls + cn + p - sx;         // f[k][c + t - s] = fb[k * FW + tl * P]
+                    for (int tl = lo; tl <= hi; tl += 2) {
+                        const float* dr = dcvs + tl * KCP;
+                        const float* fp = fb + tl * P;
+#pragma unroll
+                        for (int k = 0; k < KC; ++k)
+                            if (KC == K || k < K) acc += dr[k] * fp[k * g.FW];
+                    }
+                }
+                if (hsel == 1) r8[tid & 255] = acc;            // (barriers outside any lane-dependent branch: a wave counts once)
+                __syncthreads();
+                if (hsel == 0 && sx < Tp) granule_store(gF + (size_t)p * 512 + sx, epoch, acc + r8[tid & 255]);
+                __syncthreads();
+            }
+        }
+        clk.mark(9);
+        {
+            const int src = tid >> 5, uu_ = tid & 31;
+            const bool mine = tid < 256 && src < P && p * 32 + uu_ < D;
+            u64 wv = (u64)epoch << 32;
+            unsigned spins = 0;
+            for (;;) {
+                if (mine) wv = __hip_atomic_load(gE + (size_t)src * 256 + p * 32 + uu_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            if (tid < 256) r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+        }
+        __syncthreads();
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int src = 0; src < 8; ++src) s += r8[src * 32 + jl];
+            dsj = junit ? dsacc + s : 0.f;
+        }
+        __syncthreads();
+        clk.mark(10);
+    }
+    if (clk.on) {
+        long long* out = (long long*)((char*)abort_word + 64);
+        for (int x = 0; x < PD_NPROF; ++x) out[x] = clk.acc[1 + x];
+    }
+    // ---- epilogue: what the caller folds / uses after the loop
+    if (q == 0 && junit) gb.ds[(size_t)b * D + j] = dsj;
+    const size_t prow = (size_t)b * P + p;
+#pragma unroll
+    for (int tile = 0; tile < 4; ++tile) {
+        const int m = (4 * wave + tile) * 16 + c16;
+        float wsum_ = weacc[tile];
+        wsum_ += __shfl_xor(wsum_, 16, 64);
+        wsum_ += __shfl_xor(wsum_, 32, 64);
+        if (g4 == 0 && m < M) gb.accWe[prow * M + m] = wsum_;
+        if (KC > 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = 4 * g4 + r;
+                if (k < K && m < M) gb.accH[(prow * K + k) * M + m] = dH[tile][r];
+            }
+        }
+    }
+    if (a.e_bias && tid == 0) gb.accEb[prow] = ebacc;
+}
+
+extern "C" long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* args) {
+    if (args == nullptr) return 0;
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    PbGeom g;
+    if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pb_geom(a, g)) return 0;
+    if ((a.D & 3) != 0) return 0;
+    return 256 + (long long)a.B * (PB_NPLANE_SMALL * PD_MAXV + (long long)g.P * (512 + 256 + 512)) * 8;
+}
+
+extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_args* args, const lvsr_attdec_plain* plain, void* ws) {
+    LVSR_REQUIRE(args != nullptr && plain != nullptr && ws != nullptr, "lvsr_attdec_bwd_persistent: null argument");
+    AttBwd gb;
+    memcpy(&gb, args, sizeof(gb));
+    const AttDec& a = gb.f;
+    if (int rc = attdec_check(a, "lvsr_attdec_bwd_persistent")) return rc;
+    PbGeom g;
+    LVSR_REQUIRE(pb_geom(a, g) && (a.D & 3) == 0, "lvsr_attdec_bwd_persistent: configuration outside the persistent kernel's limits "
+                 "(lvsr_attdec_bwd_persist_ws_bytes returns 0 for it)");
+    LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd_persistent: contexts must be contiguous (Tp,B,*)");
+    LVSR_REQUIRE(plain->Ws && plain->Whg && plain->Whh && plain->AW && gb.QR && gb.DXG && gb.DSW && gb.dPA && gb.ds && gb.accWe,
+                 "lvsr_attdec_bwd_persistent: missing buffers (AW, QR and the plain weights are required)");
+    LVSR_REQUIRE(a.K == 0 || (gb.DCV && gb.accH), "lvsr_attdec_bwd_persistent: DCV / accH missing");
+    const lvsr_attdec_plain w = *plain;
+    hipStream_t s = (hipStream_t)stream;
+    int* ab = (int*)ws;
+    u64* planes = (u64*)((char*)ws + 256);
+    const size_t bytes = 256 + (size_t)a.B * (PB_NPLANE_SMALL * PD_MAXV + (size_t)g.P * (512 + 256 + 512)) * 8;
+    (void)hipMemsetAsync(ws, 0, bytes, s);
+    const dim3 grid(a.B * g.P), block(PD_THREADS);
+    switch (g.KC) {
+        case 0: hipLaunchKernelGGL(attdec_pbwd_kernel<0>, grid, block, 0, s, gb, w, g, planes, ab); break;
+        case 4: hipLaunchKernelGGL(attdec_pbwd_kernel<4>, grid, block, 0, s, gb, w, g, planes, ab); break;
+        case 10: hipLaunchKernelGGL(attdec_pbwd_kernel<10>, grid, block, 0, s, gb, w, g, planes, ab); break;
+        default: hipLaunchKernelGGL(attdec_pbwd_kernel<16>, grid, block, 0, s, gb, w, g, planes, ab); break;
+    }
+    return lvsr_check_launch("lvsr_attdec_bwd_persistent");
+}

@@ -163,10 +163,26 @@ class SequenceGenerator(object):
             return None
         return self.ws.get("gen.sync", ((nbytes + 3) // 4,), torch.int32)
 
+    def _persistent_bwd_ws(self, fwd_args):
+        """Workspace of the persistent backward kernel, or None (LVSR_DEC_BWD_PERSISTENT=0, outside its limits, or — on the CPU
+        emulator — work-groups not run concurrently)."""
+        # Not the default yet: parity-green (tests/test_emu_persistent_decoder.py, tests/test_gpu_properties.py) but at 47 us per
+        # label slower than the four step kernels (34) — its phase profile and what is left to do are in DESIGN.md 3.3c.
+        mode = os.environ.get("LVSR_DEC_BWD_PERSISTENT", "0")
+        if self.use_persistent is False or mode == "0":
+            return None
+        import ctypes as _ct
+        nbytes = int(self.lib._lvsr_attdec_bwd_persist_ws_bytes(_ct.byref(fwd_args)))
+        if self.lib.is_emulator and not self.lib.emulates_concurrency():
+            nbytes = 0
+        if nbytes == 0:
+            return None
+        return self.ws.get("gen.sync_bwd", ((nbytes + 3) // 4,), torch.int32)
+
     def check_persistent(self):
         """After a synchronisation point: raise if the persistent decoder kernel gave up waiting for its cluster."""
         for k, buf in self.ws._bufs.items():
-            if k[0] == "gen.sync" and int(buf[0]) != 0:
+            if k[0] in ("gen.sync", "gen.sync_bwd") and int(buf[0]) != 0:
                 raise RuntimeError("persistent decoder kernel aborted (a work-group of a cluster was not scheduled)")
 
     # ---- teacher-forced cost ---------------------------------------------------------------------
@@ -299,7 +315,19 @@ class SequenceGenerator(object):
             lib.call("lvsr_sgemm_batched", lib.stream_for(QR), 0, 1, L, Tp, d.E, 1.0, lib_ptr(dWA_r), B * d.E, d.E,
                      lib_ptr(sv["A"]), B * d.E, d.E, 0.0, lib_ptr(QR), B * Tp, Tp, B)
             bw.AW, bw.QR = AW.data_ptr(), QR.data_ptr()
-        lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
+        psync = self._persistent_bwd_ws(bw.f) if reassoc else None
+        if psync is not None:
+            # the whole reverse walk as one persistent launch (csrc/decoder_persist_bwd.hip); its handler / energy-vector / bias
+            # gradient partials come one row per work-group
+            P = (d.D + 31) // 32
+            accH = ws.get("gen.accH_p", (B * P, Kc * d.M), zero=True)
+            accWe = ws.get("gen.accWe_p", (B * P, d.M), zero=True)
+            accEb = ws.get("gen.accEb_p", (B * P, 1), zero=True)
+            bw.accH, bw.accWe, bw.accEb = accH.data_ptr(), accWe.data_ptr(), accEb.data_ptr()
+            plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
+            lib.call("lvsr_attdec_bwd_persistent", lib.stream_for(ds), ctypes.byref(bw), ctypes.byref(plain), lib_ptr(psync))
+        else:
+            lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
         if reassoc:
             DWA2 = DWA.view(nrows, d.E)
             DWA2.copy_(dWA_r)

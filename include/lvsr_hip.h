@@ -238,6 +238,13 @@ typedef struct lvsr_attdec_bwd_args {
     const float* QR;                      /* (L,B,Tp) dWA_r[i,b,:] . A[t,b,:] (zeros if dWA_r is NULL) */
 } lvsr_attdec_bwd_args;
 int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
+/* The backward walk as ONE persistent launch (csrc/decoder_persist_bwd.hip; same cluster layout and limits as
+ * lvsr_attdec_fwd_persistent).  Takes the plain weights and AW of lvsr_attdec_plain, and in the argument block: QR (required),
+ * dS_r, DXG, DSW, DCV, dPA, ds as lvsr_attdec_bwd; accH / accWe / accEb hold ONE ROW PER WORK-GROUP here — (B*P, K*M), (B*P, M),
+ * (B*P) with P = ceil(D/32) — written, not accumulated.  DWA is not written (see AW / QR above); dalp, dspart, dsacc, Q, dcvp,
+ * dswp and the packed weights are not used.  lvsr_attdec_bwd_persist_ws_bytes: workspace size, 0 = not available. */
+long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* a);
+int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_args* a, const lvsr_attdec_plain* w, void* ws);
 /* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block; ws: scratch of at least
  * ceil(L*B / R) * K * (2c+1) floats with R = min(4, 8192 / (K*Tp)) rows per work-group (L*B*K*(2c+1) floats always suffice) */
 int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters, float* ws,

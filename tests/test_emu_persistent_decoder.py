@@ -1,7 +1,7 @@
-"""The persistent attention-decoder forward (csrc/decoder_persist.hip: one launch for the whole label loop, a cluster of
-work-groups per utterance exchanging five phase vectors per label through {epoch,value} granules) on the emulator with
-concurrent work-groups, against the float64 oracle, the reference goldens and the step kernels (whose saved tensors the
-backward pass reads: the gradients are checked through the persistent forward)."""
+"""The persistent attention-decoder kernels (csrc/decoder_persist.hip, csrc/decoder_persist_bwd.hip: one launch for the whole
+label loop forward, one for the reverse walk; a cluster of work-groups per utterance exchanging phase vectors through
+{epoch,value} granules) on the emulator with concurrent work-groups, against the float64 oracle and the reference goldens:
+costs, alignments and every gradient."""
 import os
 
 import numpy
@@ -21,16 +21,18 @@ from test_emu_recognizer import check_against
 def concurrent_lib():
     lib = emu_lib()
     lib._dll.hipemu_set_concurrent(1)
-    old = os.environ.get("LVSR_DEC_PERSISTENT")
+    old = {k: os.environ.get(k) for k in ("LVSR_DEC_PERSISTENT", "LVSR_DEC_BWD_PERSISTENT")}
     os.environ["LVSR_DEC_PERSISTENT"] = "1"
+    os.environ["LVSR_DEC_BWD_PERSISTENT"] = "1"          # the backward kernel is opt-in (see generator._persistent_bwd_ws)
     try:
         yield lib
     finally:
         lib._dll.hipemu_set_concurrent(0)
-        if old is None:
-            os.environ.pop("LVSR_DEC_PERSISTENT", None)
-        else:
-            os.environ["LVSR_DEC_PERSISTENT"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def engaged(rec):
@@ -51,6 +53,11 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
     rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=meta["cfg"])
     cm = rec.cost_and_gradients(batch)
     assert engaged(rec), "persistent decoder did not engage"
+    # the backward kernel serves at most 32 attended positions per work-group (the long case has 75: step kernels there) and
+    # decoder widths that are a multiple of 4 (16-byte loads of the gate-gradient vector)
+    P = (rec.d.D + 31) // 32
+    bwd = any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs)
+    assert bwd == ((rec.generator._saved["Tp"] + P - 1) // P <= 32 and rec.d.D % 4 == 0), "persistent decoder backward engaged / did not engage"
     rec.generator.check_persistent()
     # the long case accumulates more float32 rounding per element (tests/test_oracle_golden.py TOL); the north-star bars inside
     # check_against (cost sum 1e-4 relative, identical alignment argmax against the reference golden) are the same for all

@@ -82,14 +82,22 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
     if prior is not None:
         cfg["prior"] = prior
     out = {}
+    import os
+    old = os.environ.get("LVSR_DEC_BWD_PERSISTENT")
+    os.environ["LVSR_DEC_BWD_PERSISTENT"] = "1"          # opt-in: the persistent reverse walk too (csrc/decoder_persist_bwd.hip)
     for persistent in (True, False):
         rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=cfg, use_persistent_decoder=persistent)
         cm = rec.cost_and_gradients(s["batch"]).cpu().numpy()
         torch.cuda.synchronize()
         rec.generator.check_persistent()
         assert any(k[0] == "gen.sync" for k in rec.ws._bufs) == persistent, "persistent decoder engaged / did not engage"
+        assert any(k[0] == "gen.sync_bwd" for k in rec.ws._bufs) == persistent, "persistent decoder backward engaged / did not engage"
         out[persistent] = (cm, rec.generator.last["weights"].cpu().numpy(), rec.generator.last["weighted_averages"].cpu().numpy(),
                            rec.store.get_grads())
+    if old is None:
+        os.environ.pop("LVSR_DEC_BWD_PERSISTENT", None)
+    else:
+        os.environ["LVSR_DEC_BWD_PERSISTENT"] = old
     (cm_p, w_p, wa_p, g_p), (cm_s, w_s, wa_s, g_s) = out[True], out[False]
     if prior is None:
         assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
