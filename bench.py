@@ -189,7 +189,7 @@ def main():
     ap.add_argument("--ragged", action="store_true",
                     help="secondary run of SURVEY.md 8(d): utterance lengths ~U{T/2..T}, zero padded; counts real frames only")
     ap.add_argument("--utterances", type=int, default=None, help="wsj_decode: number of utterances (default 1000 = configs[4])")
-    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: beam searches in flight per GPU (default 4)")
+    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: beam searches in flight per GPU (default 8)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -122,7 +122,7 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
     json_out = json_out or sys.stdout
     utterances = args.utterances or 1000
     frames, beam = 800, 16
-    streams = max(1, int(getattr(args, "streams", None) or 4))
+    streams = max(1, int(getattr(args, "streams", None) or 8))
     recs = [build(dev, beam)[0] for _ in range(streams)]
     rec = recs[0]
     if dist:
