@@ -200,7 +200,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         if (q == 0 && junit) granule_store(gA + j, epoch, dpc);
         // gradient wrt the alignment this label produced: gathered from the partial correlations of the previous iteration
         if (n > 0 && KC > 0) {
-            float v[PD_NV];
             const int src = tid >> 5, tl = tid & 31, t = tl * P + p;
             const bool mine = tid < 8 * 32 && src < P && tl < nown && t < Tp;
             // (granules of positions this work-group does not own are not waited for: sweep only the valid ones)
@@ -214,7 +213,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                     if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 }
             }
-            (void)v;
             if (tid < 8 * 32) r8b[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
         }
         clk.mark(0);
