@@ -162,13 +162,13 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
         if (2 * rt * g.P <= PERSIST_MAX_WG && rb >= want) { g.RB = rb; break; }
     }
     if (!g.RB) return false;
-    // One utterance per cluster (the default): 512-thread work-groups, two waves per SIMD — half the k-slice per thread (96
+    // One or two utterances per cluster: 512-thread work-groups, two waves per SIMD — half the k-slice per thread (96
     // instead of 192 weight registers), twice the lanes per unit, the same number of work-groups per cluster; 2.03 instead of
     // 2.12 us per step on WSJ-base (the second wave hides the first one's LDS and hand-off latencies; WSJ-base step 21.42 ->
     // 20.79 ms).  1024 threads (four waves, 48 weight registers) were measured too: 26.4 ms — the sweeps and barriers of 16
     // waves cost more than their latency hiding buys.  LVSR_PERSIST_THREADS=256 brings the one-wave version back.
     const char* envt = getenv("LVSR_PERSIST_THREADS");
-    if (g.RB == 1 && !(envt && atoi(envt) == 256)) { g.NTH = 512; g.KS /= 2; g.KSPLIT *= 2; g.UNITS = g.NTH / g.KSPLIT; }
+    if (g.RB <= 2 && !(envt && atoi(envt) == 256)) { g.NTH = 512; g.KS /= 2; g.KSPLIT *= 2; g.UNITS = g.NTH / g.KSPLIT; }
     g.rt = (B + g.RB - 1) / g.RB;
     g.grid = 2 * g.rt * g.P;
     g.plane = (long long)g.RB * g.HP;
@@ -481,8 +481,9 @@ extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
 
 template <int KS, int KSPLIT>
 static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, int* ab, int flags) {
-    if (g.NTH == 512 && g.RB == 1) {           // two waves per SIMD: half the k-slice per thread
-        hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, flags);
+    if (g.NTH == 512) {                        // two waves per SIMD: half the k-slice per thread (one or two utterances per cluster)
+        if (g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, flags);
+        else hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, flags);
         return;
     }
     switch (g.RB) {
@@ -497,8 +498,9 @@ static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64
 }
 template <int KS, int KSPLIT>
 static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, int* ab, float* dh, int Bp, int flags) {
-    if (g.NTH == 512 && g.RB == 1) {
-        hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, dh, Bp, flags);
+    if (g.NTH == 512) {
+        if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, dh, Bp, flags);
+        else hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, dh, Bp, flags);
         return;
     }
     switch (g.RB) {
