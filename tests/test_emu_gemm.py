@@ -74,3 +74,55 @@ def test_sgemm_batched(M, N, K, batch):
              ptr(C), batch * N, N, batch)
     ref = 0.5 * torch.einsum("kbm,kbn->mbn", A.double(), Bm.double()) + C0.double()
     assert_allclose(C.numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_grouped_transposed_products_and_deferral():
+    """lvsr_sgemm_tn_grouped: members of different shapes, strided operand views, one misaligned member (separate launch inside
+    the call), beta = 1, with and without a workspace (k-chunk partials + fixed-order fold vs one chunk per tile) — and the
+    host-side collection (`begin_group` / `sgemm(group=True)` / `flush_group`) incl. a dependent follow-up kept in order."""
+    lib = emu_lib()
+    rng = numpy.random.RandomState(4)
+    t = lambda *s: torch.tensor(rng.normal(size=s), dtype=torch.float32)
+    K1, K2 = 2100, 1100
+    big = t(K1, 300)
+    jobs = [(big[:, 4:4 + 130], t(K1, 70), torch.zeros(130, 70), 0.0),             # strided A view, aligned
+            (t(K2, 40), t(K2, 260)[:, 8:8 + 132], t(40, 132), 1.0),                 # M < one tile, beta = 1
+            (t(K2, 64), t(K2, 33), torch.zeros(64, 33), 0.0),                        # ldb = 33: the unaligned pass
+            (t(50, 16), t(50, 16), torch.zeros(16, 16), 0.0)]                        # K below one chunk: no split
+    for ws in (torch.empty(1 << 20), None):
+        outs = [c.clone() for _, _, c, _ in jobs]
+        if ws is None:
+            cls = lib.structs["lvsr_gemm_desc"]
+            arr = (cls * len(jobs))()
+            for d, (A, B, _, beta), C in zip(arr, jobs, outs):
+                d.A, d.B, d.C, d.M, d.N, d.K = A.data_ptr(), B.data_ptr(), C.data_ptr(), A.shape[1], B.shape[1], A.shape[0]
+                d.lda, d.ldb, d.ldc, d.beta = A.stride(0), B.stride(0), C.stride(0), beta
+            lib.call("lvsr_sgemm_tn_grouped", lib.stream_for(outs[0]), arr, len(jobs), None, 0)
+        else:
+            lib.begin_group()
+            for (A, B, _, beta), C in zip(jobs, outs):
+                lib.sgemm(A, B, C, transA=True, beta=beta, group=True)
+            # a product that reads a collected product's output must run after the grouped launch: queued behind it
+            dep = torch.zeros(16, 16)
+            lib.sgemm(outs[3], outs[3], dep, transA=True, M=16, K=16, group=True)
+            assert (outs[0] == 0).all(), "collected products must not run before flush_group"
+            lib.flush_group(ws)
+            assert_allclose(dep.numpy(), (outs[3].double().T @ outs[3].double()).numpy(), rtol=1e-4, atol=1e-4)
+        for (A, B, C0, beta), C in zip(jobs, outs):
+            ref = A.double().T @ B.double() + beta * C0.double()
+            assert_allclose(C.numpy(), ref.numpy(), rtol=2e-4, atol=2e-4)
+
+
+def test_copy_many():
+    lib = emu_lib()
+    rng = numpy.random.RandomState(5)
+    src = torch.tensor(rng.normal(size=(37, 90)), dtype=torch.float32)
+    dst = torch.zeros(40, 200)
+    vec_s, vec_d = torch.arange(50, dtype=torch.float32), torch.zeros(64)
+    pairs = [(src[:, 3:3 + 40], dst[:37, 100:140]), (src[:, 48:48 + 32], dst[:37, 4:36]), (vec_s, vec_d[7:57])]
+    pairs += [(src[i:i + 1, :8], dst[38:39, 8 * i:8 * i + 8]) for i in range(20)]            # more than one launch's worth with the above
+    pairs += [(src[:5, 60:70], dst[30:35, 180:190])] * 12
+    lib.copy_many(pairs)
+    for s_, d_ in pairs:
+        assert (s_ == d_).all()
+    assert float(dst[39].abs().sum()) == 0.0 and float(vec_d[:7].abs().sum()) == 0.0
