@@ -3,30 +3,33 @@
 // The decoder's chain per label is  s -> s W_s -> energies -> softmax -> glimpse -> gates -> r*s -> candidate -> s'; as separate
 // launches every all-to-all dependency costs a kernel boundary (~3-5 us, decoder_fwd.hip: 33 us per label on WSJ-base), inside
 // one launch it costs a granule hand-off between the CUs of a cluster (~0.85 us, persist.h / encoder_persist.hip).  Utterances
-// are independent, so a cluster of P work-groups (256 threads each: one wave per SIMD, one work-group per CU) serves ONE
+// are independent, so a cluster of P work-groups (512 threads each: two waves per SIMD, one work-group per CU) serves ONE
 // utterance and everything the label loop re-reads stays on chip for the whole sequence:
-//   * thread (unit jl = tid/8, slice q = tid%8) keeps, in REGISTERS, its 1/8 row slice of the three decoder-GRU state columns of
-//     unit j = 32 p + jl (state_to_gates u/r, state_to_state: 3 x 32 values) and of two columns of transform_states (2 x 32);
-//     thread m keeps columns m and m + 256 of the location handler (2K values) and of the energy vector;
+//   * thread (unit jl = tid/16, slice q = tid%16) keeps, in REGISTERS, its 1/16 row slice of the three decoder-GRU state columns
+//     of unit j = 32 p + jl (state_to_gates u/r, state_to_state: 3 x 16 values) and of two columns of transform_states (2 x 16);
+//     every wave keeps the handler operands of its 64 match columns and the filter taps of its MFMA tap groups;
 //   * the glimpse never exists inside the loop: the gate inputs it feeds are linear in it, wa W_d = sum_t alpha_t (A_t W_d), so
 //     the caller precomputes AW = attended @ [fork_inputs.W | fork_gate_inputs.W] (one GEMM per batch) and the work-group keeps
 //     the rows of ITS 96 gate columns in LDS: the gate inputs become a local contraction with the alignment every work-group
-//     already holds (no glimpse exchange, no glimpse weights in registers: 160 instead of 352 per thread).  The weighted
-//     averages themselves (readout, weight gradients) are one batched kernel after the loop (lvsr_attdec_glimpses);
+//     already holds (no glimpse exchange, no glimpse weights on chip: the first version kept them, 352 registers per thread of
+//     256, and spilled).  The weighted averages themselves (readout, weight gradients) are one batched kernel after the loop
+//     (lvsr_attdec_glimpses);
 //   * in LDS: the work-group's rows of the preprocessed attended (positions t = p mod P: interleaved, so any window is balanced
-//     over the cluster), its AW columns (all positions), the convolution filters and the small vectors;
+//     over the cluster; TRANSPOSED [m][position] for location-aware attention, so that an MFMA accumulator is initialised with
+//     one 16-byte read), its AW columns (all positions) and the small vectors;
 //   * per label four phase vectors travel as {epoch,value} granules (transformed state M, energies T', r*s D, s' D), everything
 //     else is local.  Work that does not sit on the chain runs in the shadow of a hand-off: the location convolution of the NEXT
-//     label (needs only the new alignment; on the matrix cores) and the update-gate / candidate-input sums behind the r*s
-//     exchange, the saved tensors' plain stores anywhere.
-// The energies (T'/P positions x M per work-group and label: K FMAs + tanh each) are the VALU-heavy part; position sums over
-// the 256 threads use a register butterfly (16 positions per round, 17 shuffles) instead of 16 block reductions.
+//     label (needs only the new alignment; on the matrix cores, 16 filters x 16 positions tiles, four taps per MFMA) and the
+//     update-gate / candidate-input sums behind the r*s exchange, the saved tensors' plain stores anywhere.
+// The energies (T'/P positions x M per work-group and label: K FMAs + tanh each) were the VALU-heavy part (4.1 us per label with
+// two columns per thread in v_pk_fma_f32): the handler contraction now runs on the matrix cores and the elementwise part on the
+// accumulators (2.4 us), see the comment at the operand registers below.
 //
 // Same results as decoder_fwd.hip up to float32 rounding (order of additions; the reassociated glimpse); it writes every tensor
 // the backward pass reads (sW, CV, EN, ZB, W, U, R, C, RH, S, pos; WA through lvsr_attdec_glimpses).  Limits (else the caller
-// uses the step kernels): D <= 256, M <= 512, T' <= 512, M <= 64 P with P = ceil(D/32), B P <= 224 work-groups, the LDS
-// budget below (T' <= ~205 at WSJ-base dims).  With the window_around_* priors the window centres of all utterances bound the
-// window: one more (B-granule) exchange per label, between all clusters.
+// uses the step kernels): D <= 256, M <= 512, T' <= 512, M <= 64 P with P = ceil(D/32), B P <= 224 work-groups, conv filter
+// width <= 256, the LDS budget below (T' <= ~205 at WSJ-base dims).  With the window_around_* priors the window centres of
+// all utterances bound the window: one more (B-granule) exchange per label, between all clusters.
 #include "decoder_persist.h"
 #include <stdlib.h>
 #include <string.h>
