@@ -9,10 +9,12 @@
 //      glimpse:  q[t] = [dpc|dpu|dpr] . AW[t] + QR[i,t] + dalpha[t]   for the OWN positions (AW rows streamed from L2, fetched
 //                behind exchange B);  C: all-gather q;  sd = sum_t alpha_t q_t;  de = alpha (q - sd)          (softmax backward)
 //   3. energies: own positions x all match columns on the matrix cores (as attbwd_energy_mfma_kernel): match = PA + sW + cv^T H,
-//                dm = de w_e (1 - tanh^2); dPA += dm; dcv = dm H^T (complete: all columns are local); handler / energy-vector
-//                gradients accumulate in REGISTERS over the whole label loop; dsW partial over the own positions
+//                dm = de w_e (1 - tanh^2); dPA += dm; dcv = dm H^T (complete: all columns are local); the handler operands are
+//                read from an LDS table, the handler gradient accumulates in LDS (one float4 per wave, tile and lane, over the
+//                whole label loop), the energy-vector gradient in registers; dsW partial over the own positions
 //   4. state:    D: reduce-scatter dsW (every work-group publishes 512 partials, gathers the 8 x 64 of its column slice);
-//                its slice's contribution dsW[slice] @ Ws^T[slice] to ALL units;  E: reduce-scatter of those (8 x 32 gathered)
+//                its slice's contribution dsW[slice] @ Ws^T[slice] to ALL units (rows of Ws streamed from L2);
+//                E: reduce-scatter of those (8 x 32 gathered)
 //                ds' = dsacc + sum                                                                     -> next label
 //   5. alignment (off the chain, behind D / E): dalpha'[s] = sum_k sum_{own t} dcv[k][t] f[k][c+t-s] for all s;
 //                F: reduce-scatter, gathered by the owners of s at the start of the next label.
@@ -25,12 +27,13 @@
 
 typedef lvsr_attdec_bwd_args AttBwd;
 
+#define PB_HS 529                   // row stride of the handler table in LDS (odd: both operand patterns spread over the banks)
 #define PB_NPLANE_SMALL 3           // A (dpc) | B (dpu, dpr: 2 x 256, packed as 512) | C (q)        : PD_MAXV granules each
 // per work-group planes: D (512) | E (256) | F (512)
 
 struct PbGeom {
     int P, nown, nownp, KC, KCP, FW, RL;
-    int o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_red, o_clk, prof, total;
+    int o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_hs, o_dh, o_red, o_clk, prof, total;
 };
 
 static int pb_kc(int K) {
@@ -71,7 +74,8 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.o_r8 = take(8 * 64);
     g.o_r8b = take(8 * 32);
     g.o_dsw = take(64);
-    g.o_ws = take(256 * 68);                  // Ws[unit][own column slice] (+4 pad per row)
+    g.o_hs = take((g.KCP > 0 ? g.KCP : 4) * PB_HS);   // handler [KCP][PB_HS]: the MFMA operands of the energy phase are read from here
+    g.o_dh = take(PD_NW * 4 * 64 * 4);        // handler-gradient accumulators: one float4 per (wave, tile, lane)
     g.o_red = take(2 * PD_NW);
     g.o_clk = take(2 * (PD_NPROF + 1));
     g.total = o;
@@ -79,6 +83,13 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.prof = env ? atoi(env) : 0;
     return o <= PD_LDS_FLOATS;
 }
+
+// Global accesses as UNIFORM base (scalar registers) + 32-bit per-lane byte offset: the loop-invariant per-lane parts are then one
+// register each (as 64-bit pointers they were hoisted out of the label loop two registers apiece and spilled)
+template <class T>
+__device__ __forceinline__ T pb_ld(const void* sbase, unsigned voff) { return *(const T*)((const char*)sbase + voff); }
+template <class T>
+__device__ __forceinline__ void pb_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
 
 template <int KC>
 __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr_attdec_plain w, PbGeom g, u64* planes, int* abort_word) {
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const qv = lds + g.o_q;        // [T'] q of all positions
     float* const des = lds + g.o_des;     // [nownp] energy gradients of the own positions
     float* const dalp = lds + g.o_dalp;   // [nownp] gradient wrt the alignment this label produced (from the next label's convolution)
-    float* const dgl = lds + g.o_dgl;     // [3][256] dpc | dpu | dpr, linear
+    float* const dgl = lds + g.o_dgl;     // [3 D] dpc | dpu | dpr, as the columns of AW
     float* const dpcs = lds + g.o_dpc;    // sliced copies for the register contractions
     float* const dpus = lds + g.o_dpu;
     float* const dprs = lds + g.o_dpr;
@@ -101,7 +112,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const r8 = lds + g.o_r8;       // [8][64]
     float* const r8b = lds + g.o_r8b;     // [8][32]
     float* const dsws = lds + g.o_dsw;    // [64] dsW of the own column slice
-    float* const WsL = lds + g.o_ws;      // [256][68] transform_states rows x the own 64 match columns
+    float* const hs = lds + g.o_hs;       // [KCP][PB_HS] handler (rows >= K and columns >= M zero)
+    float* const dHs = lds + g.o_dh;      // [PD_NW][4][64] float4: handler-gradient accumulators of (wave, tile, lane)
     float* const red = lds + g.o_red;
     const int P = g.P, nown = g.nown;
     int b, p;
@@ -112,6 +124,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L, G3 = 3 * a.D;
     const int j = p * PD_UNITS + jl;
     const bool junit = j < D;
+    const unsigned jb = 4u * (unsigned)min(j, D - 1);
     const float C2 = 2.885390081777927f;
     // ---- register-resident weights
     f32x2 whh[PD_KD / 2], whu[PD_KD / 2], whr[PD_KD / 2];        // rows j of Whh, Whg[:, :D], Whg[:, D:], slice q of the columns
@@ -132,25 +145,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             whh[x] = (f32x2){v[0][0], v[0][1]}; whu[x] = (f32x2){v[1][0], v[1][1]}; whr[x] = (f32x2){v[2][0], v[2][1]};
         }
     }
-    // MFMA operands of the energy phase: this wave's match columns [64 wave, 64 wave + 64) as four 16-column tiles
-    float Hb[4][NS], Ht[4][4], wet[4];
-    f32x4 dH[4];
-    float weacc[4], ebacc = 0.f;
+    // MFMA operands of the energy phase: this wave's match columns [64 wave, 64 wave + 64) as four 16-column tiles.  The handler
+    // operands and the handler-gradient accumulators live in LDS (hs, dHs): held per lane they are 44 registers on top of the
+    // 48 of the state weights, and the phases' working sets no longer fit beside them
+    float wet[4], weacc[4], ebacc = 0.f;
 #pragma unroll
     for (int tile = 0; tile < 4; ++tile) {
         const int m = (4 * wave + tile) * 16 + c16;
-#pragma unroll
-        for (int sq = 0; sq < NS; ++sq) {
-            const int k = 4 * sq + g4;
-            Hb[tile][sq] = (KC > 0 && k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
-        }
-#pragma unroll
-        for (int sq = 0; sq < 4; ++sq) {
-            const int mm = (4 * wave + tile) * 16 + 4 * sq + g4;
-            Ht[tile][sq] = (KC > 0 && c16 < K && mm < M) ? a.handler[(size_t)c16 * M + mm] : 0.f;
-        }
         wet[tile] = m < M ? a.w_e[m] : 0.f;
-        dH[tile] = F32X4_ZERO;
         weacc[tile] = 0.f;
     }
     // ---- LDS residents
@@ -160,10 +162,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const int tl = x / M, m = x % M, t = tl * P + p;
         if (t < Tp) PAs[m * g.RL + tl] = C2 * a.PA[(size_t)t * a.PA_ts + (size_t)b * a.PA_bs + m];
     }
-    for (int x = tid; x < 256 * 64; x += PD_THREADS) {
-        const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
-        WsL[kp * 68 + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
-    }
+    if (KC > 0)
+        for (int x = tid; x < K * M; x += PD_THREADS) hs[(x / M) * PB_HS + x % M] = a.handler[x];
     float dsj = junit ? gb.ds[(size_t)b * D + j] : 0.f;            // running gradient wrt the state (caller: zeros + readout part)
     u64* const gA = planes + (size_t)b * (PB_NPLANE_SMALL * PD_MAXV + (size_t)P * (512 + 256 + 512));
     u64* const gB = gA + PD_MAXV;
@@ -181,10 +181,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const size_t row = (size_t)i * B + b;
         const Win wi = attdec_window(a, i);
         // ---- this label's saved values
-        const float uu = junit ? a.U[row * D + j] : 0.f, rr = junit ? a.R[row * D + j] : 0.f, cc = junit ? a.C[row * D + j] : 0.f;
-        const float sp = junit ? a.S[row * D + j] : 0.f;
+        const float uu = junit ? pb_ld<float>(a.U + row * D, jb) : 0.f, rr = junit ? pb_ld<float>(a.R + row * D, jb) : 0.f;
+        const float cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f, sp = junit ? pb_ld<float>(a.S + row * D, jb) : 0.f;
         const float ym = a.ymask ? a.ymask[row] : 1.f;
-        const float dsr = (junit && gb.dS_r) ? gb.dS_r[row * D + j] : 0.f;
+        const float dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * D, jb) : 0.f;
         for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[((size_t)(i + 1) * B + b) * Tp + t];
         if (KC > 0) {
             for (int x = tid; x < nown * K; x += PD_THREADS) {
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             granule_store(gB + j, epoch, dpu);
             granule_store(gB + 256 + j, epoch, dpr);
             float* dx = gb.DXG + row * G3;
-            dx[j] = dpc; dx[D + j] = dpu; dx[2 * D + j] = dpr;
+            pb_st<float>(dx, jb, dpc); pb_st<float>(dx + D, jb, dpu); pb_st<float>(dx + 2 * D, jb, dpr);
         }
         clk.mark(2);
         // ---- 2. gates
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             }
             if (mine) {
                 const float v = __uint_as_float((unsigned)wv);
-                if (tid < 256) { dpus[pd_slot(tid, PD_KD)] = v; dgl[256 + tid] = v; }
-                else { dprs[pd_slot(tid - 256, PD_KD)] = v; dgl[512 + tid - 256] = v; }
+                if (tid < 256) { dpus[pd_slot(tid, PD_KD)] = v; dgl[D + tid] = v; }
+                else { dprs[pd_slot(tid - 256, PD_KD)] = v; dgl[2 * D + tid - 256] = v; }
             }
         }
         __syncthreads();
@@ -266,11 +266,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         // last as long as they do
         const int qtl = tid >> 4, l16 = tid & 15, qt = qtl * P + p;
         const bool qok = qtl < nown && qt < Tp && qt >= wi.begin && qt < wi.end;
+        const unsigned awoff = 4u * ((unsigned)min(qt, Tp - 1) * (unsigned)(B * G3) + 4u * l16);
         float4 awv[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
             const int col = 4 * l16 + 64 * e;
-            awv[e] = (qok && col + 3 < G3) ? *(const float4*)(w.AW + ((size_t)qt * B + b) * G3 + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            awv[e] = (qok && col + 3 < G3) ? pb_ld<float4>(w.AW + (size_t)b * G3 + 64 * e, awoff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float dsacc = part + pd_dot<PD_KD>(whu, dpus, q) + pd_dot<PD_KD>(whr, dprs, q);
         clk.mark(11);
@@ -279,9 +280,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 12; ++e) {
-                const int col = 4 * l16 + 64 * e;                 // columns [0,D) dpc, [D,2D) dpu, [2D,3D) dpr
-                const int blk = col / D, off = col - blk * D;     // (D is a multiple of 4 here: see pb_geom users)
-                const float4 dg = (col + 3 < G3) ? *(const float4*)(dgl + blk * 256 + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int col = 4 * l16 + 64 * e;                 // columns [0,D) dpc, [D,2D) dpu, [2D,3D) dpr: dgl is laid out the same
+                const float4 dg = (col + 3 < G3) ? *(const float4*)(dgl + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 s0 += awv[e].x * dg.x + awv[e].y * dg.y;
                 s1 += awv[e].z * dg.z + awv[e].w * dg.w;
             }
@@ -329,10 +329,11 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         clk.mark(5);
         // ---- 3. energies backward on the matrix cores
         float swc[4], dsw[4] = {0.f, 0.f, 0.f, 0.f};
+        const unsigned mwb = 4u * (unsigned)(64 * wave + c16);               // this lane's column of tile 0, bytes
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int m = (4 * wave + tile) * 16 + c16;
-            swc[tile] = m < M ? C2 * a.sW[row * M + m] : 0.f;
+            swc[tile] = m < M ? C2 * pb_ld<float>(a.sW + row * M + 16 * tile, mwb) : 0.f;
         }
         float* const dmw = dms + wave * 16 * 17;
         for (int tl0 = 0; tl0 < nown; tl0 += PD_CH) {
@@ -349,14 +350,15 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 derow[r] = rowok[r] ? des[tl] : 0.f;
             }
             f32x4 dcva = F32X4_ZERO;
+            // dPA[t][b][m] of (r, tile): base of (b, r, tile) uniform, the lane's (t of r = 0, m of tile 0) part one offset
+            const unsigned dpaoff = 4u * ((unsigned)(min(tl0 + 4 * g4, nown - 1) * P + p) * (unsigned)(B * M) + (unsigned)(64 * wave + c16));
             float dpo[4][4];                               // the running dPA of this lane's 16 elements: in flight during the MFMAs
 #pragma unroll
             for (int tile = 0; tile < 4; ++tile) {
                 const int m = (4 * wave + tile) * 16 + c16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int t = (tl0 + 4 * g4 + r) * P + p;
-                    dpo[tile][r] = (rowok[r] && m < M) ? gb.dPA[((size_t)t * B + b) * M + m] : 0.f;
+                    dpo[tile][r] = (rowok[r] && m < M) ? pb_ld<float>(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile, dpaoff) : 0.f;
                 }
             }
 #pragma unroll
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 f32x4 acc = (f32x4){pa.x + swc[tile], pa.y + swc[tile], pa.z + swc[tile], pa.w + swc[tile]};
                 if (KC > 0) {
 #pragma unroll
-                    for (int sq = 0; sq < NS; ++sq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], Hb[tile][sq], acc, 0, 0, 0);
+                    for (int sq = 0; sq < NS; ++sq) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], C2 * hs[(4 * sq + g4) * PB_HS + m], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -375,8 +377,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                     float d = 0.f;
                     if (rowok[r] && m < M) {
                         d = derow[r] * wet[tile] * (1.f - th * th);
-                        const int t = (tl0 + 4 * g4 + r) * P + p;
-                        gb.dPA[((size_t)t * B + b) * M + m] = dpo[tile][r] + d;
+                        pb_st<float>(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile, dpaoff, dpo[tile][r] + d);
                         weacc[tile] += derow[r] * th;
                     }
                     dsw[tile] += d;
@@ -385,13 +386,18 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 __builtin_amdgcn_wave_barrier();
                 if (KC > 0) {
                     // dcv[pos][k] += dm[pos][m] handler[k][m];  dH[k][m] += cv[pos][k] dm[pos][m]
+                    f32x4* const dHp = (f32x4*)(dHs + ((wave * 4 + tile) * 64 + lane) * 4);
+                    f32x4 dHt = *dHp;
+                    const float* const hrow = hs + min(c16, KCP - 1) * PB_HS + (4 * wave + tile) * 16 + g4;
 #pragma unroll
                     for (int sq = 0; sq < 4; ++sq) {
-                        dcva = __builtin_amdgcn_mfma_f32_16x16x4f32(dmw[c16 * 17 + 4 * sq + g4], Ht[tile][sq], dcva, 0, 0, 0);
+                        const float ht = c16 < KCP ? hrow[4 * sq] : 0.f;
+                        dcva = __builtin_amdgcn_mfma_f32_16x16x4f32(dmw[c16 * 17 + 4 * sq + g4], ht, dcva, 0, 0, 0);
                         const int tlk = min(tl0 + 4 * sq + g4, nown - 1);
                         const float cva = (c16 < KCP && tl0 + 4 * sq + g4 < nown) ? cvs[tlk * KCP + min(c16, KCP - 1)] : 0.f;
-                        dH[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(cva, dmw[(4 * sq + g4) * 17 + c16], dH[tile], 0, 0, 0);
+                        dHt = __builtin_amdgcn_mfma_f32_16x16x4f32(cva, dmw[(4 * sq + g4) * 17 + c16], dHt, 0, 0, 0);
                     }
+                    *dHp = dHt;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -452,12 +458,27 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         clk.mark(7);
         {
             // contribution of the own column slice to ALL units: thread (k' = tid / 2, half) takes 32 of the 64 columns
+            // (the rows of transform_states come from L2: 64 KB per work-group and label, fetched here, behind exchange D — issued
+            // earlier they would sit in front of its sweep in the memory pipeline)
             const float4* dv = (const float4*)(dsws + (tid & 1) * 32);
-            const float4* wv4 = (const float4*)(WsL + (tid >> 1) * 68 + (tid & 1) * 32);
+            const int kq = min(tid >> 1, D - 1), m0 = p * 64 + (tid & 1) * 32;
+            const unsigned wsoff = 4u * (unsigned)(kq * M + (tid & 1) * 32);
+            float4 wreg[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                if ((M & 3) == 0) {
+                    wreg[x] = m0 + 4 * x + 3 < M ? pb_ld<float4>(w.Ws + p * 64 + 4 * x, wsoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {                                            // rows not 16-byte aligned: element loads
+                    float e4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) e4[e] = m0 + 4 * x + e < M ? pb_ld<float>(w.Ws + p * 64 + 4 * x + e, wsoff) : 0.f;
+                    wreg[x] = make_float4(e4[0], e4[1], e4[2], e4[3]);
+                }
+            }
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-                const float4 d4 = dv[x], w4 = wv4[x];
+                const float4 d4 = dv[x], w4 = wreg[x];
                 s0 += d4.x * w4.x + d4.y * w4.y;
                 s1 += d4.z * w4.z + d4.w * w4.w;
             }
@@ -540,7 +561,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * g4 + r;
-                if (k < K && m < M) gb.accH[(prow * K + k) * M + m] = dH[tile][r];
+                if (k < K && m < M) gb.accH[(prow * K + k) * M + m] = dHs[((wave * 4 + tile) * 64 + lane) * 4 + r];
             }
         }
     }

@@ -64,3 +64,21 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
     check_against(rec, cm, z, out, grads, tol=50.0 if case.startswith("mid_") else 1.0)
 
 
+
+
+# the backward kernel's filter-count instantiations (K <= 4 / 10 / 16) and matcher widths that are / are not a multiple of 4
+# (16-byte vs element loads of the transform_states rows), clusters of one and two work-groups
+@pytest.mark.parametrize("K,M,D", [(5, 12, 8), (7, 10, 36), pytest.param(12, 9, 8, marks=pytest.mark.slow)])
+def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K, M, D):
+    _, meta = load_golden("tiny_conv_median")
+    cfg = dict(meta["cfg"])
+    cfg.update(conv_num_filters=K, dim_matcher=M, dim_dec=D)
+    params = synthetic.make_params(cfg, seed=11, scale=meta["scale"])
+    batch = synthetic.make_batch(cfg, 3, 13, 5, seed=12, ragged=True)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    out, grads = orc.cost_and_grads(batch)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=cfg)
+    cm = rec.cost_and_gradients(batch)
+    assert engaged(rec) and any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs), "persistent decoder (forward and backward) did not engage"
+    rec.generator.check_persistent()
+    check_against(rec, cm, None, out, grads)
