@@ -39,6 +39,12 @@ __device__ __forceinline__ float lvsr_dpp_quad_xor2(float v) {
 
 // lane i <- lane 7-i of its half row (8 lanes) / lane 15-i of its row (16 lanes): after the two quad exchanges every lane of
 // a quad holds the quad's sum, so one mirror folds two quads (8 lanes), a second one two half rows (16 lanes) — no LDS crossbar
+// x, through an identity lane permutation the compiler does not see through and — being a cross-lane operation — does not
+// move out of loops: index arithmetic derived from the result is redone where it is used instead of being hoisted out of a
+// long loop and kept (or spilled) across it.  One v_mov_b32_dpp.
+__device__ __forceinline__ int lvsr_unhoisted(int x) {
+    return __builtin_amdgcn_mov_dpp(x, 0xE4, 0xf, 0xf, true);                                                      // quad_perm:[0,1,2,3]
+}
 __device__ __forceinline__ float lvsr_dpp_half_mirror(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x141, 0xf, 0xf, true));   // row_half_mirror
 }
