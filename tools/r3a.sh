@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r3a; O=gpurun_out/r3a
 cd $GRAFT_REPO_ROOT
 timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base > $O/probe_bwd.txt 2>&1; tail -60 $O/probe_bwd.txt
 for ls in 0 1; do
-  LVSR_DEC_BWD_PERSISTENT=1 LVSR_PBWD_LDS_STATE=$ls timeout 200 python -m pytest tests/test_gpu_properties.py -q -x -k "persistent_decoder" > $O/parity_ls$ls.txt 2>&1; tail -3 $O/parity_ls$ls.txt
+  LVSR_TEST_PBWD=1 LVSR_PBWD_LDS_STATE=$ls timeout 200 python -m pytest tests/test_gpu_properties.py -q -x -k "persistent_decoder" > $O/parity_ls$ls.txt 2>&1; tail -3 $O/parity_ls$ls.txt
   LVSR_DEC_BWD_PERSISTENT=1 LVSR_PBWD_LDS_STATE=$ls timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_ls$ls.json 2> $O/bench_ls$ls.err; cat $O/bench_ls$ls.json
 done
 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; cat $O/bench_default.json
