@@ -226,9 +226,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     auto pf_issue = [&](int il, int tid, float& pfn, float (&pfa)[2], float (&pfc)[2]) {
         if (wave < 4) return;
         const size_t rw = (size_t)il * B + b;
-        const int x = tid - 256, vec = x >> 5, u = p * PD_UNITS + (x & 31);
-        const float* src = vec == 0 ? a.U : vec == 1 ? a.R : vec == 2 ? a.C : vec == 3 ? a.S : gb.dS_r;
-        pfn = (vec < 5 && u < D && src != nullptr) ? src[rw * D + u] : 0.f;
+        // gate values: lanes 0..31 of wave 4 / 5 / 6 / 7 fetch U / R / C / S, lanes 32..63 of wave 4 dS_readout (per-wave uniform
+        // pointers: a per-lane choice among five costs thirty registers)
+        const int x = tid - 256, u = p * PD_UNITS + (tid & 31);
+        const float* srcw = wave == 4 ? a.U : wave == 5 ? a.R : wave == 6 ? a.C : a.S;
+        const float* src = (tid & 32) == 0 ? srcw : wave == 4 ? gb.dS_r : nullptr;
+        pfn = (u < D && src != nullptr) ? src[rw * D + u] : 0.f;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int t = x + 256 * e;
@@ -242,7 +245,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     auto pf_commit = [&](int tid, const float pfn, const float (&pfa)[2], const float (&pfc)[2]) {
         if (wave < 4) return;
         const int x = tid - 256;
-        if (x < 5 * PD_UNITS) nx[x] = pfn;
+        if ((tid & 32) == 0) nx[(wave - 4) * PD_UNITS + (tid & 31)] = pfn;
+        else if (wave == 4) nx[4 * PD_UNITS + (tid & 31)] = pfn;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int t = x + 256 * e;
