@@ -143,7 +143,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L, G3 = 3 * a.D;
     const int j = p * PD_UNITS + jl;
     const bool junit = j < D;
-    const unsigned jb = 4u * (unsigned)min(j, D - 1);
     const float C2 = 2.885390081777927f;
     // ---- register-resident weights
     f32x2 whh[PD_KD / 2], whu[PD_KD / 2], whr[PD_KD / 2];        // rows j of Whh, Whg[:, :D], Whg[:, D:], slice q of the columns
