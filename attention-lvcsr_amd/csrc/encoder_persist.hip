@@ -459,6 +459,11 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
     (dir == 0 ? out_f : out_b)[j] = s;
 }
 
+// encoder_persist1.hip: one exchange per step (opt-in, LVSR_PERSIST_ONEHOP)
+int lvsr_bigru_onehop_units(int B, int H);
+void lvsr_bigru_onehop_fwd(hipStream_t s, const EncFwd& a, int units, u64* planes, int* ab, int flags);
+void lvsr_bigru_onehop_bwd(hipStream_t s, const EncBwd0& a, int units, u64* planes, int* ab, float* dh, int Bp, int flags);
+
 static int persist_flags() {
     const char* env = getenv("LVSR_PERSIST_FLAGS");
     return env ? atoi(env) : 0;
@@ -469,6 +474,12 @@ extern "C" int lvsr_bigru_persist_rows(int B, int H) {
     PersistGeom g;
     if (B <= 0 || H <= 0 || !persist_geom(B, H, g)) return 0;
     return g.RB;
+}
+
+extern "C" int lvsr_bigru_persist_onehop(int B, int H) {
+    PersistGeom g;
+    if (B <= 0 || H <= 0 || !persist_geom(B, H, g) || g.RB != 1) return 0;
+    return lvsr_bigru_onehop_units(B, H);
 }
 
 extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
@@ -523,8 +534,10 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     const size_t bytes = 256 + (size_t)2 * g.rt * 2 * g.plane * 8;
     if (a.sub == 1) a.ysub = nullptr;
     const int flags = persist_flags();
+    const int onehop = g.RB == 1 ? lvsr_bigru_onehop_units(a.B, a.H) : 0;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
+        if (onehop) { lvsr_bigru_onehop_fwd(s, a, onehop, planes, ab, flags); return; }
         switch (g.KSPLIT / (g.NTH / 256)) {
             case 2: launch_fwd<64, 2>(s, a, g, planes, ab, flags); break;
             case 4: launch_fwd<64, 4>(s, a, g, planes, ab, flags); break;
@@ -536,6 +549,7 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     key.add(&g.RB, sizeof(g.RB));
     key.add(&g.NTH, sizeof(g.NTH));
     key.add(&flags, sizeof(flags));
+    key.add(&onehop, sizeof(onehop));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_fwd(persistent)");
 }
 
@@ -548,9 +562,11 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     const int Bp = ((a.B + 15) / 16) * 16;
     float* dh = a.dh_ws;
     const int flags = persist_flags();
+    const int onehop = g.RB == 1 ? lvsr_bigru_onehop_units(a.B, a.H) : 0;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
-        switch (g.KSPLIT / (g.NTH / 256)) {
+        if (onehop) lvsr_bigru_onehop_bwd(s, a, onehop, planes, ab, dh, Bp, flags);
+        else switch (g.KSPLIT / (g.NTH / 256)) {
             case 2: launch_bwd<64, 2>(s, a, g, planes, ab, dh, Bp, flags); break;
             case 4: launch_bwd<64, 4>(s, a, g, planes, ab, dh, Bp, flags); break;
             default: launch_bwd<64, 8>(s, a, g, planes, ab, dh, Bp, flags); break;
@@ -562,5 +578,6 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     key.add(&g.RB, sizeof(g.RB));
     key.add(&g.NTH, sizeof(g.NTH));
     key.add(&flags, sizeof(flags));
+    key.add(&onehop, sizeof(onehop));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_bwd(persistent)");
 }

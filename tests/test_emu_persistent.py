@@ -38,7 +38,21 @@ def concurrent_lib(request):
                                                         ([40], [1], 17, 5, False, 8), ([140], [1], 3, 6, True, 1),
                                                         ([130, 24], [1, 2], 6, 5, True, 4), ([260], [1], 3, 4, True, 2)])
 def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask, rows):
-    lib = concurrent_lib
+    run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
+
+
+# csrc/encoder_persist1.hip (opt-in): ONE exchange per step, the reset-gate block / state_to_state block whole in every
+# work-group; clusters of 4 (LVSR_PERSIST_ONEHOP=1) or 8 (=2) work-groups, double-buffered planes
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,onehop", [([140], [1], 3, 6, True, 1, 1), ([140], [1], 3, 6, True, 1, 2),
+                                                               ([200, 130], [2, 1], 2, 5, False, 1, 2), ([256], [1], 2, 4, True, 1, 1)])
+def test_one_exchange_per_step_encoder_matches_oracle_and_step_kernels(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, onehop):
+    monkeypatch.setenv("LVSR_PERSIST_ONEHOP", str(onehop))
+    for H in Hs:
+        assert concurrent_lib._lvsr_bigru_persist_onehop(B, H) == ((64 if onehop == 1 else 32) if 128 < H <= 256 else 0)
+    run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
+
+
+def run_against_oracle_and_step_kernels(lib, Hs, sub, B, T, use_mask):
     cfg = dict(input_dim=6, num_phonemes=6, dims_bidir=Hs, subsample=sub, dim_dec=4, dim_matcher=7,
                attention_type="content", post_merge_dims=None, embed_outputs=True)
     params = synthetic.make_params(cfg, seed=3)
