@@ -101,6 +101,9 @@ template <int UNITS>
 __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
     constexpr int P = P1_HP / UNITS, UB = UNITS / 32;
     __shared__ __attribute__((aligned(16))) float ha[8 * P1_LA], hb[16 * P1_LB], rhb[16 * P1_LB];
+    __shared__ float nx_gr[P1_HP], nx_own[2 * UNITS], nx_m[4];          // PF_STAGE: the next step's operands, staged by waves 4..7
+    const bool stage = (flags & PF_STAGE) != 0;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int H = a.H, B = a.B, T = a.T;
     int cl, p;
     cluster_of_block(P, flags, cl, p);
@@ -172,6 +175,25 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes
         // per-step re-derivation of the thread indices (see lvsr_unhoisted): nothing index-shaped is kept across the steps
         const int tid = lvsr_unhoisted((int)threadIdx.x), ksl = tid & 7, ug = tid >> 3, q = tid & 15, jb = tid >> 4;
         const size_t orow = ((size_t)t * B + b) * 2 * H + (size_t)dir * H;
+        // PF_STAGE: this step's operands come from LDS (written by waves 4..7 during the previous step); waves 4..7 — which never
+        // poll — fetch the next step's now, so that no global load sits in front of a sweep in a polling wave's memory queue
+        float st_gr = 0.f, st_x = 0.f, st_u = 0.f, st_m = 1.f;
+        if (stage) {
+            if (n > 0) {
+                n_gr = nx_gr[4 * ug + (ksl & 3)];
+#pragma unroll
+                for (int e = 0; e < UB; ++e) { n_xin[e] = nx_own[jb * UB + e]; n_gu[e] = nx_own[UNITS + jb * UB + e]; }
+                n_m = nx_m[0];
+            }
+            if (wave >= 4 && n + 1 < T) {
+                const int x = tid - 256, tn = dir == 0 ? n + 1 : T - 2 - n, jx = p * UNITS + x;
+                const size_t row = (size_t)tn * B + b;
+                const float* xr = a.xg + row * 6 * H + dir * 3 * H;
+                st_gr = x < H ? xr[2 * H + x] : 0.f;
+                if (x < UNITS && jx < H) { st_x = xr[jx]; st_u = xr[H + jx]; }
+                if (a.mask) st_m = a.mask[row];
+            }
+        }
         if (n > 0) {
             float v;
             if (!p1_gather<1>(gpl + (n & 1) * P1_HP, (unsigned)n, tid, abort_word, v)) return;
@@ -199,6 +221,12 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes
             uu[e] = sigmoid_fast(group_sum<16>(p1_dot_b(wu[e], hb + q * P1_LB)) + n_gu[e]);
             if (save && q == 0 && j < H) a.u[orow + j] = uu[e];
         }
+        if (stage && wave >= 4 && n + 1 < T) {          // every read of the staged operands of THIS step lies before the first barrier
+            const int x = tid - 256;
+            nx_gr[x] = st_gr;
+            if (x < UNITS) { nx_own[x] = st_x; nx_own[UNITS + x] = st_u; }
+            if (x == 0) nx_m[0] = st_m;
+        }
         __syncthreads();
         // ---- (b) candidate, state update, mask blend; publish
 #pragma unroll
@@ -218,7 +246,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes
             hown[e] = hn;
         }
         // ---- operands of the next step (independent of the recurrence): in flight during the hand-off
-        if (n + 1 < T) {
+        if (!stage && n + 1 < T) {
             const int tn = dir == 0 ? n + 1 : T - 2 - n;
             const size_t row = (size_t)tn * B + b;
             const float* xr = a.xg + row * 6 * H + dir * 3 * H;
@@ -249,6 +277,9 @@ template <int UNITS>
 __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
     constexpr int P = P1_HP / UNITS, UB = UNITS / 32;
     __shared__ __attribute__((aligned(16))) float dca[8 * P1_LA], dub[16 * P1_LB], drb[16 * P1_LB], drr[P1_HP];
+    __shared__ float nx_r[P1_HP], nx_hp[P1_HP], nx_own[3 * UNITS], nx_m[4];      // PF_STAGE: staged by waves 4..7 (u | c | dy of the own units)
+    const bool stage = (flags & PF_STAGE) != 0;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int H = a.H, B = a.B, T = a.T;
     int cl, p;
     cluster_of_block(P, flags, cl, p);
@@ -333,6 +364,36 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
         const int tid = lvsr_unhoisted((int)threadIdx.x), ksl = tid & 7, ug = tid >> 3, q = tid & 15, jb = tid >> 4;
         u64* const gc = gpl + (size_t)(n & 1) * 2 * P1_HP;
         float* const dx = a.dxg + ((size_t)t * B + b) * 6 * H + (size_t)dir * 3 * H;
+        // PF_STAGE (see the forward kernel): this step's saved values from LDS, the next step's fetched by waves 4..7 now
+        float st_r = 0.f, st_hp = 0.f, st_u = 0.f, st_c = 0.f, st_dy = 0.f, st_m = 1.f;
+        if (stage) {
+            if (n > 0) {
+                const int ka = min(4 * ug + (ksl & 3), P1_HP - 1);
+                n_ra = nx_r[ka]; n_hpa = nx_hp[ka];
+#pragma unroll
+                for (int e = 0; e < UB; ++e) {
+                    const int jl = jb * UB + e;
+                    n_u[e] = nx_own[jl]; n_c[e] = nx_own[UNITS + jl]; n_dy[e] = nx_own[2 * UNITS + jl];
+                    n_hp[e] = nx_hp[p * UNITS + jl];
+                }
+                n_m = nx_m[0];
+            }
+            if (wave >= 4 && n + 1 < T) {
+                const int x = tid - 256, jx = p * UNITS + x, tn = dir == 0 ? t - 1 : t + 1, tp = dir == 0 ? tn - 1 : tn + 1;
+                const size_t o = ((size_t)tn * B + b) * 2 * H + (size_t)dir * H;
+                const size_t op = ((size_t)tp * B + b) * 2 * H + (size_t)dir * H;
+                const bool first = tp < 0 || tp >= T;
+                if (x < H) {
+                    st_r = a.r[o + x];
+                    st_hp = first ? a.h0[dir][x] : a.y[op + x];
+                }
+                if (x < UNITS && jx < H) {
+                    st_u = a.u[o + jx]; st_c = a.c[o + jx];
+                    st_dy = p1_dy_at(a, tp, b, dir, jx);
+                }
+                st_m = a.mask ? a.mask[(size_t)tn * B + b] : 1.f;
+            }
+        }
         // ---- everything of this step that depends on dh elementwise only; publish dpre_c and dpre_u of the own units
         float part[UB], rr_a = n_ra, hp_a = n_hpa;
 #pragma unroll
@@ -350,7 +411,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
             }
         }
         // operands of the next step: in flight during the hand-off
-        if (n + 1 < T) prefetch(dir == 0 ? t - 1 : t + 1, tid);
+        if (!stage && n + 1 < T) prefetch(dir == 0 ? t - 1 : t + 1, tid);
         {
             float v;
             if (!p1_gather<2>(gc, (unsigned)(n + 1), tid, abort_word, v)) return;
@@ -375,6 +436,12 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
         float su[UB];
 #pragma unroll
         for (int e = 0; e < UB; ++e) su[e] = p1_dot_b(wbu[e], dub + q * P1_LB);
+        if (stage && wave >= 4 && n + 1 < T) {          // every read of the staged values of THIS step lies before the first barrier
+            const int x = tid - 256;
+            nx_r[x] = st_r; nx_hp[x] = st_hp;
+            if (x < UNITS) { nx_own[x] = st_u; nx_own[UNITS + x] = st_c; nx_own[2 * UNITS + x] = st_dy; }
+            if (x == 0) nx_m[0] = st_m;
+        }
         __syncthreads();
 #pragma unroll
         for (int e = 0; e < UB; ++e) {

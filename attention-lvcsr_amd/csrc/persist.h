@@ -19,6 +19,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PF_PLAIN 4
 #define PF_NOWAIT 8      // ablation: take whatever the first sweep returns (wrong results; what the step costs without hand-off waits)
 #define PF_NODOT 16      // ablation: skip the contractions (wrong results; what the hand-offs cost alone)
+#define PF_STAGE 64      // encoder_persist1.hip: the next step's operands are fetched by the non-polling waves and staged in LDS
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
                          // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue
 __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v, int flags = 0) {

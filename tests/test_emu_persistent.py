@@ -43,10 +43,13 @@ def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, 
 
 # csrc/encoder_persist1.hip (opt-in): ONE exchange per step, the reset-gate block / state_to_state block whole in every
 # work-group; clusters of 4 (LVSR_PERSIST_ONEHOP=1) or 8 (=2) work-groups, double-buffered planes
-@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,onehop", [([140], [1], 3, 6, True, 1, 1), ([140], [1], 3, 6, True, 1, 2),
-                                                               ([200, 130], [2, 1], 2, 5, False, 1, 2), ([256], [1], 2, 4, True, 1, 1)])
-def test_one_exchange_per_step_encoder_matches_oracle_and_step_kernels(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, onehop):
+# flags 64 (PF_STAGE): the next step's operands fetched by the non-polling waves and staged in LDS
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,onehop,flags", [([140], [1], 3, 6, True, 1, 1, 0), ([140], [1], 3, 6, True, 1, 2, 64),
+                                                                     ([200, 130], [2, 1], 2, 5, False, 1, 2, 0), ([256], [1], 2, 4, True, 1, 1, 64),
+                                                                     ([130, 250], [1, 2], 3, 7, True, 1, 2, 64)])
+def test_one_exchange_per_step_encoder_matches_oracle_and_step_kernels(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, onehop, flags):
     monkeypatch.setenv("LVSR_PERSIST_ONEHOP", str(onehop))
+    monkeypatch.setenv("LVSR_PERSIST_FLAGS", str(flags))
     for H in Hs:
         assert concurrent_lib._lvsr_bigru_persist_onehop(B, H) == ((64 if onehop == 1 else 32) if 128 < H <= 256 else 0)
     run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)

@@ -17,7 +17,8 @@ if len(sys.argv) >= 4:
     shapes = [tuple(int(v) for v in sys.argv[i:i + 3]) for i in range(1, len(sys.argv) - 2, 3)]
 # name, persistent?, LVSR_PERSIST_ROWS, LVSR_PERSIST_FLAGS [, LVSR_PERSIST_ONEHOP]
 variants = [("steps+graph", False, None, None), ("persist", True, "0", "0"), ("persist one exchange, P=8", True, "0", "0", "2"),
-            ("persist one exchange, P=4", True, "0", "0", "1"), ("persist rows=2", True, "2", "0"),
+            ("persist one exchange, P=4", True, "0", "0", "1"), ("one exchange, P=8, staged", True, "0", "64", "2"),
+            ("one exchange, P=4, staged", True, "0", "64", "1"), ("persist rows=2", True, "2", "0"),
             ("persist rows=4", True, "4", "0"), ("persist nosave", True, "0", "1"), ("persist xcd", True, "0", "2"),
             ("persist xcd+plain", True, "0", "6"), ("persist xcd+plain rows=2", True, "2", "6")]
 for (H, B, T) in shapes:
@@ -60,7 +61,7 @@ for (H, B, T) in shapes:
         err = ""
         if ref is None:
             ref = (y.clone(), gx)
-        elif flags in ("0", "2", "6"):
+        elif flags in ("0", "2", "6", "64"):
             err = "  max|dy| %.2e  max|dgrad| %.2e (rel %.1e)" % (float((y - ref[0]).abs().max()), float((gx - ref[1]).abs().max()),
                                                               float((gx - ref[1]).abs().max() / ref[1].abs().max()))
         print("H=%d B=%d T=%d %-26s layer fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)%s" % (
