@@ -21,6 +21,8 @@
 //   (b) own units:   k-slice q = tid % 16 (16 inputs), UB = UNITS / 32 own units jb * UB + e, two blocks: 32 UB weights; the
 //       sixteen slices fold with DPP, every lane of the group keeps the result.
 // LDS holds the gathered vector in both slice layouts ((a): 8 rows of 32 + 4, (b): 16 rows of 16 + 4 floats).
+// LVSR_PERSIST_FLAGS & 64 (PF_STAGE): the operands of the next step that do not depend on the recurrence are fetched by waves
+// 4..7 — which take no part in the sweeps — and handed over through LDS, instead of by every thread for itself.
 #include "common.h"
 #include "graph_cache.h"
 #include "lvsr_hip.h"
