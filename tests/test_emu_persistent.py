@@ -45,7 +45,8 @@ def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, 
 # work-group; clusters of 4 (LVSR_PERSIST_ONEHOP=1) or 8 (=2) work-groups, double-buffered planes
 # flags 64 (PF_STAGE): the next step's operands fetched by the non-polling waves and staged in LDS
 @pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,onehop,flags", [([140], [1], 3, 6, True, 1, 1, 0), ([140], [1], 3, 6, True, 1, 2, 64),
-                                                                     ([200, 130], [2, 1], 2, 5, False, 1, 2, 0), ([256], [1], 2, 4, True, 1, 1, 64),
+                                                                     pytest.param([200, 130], [2, 1], 2, 5, False, 1, 2, 0, marks=pytest.mark.slow),
+                                                                     pytest.param([256], [1], 2, 4, True, 1, 1, 64, marks=pytest.mark.slow),
                                                                      ([130, 250], [1, 2], 3, 7, True, 1, 2, 64)])
 def test_one_exchange_per_step_encoder_matches_oracle_and_step_kernels(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, onehop, flags):
     monkeypatch.setenv("LVSR_PERSIST_ONEHOP", str(onehop))
