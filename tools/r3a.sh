@@ -1,5 +1,5 @@
-# First GPU call of round 3: the spill-free persistent decoder backward against the step kernels.
-#   gpurun --timeout 900 -- 'bash tools/r3a.sh'
+# First GPU call of round 3: the spill-free persistent decoder backward and the one-exchange-per-step encoder kernels against the defaults.
+#   gpurun --timeout 1500 -- 'bash tools/r3a.sh'   (≈15-20 min of box time)
 mkdir -p gpurun_out/r3a; O=gpurun_out/r3a
 cd $GRAFT_REPO_ROOT
 timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base > $O/probe_bwd.txt 2>&1; tail -60 $O/probe_bwd.txt
