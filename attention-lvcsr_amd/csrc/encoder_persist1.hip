@@ -43,13 +43,13 @@ __device__ __forceinline__ int p1_slot_b(int k) { return (k >> 4) * P1_LB + (k &
 // Wait for the 256 (NPL = 1) or 512 (NPL = 2: two planes back to back) granules of a step: thread tid takes granule tid.
 // Returns false when the cluster gave up.
 template <int NPL>
-__device__ __forceinline__ bool p1_gather(const u64* g, unsigned epoch, int tid, int* abort_word, float& out) {
+__device__ __forceinline__ bool p1_gather(const u64* g, unsigned epoch, int tid, int* abort_word, float& out, int flags) {
     const bool mine = tid < NPL * P1_HP;
     u64 w = (u64)epoch << 32;
     unsigned spins = 0;
     for (;;) {
         if (mine) w = __hip_atomic_load(g + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__all((unsigned)(w >> 32) == epoch)) break;
+        if (__all((unsigned)(w >> 32) == epoch) || (flags & PF_NOWAIT)) break;      // (PF_NOWAIT: timing ablation, wrong results)
         if (((++spins) & 127u) == 0u) {
             if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
             if (spins > PERSIST_SPIN_LIMIT) {
@@ -63,7 +63,12 @@ __device__ __forceinline__ bool p1_gather(const u64* g, unsigned epoch, int tid,
 }
 
 // sum_x w[e][x] * v[x] over a 32-float slice for four outputs (role (a)), folded over the eight slices of the unit group
-__device__ __forceinline__ void p1_dot_a(const f32x2 (&w)[4][16], const float* slice, float (&out)[4]) {
+__device__ __forceinline__ void p1_dot_a(const f32x2 (&w)[4][16], const float* slice, float (&out)[4], int flags) {
+    if (flags & PF_NODOT) {            // timing ablation (wrong results): what the step costs without the contractions
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = slice[e];
+        return;
+    }
     f32x2 acc[4][2];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e][0] = acc[e][1] = (f32x2){0.f, 0.f};
@@ -83,7 +88,8 @@ __device__ __forceinline__ void p1_dot_a(const f32x2 (&w)[4][16], const float* s
 }
 
 // sum_x w[x] * v[x] over a 16-float slice (role (b)), NOT folded
-__device__ __forceinline__ float p1_dot_b(const f32x2 (&w)[8], const float* slice) {
+__device__ __forceinline__ float p1_dot_b(const f32x2 (&w)[8], const float* slice, int flags) {
+    if (flags & PF_NODOT) return slice[0];
     const float4* hv = (const float4*)slice;
     f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
@@ -198,14 +204,14 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes
         }
         if (n > 0) {
             float v;
-            if (!p1_gather<1>(gpl + (n & 1) * P1_HP, (unsigned)n, tid, abort_word, v)) return;
+            if (!p1_gather<1>(gpl + (n & 1) * P1_HP, (unsigned)n, tid, abort_word, v, flags)) return;
             if (tid < P1_HP) { ha[p1_slot_a(tid)] = v; hb[p1_slot_b(tid)] = v; }
         }
         __syncthreads();
         // ---- (a) reset gate and r*h of ALL units
         {
             float s[4];
-            p1_dot_a(wrf, ha + ksl * P1_LA, s);
+            p1_dot_a(wrf, ha + ksl * P1_LA, s, flags);
             const int e = ksl & 3, u = 4 * ug + e;
             const float mine = e == 0 ? s[0] : e == 1 ? s[1] : e == 2 ? s[2] : s[3];
             const float r = sigmoid_fast(mine + n_gr);
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
             const int j = p * UNITS + jb * UB + e;
-            uu[e] = sigmoid_fast(group_sum<16>(p1_dot_b(wu[e], hb + q * P1_LB)) + n_gu[e]);
+            uu[e] = sigmoid_fast(group_sum<16>(p1_dot_b(wu[e], hb + q * P1_LB, flags)) + n_gu[e]);
             if (save && q == 0 && j < H) a.u[orow + j] = uu[e];
         }
         if (stage && wave >= 4 && n + 1 < T) {          // every read of the staged operands of THIS step lies before the first barrier
@@ -234,7 +240,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1fwd_kernel(EncFwd a, u64* planes
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
             const int j = p * UNITS + jb * UB + e;
-            const float cand = tanh_fast(group_sum<16>(p1_dot_b(wc[e], rhb + q * P1_LB)) + n_xin[e]);
+            const float cand = tanh_fast(group_sum<16>(p1_dot_b(wc[e], rhb + q * P1_LB, flags)) + n_xin[e]);
             float hn = cand * uu[e] + hown[e] * (1.f - uu[e]);
             hn = n_m * hn + (1.f - n_m) * hown[e];
             if (j >= H) hn = 0.f;
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
         if (!stage && n + 1 < T) prefetch(dir == 0 ? t - 1 : t + 1, tid);
         {
             float v;
-            if (!p1_gather<2>(gc, (unsigned)(n + 1), tid, abort_word, v)) return;
+            if (!p1_gather<2>(gc, (unsigned)(n + 1), tid, abort_word, v, flags)) return;
             if (tid < P1_HP) dca[p1_slot_a(tid)] = v;
             else dub[p1_slot_b(tid - P1_HP)] = v;
         }
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
         // ---- (a) d(r*h) and dpre_r of ALL units
         {
             float s[4];
-            p1_dot_a(waf, dca + ksl * P1_LA, s);
+            p1_dot_a(waf, dca + ksl * P1_LA, s, flags);
             const int e = ksl & 3, k = 4 * ug + e;
             const float drh = e == 0 ? s[0] : e == 1 ? s[1] : e == 2 ? s[2] : s[3];
             const float dpr = k < H ? drh * hp_a * rr_a * (1.f - rr_a) : 0.f;
@@ -437,7 +443,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
         // ---- (b) dpre_u @ Whg[:, :H]^T of the own units (needs nothing of (a))
         float su[UB];
 #pragma unroll
-        for (int e = 0; e < UB; ++e) su[e] = p1_dot_b(wbu[e], dub + q * P1_LB);
+        for (int e = 0; e < UB; ++e) su[e] = p1_dot_b(wbu[e], dub + q * P1_LB, flags);
         if (stage && wave >= 4 && n + 1 < T) {          // every read of the staged values of THIS step lies before the first barrier
             const int x = tid - 256;
             nx_r[x] = st_r; nx_hp[x] = st_hp;
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(P1_NTH) void enc_p1bwd_kernel(EncBwd0 a, u64* plane
 #pragma unroll
         for (int e = 0; e < UB; ++e) {
             const int j = p * UNITS + jb * UB + e;
-            const float sum = group_sum<16>(su[e] + p1_dot_b(wbr[e], drb + q * P1_LB));
+            const float sum = group_sum<16>(su[e] + p1_dot_b(wbr[e], drb + q * P1_LB, flags));
             dh[e] = j < H ? part[e] + drr[min(j, P1_HP - 1)] + sum : 0.f;
         }
     }
