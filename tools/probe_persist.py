@@ -18,7 +18,8 @@ if len(sys.argv) >= 4:
 # name, persistent?, LVSR_PERSIST_ROWS, LVSR_PERSIST_FLAGS [, LVSR_PERSIST_ONEHOP]
 variants = [("steps+graph", False, None, None), ("persist", True, "0", "0"), ("persist one exchange, P=8", True, "0", "0", "2"),
             ("persist one exchange, P=4", True, "0", "0", "1"), ("one exchange, P=8, staged", True, "0", "64", "2"),
-            ("one exchange, P=4, staged", True, "0", "64", "1"), ("persist rows=2", True, "2", "0"),
+            ("one exchange, P=4, staged", True, "0", "64", "1"), ("one exchange, P=8, no waiting", True, "0", "8", "2"),
+            ("one exchange, P=8, no dots", True, "0", "16", "2"), ("persist rows=2", True, "2", "0"),
             ("persist rows=4", True, "4", "0"), ("persist nosave", True, "0", "1"), ("persist xcd", True, "0", "2"),
             ("persist xcd+plain", True, "0", "6"), ("persist xcd+plain rows=2", True, "2", "6")]
 for (H, B, T) in shapes:

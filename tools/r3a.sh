@@ -4,7 +4,7 @@ mkdir -p gpurun_out/r3a; O=gpurun_out/r3a
 cd $GRAFT_REPO_ROOT
 timeout 200 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_default.json 2> $O/bench_default.err; cat $O/bench_default.json
 # the encoder with ONE exchange per step (csrc/encoder_persist1.hip): layer probe (us per step, error against the step kernels), then the bench
-timeout 300 python tools/probe_persist.py 256 16 800 > $O/probe_enc.txt 2>&1; head -16 $O/probe_enc.txt
+timeout 300 python tools/probe_persist.py 256 16 800 > $O/probe_enc.txt 2>&1; head -20 $O/probe_enc.txt
 # (clusters of 8 need all 256 work-groups co-resident: skip their bench if the probe saw a cluster give up)
 OHS="2 1"; grep -q "P=8.*FAILED" $O/probe_enc.txt && OHS="1"
 for oh in $OHS; do
