@@ -198,6 +198,9 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     u64* const gRS = gSW + 2 * PD_MAXV;
     u64* const gS = gSW + 3 * PD_MAXV;
     u64* const gPOS = planes + (size_t)B * PD_NPLANE * PD_MAXV;      // [2][Bp], shared by all clusters
+    // plain stores for the exchanges INSIDE the cluster when its work-groups share an XCD (persist.h); the window centres travel
+    // between clusters and stay write-through.  The XCC_ID granules use the unused upper half of the S plane (D <= 256).
+    const bool plain = cluster_shares_xcd(gS + 256, P, p, abort_word);
     const bool winprior = K > 0 && a.prior_type != 0;
     const bool pos_wave = p == P - 1 && wave == PD_NW - 1;           // the wave that derives this utterance's window centre
     __syncthreads();
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
 #pragma unroll
                 for (int c = 1; c < PD_MC; ++c) mine = q == c ? sw[c] : mine;
                 if (m < M) {
-                    granule_store(gSW + m, epoch, mine);
+                    granule_store(gSW + m, epoch, mine, plain);
                     a.sW[row * M + m] = mine;
                 }
             }
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                         float e = 0.f;
 #pragma unroll
                         for (int wv = 0; wv < PD_NW; ++wv) e += xw[wv * PD_CH + tid];
-                        granule_store(gEN + t, epoch, (t >= wi.begin && t < wi.end) ? e : 0.f);
+                        granule_store(gEN + t, epoch, (t >= wi.begin && t < wi.end) ? e : 0.f, plain);
                     }
                 }
                 if (tl0 + PD_CH < nown) __syncthreads();
@@ -442,7 +445,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 if (tl < nown && t < Tp) {
                     const float* xr = xw + (tid & 1) * 4 * 8 + (tid >> 1);       // the four waves of this position's half
                     const float e = (xr[0] + xr[8]) + (xr[16] + xr[24]);
-                    granule_store(gEN + t, epoch, (t >= wi.begin && t < wi.end) ? e : 0.f);
+                    granule_store(gEN + t, epoch, (t >= wi.begin && t < wi.end) ? e : 0.f, plain);
                 }
             }
             if (tl0 + PD_CH < nown) __syncthreads();
@@ -512,7 +515,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         const float rr = sigmoid_fast(fr + gr + gr2);
         const float rs = junit ? rr * sj : 0.f;
         if (q == 0 && junit) {
-            granule_store(gRS + j, epoch, rs);
+            granule_store(gRS + j, epoch, rs, plain);
             a.R[row * D + j] = rr;
             a.RH[row * D + j] = rs;
         }
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         sn = ym * sn + (1.f - ym) * sj;
         if (!junit) sn = 0.f;
         if (q == 0 && junit) {
-            if (i + 1 < L) granule_store(gS + j, epoch, sn);
+            if (i + 1 < L) granule_store(gS + j, epoch, sn, plain);
             a.C[row * D + j] = cand;
             a.S[((size_t)(i + 1) * B + b) * D + j] = sn;
         }

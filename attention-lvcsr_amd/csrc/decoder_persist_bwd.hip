@@ -216,6 +216,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     u64* const gD = gA + 3 * PD_MAXV;                 // [P][512]
     u64* const gE = gD + (size_t)P * 512;             // [P][256]
     u64* const gF = gE + (size_t)P * 256;             // [P][512]
+    const bool plain = cluster_shares_xcd(gA + 256, P, p, abort_word);     // XCC_ID granules: the unused upper half of plane A (D <= 256)
     __syncthreads();
     // What a label reads from the forward's saved tensors — the gate values of the own units, the alignment the label produced,
     // the convolution features of the own positions — is fetched one label ahead by waves 4..7, which poll in none of the
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const float dpc = junit ? dsn * uu * (1.f - cc * cc) : 0.f;
         const float dpu = junit ? dsn * (cc - sp) * uu * (1.f - uu) : 0.f;
         float part = dsn * (1.f - uu) + (1.f - ym) * dsj + dsr;
-        if (q == 0 && junit) granule_store(gA + j, epoch, dpc);
+        if (q == 0 && junit) granule_store(gA + j, epoch, dpc, plain);
         // gradient wrt the alignment this label produced: gathered from the partial correlations of the previous iteration
         if (n > 0 && KC > 0) {
             const int src = tid >> 5, tl = tid & 31, t = tl * P + p;
@@ -335,8 +336,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const float dpr = junit ? drh * sp * rr * (1.f - rr) : 0.f;
         part += drh * rr;
         if (q == 0 && junit) {
-            granule_store(gB + j, epoch, dpu);
-            granule_store(gB + 256 + j, epoch, dpr);
+            granule_store(gB + j, epoch, dpu, plain);
+            granule_store(gB + 256 + j, epoch, dpr, plain);
             float* dx = gb.DXG + row * G3;
             pb_st<float>(dx, jb, dpc); pb_st<float>(dx + D, jb, dpu); pb_st<float>(dx + 2 * D, jb, dpr);
         }
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             float qs = group_sum<16>(s0 + s1);
             if (qok) qs += gb.QR[row * Tp + qt] + (KC > 0 ? dalp[qtl] : 0.f);
             else qs = 0.f;
-            if (l16 == 0 && qtl < nown && qt < Tp) granule_store(gC + qt, epoch, qs);
+            if (l16 == 0 && qtl < nown && qt < Tp) granule_store(gC + qt, epoch, qs, plain);
         }
         clk.mark(4);
         {
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         for (int tile = 0; tile < 4; ++tile) {
             dsw[tile] += __shfl_xor(dsw[tile], 16, 64);
             dsw[tile] += __shfl_xor(dsw[tile], 32, 64);
-            if (g4 == 0) granule_store(gD + (size_t)p * 512 + (4 * wave + tile) * 16 + c16, epoch, dsw[tile]);
+            if (g4 == 0) granule_store(gD + (size_t)p * 512 + (4 * wave + tile) * 16 + c16, epoch, dsw[tile], plain);
         }
         {
             const int src = tid >> 6, mm = tid & 63;
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             }
             float s = s0 + s1;
             s += lvsr_dpp_quad_xor1(s);
-            if ((tid & 1) == 0 && (tid >> 1) < D) granule_store(gE + (size_t)p * 256 + (tid >> 1), epoch, s);
+            if ((tid & 1) == 0 && (tid >> 1) < D) granule_store(gE + (size_t)p * 256 + (tid >> 1), epoch, s, plain);
         }
         clk.mark(8);
         float pfn = 0.f, pfa[2] = {0.f, 0.f}, pfc[2] = {0.f, 0.f};
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 }
                 if (hsel == 1) r8[tid & 255] = acc;            // (barriers outside any lane-dependent branch: a wave counts once)
                 __syncthreads();
-                if (hsel == 0 && sx < Tp) granule_store(gF + (size_t)p * 512 + sx, epoch, acc + r8[tid & 255]);
+                if (hsel == 0 && sx < Tp) granule_store(gF + (size_t)p * 512 + sx, epoch, acc + r8[tid & 255], plain);
                 __syncthreads();
             }
         }

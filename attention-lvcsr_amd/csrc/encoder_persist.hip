@@ -12,10 +12,12 @@
 //     partial sums with DPP.  A 256-thread work-group therefore holds 192 KiB of weights = 256/KSPLIT units, and a
 //     (direction, row group) cluster is only P = H*KSPLIT/256 work-groups (4 at H = 256, 16 at H = 512, ONE at H <= 128:
 //     no exchange at all), one per CU;
-//   * the phase vector (RB x H floats) travels as 8-byte {epoch, value} granules: relaxed agent-scope atomic stores
-//     (sc1, write-through) polled with relaxed agent-scope atomic loads (MI355X_MICROARCH.md "handoff-1to1", granule
-//     form R2: no fences, no flags, placement independent).  All 256 threads sweep the plane coalesced (RB*H/256 loads
-//     per lane) into LDS; every thread then reads its K slice from LDS as broadcast ds_read_b128;
+//   * the phase vector (RB x H floats) travels as 8-byte {epoch, value} granules polled with relaxed agent-scope atomic
+//     loads (sc1; MI355X_MICROARCH.md "handoff-1to1", granule form R2: no fences, no flags).  A cluster whose work-groups
+//     were verified to share an XCD (persist.h cluster_shares_xcd, once per launch) publishes with plain stores — the
+//     granules stay in the XCD's L2 —, any other cluster with write-through (sc1) stores: correct under every placement,
+//     fast under the usual one.  All threads sweep the plane coalesced (RB*H/256 loads per lane) into LDS; every thread
+//     then reads its K slice from LDS as broadcast ds_read_b128;
 //   * only what the NEXT exchange waits for is computed before publishing (reset gate forward, d(r*h) backward); the update
 //     gate / the dpre_u contraction run in the shadow of the hand-off;
 //   * epoch = step + 1, planes zeroed by a memset node before every launch (graph-replay safe); a plane is overwritten only
@@ -179,7 +181,7 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
-__global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, int* abort_word, int flags) {
+__global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, u64* hello, int* abort_word, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;     // wave-private operand buffers, see gather_plane
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, in
     int cl, p;
     cluster_of_block(P, flags, cl, p);
     const bool save = !(flags & PF_NOSAVE);
+    const bool plain = P > 1 && cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
     const int dir = cl / rt, b0 = (cl % rt) * RB;
     const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
     const bool junit = j < H;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, in
                 rr[i] = sigmoid_fast(pick_row<RB, KSPLIT>(s, q, i) + gr[i]);
                 const float rh = rvalid[i] ? rr[i] * hown[i] : 0.f;
                 if (P == 1) lds_publish<KS, LDH, KSPLIT>(hbuf[1], r, j, rh);
-                else granule_store(grh + (size_t)r * HP + j, (unsigned)(n + 1), rh, flags);
+                else granule_store(grh + (size_t)r * HP + j, (unsigned)(n + 1), rh, plain);
                 if (rvalid[i] && save) {
                     const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
                     a.r[o] = rr[i]; a.rh[o] = rh;
@@ -286,7 +289,7 @@ __global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, in
                 hn = m[i] * hn + (1.f - m[i]) * hown[i];
                 if (!rvalid[i]) hn = 0.f;
                 if (P == 1) lds_publish<KS, LDH, KSPLIT>(hbuf[0], r, j, hn);
-                else if (n + 1 < T) granule_store(gh + (size_t)r * HP + j, (unsigned)(n + 1), hn, flags);
+                else if (n + 1 < T) granule_store(gh + (size_t)r * HP + j, (unsigned)(n + 1), hn, plain);
                 if (rvalid[i]) {
                     const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
                     if (save) a.c[o] = cand;
@@ -326,7 +329,7 @@ __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int di
 }
 
 template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
-__global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, int* abort_word, float* dh_out, int Bp, int flags) {
+__global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, u64* hello, int* abort_word, float* dh_out, int Bp, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
     int cl, p;
     cluster_of_block(P, flags, cl, p);
     const bool save = !(flags & PF_NOSAVE);
+    const bool plain = P > 1 && cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
     const int dir = cl / rt, b0 = (cl % rt) * RB;
     const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
     const bool junit = j < H;
@@ -401,8 +405,8 @@ __global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
                     lds_publish<KS, LDH, KSPLIT>(vbuf[0], r, j, dpc);
                     lds_publish<KS, LDH, KSPLIT>(vbuf[1], r, j, dpu);
                 } else {
-                    granule_store(gc + (size_t)r * HP + j, (unsigned)(n + 1), dpc, flags);
-                    granule_store(gu + (size_t)r * HP + j, (unsigned)(n + 1), dpu, flags);
+                    granule_store(gc + (size_t)r * HP + j, (unsigned)(n + 1), dpc, plain);
+                    granule_store(gu + (size_t)r * HP + j, (unsigned)(n + 1), dpu, plain);
                 }
                 part[i] = dhn * (1.f - uu[i]) + (1.f - n_m[i]) * dh[i] + n_dy[i];
                 if (rvalid[i] && save) {
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, i
                 const float drh = pick_row<RB, KSPLIT>(s, q, i);
                 const float dpr = rvalid[i] ? drh * hp[i] * rr[i] * (1.f - rr[i]) : 0.f;
                 if (P == 1) lds_publish<KS, LDH, KSPLIT>(vbuf[2], r, j, dpr);
-                else granule_store(gr + (size_t)r * HP + j, (unsigned)(n + 1), dpr, flags);
+                else granule_store(gr + (size_t)r * HP + j, (unsigned)(n + 1), dpr, plain);
                 part[i] += drh * rr[i];
                 if (rvalid[i] && save) a.dxg[((size_t)t * B + b0 + r) * 6 * H + dir * 3 * H + 2 * H + j] = dpr;
             }
@@ -459,11 +463,6 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
     (dir == 0 ? out_f : out_b)[j] = s;
 }
 
-// encoder_persist1.hip: one exchange per step (opt-in, LVSR_PERSIST_ONEHOP)
-int lvsr_bigru_onehop_units(int B, int H);
-void lvsr_bigru_onehop_fwd(hipStream_t s, const EncFwd& a, int units, u64* planes, int* ab, int flags);
-void lvsr_bigru_onehop_bwd(hipStream_t s, const EncBwd0& a, int units, u64* planes, int* ab, float* dh, int Bp, int flags);
-
 static int persist_flags() {
     const char* env = getenv("LVSR_PERSIST_FLAGS");
     return env ? atoi(env) : 0;
@@ -476,52 +475,46 @@ extern "C" int lvsr_bigru_persist_rows(int B, int H) {
     return g.RB;
 }
 
-extern "C" int lvsr_bigru_persist_onehop(int B, int H) {
-    PersistGeom g;
-    if (B <= 0 || H <= 0 || !persist_geom(B, H, g) || g.RB != 1) return 0;
-    return lvsr_bigru_onehop_units(B, H);
-}
-
 extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
     PersistGeom g;
     if (B <= 0 || H <= 0) return 0;
     // sized for one utterance per cluster (the largest number of clusters) so LVSR_PERSIST_ROWS cannot outgrow it
     if (!persist_geom(B, H, g)) return 0;
-    return 256 + (long long)2 * (B + 16) * 4 * g.HP * 8;              // abort word + 4 planes per (direction, utterance)
+    return 256 + (long long)2 * (B + 16) * 4 * g.HP * 8 + 8 * 1024;     // abort word + 4 planes per (direction, utterance) + XCC_ID granules
 }
 
 template <int KS, int KSPLIT>
-static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, int* ab, int flags) {
+static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, u64* hello, int* ab, int flags) {
     if (g.NTH == 512) {                        // two waves per SIMD: half the k-slice per thread (one or two utterances per cluster)
-        if (g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, flags);
-        else hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, flags);
+        if (g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
+        else hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         return;
     }
     switch (g.RB) {
         case 1:
-            if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags);
-            else hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, true>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags);
+            if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, flags);
+            else hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 1, true>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, flags);
             break;
-        case 2: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 2, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
-        case 4: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 4, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
-        default: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 8, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, flags); break;
+        case 2: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 2, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, flags); break;
+        case 4: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 4, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, flags); break;
+        default: hipLaunchKernelGGL((enc_pfwd_kernel<KS, KSPLIT, 8, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, flags); break;
     }
 }
 template <int KS, int KSPLIT>
-static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, int* ab, float* dh, int Bp, int flags) {
+static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, u64* hello, int* ab, float* dh, int Bp, int flags) {
     if (g.NTH == 512) {
-        if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, dh, Bp, flags);
-        else hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, ab, dh, Bp, flags);
+        if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        else hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         return;
     }
     switch (g.RB) {
         case 1:
-            if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags);
-            else hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, true>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags);
+            if (!(flags & PF_PRIVATE)) hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, dh, Bp, flags);
+            else hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 1, true>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, dh, Bp, flags);
             break;
-        case 2: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 2, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
-        case 4: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 4, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
-        default: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 8, false>), dim3(g.grid), dim3(256), 0, s, a, planes, ab, dh, Bp, flags); break;
+        case 2: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 2, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, dh, Bp, flags); break;
+        case 4: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 4, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, dh, Bp, flags); break;
+        default: hipLaunchKernelGGL((enc_pbwd_kernel<KS, KSPLIT, 8, false>), dim3(g.grid), dim3(256), 0, s, a, planes, hello, ab, dh, Bp, flags); break;
     }
 }
 
@@ -531,17 +524,16 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     LVSR_REQUIRE(persist_geom(a.B, a.H, g) && a.sync_ws, "lvsr_bigru_fwd: persistent mode not available for B=%d H=%d", a.B, a.H);
     int* ab = (int*)a.sync_ws;
     u64* planes = (u64*)((char*)a.sync_ws + 256);
-    const size_t bytes = 256 + (size_t)2 * g.rt * 2 * g.plane * 8;
+    u64* hello = planes + (size_t)2 * g.rt * 2 * g.plane;          // one {1, XCC_ID} granule per work-group, behind the planes
+    const size_t bytes = 256 + (size_t)2 * g.rt * 2 * g.plane * 8 + (size_t)g.grid * 8;
     if (a.sub == 1) a.ysub = nullptr;
     const int flags = persist_flags();
-    const int onehop = g.RB == 1 ? lvsr_bigru_onehop_units(a.B, a.H) : 0;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
-        if (onehop) { lvsr_bigru_onehop_fwd(s, a, onehop, planes, ab, flags); return; }
         switch (g.KSPLIT / (g.NTH / 256)) {
-            case 2: launch_fwd<64, 2>(s, a, g, planes, ab, flags); break;
-            case 4: launch_fwd<64, 4>(s, a, g, planes, ab, flags); break;
-            default: launch_fwd<64, 8>(s, a, g, planes, ab, flags); break;
+            case 2: launch_fwd<64, 2>(s, a, g, planes, hello, ab, flags); break;
+            case 4: launch_fwd<64, 4>(s, a, g, planes, hello, ab, flags); break;
+            default: launch_fwd<64, 8>(s, a, g, planes, hello, ab, flags); break;
         }
     };
     GraphKey key("bigru_pfwd");
@@ -549,7 +541,6 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     key.add(&g.RB, sizeof(g.RB));
     key.add(&g.NTH, sizeof(g.NTH));
     key.add(&flags, sizeof(flags));
-    key.add(&onehop, sizeof(onehop));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_fwd(persistent)");
 }
 
@@ -558,18 +549,17 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     LVSR_REQUIRE(persist_geom(a.B, a.H, g) && a.sync_ws, "lvsr_bigru_bwd: persistent mode not available for B=%d H=%d", a.B, a.H);
     int* ab = (int*)a.sync_ws;
     u64* planes = (u64*)((char*)a.sync_ws + 256);
-    const size_t bytes = 256 + (size_t)2 * g.rt * 4 * g.plane * 8;
+    u64* hello = planes + (size_t)2 * g.rt * 4 * g.plane;
+    const size_t bytes = 256 + (size_t)2 * g.rt * 4 * g.plane * 8 + (size_t)g.grid * 8;
     const int Bp = ((a.B + 15) / 16) * 16;
     float* dh = a.dh_ws;
     const int flags = persist_flags();
-    const int onehop = g.RB == 1 ? lvsr_bigru_onehop_units(a.B, a.H) : 0;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
-        if (onehop) lvsr_bigru_onehop_bwd(s, a, onehop, planes, ab, dh, Bp, flags);
-        else switch (g.KSPLIT / (g.NTH / 256)) {
-            case 2: launch_bwd<64, 2>(s, a, g, planes, ab, dh, Bp, flags); break;
-            case 4: launch_bwd<64, 4>(s, a, g, planes, ab, dh, Bp, flags); break;
-            default: launch_bwd<64, 8>(s, a, g, planes, ab, dh, Bp, flags); break;
+        switch (g.KSPLIT / (g.NTH / 256)) {
+            case 2: launch_bwd<64, 2>(s, a, g, planes, hello, ab, dh, Bp, flags); break;
+            case 4: launch_bwd<64, 4>(s, a, g, planes, hello, ab, dh, Bp, flags); break;
+            default: launch_bwd<64, 8>(s, a, g, planes, hello, ab, dh, Bp, flags); break;
         }
         hipLaunchKernelGGL(enc_pbwd_h0_kernel, dim3((a.H + 255) / 256, 1, 2), dim3(256), 0, s, dh, Bp, a.B, a.H, a.dh0[0], a.dh0[1]);
     };
@@ -578,6 +568,5 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     key.add(&g.RB, sizeof(g.RB));
     key.add(&g.NTH, sizeof(g.NTH));
     key.add(&flags, sizeof(flags));
-    key.add(&onehop, sizeof(onehop));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_bigru_bwd(persistent)");
 }

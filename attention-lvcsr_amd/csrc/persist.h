@@ -10,22 +10,55 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PERSIST_MAX_WG 224
 
 // The work-groups of a cluster are numbered so that they land on ONE XCD (block b runs on XCD b % 8: observed on MI355X,
-// not promised by HIP — nothing depends on it but speed: 2.7 instead of 3.2 us per step at H = 256).
-// Experiment switches (LVSR_PERSIST_FLAGS, read per call): 1 = do not write the saved tensors (timing only, results unusable
-// for BPTT), 2 = consecutive blocks form a cluster instead (members spread over the XCDs), 4 = publish with plain stores
-// (they stay in the XCD's L2: only correct when the XCD placement holds; measured SLOWER than write-through sc1 stores)
+// not promised by HIP — nothing depends on it but speed).  Whether they did is CHECKED per launch (cluster_shares_xcd): the
+// members exchange their XCC_ID once, and only a cluster that shares an XCD publishes with plain stores (the granules then
+// live in the XCD's L2, which the members' sc1 polls read: 0.91 instead of 1.33 us per exchange, profiles/r03_hop_probe.txt);
+// any other cluster keeps write-through (sc1) stores, which are correct under every placement.
+// Experiment switches (flags argument of the kernels): 1 = do not write the saved tensors (timing only, results unusable
+// for BPTT), 2 = consecutive blocks form a cluster instead (members spread over the XCDs), 4 = write-through stores even
+// when the cluster shares an XCD (the round-2 hand-off)
 #define PF_NOSAVE 1
 #define PF_SPREAD 2
-#define PF_PLAIN 4
+#define PF_SC1 4
 #define PF_NOWAIT 8      // ablation: take whatever the first sweep returns (wrong results; what the step costs without hand-off waits)
 #define PF_NODOT 16      // ablation: skip the contractions (wrong results; what the hand-offs cost alone)
-#define PF_STAGE 64      // encoder_persist1.hip: the next step's operands are fetched by the non-polling waves and staged in LDS
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
                          // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue
-__device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v, int flags = 0) {
+// plain = true: a store without cache-policy bits (wavefront-scope atomic = global_store_dwordx2; NOT a volatile store, which
+// is emitted as flat_store sc0 sc1): it is visible to the other CUs of the SAME XCD once it reaches the XCD's L2 (the vector
+// L1 is write-through) — only for granules whose every reader was verified to share the XCD.
+__device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v, bool plain = false) {
     const u64 w = ((u64)epoch << 32) | (u64)__float_as_uint(v);
-    if (flags & PF_PLAIN) *(volatile u64*)p = w;
+    if (plain) __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Do the P work-groups of this cluster run on one XCD?  Member p publishes its XCC_ID (hardware register 20, bits 3:0) as a
+// write-through granule {1, id} into hello[p] (zeroed by the launch's memset node) and wave 0 polls the P slots; every member
+// sees the same P values, so the answer is uniform over the cluster.  Called once per launch by all threads (it contains a
+// work-group barrier).  Returns false as well when a member does not show up within the spin limit (the abort word is raised;
+// the first exchange of the sequence then makes everybody leave).
+__device__ __forceinline__ bool cluster_shares_xcd(u64* hello, int P, int p, int* abort_word) {
+    __shared__ int same_xcd;
+    if (threadIdx.x < 64) {
+        const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u;       // hwreg(HW_REG_XCC_ID, 0, 4)
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(hello + p, ((u64)1 << 32) | (u64)xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        unsigned spins = 0;
+        for (;;) {
+            u64 w = ((u64)1 << 32) | (u64)xcc;
+            if (lane < P) w = __hip_atomic_load(hello + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all((unsigned)(w >> 32) == 1u)) { ok = __all(((unsigned)w & 15u) == xcc); break; }
+            if (++spins > PERSIST_SPIN_LIMIT || ((spins & 127u) == 0u && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+        }
+        if (lane == 0) same_xcd = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return same_xcd != 0;
 }
 // cluster / member index of a work-group
 __device__ __forceinline__ void cluster_of_block(int P, int flags, int& cl, int& p) {

@@ -132,10 +132,6 @@ int lvsr_bigru_bwd(void* stream, const lvsr_bigru_bwd_args* a, int use_graph);
  * the first int of sync_ws is non-zero if a work-group gave up waiting (results invalid). */
 int lvsr_bigru_persist_rows(int B, int H);
 long long lvsr_bigru_persist_ws_bytes(int B, int H);
-/* Opt-in variant with ONE exchange per step (csrc/encoder_persist1.hip; environment LVSR_PERSIST_ONEHOP=1 / 2, 128 < H <= 256,
- * one utterance per cluster): units per work-group the persistent calls would use for (B,H) — 64 (clusters of 4) or 32
- * (clusters of 8, 16 B work-groups: the whole chip at B = 16) — or 0 when the variant is off / does not apply. */
-int lvsr_bigru_persist_onehop(int B, int H);
 
 /* ---- attention decoder (teacher forced or one generation step) ------------------------------------
  * AttentionRecurrent.do_apply / take_glimpses / compute_states (libs/blocks/blocks/bricks/attention.py:

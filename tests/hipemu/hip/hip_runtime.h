@@ -234,6 +234,15 @@ inline int __shfl_down(int v, unsigned d, int width = 64) {
 // ---- agent-scope atomics / wave votes used by the persistent kernels.  Kernels that wait for OTHER work-groups need
 // hipemu_set_concurrent(1); with work-groups run one after another they would spin until their own bound trips ----
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WAVEFRONT 2
+// s_getreg_b32 hwreg(HW_REG_XCC_ID): the XCD a work-group runs on.  Here: block b 'runs' on XCD b % HIPEMU_XCDS (environment,
+// default 1 = every cluster shares its XCD; 8 mimics MI355X's round-robin dispatch)
+inline unsigned hipemu_xcc_id() {
+    const char* e = getenv("HIPEMU_XCDS");
+    const int n = e ? atoi(e) : 1;
+    return n > 1 ? (unsigned)(blockIdx.x % (unsigned)n) : 0u;
+}
+inline unsigned __builtin_amdgcn_s_getreg(int) { return hipemu_xcc_id(); }
 template <typename T, typename V> inline void hipemu_atomic_store(T* p, V v) { __atomic_store_n(p, (T)v, __ATOMIC_SEQ_CST); }
 template <typename T> inline T hipemu_atomic_load(const T* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)

@@ -41,18 +41,14 @@ def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, 
     run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
 
 
-# csrc/encoder_persist1.hip (opt-in): ONE exchange per step, the reset-gate block / state_to_state block whole in every
-# work-group; clusters of 4 (LVSR_PERSIST_ONEHOP=1) or 8 (=2) work-groups, double-buffered planes
-# flags 64 (PF_STAGE): the next step's operands fetched by the non-polling waves and staged in LDS
-@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,onehop,flags", [([140], [1], 3, 6, True, 1, 1, 0), ([140], [1], 3, 6, True, 1, 2, 64),
-                                                                     pytest.param([200, 130], [2, 1], 2, 5, False, 1, 2, 0, marks=pytest.mark.slow),
-                                                                     pytest.param([256], [1], 2, 4, True, 1, 1, 64, marks=pytest.mark.slow),
-                                                                     ([130, 250], [1, 2], 3, 7, True, 1, 2, 64)])
-def test_one_exchange_per_step_encoder_matches_oracle_and_step_kernels(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, onehop, flags):
-    monkeypatch.setenv("LVSR_PERSIST_ONEHOP", str(onehop))
-    monkeypatch.setenv("LVSR_PERSIST_FLAGS", str(flags))
-    for H in Hs:
-        assert concurrent_lib._lvsr_bigru_persist_onehop(B, H) == ((64 if onehop == 1 else 32) if 128 < H <= 256 else 0)
+# The publish form is chosen per cluster and launch from the work-groups' XCC_ID (persist.h cluster_shares_xcd): plain stores
+# when the members share an XCD, write-through stores otherwise.  HIPEMU_XCDS=8 places block b on "XCD" b % 8 as the MI355X
+# does: clusters whose count is not a multiple of 8 are then numbered consecutively and straddle XCDs (the write-through
+# path); the default places every block on XCD 0 (the plain path).  Both must give the same numbers.
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,xcds", [([140], [1], 3, 6, True, 1, 8), ([140, 130], [1, 2], 4, 5, True, 1, 8),
+                                                             ([260], [1], 2, 4, False, 2, 4)])
+def test_persistent_encoder_when_clusters_straddle_xcds(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, xcds):
+    monkeypatch.setenv("HIPEMU_XCDS", str(xcds))
     run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
 
 
