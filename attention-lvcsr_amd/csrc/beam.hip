@@ -144,9 +144,11 @@ __global__ __launch_bounds__(BEAM_THREADS) void topk_kernel(const float* costs, 
 // ---------------------------------------------------------------------------------------------------------------
 // one beam step
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float fin_score_of(const lvsr_beam_args& a, float cost, int pos) {
-    // running[-1] - char_discount * len(running): the column has pos + 2 rows (the initial zero + one per position)
-    return cost - (float)(a.char_discount * (double)(pos + 2));
+__device__ __forceinline__ double fin_score_of(const lvsr_beam_args& a, float cost, int pos) {
+    // running[-1] - char_discount * len(running): the column has pos + 2 rows (the initial zero + one per position).  In double:
+    // the reference subtracts a Python float from a numpy.float32 (float64 under the numpy it was written for), and the host's
+    // final ranking (search.py _collect) does the same — near-equal scores must order identically here and there
+    return (double)cost - a.char_discount * (double)(pos + 2);
 }
 
 __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_args a) {
@@ -160,32 +162,34 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
     __shared__ float f_score[2 * BEAM_MAX_K], f_cost[2 * BEAM_MAX_K];
     __shared__ int f_pos[2 * BEAM_MAX_K], f_col[2 * BEAM_MAX_K];
     __shared__ int s_ctl[8];
-    __shared__ float s_best;
+    __shared__ double s_best, f_scd[2 * BEAM_MAX_K];
     __shared__ int s_stop, s_bad;
     int* ctl = a.ctl;
     const int tid = threadIdx.x, nt = blockDim.x, K = a.K, V = a.V;
     if (tid < 8) s_ctl[tid] = ctl[tid];
-    if (tid == 8) s_best = a.fctl[0];
+    // best finished score so far: a double in fctl[2..3]; before the first position the caller's float in fctl[0] (1000)
+    if (tid == 8) s_best = ctl[CTL_POS] == 0 ? (double)a.fctl[0] : *(const double*)(a.fctl + 2);
     __syncthreads();
     if (s_ctl[CTL_DONE] != 0) return;
     const int n = s_ctl[CTL_NLIVE], p = s_ctl[CTL_POS];
     int nf = s_ctl[CTL_NFIN];
     for (int i = tid; i < n; i += nt) { s_run[i] = a.running[i]; s_col[i] = a.live_col[i]; }
     // ---- stopping rules of the loop head (search.py:300-330), on the state the previous step left
-    if (a.stop_on == 0) {
+    if (a.stop_on == 0 && n > 0) {          // (an empty beam ends the search BEFORE the list is sorted and cut: search.py:301-302)
         // finished.sort(key=score); del finished[beam_size:] — stable rank sort of the (at most 2K) entries
         for (int i = tid; i < nf; i += nt) {
             f_score[i] = a.fin_score[i]; f_cost[i] = a.fin_cost[i]; f_pos[i] = a.fin_pos[i]; f_col[i] = a.fin_col[i];
+            f_scd[i] = fin_score_of(a, f_cost[i], f_pos[i]);
         }
         __syncthreads();
         for (int i = tid; i < nf; i += nt) {
-            const float sc = f_score[i];
+            const double sc = f_scd[i];
             int rank = 0;
-            for (int j = 0; j < nf; ++j) rank += (f_score[j] < sc) || (f_score[j] == sc && j < i);
+            for (int j = 0; j < nf; ++j) rank += (f_scd[j] < sc) || (f_scd[j] == sc && j < i);
             if (rank < K) {
-                a.fin_score[rank] = sc; a.fin_cost[rank] = f_cost[i]; a.fin_pos[rank] = f_pos[i]; a.fin_col[rank] = f_col[i];
+                a.fin_score[rank] = f_score[i]; a.fin_cost[rank] = f_cost[i]; a.fin_pos[rank] = f_pos[i]; a.fin_col[rank] = f_col[i];
             }
-            if (rank == 0) scal[4] = __float_as_uint(sc);
+            if (rank == 0) scal[4] = i;
         }
         __syncthreads();
         if (nf > K) nf = K;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         if (n == 0) stop = 2;
         else if (a.stop_on == 0) {
             if (nf > 0) {
-                const float leader = __uint_as_float((unsigned)scal[4]);
+                const double leader = f_scd[scal[4]];
                 if (leader < s_best) { s_best = leader; s_ctl[CTL_PATIENCE] = BEAM_PATIENCE; }
                 else if (s_ctl[CTL_PATIENCE] < 0) { s_ctl[CTL_ERR] = 3; stop = 1; }
                 else if (--s_ctl[CTL_PATIENCE] == 0) stop = 1;
@@ -205,8 +209,8 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         } else if (nf >= K) {
             float mn = s_run[0];
             for (int i = 1; i < n; ++i) mn = fminf(mn, s_run[i]);
-            const float bound = mn - (float)(a.char_discount * (double)a.max_length);
-            if (a.fin_score[K - 1] < bound) stop = 1;
+            const double bound = (double)mn - a.char_discount * (double)a.max_length;
+            if (fin_score_of(a, a.fin_cost[K - 1], a.fin_pos[K - 1]) < bound) stop = 1;
         }
         s_stop = stop; s_bad = 0;
     }
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
     if (s_stop) {
         if (tid == 0) {
             ctl[CTL_DONE] = s_stop; ctl[CTL_NFIN] = s_ctl[CTL_NFIN]; ctl[CTL_PATIENCE] = s_ctl[CTL_PATIENCE];
-            ctl[CTL_ERR] = s_ctl[CTL_ERR]; a.fctl[0] = s_best;
+            ctl[CTL_ERR] = s_ctl[CTL_ERR]; a.fctl[0] = (float)s_best; *(double*)(a.fctl + 2) = s_best;
         }
         return;
     }
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
     for (int k = tid; k < nsel; k += nt) {
         const int slot = s_finslot[k];
         if (slot >= 0) {
-            a.fin_pos[slot] = p; a.fin_col[slot] = k; a.fin_cost[slot] = s_cost[k]; a.fin_score[slot] = fin_score_of(a, s_cost[k], p);
+            a.fin_pos[slot] = p; a.fin_col[slot] = k; a.fin_cost[slot] = s_cost[k]; a.fin_score[slot] = (float)fin_score_of(a, s_cost[k], p);
         }
     }
     for (int i = tid; i < K; i += nt) {
@@ -286,7 +290,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         ctl[CTL_ERR] = s_ctl[CTL_ERR];
         ctl[CTL_STEPS] = s_ctl[CTL_STEPS] + 1;
         if (p + 1 >= a.max_length) ctl[CTL_DONE] = 3;
-        a.fctl[0] = s_best;
+        a.fctl[0] = (float)s_best; *(double*)(a.fctl + 2) = s_best;
     }
 }
 

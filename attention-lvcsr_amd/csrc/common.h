@@ -13,6 +13,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void lvsr_set_error(const char* fmt, ...);
 int lvsr_check_launch(const char* what);
+// tuning knobs (include/lvsr_hip.h LVSR_KNOB_*; process-wide, part of every cached graph's key through lvsr_knob_bytes)
+int lvsr_knob(int knob);
+// Largest grid of a persistent cluster launch (its work-groups wait for each other, so all of them must be resident at once, one
+// per CU): the device's CU count minus a reserve of 32 for whatever else is running — 224 on MI355X — unless
+// LVSR_KNOB_MAX_CLUSTER_WGS overrides it.
+int lvsr_max_cluster_wgs();
 
 #define LVSR_REQUIRE(cond, ...)                 \
     do {                                        \

@@ -567,7 +567,7 @@ struct DswSrc {      // A operand of B5: dsW[b][m] = sum over position tiles of 
 // remaining blocks, one per (utterance b, filter k): fold the per-slice dcv partials of row k (stored as DCV[i]
 // for the filter gradient) and correlate with filter k inside the window:
 //   dalp[b,k,t] = sum_d f[k,c+d] * dcv[k,t+d];   the q kernel of the next (earlier) step adds the K rows up.
-__global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i, int ablate) {
+__global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i) {
     __shared__ float row[ATT_MAX_T + ATT_MAX_FW + 272];
     __shared__ float fl[ATT_MAX_FW + 496];
     __shared__ float cpart[4][16][17];
@@ -577,8 +577,6 @@ __global__ __launch_bounds__(256) void attbwd_post_kernel(AttBwd g, int i, int a
     const int ntile = (Tp + ATT_TT - 1) / ATT_TT;
     int blk = blockIdx.x;
     // ablation switch of tools/r2p.sh (LVSR_ATTBWD_POST_ABLATE: 1 skip the state product, 2 the folds, 4 the correlations; wrong results)
-    if (ablate && (((ablate & 1) && blk < nmm) || ((ablate & 2) && blk >= nmm && blk < nmm + (B * M + 255) / 256) ||
-                   ((ablate & 4) && blk >= nmm + (B * M + 255) / 256))) return;
     if (blk < nmm) {
         const int tile = blk % ntD, b0 = (blk / ntD) * 16;
         const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
@@ -741,8 +739,6 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     hipStream_t s = (hipStream_t)stream;
     const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;
     const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, ntile = (a.Tp + ATT_TT - 1) / ATT_TT, nslice = (a.M + ATT_MS - 1) / ATT_MS;
-    const char* abl = getenv("LVSR_ATTBWD_POST_ABLATE");
-    const int ablate = abl ? atoi(abl) : 0;
     auto enqueue = [&]() {
         for (int i = a.L - 1; i >= 0; --i) {
             hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
@@ -760,12 +756,11 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
                 case 3: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<12>, eg, dim3(256), 0, s, g, i); break;
                 default: hipLaunchKernelGGL(attbwd_energy_mfma_kernel<16>, eg, dim3(256), 0, s, g, i); break;
             }
-            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.B * a.M + 255) / 256 + a.B * a.K), dim3(256), 0, s, g, i, ablate);
+            hipLaunchKernelGGL(attbwd_post_kernel, dim3(ntD * rt + (a.B * a.M + 255) / 256 + a.B * a.K), dim3(256), 0, s, g, i);
         }
     };
     GraphKey key("attdec_bwd");
     key.add(&g, sizeof(g));
-    key.add(&ablate, sizeof(ablate));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_bwd");
 }
 

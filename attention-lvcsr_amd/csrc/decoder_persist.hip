@@ -54,7 +54,7 @@ static bool pd_geom(const AttDec& a, PdGeom& g) {
     if (g.KC < 0) return false;
     g.KCP = (g.KC + 3) / 4 * 4;
     g.P = (a.D + PD_UNITS - 1) / PD_UNITS;
-    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > PERSIST_MAX_WG) return false;
+    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > lvsr_max_cluster_wgs()) return false;
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
     g.FW = 2 * a.c + 1;
@@ -78,8 +78,7 @@ static bool pd_geom(const AttDec& a, PdGeom& g) {
     g.o_clk = take(2 * (PD_NPROF + 1));
     g.o_cp = take(PD_NW * 16 * 17);
     g.total = o;
-    const char* env = getenv("LVSR_PD_PROF");          // phase clock of work-group 0 (tools/probe_decoder_persist.py); costs ~1 us per label
-    g.prof = env ? atoi(env) : 0;
+    g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);         // phase clock of work-group 0 (tools/probe_decoder_persist.py); costs ~1 us per label
     return o <= PD_LDS_FLOATS;
 }
 
@@ -286,6 +285,13 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     for (int i = 0; i < L; ++i) {
         const unsigned epoch = (unsigned)(i + 1);
         const size_t row = (size_t)i * B + b;
+        // the per-thread indices are re-derived per label from an opaque copy of the thread id (common.h lvsr_unhoisted): derived
+        // from the loop-invariant one, every address / predicate built on them is hoisted out of the label loop and kept (or
+        // spilled: 16 registers, 68 bytes of scratch per lane) across it
+        const int tid = lvsr_unhoisted((int)threadIdx.x), q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
+        const int j = p * PD_UNITS + jl;
+        const bool junit = j < D;
+        const int mp = tid & (PD_MP - 1), c16 = lane & 15, g4 = lane >> 4;
         // per-label operands that do not depend on the recurrence
         const float* xr = a.xg + row * 3 * D;
         const float fx = junit ? xr[j] : 0.f, fu = junit ? xr[D + j] : 0.f, fr = junit ? xr[2 * D + j] : 0.f;

@@ -9,11 +9,11 @@
 //      glimpse:  q[t] = [dpc|dpu|dpr] . AW[t] + QR[i,t] + dalpha[t]   for the OWN positions (AW rows streamed from L2, fetched
 //                behind exchange B);  C: all-gather q;  sd = sum_t alpha_t q_t;  de = alpha (q - sd)          (softmax backward)
 //   3. energies: own positions x all match columns on the matrix cores (as attbwd_energy_mfma_kernel): match = PA + sW + cv^T H,
-//                dm = de w_e (1 - tanh^2); dPA += dm; dcv = dm H^T (complete: all columns are local); the handler operands are
-//                read from an LDS table, the handler gradient accumulates in LDS (one float4 per wave, tile and lane, over the
-//                whole label loop), the energy-vector gradient in registers; dsW partial over the own positions
+//                dm = de w_e (1 - tanh^2); dPA += dm; dcv = dm H^T (complete: all columns are local); the handler operands
+//                and the handler / energy-vector gradient accumulators (over the whole label loop) are per-lane registers; dsW
+//                partial over the own positions
 //   4. state:    D: reduce-scatter dsW (every work-group publishes 512 partials, gathers the 8 x 64 of its column slice);
-//                its slice's contribution dsW[slice] @ Ws^T[slice] to ALL units (rows of Ws streamed from L2);
+//                its slice's contribution dsW[slice] @ Ws^T[slice] to ALL units (the Ws column slice is LDS resident);
 //                E: reduce-scatter of those (8 x 32 gathered)
 //                ds' = dsacc + sum                                                                     -> next label
 //   5. alignment (off the chain, behind D / E): dalpha'[s] = sum_k sum_{own t} dcv[k][t] f[k][c+t-s] for all s;
@@ -27,13 +27,12 @@
 
 typedef lvsr_attdec_bwd_args AttBwd;
 
-#define PB_HS 529                   // row stride of the handler table in LDS (odd: both operand patterns spread over the banks)
 #define PB_NPLANE_SMALL 3           // A (dpc) | B (dpu, dpr: 2 x 256, packed as 512) | C (q)        : PD_MAXV granules each
 // per work-group planes: D (512) | E (256) | F (512)
 
 struct PbGeom {
-    int P, nown, nownp, KC, KCP, FW, RL, LS, AWL, AWS;
-    int o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_nx, o_ws, o_hs, o_dh, o_aw, o_red, o_clk, prof, total;
+    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS;
+    int o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
 };
 
 static int pb_kc(int K) {
@@ -50,7 +49,7 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     if (g.KC < 0) return false;
     g.KCP = (g.KC + 3) / 4 * 4;
     g.P = (a.D + PD_UNITS - 1) / PD_UNITS;
-    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > PERSIST_MAX_WG) return false;
+    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > lvsr_max_cluster_wgs()) return false;
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
     if (g.nown > 32) return false;            // the q / alignment-gradient phases map one 16-lane group / one granule row per own position
@@ -74,29 +73,16 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.o_r8 = take(8 * 64);
     g.o_r8b = take(8 * 32);
     g.o_dsw = take(64);
-    g.o_nx = take(5 * PD_UNITS);              // saved gate values of the own units for the label about to be processed
-    // Where the handler state lives (LVSR_PBWD_LDS_STATE): 0 = handler operands and handler-gradient accumulators in registers (44
-    // per lane), the transform_states slice in LDS; 1 = operands and accumulators in LDS, transform_states rows streamed from L2
-    const char* ls = getenv("LVSR_PBWD_LDS_STATE");
-    g.LS = ls ? (atoi(ls) != 0) : 0;
-    g.o_ws = g.o_hs = g.o_dh = 0;
-    if (g.LS) {
-        g.o_hs = take((g.KCP > 0 ? g.KCP : 4) * PB_HS);   // handler [KCP][PB_HS]: the MFMA operands of the energy phase are read from here
-        g.o_dh = take(PD_NW * 4 * 64 * 4);                // handler-gradient accumulators: one float4 per (wave, tile, lane)
-    } else {
-        g.o_ws = take(256 * 68);                          // Ws[unit][own column slice] (+4 pad per row)
-    }
+    g.o_ws = take(256 * 68);                              // Ws[unit][own column slice] (+4 pad per row)
     g.o_red = take(2 * PD_NW);
     g.o_clk = take(2 * (PD_NPROF + 1));
-    // the AW rows of the own positions are the same for every label: resident in LDS when they fit beside the rest (LS layouts,
-    // short contexts: 13 x 768 floats at WSJ-base), else streamed from L2 per label (LVSR_PBWD_AW_LDS=0 forces that)
-    const char* al_ = getenv("LVSR_PBWD_AW_LDS");
+    // the AW rows of the own positions are the same for every label: resident in LDS when they fit beside the rest (short
+    // contexts), else streamed from L2 per label
     g.AWS = (3 * a.D + 3) / 4 * 4 + 4;
-    g.AWL = (al_ ? atoi(al_) != 0 : 1) && o + g.nown * g.AWS <= PD_LDS_FLOATS;
+    g.AWL = o + g.nown * g.AWS <= PD_LDS_FLOATS;
     g.o_aw = g.AWL ? take(g.nown * g.AWS) : 0;
     g.total = o;
-    const char* env = getenv("LVSR_PD_PROF");
-    g.prof = env ? atoi(env) : 0;
+    g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);
     return o <= PD_LDS_FLOATS;
 }
 
@@ -107,7 +93,7 @@ __device__ __forceinline__ T pb_ld(const void* sbase, unsigned voff) { return *(
 template <class T>
 __device__ __forceinline__ void pb_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
 
-template <int KC, bool LS>
+template <int KC>
 __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr_attdec_plain w, PbGeom g, u64* planes, int* abort_word) {
     constexpr int KCP = (KC + 3) / 4 * 4;
     constexpr int NS = KCP / 4 > 0 ? KCP / 4 : 1;
@@ -128,11 +114,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const r8 = lds + g.o_r8;       // [8][64]
     float* const r8b = lds + g.o_r8b;     // [8][32]
     float* const dsws = lds + g.o_dsw;    // [64] dsW of the own column slice
-    float* const nx = lds + g.o_nx;       // [5][32] U | R | C | S | dS_readout rows of the own units, staged one label ahead
-    float* const WsL = lds + g.o_ws;      // !LS: [256][68] transform_states rows x the own 64 match columns
-    float* const hs = lds + g.o_hs;       // LS: [KCP][PB_HS] handler (rows >= K and columns >= M zero)
+    float* const WsL = lds + g.o_ws;      // [256][68] transform_states rows x the own 64 match columns
     float* const AWl = lds + g.o_aw;      // AWL: [nown][AWS] rows of AW of the own positions
-    float* const dHs = lds + g.o_dh;      // LS: [PD_NW][4][64] float4: handler-gradient accumulators of (wave, tile, lane)
     float* const red = lds + g.o_red;
     const int P = g.P, nown = g.nown;
     int b, p;
@@ -164,27 +147,25 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         }
     }
     // MFMA operands of the energy phase: this wave's match columns [64 wave, 64 wave + 64) as four 16-column tiles.  The handler
-    // operands and the handler-gradient accumulators are per-lane registers (!LS: 44 on top of the 48 of the state weights) or
-    // live in LDS (LS: hs, dHs)
+    // operands and the handler-gradient accumulators are per-lane registers (44 on top of the 48 of the state weights; keeping
+    // them in LDS instead was measured slower: 35.5 vs 33.4 us per label, profiles/r03_decoder_bwd_persist_probe.txt)
     float Hb[4][NS], Ht[4][4];
     f32x4 dH[4];
     float wet[4], weacc[4], ebacc = 0.f;
 #pragma unroll
     for (int tile = 0; tile < 4; ++tile) {
         const int m = (4 * wave + tile) * 16 + c16;
-        if constexpr (!LS) {
 #pragma unroll
-            for (int sq = 0; sq < NS; ++sq) {
-                const int k = 4 * sq + g4;
-                Hb[tile][sq] = (KC > 0 && k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
-            }
-#pragma unroll
-            for (int sq = 0; sq < 4; ++sq) {
-                const int mm = (4 * wave + tile) * 16 + 4 * sq + g4;
-                Ht[tile][sq] = (KC > 0 && c16 < K && mm < M) ? a.handler[(size_t)c16 * M + mm] : 0.f;
-            }
-            dH[tile] = F32X4_ZERO;
+        for (int sq = 0; sq < NS; ++sq) {
+            const int k = 4 * sq + g4;
+            Hb[tile][sq] = (KC > 0 && k < K && m < M) ? C2 * a.handler[(size_t)k * M + m] : 0.f;
         }
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+            const int mm = (4 * wave + tile) * 16 + 4 * sq + g4;
+            Ht[tile][sq] = (KC > 0 && c16 < K && mm < M) ? a.handler[(size_t)c16 * M + mm] : 0.f;
+        }
+        dH[tile] = F32X4_ZERO;
         wet[tile] = m < M ? a.w_e[m] : 0.f;
         weacc[tile] = 0.f;
     }
@@ -200,14 +181,9 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             const int tl = x / G3, col = x % G3, t = tl * P + p;
             AWl[tl * g.AWS + col] = t < Tp ? w.AW[((size_t)t * B + b) * G3 + col] : 0.f;
         }
-    if constexpr (LS) {
-        if (KC > 0)
-            for (int x = tid; x < K * M; x += PD_THREADS) hs[(x / M) * PB_HS + x % M] = a.handler[x];
-    } else {
-        for (int x = tid; x < 256 * 64; x += PD_THREADS) {
-            const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
-            WsL[kp * 68 + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
-        }
+    for (int x = tid; x < 256 * 64; x += PD_THREADS) {
+        const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
+        WsL[kp * 68 + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
     }
     float dsj = junit ? gb.ds[(size_t)b * D + j] : 0.f;            // running gradient wrt the state (caller: zeros + readout part)
     u64* const gA = planes + (size_t)b * (PB_NPLANE_SMALL * PD_MAXV + (size_t)P * (512 + 256 + 512));
@@ -218,51 +194,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     u64* const gF = gE + (size_t)P * 256;             // [P][512]
     const bool plain = cluster_shares_xcd(gA + 256, P, p, abort_word);     // XCC_ID granules: the unused upper half of plane A (D <= 256)
     __syncthreads();
-    // What a label reads from the forward's saved tensors — the gate values of the own units, the alignment the label produced,
-    // the convolution features of the own positions — is fetched one label ahead by waves 4..7, which poll in none of the
-    // exchanges between the issue (after the partials of exchange E are published) and the commit (before its gather): their
-    // loads queue in front of no sweep, and the label starts from LDS instead of from five dependent trips to L2.  (LS layouts
-    // only: beside the register-resident handler state the compiler has no room for it.)
-    auto pf_issue = [&](int il, int tid, float& pfn, float (&pfa)[2], float (&pfc)[2]) {
-        if (wave < 4) return;
-        const size_t rw = (size_t)il * B + b;
-        // gate values: lanes 0..31 of wave 4 / 5 / 6 / 7 fetch U / R / C / S, lanes 32..63 of wave 4 dS_readout (per-wave uniform
-        // pointers: a per-lane choice among five costs thirty registers)
-        const int x = tid - 256, u = p * PD_UNITS + (tid & 31);
-        const float* srcw = wave == 4 ? a.U : wave == 5 ? a.R : wave == 6 ? a.C : a.S;
-        const float* src = (tid & 32) == 0 ? srcw : wave == 4 ? gb.dS_r : nullptr;
-        pfn = (u < D && src != nullptr) ? src[rw * D + u] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int t = x + 256 * e;
-            pfa[e] = t < Tp ? a.W[((size_t)(il + 1) * B + b) * Tp + t] : 0.f;
-            if (KC > 0) {
-                const int tl = t / K, k = t - tl * K, tt = tl * P + p;
-                pfc[e] = (t < nown * K && tt < Tp) ? a.CV[((rw * K) + k) * Tp + tt] : 0.f;
-            }
-        }
-    };
-    auto pf_commit = [&](int tid, const float pfn, const float (&pfa)[2], const float (&pfc)[2]) {
-        if (wave < 4) return;
-        const int x = tid - 256;
-        if ((tid & 32) == 0) nx[(wave - 4) * PD_UNITS + (tid & 31)] = pfn;
-        else if (wave == 4) nx[4 * PD_UNITS + (tid & 31)] = pfn;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int t = x + 256 * e;
-            if (t < Tp) al[t] = pfa[e];
-            if (KC > 0) {
-                const int tl = t / K, k = t - tl * K;
-                if (t < nown * K) cvs[tl * KCP + k] = pfc[e];
-            }
-        }
-    };
-    if constexpr (LS) {
-        float pfn = 0.f, pfa[2] = {0.f, 0.f}, pfc[2] = {0.f, 0.f};
-        pf_issue(L - 1, tid, pfn, pfa, pfc);
-        pf_commit(tid, pfn, pfa, pfc);
-        __syncthreads();
-    }
     PdClock clk;
     clk.start(g.prof != 0 && blockIdx.x == 0 && tid == 0, lds + g.o_clk);
 
@@ -279,19 +210,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const Win wi = attdec_window(a, i);
         // ---- this label's saved values
         float uu, rr, cc, sp, dsr;
-        if constexpr (LS) {
-            // staged by waves 4..7 during the previous label (pf_issue / pf_commit) together with `al` and `cvs`
-            uu = nx[jl]; rr = nx[PD_UNITS + jl]; cc = nx[2 * PD_UNITS + jl]; sp = nx[3 * PD_UNITS + jl]; dsr = nx[4 * PD_UNITS + jl];
-        } else {
-            uu = junit ? pb_ld<float>(a.U + row * D, jb) : 0.f; rr = junit ? pb_ld<float>(a.R + row * D, jb) : 0.f;
-            cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f; sp = junit ? pb_ld<float>(a.S + row * D, jb) : 0.f;
-            dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * D, jb) : 0.f;
-            for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[((size_t)(i + 1) * B + b) * Tp + t];
-            if (KC > 0) {
-                for (int x = tid; x < nown * K; x += PD_THREADS) {
-                    const int tl = x / K, k = x % K, t = tl * P + p;
-                    cvs[tl * KCP + k] = t < Tp ? a.CV[((row * K) + k) * Tp + t] : 0.f;
-                }
+        uu = junit ? pb_ld<float>(a.U + row * D, jb) : 0.f; rr = junit ? pb_ld<float>(a.R + row * D, jb) : 0.f;
+        cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f; sp = junit ? pb_ld<float>(a.S + row * D, jb) : 0.f;
+        dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * D, jb) : 0.f;
+        for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[((size_t)(i + 1) * B + b) * Tp + t];
+        if (KC > 0) {
+            for (int x = tid; x < nown * K; x += PD_THREADS) {
+                const int tl = x / K, k = x % K, t = tl * P + p;
+                cvs[tl * KCP + k] = t < Tp ? a.CV[((row * K) + k) * Tp + t] : 0.f;
             }
         }
         const float ym = a.ymask ? a.ymask[row] : 1.f;
@@ -473,7 +399,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 if (KC > 0) {
 #pragma unroll
                     for (int sq = 0; sq < NS; ++sq)
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], LS ? C2 * hs[(4 * sq + g4) * PB_HS + m] : Hb[tile][sq], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], Hb[tile][sq], acc, 0, 0, 0);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -491,19 +417,16 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 __builtin_amdgcn_wave_barrier();
                 if (KC > 0) {
                     // dcv[pos][k] += dm[pos][m] handler[k][m];  dH[k][m] += cv[pos][k] dm[pos][m]
-                    f32x4* const dHp = (f32x4*)(dHs + ((wave * 4 + tile) * 64 + lane) * 4);
-                    f32x4 dHt = LS ? *dHp : dH[tile];
-                    const float* const hrow = hs + min(c16, KCP - 1) * PB_HS + (4 * wave + tile) * 16 + g4;
+                    f32x4 dHt = dH[tile];
 #pragma unroll
                     for (int sq = 0; sq < 4; ++sq) {
-                        const float ht = !LS ? Ht[tile][sq] : c16 < KCP ? hrow[4 * sq] : 0.f;
+                        const float ht = Ht[tile][sq];
                         dcva = __builtin_amdgcn_mfma_f32_16x16x4f32(dmw[c16 * 17 + 4 * sq + g4], ht, dcva, 0, 0, 0);
                         const int tlk = min(tl0 + 4 * sq + g4, nown - 1);
                         const float cva = (c16 < KCP && tl0 + 4 * sq + g4 < nown) ? cvs[tlk * KCP + min(c16, KCP - 1)] : 0.f;
                         dHt = __builtin_amdgcn_mfma_f32_16x16x4f32(cva, dmw[(4 * sq + g4) * 17 + c16], dHt, 0, 0, 0);
                     }
-                    if constexpr (LS) *dHp = dHt;
-                    else dH[tile] = dHt;
+                    dH[tile] = dHt;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -564,24 +487,11 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         clk.mark(7);
         {
             // contribution of the own column slice to ALL units: thread (k' = tid / 2, half) takes 32 of the 64 columns
-            // (the rows of transform_states come from L2: 64 KB per work-group and label, fetched here, behind exchange D — issued
-            // earlier they would sit in front of its sweep in the memory pipeline)
             const float4* dv = (const float4*)(dsws + (tid & 1) * 32);
-            const int kq = min(tid >> 1, D - 1), m0 = p * 64 + (tid & 1) * 32;
-            const unsigned wsoff = 4u * (unsigned)(kq * M + (tid & 1) * 32);
             float4 wreg[8];
 #pragma unroll
             for (int x = 0; x < 8; ++x) {
-                if constexpr (!LS) {
-                    wreg[x] = *(const float4*)(WsL + (tid >> 1) * 68 + (tid & 1) * 32 + 4 * x);
-                } else if ((M & 3) == 0) {
-                    wreg[x] = m0 + 4 * x + 3 < M ? pb_ld<float4>(w.Ws + p * 64 + 4 * x, wsoff) : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {                                            // rows not 16-byte aligned: element loads
-                    float e4[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) e4[e] = m0 + 4 * x + e < M ? pb_ld<float>(w.Ws + p * 64 + 4 * x + e, wsoff) : 0.f;
-                    wreg[x] = make_float4(e4[0], e4[1], e4[2], e4[3]);
-                }
+                wreg[x] = *(const float4*)(WsL + (tid >> 1) * 68 + (tid & 1) * 32 + 4 * x);
             }
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
@@ -595,8 +505,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             if ((tid & 1) == 0 && (tid >> 1) < D) granule_store(gE + (size_t)p * 256 + (tid >> 1), epoch, s, plain);
         }
         clk.mark(8);
-        float pfn = 0.f, pfa[2] = {0.f, 0.f}, pfc[2] = {0.f, 0.f};
-        if (LS && i > 0) pf_issue(i - 1, tid, pfn, pfa, pfc);
         // ---- 5. alignment gradient for the previous label, partial over the own positions: behind exchange E
         if (KC > 0 && i > 0) {
             // thread (s = tid % 256 [+256], half = tid / 256): the own positions tl = half, half + 2, ... whose taps reach s
@@ -628,7 +536,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             }
         }
         clk.mark(9);
-        if (LS && i > 0) pf_commit(tid, pfn, pfa, pfc);
         {
             const int src = tid >> 5, uu_ = tid & 31;
             const bool mine = tid < 256 && src < P && p * 32 + uu_ < D;
@@ -672,7 +579,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = 4 * g4 + r;
-                if (k < K && m < M) gb.accH[(prow * K + k) * M + m] = LS ? dHs[((wave * 4 + tile) * 64 + lane) * 4 + r] : dH[tile][r];
+                if (k < K && m < M) gb.accH[(prow * K + k) * M + m] = dH[tile][r];
             }
         }
     }
@@ -709,17 +616,11 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     const size_t bytes = 256 + (size_t)a.B * (PB_NPLANE_SMALL * PD_MAXV + (size_t)g.P * (512 + 256 + 512)) * 8;
     (void)hipMemsetAsync(ws, 0, bytes, s);
     const dim3 grid(a.B * g.P), block(PD_THREADS);
-#define PB_LAUNCH(KC_, LS_) hipLaunchKernelGGL((attdec_pbwd_kernel<KC_, LS_>), grid, block, 0, s, gb, w, g, planes, ab)
-    switch (g.KC * 2 + g.LS) {
-        case 0: PB_LAUNCH(0, false); break;
-        case 1: PB_LAUNCH(0, true); break;
-        case 8: PB_LAUNCH(4, false); break;
-        case 9: PB_LAUNCH(4, true); break;
-        case 20: PB_LAUNCH(10, false); break;
-        case 21: PB_LAUNCH(10, true); break;
-        case 32: PB_LAUNCH(16, false); break;
-        default: PB_LAUNCH(16, true); break;
+    switch (g.KC) {
+        case 0: hipLaunchKernelGGL(attdec_pbwd_kernel<0>, grid, block, 0, s, gb, w, g, planes, ab); break;
+        case 4: hipLaunchKernelGGL(attdec_pbwd_kernel<4>, grid, block, 0, s, gb, w, g, planes, ab); break;
+        case 10: hipLaunchKernelGGL(attdec_pbwd_kernel<10>, grid, block, 0, s, gb, w, g, planes, ab); break;
+        default: hipLaunchKernelGGL(attdec_pbwd_kernel<16>, grid, block, 0, s, gb, w, g, planes, ab); break;
     }
-#undef PB_LAUNCH
     return lvsr_check_launch("lvsr_attdec_bwd_persistent");
 }

@@ -30,7 +30,6 @@
 #include "graph_cache.h"
 #include "lvsr_hip.h"
 #include "persist.h"
-#include <stdlib.h>
 
 typedef lvsr_bigru_fwd_args EncFwd;
 typedef lvsr_bigru_bwd_args EncBwd0;
@@ -147,6 +146,7 @@ __device__ __forceinline__ float pick_row(const float (&s)[RB], int q, int i) {
 }
 
 struct PersistGeom { int KS, KSPLIT, HP, UNITS, P, RB, rt, grid, NTH; long long plane; };
+static int wide_cluster_capacity();      // defined behind the kernels
 // Variant for a hidden size: the smallest padded size HP = KS*KSPLIT >= H among the built ones; RB = the smallest number of
 // utterances per cluster (1, 2, 4, 8) whose grid fits the chip with one work-group per CU.
 static bool persist_geom(int B, int H, PersistGeom& g) {
@@ -156,22 +156,29 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
     else return false;
     g.NTH = 256;
     g.HP = g.KS * g.KSPLIT; g.UNITS = g.NTH / g.KSPLIT; g.P = g.HP / g.UNITS;
-    const char* env = getenv("LVSR_PERSIST_ROWS");
-    const int want = env ? min(8, atoi(env)) : 0;
+    const int want = min(8, lvsr_knob(LVSR_KNOB_PERSIST_ROWS));
     g.RB = 0;
     for (int rb = 1; rb <= 8; rb *= 2) {
         const int rt = (B + rb - 1) / rb;
-        if (2 * rt * g.P <= PERSIST_MAX_WG && rb >= want) { g.RB = rb; break; }
+        if (2 * rt * g.P <= lvsr_max_cluster_wgs() && rb >= want) { g.RB = rb; break; }
     }
     if (!g.RB) return false;
     // One or two utterances per cluster: 512-thread work-groups, two waves per SIMD — half the k-slice per thread (96
     // instead of 192 weight registers), twice the lanes per unit, the same number of work-groups per cluster; 2.03 instead of
     // 2.12 us per step on WSJ-base (the second wave hides the first one's LDS and hand-off latencies; WSJ-base step 21.42 ->
     // 20.79 ms).  1024 threads (four waves, 48 weight registers) were measured too: 26.4 ms — the sweeps and barriers of 16
-    // waves cost more than their latency hiding buys.  LVSR_PERSIST_THREADS=256 brings the one-wave version back.
-    const char* envt = getenv("LVSR_PERSIST_THREADS");
-    if (g.RB <= 2 && !(envt && atoi(envt) == 256)) { g.NTH = 512; g.KS /= 2; g.KSPLIT *= 2; g.UNITS = g.NTH / g.KSPLIT; }
+    // waves cost more than their latency hiding buys.  Knob LVSR_KNOB_PERSIST_THREADS = 256 brings the one-wave version back.
+    if (g.RB <= 2 && lvsr_knob(LVSR_KNOB_PERSIST_THREADS) != 256) { g.NTH = 512; g.KS /= 2; g.KSPLIT *= 2; g.UNITS = g.NTH / g.KSPLIT; }
     g.rt = (B + g.RB - 1) / g.RB;
+    // 128 < H <= 256, one or two utterances per cluster: clusters of 8 work-groups of 32 units (thread = 16 rows of its unit's
+    // columns, 48 weight registers) instead of 4 of 64 — half the LDS operand traffic per CU and contraction (the contractions
+    // are LDS-broadcast bound), twice the CUs: 2.01 / 2.20 instead of 2.13 / 2.38 us per forward / BPTT step of the layer probe,
+    // WSJ-base step 17.5 -> 16.7 ms (profiles/r03_persist_probe_wide.txt).  At B = 16 that is 256 work-groups: the limit is what the
+    // device can hold at once — the occupancy the runtime reports for these kernels (two work-groups per CU) times the CUs,
+    // minus the usual reserve — not one work-group per CU.  PF_NARROW keeps clusters of 4.
+    if (!(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NARROW) && g.NTH == 512 && g.HP == 256 && 2 * g.rt * 8 <= wide_cluster_capacity()) {
+        g.KS = 16; g.KSPLIT = 16; g.UNITS = 32; g.P = 8;
+    }
     g.grid = 2 * g.rt * g.P;
     g.plane = (long long)g.RB * g.HP;
     return true;
@@ -181,7 +188,7 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
 // forward
 // ---------------------------------------------------------------------------------------------------------------
 template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
-__global__ __launch_bounds__(NTH) void enc_pfwd_kernel(EncFwd a, u64* planes, u64* hello, int* abort_word, int flags) {
+__global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfwd_kernel(EncFwd a, u64* planes, u64* hello, int* abort_word, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;     // wave-private operand buffers, see gather_plane
@@ -328,8 +335,10 @@ __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int di
     return a.dy[((size_t)(t / a.sub) * a.B + b) * 2 * a.H + dir * a.H + j];
 }
 
+// (clusters of 8 — KS = 16 — are sized by what the device holds at once, wide_cluster_capacity(): two of their work-groups must fit
+// a CU, i.e. 4 waves per SIMD = at most 128 registers)
 template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
-__global__ __launch_bounds__(NTH) void enc_pbwd_kernel(EncBwd0 a, u64* planes, u64* hello, int* abort_word, float* dh_out, int Bp, int flags) {
+__global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbwd_kernel(EncBwd0 a, u64* planes, u64* hello, int* abort_word, float* dh_out, int Bp, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;
@@ -463,10 +472,24 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
     (dir == 0 ? out_f : out_b)[j] = s;
 }
 
-static int persist_flags() {
-    const char* env = getenv("LVSR_PERSIST_FLAGS");
-    return env ? atoi(env) : 0;
+// How many work-groups of the wide (8 per cluster) kernels the device holds at once: occupancy per CU as the runtime computes it
+// from their registers / LDS (2 on MI355X) x (CUs - reserve); a launch at most this large is resident as a whole, which the
+// clusters' mutual waiting needs.  The forward and BPTT kernels of both row counts are asked; the smallest answer counts.
+static int wide_cluster_capacity() {
+    static int cap = -1;
+    if (cap < 0) {
+        int occ = 1 << 20, n = 0;
+        const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pfwd_kernel<16, 16, 1, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0 &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pfwd_kernel<16, 16, 2, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0 &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pbwd_kernel<16, 16, 1, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0 &&
+                        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pbwd_kernel<16, 16, 2, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0;
+        if (!ok) { (void)hipGetLastError(); occ = 0; }
+        cap = min(occ, 2) * lvsr_max_cluster_wgs();
+    }
+    return cap;
 }
+
+static int persist_flags() { return lvsr_knob(LVSR_KNOB_PERSIST_FLAGS); }
 
 // utterances per cluster the persistent kernels would use for (B,H); 0 = not available
 extern "C" int lvsr_bigru_persist_rows(int B, int H) {
@@ -486,7 +509,9 @@ extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
 template <int KS, int KSPLIT>
 static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, u64* hello, int* ab, int flags) {
     if (g.NTH == 512) {                        // two waves per SIMD: half the k-slice per thread (one or two utterances per cluster)
-        if (g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
+        if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
+        else if (g.P == 8 && g.KS == 16) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
+        else if (g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         else hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         return;
     }
@@ -503,7 +528,9 @@ static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64
 template <int KS, int KSPLIT>
 static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, u64* hello, int* ab, float* dh, int Bp, int flags) {
     if (g.NTH == 512) {
-        if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        else if (g.P == 8 && g.KS == 16) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        else if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         else hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         return;
     }

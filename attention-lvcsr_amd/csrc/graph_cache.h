@@ -4,13 +4,18 @@
 // full argument block; the host side keeps its workspaces stable per shape so replays hit.
 #pragma once
 #include "common.h"
+#include "lvsr_hip.h"
 #include <string.h>
 #include <string>
 #include <vector>
 
 struct GraphKey {
     std::string bytes;
-    explicit GraphKey(const char* tag) : bytes(tag) {}
+    // the tuning knobs select kernel variants, so their values belong to every key: a graph captured under one setting is never
+    // replayed under another
+    explicit GraphKey(const char* tag) : bytes(tag) {
+        for (int k = 0; k < LVSR_KNOB_COUNT; ++k) { const int v = lvsr_knob(k); add(&v, sizeof(v)); }
+    }
     void add(const void* p, size_t n) { bytes.append((const char*)p, n); }
 };
 

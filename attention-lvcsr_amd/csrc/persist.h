@@ -7,7 +7,7 @@ typedef unsigned long long u64;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define PERSIST_SPIN_LIMIT (1u << 21)
-#define PERSIST_MAX_WG 224
+// (how many work-groups a cluster launch may have: lvsr_max_cluster_wgs(), common.h — derived from the device's CU count)
 
 // The work-groups of a cluster are numbered so that they land on ONE XCD (block b runs on XCD b % 8: observed on MI355X,
 // not promised by HIP — nothing depends on it but speed).  Whether they did is CHECKED per launch (cluster_shares_xcd): the
@@ -22,6 +22,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PF_SC1 4
 #define PF_NOWAIT 8      // ablation: take whatever the first sweep returns (wrong results; what the step costs without hand-off waits)
 #define PF_NODOT 16      // ablation: skip the contractions (wrong results; what the hand-offs cost alone)
+#define PF_NARROW 64     // encoder, 128 < H <= 256: clusters of 4 work-groups (64 units each) instead of 8 — see persist_geom
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
                          // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue
 // plain = true: a store without cache-policy bits (wavefront-scope atomic = global_store_dwordx2; NOT a volatile store, which

@@ -26,6 +26,28 @@ int lvsr_check_launch(const char* what) {
     return LVSR_OK;
 }
 
+// ---- tuning knobs ---------------------------------------------------------------------------------
+#include "lvsr_hip.h"
+#include <atomic>
+static std::atomic<int> g_knobs[LVSR_KNOB_COUNT];
+int lvsr_knob(int knob) { return (knob >= 0 && knob < LVSR_KNOB_COUNT) ? g_knobs[knob].load(std::memory_order_relaxed) : 0; }
+int lvsr_max_cluster_wgs() {
+    const int forced = lvsr_knob(LVSR_KNOB_MAX_CLUSTER_WGS);
+    if (forced > 0) return forced;
+    static std::atomic<int> cached{0};
+    int v = cached.load(std::memory_order_relaxed);
+    if (v == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+            (void)hipGetLastError();
+            cus = 256;
+        }
+        v = cus > 64 ? cus - 32 : cus;
+        cached.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
 // ---- graph cache (LRU, bounded) ----------------------------------------------------------------
 namespace {
 struct Entry { hipGraphExec_t exec; std::list<std::string>::iterator it; };
@@ -152,5 +174,11 @@ int lvsr_graph_count(void) {
     return n;
 }
 const char* lvsr_last_error(void) { return g_err; }
+int lvsr_set_knob(int knob, int value) {
+    LVSR_REQUIRE(knob >= 0 && knob < LVSR_KNOB_COUNT, "lvsr_set_knob: unknown knob %d", knob);
+    g_knobs[knob].store(value, std::memory_order_relaxed);
+    return LVSR_OK;
+}
+int lvsr_get_knob(int knob) { return lvsr_knob(knob); }
 int lvsr_abi_version(void) { return 1; }
 }

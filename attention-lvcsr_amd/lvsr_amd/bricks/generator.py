@@ -166,9 +166,9 @@ class SequenceGenerator(object):
     def _persistent_bwd_ws(self, fwd_args):
         """Workspace of the persistent backward kernel, or None (LVSR_DEC_BWD_PERSISTENT=0, outside its limits, or — on the CPU
         emulator — work-groups not run concurrently)."""
-        # Not the default yet: parity-green (tests/test_emu_persistent_decoder.py, tests/test_gpu_properties.py) but at 47 us per
-        # label slower than the four step kernels (34) — its phase profile and what is left to do are in DESIGN.md 3.3c.
-        mode = os.environ.get("LVSR_DEC_BWD_PERSISTENT", "0")
+        # Default since round 3: 33.4 us per label against 41.5 for the four step kernels (profiles/r03_decoder_bwd_persist_probe.txt),
+        # WSJ-base step 18.3 -> 17.4 ms.
+        mode = os.environ.get("LVSR_DEC_BWD_PERSISTENT", "auto")
         if self.use_persistent is False or mode == "0":
             return None
         import ctypes as _ct
@@ -697,9 +697,14 @@ def _beam_methods():
             L["weights_live"].copy_(first["weights"])
             L["add_live"].copy_(first["add"])
         st["on_dev_lm"] = on_dev_lm
+        st["stop_on"] = stop_on
+        # everything the captured launches depend on belongs to the key: the language model's weighting and normalisation flags are
+        # kernel arguments of the readout, its tables and error word are pointers inside the FST walk's argument block
+        lm_key = None if lm is None else (float(lm.lm_weight), float(lm.am_beta), tuple(bool(v) for v in lm.norm), float(getattr(lm, "no_transition_cost", 0.0)))
+        lm_ptrs = () if not on_dev_lm else tuple(sorted((k, t.data_ptr()) for k, t in lm._dev.items())) + (lm._err.data_ptr(),)
         st["key"] = ("beam_step", K, Tp, int(max_length), stop_on, int(bool(ignore_first_eol)), int(eol), float(char_discount),
-                     float(round_to_inf), lm is not None, on_dev_lm)
-        st["volatile"] = (g["A"].data_ptr(), g["PA"].data_ptr(), g["Am"].data_ptr(), ws.generation, id(pk), self.store.version)
+                     float(round_to_inf), lm is not None, on_dev_lm, lm_key)
+        st["volatile"] = (g["A"].data_ptr(), g["PA"].data_ptr(), g["Am"].data_ptr(), ws.generation, id(pk), self.store.version, lm_ptrs)
         self._beam = st
         return st
 

@@ -50,13 +50,17 @@ def validate(recognizer, data, part="valid"):
     for batch in data.get_stream(part, shuffle=False):
         cm = recognizer.cost(recordings=batch["recordings"], inputs_mask=batch["recordings_mask"], labels=batch["labels"],
                              labels_mask=batch["labels_mask"], save_for_backward=False)
-        total += float(cm.sum())
+        total += float(cm.sum())                      # (synchronises)
+        # a persistent cluster that gave up leaves garbage costs, and the next launch's memset would erase its abort word:
+        # check per batch — valid_cost drives the _best_ll checkpoint and the patience stop
+        recognizer.encoder.check_persistent()
+        recognizer.generator.check_persistent()
         count += int(batch["labels"].shape[1])
     return total / max(1, count)
 
 
 def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=None, distributed=None, search_subset=10,
-          resume=False):
+          resume=False, stage=None):
     """One stage.  `config`: a (stage) configuration mapping with `net`, `training`, optional `regularization`,
     `monitoring`, `initialization`; `data`: lvsr_amd.data.Data.  Returns (recognizer, log).
     `resume=True`: `params` is a checkpoint of THIS stage written by an earlier call: besides the parameters, the optimiser
@@ -95,14 +99,20 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
         state = load_member(params, "_training_state") if params else None
         if state is None:
             raise ValueError("resume=True needs a checkpoint with a `_training_state` member (written by this driver)")
+        if stage is not None and "stage" in state and str(state["stage"]) != str(stage):
+            raise ValueError("resume=True: the checkpoint holds the training state of stage %r, not of %r" % (str(state["stage"]), stage))
         trainer.load_state_dict(state)
         iterations, epoch = int(state["iterations_done"]), int(state["epochs_done"])
+        if num_batches and iterations >= num_batches:        # the stage had already finished on its batch budget: nothing left to do
+            return rec, log
         best_ll, best_per, best_epoch = float(state["best_ll"]), float(state["best_per"]), int(state["best_epoch"])
     has_valid = "valid" in data.datasets
     while not done:
         costs = []
         # data parallel: every rank walks the same seeded stream and keeps utterances rank::world of each global minibatch
         for batch in data.get_stream("train", shuffle=True, seed=epoch, rank=rank, world=world):
+            if batch is None:                       # a global minibatch smaller than the world leaves this rank without utterances
+                continue
             gbs = batch.pop("global_batch_size", None)
             cm = trainer.train_step(batch, global_batch_size=gbs)
             iterations += 1
@@ -144,7 +154,8 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                         _save_atomically(rec, root + "_best" + ext)
         if rank == 0:
             _save_atomically(rec, save_path, trainer, dict(iterations_done=iterations, epochs_done=epoch, best_ll=best_ll,
-                                                           best_per=best_per, best_epoch=best_epoch))
+                                                           best_per=best_per, best_epoch=best_epoch,
+                                                           **({} if stage is None else {"stage": str(stage)})))
         barrier()                 # the next stage (any rank) may read the checkpoint as soon as its training returns
         log.append(row)
         if num_epochs and epoch >= num_epochs:
@@ -159,12 +170,16 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
     return rec, log
 
 
-def train_multistage(config, data, save_path, params=None, start_stage=None, **kwargs):
-    """lvsr/main.py:896-922: stages in `number` order; stage k > 0 restarts from `<save_path>/<stage k-1><restart_from>.zip`."""
+def train_multistage(config, data, save_path, params=None, start_stage=None, resume=False, **kwargs):
+    """lvsr/main.py:896-922: stages in `number` order; stage k > 0 restarts from `<save_path>/<stage k-1><restart_from>.zip`.
+    `resume=True` applies to the FIRST stage run only (its `params` is that stage's own checkpoint); later stages start fresh
+    from their predecessor's parameters."""
     if not getattr(config, "multi_stage", False):
-        return train(config, data, save_path, params, **kwargs)
-    if not start_stage and not os.path.isdir(save_path):
-        os.mkdir(save_path)
+        return train(config, data, save_path, params, resume=resume, **kwargs)
+    rank, _, barrier = _dist_state(kwargs.get("distributed"))
+    if not start_stage and rank == 0:
+        os.makedirs(save_path, exist_ok=True)
+    barrier()
     stages = list(config.ordered_stages.items())
     first = list(config.ordered_stages).index(start_stage) if start_stage else 0
     rec, log = None, []
@@ -176,5 +191,5 @@ def train_multistage(config, data, save_path, params=None, start_stage=None, **k
         else:
             stage_params, params = params, None
         log.append(dict(stage=name))
-        rec, log = train(stage_config, data, stage_save_path, stage_params, log=log, **kwargs)
+        rec, log = train(stage_config, data, stage_save_path, stage_params, log=log, resume=resume and number == first, stage=name, **kwargs)
     return rec, log

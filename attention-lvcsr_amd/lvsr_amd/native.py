@@ -140,6 +140,8 @@ class Lib(object):
         self._gstream = None
         self.capturing = False          # inside a Region capture: no host synchronisation, no nested graphs
         self.structs, self.functions = parse_header()
+        self.knobs = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+LVSR_KNOB_(\w+)\s+(\d+)", open(HEADER).read())
+                      if m.group(1) != "COUNT"}
         for name, (res, args, _) in self.functions.items():
             try:
                 fn = getattr(self._dll, name)
@@ -189,6 +191,22 @@ class Lib(object):
 
     def last_error(self):
         return self._lvsr_last_error().decode()
+
+    # ---- tuning knobs (include/lvsr_hip.h LVSR_KNOB_*): kernel-variant switches for probes and A/B measurements ------------
+    def set_knob(self, name, value):
+        """name: 'persist_rows', 'persist_flags', 'persist_threads', 'phase_clock', 'max_cluster_wgs' (or the integer id)."""
+        self.call("lvsr_set_knob", name if isinstance(name, int) else self.knobs[name.upper()], int(value))
+
+    def get_knob(self, name):
+        return int(self._lvsr_get_knob(name if isinstance(name, int) else self.knobs[name.upper()]))
+
+    def knobs_from_env(self, environ=None):
+        """For the tools under tools/: LVSR_KNOB_<NAME>=<int> in the environment -> set_knob.  The library itself never reads
+        the environment and the product never calls this."""
+        environ = os.environ if environ is None else environ
+        for name in self.knobs:
+            v = environ.get("LVSR_KNOB_" + name)
+            self.set_knob(name, int(v) if v not in (None, "") else 0)
 
     # ---- thin typed wrappers -----------------------------------------------------------------
     # ---- grouped weight-gradient products ---------------------------------------------------------

@@ -171,7 +171,10 @@ class BeamSearch(object):
                     add[:n] = lm_states["add"][:n]
                     add[n:] = add[0]
                 st["lm"]["add_live"].copy_(torch.from_numpy(add))
+            # where this position's finished hypotheses will land: in patience mode the kernel first sorts the list and cuts it to K
             nfin_before = int(ctl[CTL["nfin"]])
+            if st["stop_on"] == "patience" and int(ctl[CTL["nlive"]]) > 0:
+                nfin_before = min(nfin_before, K)
             gen.beam_costs()
             gen.beam_select()
             ctl = st["ctl"].cpu().numpy()
@@ -235,7 +238,8 @@ class BeamSearch(object):
             hyps.append((tokens, running))
         # final ranking: cumulative cost minus the discount per row of the cost column; Python's sort is stable, so equal
         # scores keep the order of completion (patience mode: of the truncated, sorted list)
-        hyps.sort(key=lambda h: h[1][-1] - char_discount * len(h[1]))
+        # (float64, as numpy.float32 - Python float was under the numpy the reference was written for, and as csrc/beam.hip ranks)
+        hyps.sort(key=lambda h: float(h[1][-1]) - float(char_discount) * len(h[1]))
         longest = max(len(t) for t, _ in hyps)
         out_tokens = numpy.zeros((longest, len(hyps)))
         out_mask = numpy.zeros((longest, len(hyps)))

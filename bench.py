@@ -38,12 +38,22 @@ def log(*a):
 
 TRAIN_CONF = dict(gradient_threshold=100.0, rules=("momentum", "adadelta"), scale=0.1, momentum=0.0, decay_rate=0.95,
                   epsilon=1e-8, max_norm=1.0)        # exp/wsj/configs/wsj_jan_new.yaml training/regularization sections
-STRONG_GLOBAL_BATCH = {"wsj_base": 128, "wsj_deep": 64, "timit_tiny": 16, "toy": 8}     # configs[2] for wsj_base
+STRONG_GLOBAL_BATCH = {"wsj_base": 128, "wsj_deep": 64, "timit_tiny": 16}     # configs[2] for wsj_base
 TRAIN_FLOP_PER_FRAME = {"wsj_base": 22.730e6, "wsj_deep": 143.43e6, "timit_tiny": 1.382e6}
 PEAK_FP32_MFMA = 157.3          # TFLOP/s dense fp32 matrix (MI355X_MICROARCH.md)
-# Test hook (tests/test_bench_launch.py): run the launcher / sharding / JSON plumbing on CPU ranks over gloo with the kernel
-# sources on the fiber emulator (tests/hipemu) and a toy network.  Never set on a GPU box.
-EMULATED = os.environ.get("LVSR_BENCH_EMU") == "1"
+
+
+class GpuBackend(object):
+    """Where the benchmark runs: one MI355X per rank, RCCL between ranks.  (tests/bench_cpu_launch.py passes a CPU stand-in to
+    main() to exercise the launcher / sharding / JSON plumbing without a GPU; bench.py itself knows no other backend.)"""
+    measured = True             # the roofline / cpu_baseline / decode legs run
+    collective = "nccl"
+    workloads = {}              # extra workloads (name -> (factory, B, T, L))
+
+    def open(self, local_rank):
+        assert torch.cuda.is_available(), "bench.py needs an MI355X"
+        torch.cuda.set_device(local_rank)
+        return torch.device("cuda", local_rank), None
 
 
 def _free_port():
@@ -57,18 +67,12 @@ def _free_port():
 def respawn_under_torchrun(n):
     """`python bench.py --gpus N` as the driver calls it: become N ranks of one node (one process per GPU)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(_free_port()), os.path.abspath(sys.argv[0])] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     log("bench: launching %d ranks: %s" % (n, " ".join(cmd)))
     return subprocess.call(cmd, env=env)
-
-
-def toy_config():
-    return dict(input_dim=5, num_phonemes=6, dims_bidir=[3, 3], subsample=[1, 2], dim_dec=4, dim_matcher=7,
-                attention_type="content_and_conv", conv_n=2, conv_num_filters=3, post_merge_dims=[8],
-                post_merge_activation="maxout2", embed_outputs=False, data_prepend_eos=False)
 
 
 def dominant_kernel_probe(rec, dims, T, B):
@@ -106,8 +110,9 @@ def dominant_kernel_probe(rec, dims, T, B):
     avg = sorted(times[1:])[len(times[1:]) // 2]
     # algorithmic HBM bytes of one launch: reads of u, r, c, y (+ dy), writes of dxg, the recurrent weights once
     per_step = B * 2 * H * 4 * (4 + 1 + 3)
-    abytes = per_step * T + 2 * 3 * H * H * 4 if sync is not None else per_step + 2 * H * H * 4
-    return dict(kernel=name, launch_s=avg, flops=flops, steps_per_launch=(T if sync is not None else 1), algorithmic_bytes=abytes)
+    abytes = (lambda t: per_step * t + 2 * 3 * H * H * 4) if sync is not None else (lambda t: per_step + 2 * H * H * 4)
+    return dict(kernel=name, launch_s=avg, flops=flops, steps_per_launch=(T if sync is not None else 1), algorithmic_bytes=abytes(T),
+                algorithmic_bytes_at=abytes)
 
 
 def gemm_probe(rec, dims, T, B):
@@ -130,18 +135,50 @@ def gemm_probe(rec, dims, T, B):
     return dict(kernel="lvsr_sgemm128_kernel", shape=[M, N, K], launch_us=sec * 1e6, achieved=2.0 * M * N * K / sec / 1e12, unit="TFLOP/s")
 
 
+PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc_bench.json")
+
+
+def csrc_sha():
+    import hashlib
+    csrc = os.path.join(REPO, "attention-lvcsr_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_record(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over THIS benchmark's step
-    (profiles/r02_pmc_bench.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B coalesced reads).  None when no record exists."""
-    path = os.path.join(REPO, "profiles", "r02_pmc_bench.json")
-    if not os.path.exists(path):
-        return None
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes over THIS benchmark's step (PMC_FILE, written
+    by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes).
+    The record carries a hash of the kernel sources it was measured on: -> (record, None), or (None, why) when there is no
+    record or the sources have changed since (a stale traffic figure is not printed)."""
+    if not os.path.exists(PMC_FILE):
+        return None, "no PMC record (%s)" % os.path.basename(PMC_FILE)
     try:
-        rec = json.load(open(path)).get(kernel)
-    except Exception:
-        return None
-    return rec
+        doc = json.load(open(PMC_FILE))
+    except Exception as exc:
+        return None, "unreadable PMC record: %s" % exc
+    stamp = (doc.get("__stamp__") or {}).get("csrc_sha256")
+    if stamp != csrc_sha():
+        return None, "PMC record is stale: taken on kernel sources %s, this run has %s" % (stamp, csrc_sha())
+    rec = doc.get(kernel)
+    return (rec, None) if rec else (None, "kernel %s not in the PMC record" % kernel)
+
+
+def decode_leg(dev, utterances, streams=8):
+    """configs[4] in the default line: a bounded sample of the decode workload (`--workload wsj_decode` runs all 1000 utterances) —
+    beam 16 + char-trigram FST LM on the device, window_around_median(10, 100), exp/wsj/decode.sh settings, 800-frame synthetic
+    utterances, `streams` searches in flight on one GPU (tools/bench_decode.py)."""
+    from tools.bench_decode import build, run_concurrent
+    recs = [build(dev, 16)[0] for _ in range(streams)]
+    sec, done, nframes, chars, steps = run_concurrent(recs, utterances, 800)
+    return dict(workload="wsj_decode sample: %d of the 1000 synthetic 800-frame utterances, WSJ-base weights, beam 16, device FST LM "
+                         "(weight 0.5, no_transition_cost 20), char_discount 1.0, max length T/3" % done,
+                utterances=done, ms_per_utterance=sec / done * 1e3, utterances_per_s=done / sec, frames_per_s=nframes / sec,
+                searches_in_flight=streams, positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1),
+                mean_best_hypothesis_length=chars / max(done, 1),
+                parity="tests/test_decode_golden.py::test_full_size_wsj_decode_matches_the_reference_gpu (reference-generated golden)")
 
 
 def cpu_baseline(cfg, params, B, T, L, workload):
@@ -175,7 +212,8 @@ def cpu_baseline(cfg, params, B, T, L, workload):
     return out
 
 
-def main():
+def main(backend=None):
+    backend = backend or GpuBackend()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -184,6 +222,10 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (weak) / global batch (strong) override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (configs[4] sample) of the default line")
+    ap.add_argument("--decode-utterances", type=int, default=32)
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
+                    help="tuning knob of the library (include/lvsr_hip.h LVSR_KNOB_*), for A/B measurements; recorded in config.knobs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (RCCL) even with one rank")
     ap.add_argument("--ragged", action="store_true",
@@ -207,51 +249,49 @@ def main():
     if args.workload == "wsj_decode":
         from tools.bench_decode import decode_bench
         return decode_bench(args, rank, world, local_rank, json_out)
-    if EMULATED:
-        sys.path.insert(0, os.path.join(REPO, "tests"))
-        from emu import emu_lib
-        dev, lib, backend = torch.device("cpu"), emu_lib(), "gloo"
-    else:
-        assert torch.cuda.is_available(), "bench.py needs an MI355X"
-        torch.cuda.set_device(local_rank)
-        dev, lib, backend = torch.device("cuda", local_rank), None, "nccl"
+    dev, lib = backend.open(local_rank)
     dist = world > 1 or args.force_dist
     if dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500))
-        kw = dict(device_id=dev) if backend == "nccl" else {}
-        torch.distributed.init_process_group(backend, rank=rank, world_size=world, **kw)
+        kw = dict(device_id=dev) if backend.collective == "nccl" else {}
+        torch.distributed.init_process_group(backend.collective, rank=rank, world_size=world, **kw)
 
     from lvsr_amd import spec, synthetic
     from lvsr_amd.bricks.recognizer import SpeechRecognizer
     from lvsr_amd.training import Trainer
 
-    if args.workload == "toy":
-        assert EMULATED, "the toy workload exists for the CPU launch test only"
-        factory, B0, T, L = toy_config, 4, 13, 5
-    else:
-        factory, B0, T, L = spec.WORKLOADS[args.workload]
+    factory, B0, T, L = backend.workloads[args.workload] if args.workload in backend.workloads else spec.WORKLOADS[args.workload]
     cfg = factory()
     dims = spec.Dims(cfg)
     if args.scaling == "weak":
         B = args.batch or B0
         global_batch = B * world
     else:
-        global_batch = args.batch or STRONG_GLOBAL_BATCH[args.workload]
+        global_batch = args.batch or STRONG_GLOBAL_BATCH.get(args.workload, 2 * B0)
         if global_batch % world:
             raise SystemExit("strong scaling: the global batch %d does not divide over %d ranks" % (global_batch, world))
         B = global_batch // world
     params = synthetic.make_params(cfg, seed=10)
     rec = SpeechRecognizer(device=dev, params=params, lib=lib, net_config=cfg, use_graph=not args.no_graph)
+    knobs = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.knob}
+    for k, v in knobs.items():
+        rec.lib.set_knob(k, v)
     trainer = Trainer(rec, distributed=dist, **TRAIN_CONF)
     nsteps = args.steps + args.warmup
-    # synthetic global batches, seeded identically on every rank; rank r keeps utterances r::world; staged in HBM
+    # synthetic global batches, seeded identically on every rank; rank r keeps utterances r::world.  `value` is measured with the
+    # minibatches resident in HBM (the bench contract); the same K steps are then repeated with the minibatches waiting in PINNED
+    # HOST memory and copied per step (four asynchronous copies on the recognizer's stream in front of the step's graph): the
+    # H2D-inclusive step of SURVEY.md 8(d), reported beside it as config.with_h2d.
     nstage = min(nsteps, 4)
-    staged = []
+    staged, staged_host = [], []
     for s in range(nstage):
         gb = synthetic.make_batch(cfg, global_batch, T, L, seed=1234 + s, ragged=args.ragged)
         sh = synthetic.shard_batch(gb, rank, world)
         staged.append({k: torch.from_numpy(v).to(dev) for k, v in sh.items()})
+        if dev.type == "cuda":
+            staged_host.append({k: torch.from_numpy(v).pin_memory() for k, v in sh.items()})
+    h2d_bytes = sum(v.numel() * v.element_size() for v in staged[0].values())
     # real (unpadded) frames per step over all ranks: every rank holds global_batch/world utterances of the same lengths
     # distribution; with the default all-ones masks this is exactly global_batch*T
     frames_local = float(sum(float(b["recordings_mask"].sum()) for b in staged)) / len(staged)
@@ -273,7 +313,7 @@ def main():
     sync()
     # setup, not warm-up: the first step of a shape allocates the workspaces, the second captures the whole-step hipGraph
     # (lvsr_amd.native.Region); whatever --warmup says, the timed steps are replays.  Reported as config.priming_steps.
-    PRIME = 2 if (not args.no_graph and not EMULATED) else 0
+    PRIME = 2 if (not args.no_graph and backend.measured) else 0
     for s in range(PRIME):
         trainer.train_step(staged[s % nstage], global_batch_size=global_batch)
     for s in range(args.warmup):
@@ -282,12 +322,34 @@ def main():
     barrier()
     sync()
     t0 = time.perf_counter()
+    marks = [t0]
     for s in range(args.steps):
         cm = trainer.train_step(staged[(args.warmup + s) % nstage], global_batch_size=global_batch)
+        marks.append(time.perf_counter())       # host clock when the step's call returned (the whole-step graph blocks the host)
     sync()
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    marks[-1] = t0 + elapsed
+    per_step = sorted((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
+    ms_median = per_step[len(per_step) // 2] if len(per_step) % 2 else 0.5 * (per_step[len(per_step) // 2 - 1] + per_step[len(per_step) // 2])
+    with_h2d = None
+    if staged_host:
+        trainer.train_step(staged_host[0], global_batch_size=global_batch)
+        sync()
+        barrier()
+        th = time.perf_counter()
+        for s in range(args.steps):
+            cm = trainer.train_step(staged_host[(args.warmup + s) % nstage], global_batch_size=global_batch)
+        sync()
+        barrier()
+        eh = time.perf_counter() - th
+        if dist:
+            t = torch.tensor([eh], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            eh = float(t[0])
+        with_h2d = dict(ms_per_step=eh / args.steps * 1e3, bytes_per_step=h2d_bytes,
+                        how="minibatch copied per step from pinned host memory on the compute stream, not overlapped")
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -316,7 +378,8 @@ def main():
 
     if rank == 0:
         out = dict(metric="encoder+attention+decoder training frames/sec (whole node)", value=value, unit="frames/s",
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, higher_is_better=True,
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms, ms_per_step_median=ms_median,
+                   higher_is_better=True,
                    scaling=args.scaling, vs_baseline=None, dtype="f32", data="synthetic",
                    config=dict(workload="%s: B=%d utterances x T=%d frames x F=%d fbank per GPU, L=%d labels; %s" % (
                        args.workload, B, T, dims.F, L, "x".join(str(h) for h in dims.Hs) + " BiGRU subsample " +
@@ -325,34 +388,48 @@ def main():
                        ragged=bool(args.ragged), parallelism="dp%d" % world, optimizer="clip100+adadelta+maxnorm1",
                        hip_graph=not args.no_graph, priming_steps=PRIME,
                        encoder_kernels=("persistent clusters" if rec.encoder._sync_ws(0, B, dims.Hs[0]) is not None else "step kernels"),
-                       h2d="excluded: minibatches are resident in HBM when the timed region starts (2.1 MB per WSJ-base batch, "
-                           "~35 us at PCIe rate)",
-                       final_cost_per_utterance=last_cost / B))
+                       h2d="value: minibatches resident in HBM when the timed region starts (bench contract); with_h2d: the same steps fed from pinned host memory",
+                       with_h2d=(dict(with_h2d, value=frames_per_step / (with_h2d["ms_per_step"] * 1e-3)) if with_h2d else None),
+                       value_is="steps * frames_per_step / wall time of the K steps (mean); ms_per_step_median = median of the per-step host intervals",
+                       final_cost_per_utterance=last_cost / B, knobs=knobs))
         if dist:
             out["config"].update(collective_backend=torch.distributed.get_backend(), collective_world_size=torch.distributed.get_world_size(),
                                  allreduce_ms=allreduce_ms, allreduce_bytes=int(rec.store.grad.numel()) * 4,
                                  whole_step_graph_region=bool(trainer.dp_region))
-        if not EMULATED:
+        if backend.measured:
             pr = dominant_kernel_probe(rec, dims, T, B)
             ach = pr["flops"] / pr["launch_s"] / 1e12
-            pmc = pmc_record(pr["kernel"] + "@%s" % args.workload) if B == B0 else None
+            pmc, pmc_why = pmc_record(pr["kernel"] + "@%s" % args.workload) if B == B0 else (None, "PMC record is for the default per-GPU batch")
+            # the PMC figure is the mean over the launches of ALL layers; their time steps differ (subsampling): price the
+            # algorithmic bytes at the mean number of steps per launch, not at layer 0's
+            layer_T, t_ = [], T
+            for sub in dims.subsample:
+                layer_T.append(t_)
+                t_ = (t_ + sub - 1) // sub
+            mean_T = sum(layer_T) / float(len(layer_T))
             roof = dict(bound="mfma", kernel=pr["kernel"], achieved=ach, peak=PEAK_FP32_MFMA, unit="TFLOP/s", frac=ach / PEAK_FP32_MFMA,
                         traffic=(pmc["hbm_bytes_per_launch"] if pmc else None), launch_us=pr["launch_s"] * 1e6,
                         us_per_recurrent_step=pr["launch_s"] * 1e6 / pr["steps_per_launch"], flops_per_launch=pr["flops"],
                         algorithmic_bytes_per_launch=pr["algorithmic_bytes"],
-                        frac_source="HIP events around the kernel on the recognizer's stream inside this run (rocprofv3 agrees: "
-                                    "profiles/r02_bench_wsj_base_kernel_stats.md)",
+                        frac_source="HIP events around the kernel on the recognizer's stream inside this run (layer 0, T steps; rocprofv3 "
+                                    "of the same command: profiles/r03_bench_wsj_base_kernel_stats.md)",
                         note="latency bound by construction: a chain of T dependent GRU steps, two cluster-wide exchanges each; the "
                              "contraction runs on the VALU (GEMV per utterance), formally priced against the fp32 MFMA peak")
             if pmc:
-                roof.update(traffic_source=pmc.get("source"), traffic_over_algorithmic=pmc["hbm_bytes_per_launch"] / pr["algorithmic_bytes"],
+                roof.update(traffic_source=pmc.get("source"), traffic_steps_per_launch=mean_T,
+                            traffic_algorithmic_bytes=pr["algorithmic_bytes_at"](mean_T),
+                            traffic_over_algorithmic=pmc["hbm_bytes_per_launch"] / pr["algorithmic_bytes_at"](mean_T),
                             mfma_busy=pmc.get("mfma_busy"), valu_busy=pmc.get("valu_busy"))
+            else:
+                roof["traffic_note"] = pmc_why
             if args.workload in TRAIN_FLOP_PER_FRAME:
                 tf = value / world * TRAIN_FLOP_PER_FRAME[args.workload] / 1e12
                 roof.update(whole_step_tflops=tf, whole_step_frac=tf / PEAK_FP32_MFMA)
             roof["dense_gemm"] = gemm_probe(rec, dims, T, B)
             roof["dense_gemm"]["frac"] = roof["dense_gemm"]["achieved"] / PEAK_FP32_MFMA
             out["roofline"] = roof
+            if world == 1 and not args.no_decode and args.workload == "wsj_base":
+                out["decode"] = decode_leg(dev, args.decode_utterances)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg, params, B0, T, L, args.workload)
         print(json.dumps(out), file=json_out, flush=True)

@@ -38,6 +38,17 @@ int lvsr_graph_count(void);
 void lvsr_graph_suppress(int on);   /* 1: use_graph arguments are ignored (eager launches, nothing cached) until switched off */
 int lvsr_region_begin(void* stream, const char* key, long long key_bytes);
 int lvsr_region_end(void* stream, int keep);
+/* Tuning knobs: process-wide integers that select kernel variants for probing and A/B measurements (tools/probe_*.py).  The
+ * defaults (all 0) are the benchmarked configuration; the library never reads the environment.  Knob values are part of the
+ * key of every cached graph, so a graph captured under one setting is not replayed under another. */
+#define LVSR_KNOB_PERSIST_ROWS 0      /* utterances per encoder cluster: 0 = the smallest number whose grid fits the chip; 1, 2, 4, 8 = at least that */
+#define LVSR_KNOB_PERSIST_FLAGS 1     /* experiment bits of csrc/persist.h (PF_*): 1 no saved tensors, 2 clusters spread over XCDs, 4 write-through publish, 64 clusters of 4, ... */
+#define LVSR_KNOB_PERSIST_THREADS 2   /* 0 = 512-thread work-groups when a cluster serves <= 2 utterances; 256 = always 256 */
+#define LVSR_KNOB_PHASE_CLOCK 3       /* 1 = work-group 0 of the persistent decoder kernels leaves per-phase times in the workspace header */
+#define LVSR_KNOB_MAX_CLUSTER_WGS 4   /* 0 = device CU count - 32 (224 on MI355X); else the largest grid a cluster launch may have */
+#define LVSR_KNOB_COUNT 5
+int lvsr_set_knob(int knob, int value);
+int lvsr_get_knob(int knob);
 
 /* ---- dense helpers (Linear bricks: libs/blocks/blocks/bricks/simple.py:59-76) ------------------ */
 /* C[M,N] = alpha*op(A)[M,K]*op(B)[K,N] + beta*C + bias[N]; fp32 MFMA; ws: optional split-K workspace */
@@ -327,7 +338,8 @@ int lvsr_softmax_emit(void* stream, const float* logits, int ld, const float* un
  *   ctl[0] live hypotheses, [1] position, [2] done (0 running, 1 stopping rule, 2 beam empty, 3 max_length), [3] finished
  *   hypotheses, [4] patience left (-1 = unassigned), [5] rows selected by the last step, [6] error (1 non-finite step cost,
  *   2 finished list full, 3 patience used before assignment = the reference's UnboundLocalError), [7] steps executed;
- *   fctl[0] best finished score seen (patience rule; the caller initialises it to 1000).
+ *   fctl[0] best finished score seen (patience rule; the caller initialises it to 1000), fctl[2..3] the same as a double
+ *   (maintained by the kernel; scores are compared in double like the reference's float32 - Python-float arithmetic).
  * The caller zeroes ctl (ctl[0] = 1, ctl[4] = -1), running[0] = 0, live_col[0] = 0 and fills row 0 of the live buffers. */
 typedef struct lvsr_beam_args {
     int K, V, eol, ignore_first_eol;      /* beam size, characters, <eol> label, keep <eol> hypotheses alive at position 0 */

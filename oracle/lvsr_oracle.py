@@ -378,10 +378,10 @@ class OracleRecognizer(object):
             if states["states"].numel() == 0:
                 break
             if stop_on == "patience":
-                done = sorted(done, key=lambda z: z[1][-1] - char_discount * len(z[1]))
+                done = sorted(done, key=lambda z: float(z[1][-1]) - float(char_discount) * len(z[1]))
                 done = done[:beam_size]
                 if done:
-                    cur = done[0][1][-1] - char_discount * len(done[0][1])
+                    cur = float(done[0][1][-1]) - float(char_discount) * len(done[0][1])
                     if cur < min_cost:
                         min_cost = cur
                         patience = 30
@@ -391,9 +391,9 @@ class OracleRecognizer(object):
                             break
             elif stop_on == "optimistic_future_cost":
                 if len(done) >= beam_size:
-                    optimistic = all_costs[-1, :].min() - char_discount * max_length
+                    optimistic = float(all_costs[-1, :].min()) - float(char_discount) * max_length
                     last = done[beam_size - 1][1]
-                    if last[-1] - char_discount * len(last) < optimistic:
+                    if float(last[-1]) - float(char_discount) * len(last) < optimistic:
                         break
             else:
                 raise ValueError("Unknown stopping criterion {}".format(stop_on))
@@ -424,7 +424,7 @@ class OracleRecognizer(object):
             all_costs = numpy.take(all_costs, unfinished, axis=1)
         if not done:
             raise LookupError("CandidateNotFoundError")
-        done = sorted(done, key=lambda z: z[1][-1] - char_discount * len(z[1]))
+        done = sorted(done, key=lambda z: float(z[1][-1]) - float(char_discount) * len(z[1]))
         outs = [[int(t) for t in seq[1:]] for seq, _ in done]
         # search.py:384-407: per-step cost differences of the padded float64 arrays, summed per hypothesis
         costs = [float(numpy.sum(numpy.diff(c.astype(numpy.float64)))) for _, c in done]

@@ -369,6 +369,15 @@ CASES = {
     "mid_conv_median": lambda: run_case(
         "mid_conv_median", mid_cfg(dict(type="window_around_median", before=10, after=100)),
         B=3, T=300, L=20, ragged=True, param_seed=51, batch_seed=52, scale=2.0),
+    # configs[4] at FULL size: the WSJ-base network (4x256 BiGRU, D = 256, M = 512, 10 filters of 201 taps, T = 800 -> T' = 200),
+    # beam 16, window_around_median(10, 100), FST LM, exp/wsj/decode.sh:12-25 settings.  Scale 2.0 chosen with
+    # tools/probes/wsj_decode_conditioning.py: the float32 and float64 oracles agree on the first 6-7 ranked hypotheses (up to 18
+    # characters) there; at scale 1.0 only two hypotheses ever finish
+    "wsj_decode_full": lambda: run_lm_case(
+        "wsj_decode_full", dict(spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100)),
+                                max_decoded_length_scale=3.0), T=800,
+        param_seed=10, fst_seed=9, scale=2.0, utterances=2, lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
+        beams=[dict(beam_size=16, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")]),
     "tiny_conv_generate": lambda: run_generate_case(
         "tiny_conv_generate", tiny_cfg(dict(type="window_around_median", before=1, after=2)), B=3, T=13, n_steps=7,
         param_seed=3, batch_seed=13, scale=2.0),
@@ -386,6 +395,6 @@ CASES = {
 }
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "mid_conv_lm_decode")]
+    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "mid_conv_lm_decode", "wsj_decode_full")]
     for k in which:
         CASES[k]()

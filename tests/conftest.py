@@ -49,4 +49,8 @@ def gpu_device():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    # A/B runs of the GPU suite under a kernel variant: LVSR_KNOB_<NAME>=<int> (tools/r3*.sh); nothing set = the defaults
+    if any(k.startswith("LVSR_KNOB_") for k in os.environ):
+        from lvsr_amd import native
+        native.get().knobs_from_env()
     return torch.device("cuda:0")

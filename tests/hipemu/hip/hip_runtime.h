@@ -375,3 +375,7 @@ inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorUnknown; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+template <class K> inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, size_t) { *n = 2; return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }      // an MI355X's CU count

@@ -1,7 +1,7 @@
 """bench.py's multi-rank plumbing on CPU: `python bench.py --gpus 2` (as the driver calls it, no torchrun environment)
-re-launches itself as two ranks; LVSR_BENCH_EMU=1 swaps the GPU for gloo + the fiber emulator and a toy network, so the
-launcher, the r::world sharding, weak/strong batch arithmetic, the single all-reduce and the JSON contract are exercised
-without a GPU.  Numbers are meaningless here; the fields are not."""
+re-launches itself as two ranks; tests/bench_cpu_launch.py calls bench.main() with a stand-in backend (gloo + the fiber emulator
+and a toy network), so the launcher, the r::world sharding, weak/strong batch arithmetic, the single all-reduce and the JSON
+contract are exercised without a GPU.  Numbers are meaningless here; the fields are not."""
 import json
 import os
 import subprocess
@@ -13,10 +13,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*flags):
-    env = dict(os.environ, LVSR_BENCH_EMU="1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "toy", "--steps", "2", "--warmup", "1"] + list(flags),
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tests", "bench_cpu_launch.py"), "--workload", "toy", "--steps", "2", "--warmup", "1"] + list(flags),
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -134,3 +134,32 @@ def test_validate_solution_function_vetoes_finished_hypotheses():
     best = outs[0]
     outs2, _ = rec.beam_search({"recordings": x}, validate_solution_function=lambda inp, toks: list(toks[1:]) != best, **s)
     assert best not in outs2 and len(outs2) > 0                 # the search goes on without it (other hypotheses may appear)
+
+
+def test_validator_sees_every_finished_hypothesis_once_the_patience_list_was_cut():
+    """stop_on='patience' sorts the finished list and cuts it to beam_size BEFORE each position (search.py:306-309), so once more
+    than beam_size hypotheses have finished the new ones land at slot beam_size, not behind the previous count: the validator must
+    still see every one of them (search.py:372-374) and vetoed ones must not come back.  Compared with the oracle's host search
+    under the same validator."""
+    import torch
+    from oracle import lvsr_oracle as O
+    z, meta = load_golden("tiny_conv_nowindow")
+    cfg = dict(meta["cfg"], max_decoded_length_scale=1.0)
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(cfg, meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    x = batch["recordings"][: int(batch["recordings_mask"][:, 0].sum()), 0]
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
+    rec.init_beam_search(2)
+    kw = dict(char_discount=0.0, round_to_inf=1e9, stop_on="patience")
+    seen = []
+
+    def validate(inputs, tokens):               # veto every hypothesis with an even number of tokens
+        seen.append([int(t) for t in tokens])
+        return len(tokens) % 2 == 1
+    outs, costs = rec.beam_search({"recordings": x}, validate_solution_function=validate, **kw)
+    seen_dev, seen[:] = list(seen), []
+    ref_outs, ref_costs = O.OracleRecognizer(cfg, params, dtype=torch.float32).beam_search(x, 2, validate_solution_function=validate, **kw)
+    assert len(seen_dev) > 2, "the scenario needs more than beam_size finished hypotheses"
+    assert seen_dev == seen                                       # the same hypotheses were shown to the validator, in the same order
+    assert outs == ref_outs and all(len(o) % 2 == 0 for o in outs)          # (+1 initial pseudo-token = odd length as the validator counts)
+    assert_allclose(costs, ref_costs, rtol=2e-5, atol=2e-5)

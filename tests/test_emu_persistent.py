@@ -19,17 +19,13 @@ from lvsr_amd.params import ParameterStore, Workspace
 def concurrent_lib(request):
     lib = emu_lib()
     lib._dll.hipemu_set_concurrent(1)
-    old = os.environ.get("LVSR_PERSIST_ROWS")
     # utterances per cluster (1, 2, 4 or 8): decides how many work-groups (OS threads here) a launch has
-    os.environ["LVSR_PERSIST_ROWS"] = str(request.node.callspec.params.get("rows", 8))
+    lib.set_knob("persist_rows", request.node.callspec.params.get("rows", 8))
     try:
         yield lib
     finally:
         lib._dll.hipemu_set_concurrent(0)
-        if old is None:
-            os.environ.pop("LVSR_PERSIST_ROWS", None)
-        else:
-            os.environ["LVSR_PERSIST_ROWS"] = old
+        lib.set_knob("persist_rows", 0)
 
 
 # H <= 128: one work-group per cluster (no exchange); 128 < H <= 256: 4 work-groups exchange the phase vectors;

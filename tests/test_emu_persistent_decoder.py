@@ -68,11 +68,8 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
 
 # the backward kernel's filter-count instantiations (K <= 4 / 10 / 16) and matcher widths that are / are not a multiple of 4
 # (16-byte vs element loads of the transform_states rows), clusters of one and two work-groups
-# ... and both placements of the handler state (LVSR_PBWD_LDS_STATE: registers + transform_states slice in LDS | LDS + rows from L2)
-@pytest.mark.parametrize("K,M,D,ls", [(5, 12, 8, 0), (5, 12, 8, 1), (7, 10, 36, 1), (3, 7, 36, 0),
-                                      pytest.param(12, 9, 8, 0, marks=pytest.mark.slow), pytest.param(12, 9, 8, 1, marks=pytest.mark.slow)])
-def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, monkeypatch, K, M, D, ls):
-    monkeypatch.setenv("LVSR_PBWD_LDS_STATE", str(ls))
+@pytest.mark.parametrize("K,M,D", [(5, 12, 8), (7, 10, 36), (3, 7, 36), pytest.param(12, 9, 8, marks=pytest.mark.slow)])
+def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K, M, D):
     _, meta = load_golden("tiny_conv_median")
     cfg = dict(meta["cfg"])
     cfg.update(conv_num_filters=K, dim_matcher=M, dim_dec=D)

@@ -83,12 +83,8 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
         cfg["prior"] = prior
     out = {}
     import os
-    # The persistent reverse walk (csrc/decoder_persist_bwd.hip, opt-in in the product too) takes part when LVSR_TEST_PBWD=1:
-    # it was restructured (spill-free) after this round's GPU budget was spent — parity of the new build is
-    # pinned on the emulator (tests/test_emu_persistent_decoder.py), its first run on the MI355X is tools/r3a.sh
-    pbwd = os.environ.get("LVSR_TEST_PBWD", "0") == "1"
-    old = os.environ.get("LVSR_DEC_BWD_PERSISTENT")
-    os.environ["LVSR_DEC_BWD_PERSISTENT"] = "1" if pbwd else "0"
+    # the persistent reverse walk (csrc/decoder_persist_bwd.hip) is the default and takes part
+    pbwd = True
     for persistent in (True, False):
         rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=cfg, use_persistent_decoder=persistent)
         cm = rec.cost_and_gradients(s["batch"]).cpu().numpy()
@@ -98,10 +94,6 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
         assert any(k[0] == "gen.sync_bwd" for k in rec.ws._bufs) == (persistent and pbwd), "persistent decoder backward engaged / did not engage"
         out[persistent] = (cm, rec.generator.last["weights"].cpu().numpy(), rec.generator.last["weighted_averages"].cpu().numpy(),
                            rec.store.get_grads())
-    if old is None:
-        os.environ.pop("LVSR_DEC_BWD_PERSISTENT", None)
-    else:
-        os.environ["LVSR_DEC_BWD_PERSISTENT"] = old
     (cm_p, w_p, wa_p, g_p), (cm_s, w_s, wa_s, g_s) = out[True], out[False]
     if prior is None:
         assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
@@ -116,12 +108,14 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
         # With random weights of this size the label loop amplifies rounding: the two forwards agree to float32 rounding at label 0
         # (energies to 3e-6) and drift apart by ~1.7x per label (tools/probes/pd_diff_probe.py); a window centre is a step
         # function of the alignment, so after ~30 labels one of them flips and single labels differ.  What can be asserted at
-        # this size: the first labels tightly, the summed cost within the north-star tolerance.  (Exact parity of the
-        # window_around_* path is pinned by the reference goldens, tests/test_gpu_kernels.py and tests/test_emu_persistent_decoder.py.)
+        # this size: the first labels tightly, the summed cost loosely — the float32 and float64 ORACLES themselves differ by 1.1e-3
+        # in the summed cost on this network (tools/probes/wsj_train_conditioning.py), so 2e-3 is what "the same computation" means
+        # here.  (Exact parity of the window_around_* path is pinned by the reference goldens — tests/test_gpu_kernels.py,
+        # tests/test_emu_persistent_decoder.py — and at full size by tests/test_decode_golden.py's wsj_decode_full.)
         assert_allclose(cm_p[:8], cm_s[:8], rtol=1e-4, atol=1e-4)
         assert_allclose(w_p[:8], w_s[:8], rtol=2e-3, atol=1e-5)
         assert (w_p[:8].argmax(axis=2) == w_s[:8].argmax(axis=2)).all()
-        assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 2e-4
+        assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 2e-3
 
 
 def test_shard_gradients_add_up_to_the_batch_gradient(gpu_device, setup):

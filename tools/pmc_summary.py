@@ -1,7 +1,7 @@
 """Summarise PMC passes of rocprofv3 (rocpd sqlite): per kernel name, mean counter value per dispatch.
 Usage: python tools/pmc_summary.py [--json out.json --tag wsj_base] db1 [db2 ...] > summary.md
 
---json writes the record bench.py reads (profiles/r02_pmc_bench.json): per kernel "<name>@<tag>"
+--json writes the record bench.py reads (profiles/r03_pmc_bench.json): per kernel "<name>@<tag>"
   hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE in bytes (rocprofv3 reports KiB; FETCH_SIZE on gfx950 counts 64 B per
   128-B request of a wide coalesced read, MI355X_MICROARCH.md "HBM": doubled as prescribed; WRITE_SIZE uncorrected),
   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, valu_busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES (per-SE aggregates
@@ -57,20 +57,26 @@ if json_out:
         base = re.sub(r"<.*", "", k)
         # the persistent recurrent kernels read 4 B per lane on every 4th lane (64-B segments): NOT the 16-B-per-lane streaming
         # pattern the x2 calibration of the guide was made on -> raw FETCH_SIZE for them, x2 for everything else
-        narrow = base.startswith("enc_p")
-        fx = 1.0 if narrow else 2.0
+        fx = 2.0          # the guide's gfx950 correction, applied to every kernel (the raw figure rides along as *_fetch_x1)
         rec = dict(fetch_kib=mean["FETCH_SIZE"], write_kib=mean["WRITE_SIZE"], fetch_factor=fx,
                    hbm_bytes_per_launch=(fx * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0,
-                   hbm_bytes_per_launch_fetch_x2=(2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0,
+                   hbm_bytes_per_launch_fetch_x1=(mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0,
                    dispatches=max(v[1] for v in d.values()),
                    source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --no-graph` of this "
-                          "workload, mean over the dispatches of all layers; KiB -> bytes; FETCH_SIZE x%g (%s)" % (
-                              fx, "4-B-per-lane reads of 64-B segments: outside the calibrated pattern, taken raw; WRITE_SIZE includes "
-                              "the write-through granule hand-offs" if narrow else "gfx950 correction for 16-B coalesced reads"))
+                          "workload, mean over the dispatches of all layers; KiB -> bytes; FETCH_SIZE x2 (MI355X_MICROARCH.md gfx950 "
+                          "correction), WRITE_SIZE as reported")
         if mean.get("SQ_BUSY_CYCLES"):
             if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
                 rec["mfma_busy"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / mean["SQ_BUSY_CYCLES"]
             if "SQ_ACTIVE_INST_VALU" in mean:
                 rec["valu_busy"] = mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_BUSY_CYCLES"]
         out["%s@%s" % (base, tag)] = rec
+    # stamp: the record is valid for the kernel sources it was measured on (bench.py refuses it otherwise)
+    import hashlib, os
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "attention-lvcsr_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(csrc, f), "rb").read())
+    out["__stamp__"] = dict(csrc_sha256=h.hexdigest()[:16])
     json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)

@@ -7,6 +7,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "attention-lvcsr_amd"))
 import numpy, torch
 from lvsr_amd import spec, synthetic
+from lvsr_amd import native
 from lvsr_amd.bricks.recognizer import SpeechRecognizer
 
 name = sys.argv[1] if len(sys.argv) > 1 else "wsj_base"
@@ -22,7 +23,7 @@ PH = ["S gather", "A: sW/sg dots + publish", "SW gather", "B: energies", "EN gat
 ref = None
 for mode, prof in (("0", "0"), ("1", "0"), ("1", "1")):
     os.environ["LVSR_DEC_PERSISTENT"] = mode
-    os.environ["LVSR_PD_PROF"] = prof
+    native.get().set_knob("phase_clock", int(prof))
     rec = SpeechRecognizer(device="cuda:0", params=params, net_config=cfg)
     gen = rec.generator
     x = torch.from_numpy(batch["recordings"]).cuda(); xm = torch.from_numpy(batch["recordings_mask"]).cuda()

@@ -16,13 +16,11 @@ params = synthetic.make_params(cfg, seed=1)
 batch = synthetic.make_batch(cfg, B, T, L, seed=2, ragged=False)
 PH = ["loads + publish dpc + alignment-gradient gather", "A gather", "drh, publish B, AW loads", "B gather", "dsacc + q + publish",
       "C gather + sd + de", "energies backward", "dsW publish + D gather", "Ws^T part + E publish", "alignment correlation", "E gather + ds", "  (dsacc dots)", "  (q contraction)"]
-# (persistent?, phase clock?, LVSR_PBWD_LDS_STATE, LVSR_PBWD_AW_LDS): the step kernels, then both placements of the handler state
-for mode, prof, ls, awl in (("0", "0", "0", "1"), ("1", "0", "0", "1"), ("1", "1", "0", "1"), ("1", "0", "1", "1"), ("1", "1", "1", "1"),
-                            ("1", "0", "1", "0")):
+from lvsr_amd import native
+# (persistent?, phase clock?): the step kernels, then the persistent kernel without / with the phase clock of work-group 0
+for mode, prof in (("0", "0"), ("1", "0"), ("1", "1")):
     os.environ["LVSR_DEC_BWD_PERSISTENT"] = mode
-    os.environ["LVSR_PD_PROF"] = prof
-    os.environ["LVSR_PBWD_LDS_STATE"] = ls
-    os.environ["LVSR_PBWD_AW_LDS"] = awl
+    native.get().set_knob("phase_clock", int(prof))
     rec = SpeechRecognizer(device="cuda:0", params=params, net_config=cfg)
     gen = rec.generator
     x = torch.from_numpy(batch["recordings"]).cuda(); xm = torch.from_numpy(batch["recordings_mask"]).cuda()
@@ -38,8 +36,7 @@ for mode, prof, ls, awl in (("0", "0", "0", "1"), ("1", "0", "0", "1"), ("1", "1
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
     gen.check_persistent()
-    what = "step kernels" if mode == "0" else "persistent%s, handler state in %s%s" % (
-        " + phase clock" if prof == "1" else "", "LDS" if ls == "1" else "registers", "" if awl == "1" else ", AW rows from L2")
+    what = "step kernels" if mode == "0" else "persistent%s" % (" + phase clock" if prof == "1" else "")
     print("%s generator.backward, %s: %.3f ms (%.2f us/label)" % (name, what, best, best * 1e3 / L), flush=True)
     if prof == "1":
         sync = [b for k, b in gen.ws._bufs.items() if k[0] == "gen.sync_bwd"][0]

@@ -15,13 +15,14 @@ lib = native.get()
 shapes = [(256, 16, 800), (512, 8, 800), (128, 2, 200), (250, 16, 800)]
 if len(sys.argv) >= 4:
     shapes = [tuple(int(v) for v in sys.argv[i:i + 3]) for i in range(1, len(sys.argv) - 2, 3)]
-# name, persistent?, LVSR_PERSIST_ROWS, LVSR_PERSIST_FLAGS (persist.h: 1 no saves, 2 clusters spread over the XCDs, 4 write-through
-# stores even inside an XCD = the round-2 hand-off, 8 no waiting, 16 no contractions)
+# name, persistent?, knob persist_rows, knob persist_flags (persist.h: 1 no saves, 2 clusters spread over the XCDs, 4 write-through
+# stores even inside an XCD = the round-2 hand-off, 8 no waiting, 16 no contractions, 64 clusters of 4 instead of 8 work-groups)
 variants = [("steps+graph", False, None, None), ("persist", True, "0", "0"), ("persist, write-through stores", True, "0", "4"),
             ("persist, no waiting", True, "0", "8"), ("persist, no dots", True, "0", "16"), ("persist rows=2", True, "2", "0"),
             ("persist rows=2, write-through", True, "2", "4"), ("persist rows=4", True, "4", "0"), ("persist nosave", True, "0", "1"),
             ("persist spread over XCDs", True, "0", "2"), ("persist 256 threads", True, "0", "0", "256"),
-            ("persist 256 threads, write-through", True, "0", "4", "256")]
+            ("persist 256 threads, write-through", True, "0", "4", "256"), ("persist, clusters of 4", True, "0", "64"),
+            ("persist, clusters of 4, no dots", True, "0", "80"), ("persist, clusters of 4, write-through", True, "0", "68")]
 for (H, B, T) in shapes:
     F = 2 * H
     cfg = dict(input_dim=F, num_phonemes=6, dims_bidir=[H], subsample=[1], dim_dec=4, dim_matcher=7,
@@ -33,11 +34,8 @@ for (H, B, T) in shapes:
     stream = torch.cuda.Stream()
     ref = None
     for name, persistent, rows, flags, *more in variants:
-        for k, v in (("LVSR_PERSIST_ROWS", rows), ("LVSR_PERSIST_FLAGS", flags), ("LVSR_PERSIST_THREADS", more[0] if more else None)):
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k, v in (("persist_rows", rows), ("persist_flags", flags), ("persist_threads", more[0] if more else None)):
+            lib.set_knob(k, int(v or 0))
         enc = Encoder(spec.Dims(cfg), store, lib, Workspace(dev), use_graph=True, use_persistent=persistent)
         best = [1e9, 1e9]
         with torch.cuda.stream(stream):
@@ -62,7 +60,7 @@ for (H, B, T) in shapes:
         err = ""
         if ref is None:
             ref = (y.clone(), gx)
-        elif flags in ("0", "2", "4"):
+        elif flags in ("0", "2", "4", "64", "68"):
             err = "  max|dy| %.2e  max|dgrad| %.2e (rel %.1e)" % (float((y - ref[0]).abs().max()), float((gx - ref[1]).abs().max()),
                                                               float((gx - ref[1]).abs().max() / ref[1].abs().max()))
         print("H=%d B=%d T=%d %-26s layer fwd %.3f ms (%.2f us/step)  bwd %.3f ms (%.2f us/step)%s" % (
