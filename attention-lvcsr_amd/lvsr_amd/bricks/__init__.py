@@ -91,7 +91,7 @@ class Encoder(object):
         self._pack_cache = {}
         # weight-gradient GEMMs on a second stream: measured SLOWER on MI355X (70.0 vs 66.4 ms per WSJ-base step: the
         # concurrent GEMM work-groups delay the latency-bound step kernels more than the overlap saves), so off by default
-        self.overlap = os.environ.get("LVSR_OVERLAP", "0") == "1"
+        self.overlap = False        # measured and rejected (comment above); the attribute keeps the second-stream code reachable for probes
         self._side = None
         self._side_pending = False
 

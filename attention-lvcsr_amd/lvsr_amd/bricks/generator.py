@@ -230,12 +230,8 @@ class SequenceGenerator(object):
             plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
             lib.call("lvsr_attdec_fwd_persistent", lib.stream_for(S), _ct.byref(fwd_args), _ct.byref(plain), lib_ptr(sync), 0)
             lib.call("lvsr_attdec_glimpses", lib.stream_for(S), _ct.byref(fwd_args))
-        elif os.environ.get("LVSR_SYNC_DEC_FWD", "1") == "1":
-            fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
         else:
-            import ctypes as _ct
-            fwd_args = lib.make("lvsr_attdec_args", **fields)
-            lib.call("lvsr_attdec_fwd", lib.stream_for(S), _ct.byref(fwd_args), int(self.use_graph))
+            fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
         WA = bufs["WA"]
         S2, WA2 = S[:L].view(L * B, d.D), WA.view(L * B, d.E)
         R1, R2, logits = self._readout(S2, WA2, L * B, "")
@@ -304,7 +300,7 @@ class SequenceGenerator(object):
                       dswp=ws.get("gen.dswp", (B, ntile, d.M)))
         bw.f = lib.make("lvsr_attdec_args", **sv["fields"])
         import ctypes
-        reassoc = os.environ.get("LVSR_DEC_BWD_REASSOC", "1") == "1"
+        reassoc = True
         if reassoc:
             # the glimpse contraction reassociated (as in the persistent forward): q = DXG . AW + QR, one launch less per label
             wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
@@ -332,8 +328,6 @@ class SequenceGenerator(object):
             DWA2 = DWA.view(nrows, d.E)
             DWA2.copy_(dWA_r)
             lib.sgemm(DXG, wd, DWA2, transB=True, beta=1.0)
-        if self.use_graph and os.environ.get("LVSR_SYNC_DEC_BWD", "0") == "1":
-            lib.after_graph(ds, L)
         # ---- weight gradients as batched GEMMs over all steps
         dpc, dg = DXG[:, : d.D], DXG[:, d.D:]
         RH2 = bufs["RH"].view(nrows, d.D)
@@ -366,8 +360,10 @@ class SequenceGenerator(object):
             lib.colsum(accEb, g[n["eb"]], ws=gws)
         if d.conv:
             lib.colsum(accH, g[n["handler"]].view(-1), ws=gws)
-            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]), lib_ptr(gws),
-                     gws.numel() * 4)
+            # partial sums per chunk of (label, utterance) rows: at most one chunk per row (large per-GPU batches outgrow gemm_ws)
+            fws = ws.get("gen.filter_ws", (max(1 << 20, L * B * d.K * (2 * d.c + 1)),))
+            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]), lib_ptr(fws),
+                     fws.numel() * 4)
         # ---- attended: preprocess backward + glimpse backward
         A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
         lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws, group=True)

@@ -183,8 +183,8 @@ class SpeechRecognizer(object):
         """Gradient of cost.sum() wrt all parameters -> self.store.grad (flat) / self.store.g (named views)."""
         with self._on_stream():
             # the small weight-gradient products of decoder and encoder (recurrent matrices, readout, ...) are collected and
-            # run as ONE grouped launch at the end: alone none of them fills the chip (LVSR_GROUP_GEMM=0: one launch each)
-            grouped = os.environ.get("LVSR_GROUP_GEMM", "1") == "1"
+            # run as ONE grouped launch at the end: alone none of them fills the chip
+            grouped = True
             if grouped:
                 self.lib.begin_group()
             d_encoded = self.generator.backward()
@@ -213,7 +213,7 @@ class SpeechRecognizer(object):
             key = ("train_step", tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
             volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
                         self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
-            plain = region and self.use_graph and (not self.encoder.overlap or os.environ.get('LVSR_OVERLAP_REGION', '0') == '1')
+            plain = region and self.use_graph and not self.encoder.overlap
             return self.lib.region(self, key, x, enabled=plain, volatile=volatile).run(enqueue)
 
     # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------

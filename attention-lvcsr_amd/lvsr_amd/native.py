@@ -18,12 +18,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "liblvsr_hip.so")
 HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "lvsr_hip.h")
 
-_GRAPH_STREAM = os.environ.get("LVSR_GRAPH_STREAM", "0") == "1"
 # Measured on MI355X / ROCm 7.2 (WSJ-base step): when the host keeps submitting work while a 1600-node time-loop graph
 # replays, the graph's kernels run ~25 % slower (6.2 -> 8.0 us per encoder step); blocking the host until the graph has
-# drained gives 57.3 ms per step instead of 66.4 (sync BEFORE the launch: 58.6; a dedicated graph stream: 71).  Default on.
+# drained gives 57.3 ms per step instead of 66.4 (sync BEFORE the launch: 58.6; a dedicated graph stream: 71 — both removed).  Default on.
 _SYNC_AFTER_GRAPH = os.environ.get("LVSR_SYNC_AFTER_GRAPH", "1") == "1"
-_SYNC_BEFORE_GRAPH = os.environ.get("LVSR_SYNC_BEFORE_GRAPH", "0") == "1"
 
 # Whole-step graph regions (lvsr_region_begin/end): one hipGraph launch per training step.  LVSR_STEP_GRAPH=0 keeps the
 # per-layer time-loop graphs with eager launches between them.
@@ -309,17 +307,6 @@ class Lib(object):
     def run(self, fn, struct_name, ref_tensor, use_graph=None, **fields):
         """Call an args-struct entry point: fn(stream, &args[, use_graph])."""
         a = self.make(struct_name, **fields)
-        if _SYNC_BEFORE_GRAPH and use_graph and ref_tensor.is_cuda and not self.capturing:
-            torch.cuda.current_stream(ref_tensor.device).synchronize()      # experiment knob, see DESIGN.md
-        if _GRAPH_STREAM and use_graph and ref_tensor.is_cuda and not self.capturing:
-            cur = torch.cuda.current_stream(ref_tensor.device)
-            if self._gstream is None:
-                self._gstream = torch.cuda.Stream(ref_tensor.device)
-            self._gstream.wait_stream(cur)
-            with torch.cuda.stream(self._gstream):
-                self.call(fn, self.stream_for(ref_tensor), ctypes.byref(a), int(use_graph))
-            cur.wait_stream(self._gstream)
-            return a
         if use_graph is None:
             self.call(fn, self.stream_for(ref_tensor), ctypes.byref(a))
         else:

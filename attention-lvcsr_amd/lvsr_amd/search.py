@@ -110,7 +110,7 @@ class BeamSearch(object):
             return False
         with rec._on_stream():
             n = min(int(positions), run["max_length"] - run["positions"])
-            if n == POLL_EVERY and os.environ.get("LVSR_BEAM_MULTI", "1") == "1":
+            if n == POLL_EVERY:
                 gen.beam_steps(n)                          # one graph launch for the whole stretch between two looks
             else:
                 for _ in range(n):

@@ -82,6 +82,8 @@ def normalize_net_config(cfg):
     out["bottom_dims"] = [int(v) for v in (out["bottom_dims"] or [])]
     if out["bottom_dims"] and out["bottom_activation"] not in ("rectifier", "tanh", "identity"):
         raise NotImplementedError("bottom activation %r is not built" % out["bottom_activation"])
+    if not out["post_merge_dims"]:
+        out["post_merge_dims"] = None            # `post_merge_dims: []` (exp/wsj/configs/wsj_small.yaml) = no post-merge (recognizer.py:305 `if post_merge_dims:`)
     if out["post_merge_dims"] is not None:
         if len(out["post_merge_dims"]) != 1:
             raise NotImplementedError("only single-layer post_merge_dims is built")

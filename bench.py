@@ -116,23 +116,35 @@ def dominant_kernel_probe(rec, dims, T, B):
 
 
 def gemm_probe(rec, dims, T, B):
-    """The step's largest dense contraction (a layer's gate projection, (T*B, 2H_prev) x (2H_prev, 2H)) timed alone with HIP
-    events on the recognizer's stream: the MFMA-bound part of the path, reported beside the latency-bound dominant kernel."""
-    lib = rec.lib
-    M, K, N = T * B, 2 * dims.Hs[0], 2 * dims.Hs[0]
-    dev = rec.device
-    A, Bm, C = (torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), torch.empty(M, N, device=dev))
+    """The step's dense contractions timed alone with HIP events on the recognizer's stream — the MFMA-bound part of the path,
+    reported beside the latency-bound dominant kernel.  The three big shapes of an encoder layer above the first: the input
+    projection of both directions and all gates as ONE product (T*B, 2H) x (2H, 6H) [the largest contraction of the step], its
+    input gradient (T*B, 6H) x (6H, 2H)^T and its weight gradient (2H, T*B)^T x (T*B, 6H) (deterministic split-K)."""
+    lib, dev = rec.lib, rec.device
+    H = dims.Hs[0]
+    M, K, N = T * B, 2 * H, 6 * H
+    X, W, XG = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), torch.randn(M, N, device=dev)
+    dX, dW, ws = torch.empty(M, K, device=dev), torch.empty(K, N, device=dev), torch.empty(64 << 20, device=dev)
+    calls = [("projection", lambda: lib.sgemm(X, W, XG), [M, N, K]),
+             ("input_gradient", lambda: lib.sgemm(XG, W, dX, transB=True), [M, K, N]),
+             ("weight_gradient", lambda: lib.sgemm(X, XG, dW, transA=True, ws=ws), [K, N, M])]
+    out = {}
     with torch.cuda.stream(rec.stream):
-        for _ in range(3):
-            lib.sgemm(A, Bm, C)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(rec.stream)
-        for _ in range(20):
-            lib.sgemm(A, Bm, C)
-        e1.record(rec.stream)
-        e1.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / 20
-    return dict(kernel="lvsr_sgemm128_kernel", shape=[M, N, K], launch_us=sec * 1e6, achieved=2.0 * M * N * K / sec / 1e12, unit="TFLOP/s")
+        for name, fn, shape in calls:
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(rec.stream)
+            for _ in range(20):
+                fn()
+            e1.record(rec.stream)
+            e1.synchronize()
+            sec = e0.elapsed_time(e1) * 1e-3 / 20
+            ach = 2.0 * shape[0] * shape[1] * shape[2] / sec / 1e12
+            out[name] = dict(shape_mnk=shape, launch_us=sec * 1e6, achieved=ach, frac=ach / PEAK_FP32_MFMA)
+    big = out["projection"]
+    return dict(kernel="lvsr_sgemm128_kernel", shape=big["shape_mnk"], launch_us=big["launch_us"], achieved=big["achieved"], unit="TFLOP/s",
+                frac=big["frac"], layer_shapes=out)
 
 
 PMC_FILE = os.path.join(REPO, "profiles", "r03_pmc_bench.json")
@@ -426,7 +438,6 @@ def main(backend=None):
                 tf = value / world * TRAIN_FLOP_PER_FRAME[args.workload] / 1e12
                 roof.update(whole_step_tflops=tf, whole_step_frac=tf / PEAK_FP32_MFMA)
             roof["dense_gemm"] = gemm_probe(rec, dims, T, B)
-            roof["dense_gemm"]["frac"] = roof["dense_gemm"]["achieved"] / PEAK_FP32_MFMA
             out["roofline"] = roof
             if world == 1 and not args.no_decode and args.workload == "wsj_base":
                 out["decode"] = decode_leg(dev, args.decode_utterances)

@@ -50,15 +50,29 @@ import pytest        # noqa: E402
 
 @pytest.mark.gpu
 def test_decode_driver_gpu(gpu_device):
-    """lvsr_amd.decode.search on the MI355X: the same report as through the emulated kernels (beam search, analyze of the
-    ground truth and of the best hypothesis, error counts)."""
-    from emu import emu_lib
-    got, ref = _decode_driver(gpu_device, None), _decode_driver("cpu", emu_lib())
-    for a, b in zip(got["per_utterance"], ref["per_utterance"]):
-        assert a["recognized"] == b["recognized"] and a["char_errors"] == b["char_errors"]
-        assert_allclose(a["groundtruth_cost"], b["groundtruth_cost"], rtol=1e-4)
-        assert_allclose(a["search_cost"], b["search_cost"], rtol=1e-4)
-    assert got["cer"] == ref["cer"] and got["wer"] == ref["wer"]
+    """lvsr_amd.decode.search on the MI355X against the ORACLE (oracle/lvsr_oracle.py, pinned to the reference's goldens): the
+    recognised sequence and its search cost = the oracle's host beam search on the same utterance, the ground-truth cost = the
+    oracle's `analyze`, error counts from those."""
+    import torch
+    from oracle import lvsr_oracle as O
+    from lvsr_amd import synthetic
+    got = _decode_driver(gpu_device, None)
+    cfg = dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",
+               post_merge_dims=None, embed_outputs=True, data_prepend_eos=False)
+    orc = O.OracleRecognizer(cfg, synthetic.make_params(cfg, seed=5), dtype=torch.float32)
+    rng = numpy.random.RandomState(0)
+    utts = [(rng.normal(size=(9, 5)).astype(numpy.float32), [1, 2, 5]), (rng.normal(size=(7, 5)).astype(numpy.float32), [3, 5])]
+    tot_err = tot_len = 0
+    for row, (x, gt) in zip(got["per_utterance"], utts):
+        outs, costs = orc.beam_search(x, 3, char_discount=0.3, round_to_inf=1e9, stop_on="patience")
+        assert row["recognized"] == outs[0]
+        assert_allclose(row["search_cost"], costs[0], rtol=1e-4, atol=1e-5)
+        gt_cost, _ = orc.analyze(x, numpy.asarray(gt))
+        assert_allclose(row["groundtruth_cost"], float(gt_cost.sum()), rtol=1e-4)
+        assert row["char_errors"] == ER.edit_distance(gt, outs[0])
+        tot_err += row["char_errors"]
+        tot_len += len(gt)
+    assert_allclose(got["cer"], tot_err / float(tot_len))
 
 
 def test_host_side_pieces_match_the_reference_functions():

@@ -228,27 +228,35 @@ def test_one_recognizer_many_shapes_gpu(gpu_device):
 
 def test_whole_step_graph_region_gpu(gpu_device):
     """Trainer.train_step on the GPU = one graph region per minibatch shape (eager pass, capture, then replays), with the
-    optimiser inside.  Five steps on changing batches of two shapes must track the same trainer run through the emulated
-    library step by step (costs) and end at the same parameters."""
-    from emu import emu_lib
+    optimiser inside.  Eight steps on changing batches of two shapes must track the ORACLES step by step: the float64 torch
+    restatement of the recognizer (oracle/lvsr_oracle.py, pinned to the reference's goldens) for cost and gradients, fed into the
+    restatement of the reference's step rules (oracle/optimizer_oracle.py, pinned to the reference's own known-answer tests and
+    Theano-evaluated fixtures) for the parameter update — and end at the same parameters."""
+    from collections import OrderedDict
+    from oracle import optimizer_oracle as OO
     from lvsr_amd.training import Trainer
     z, meta = load_golden("tiny_conv_median")
     cfg = meta["cfg"]
     params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
     conf = dict(gradient_threshold=100.0, rules=("momentum", "adadelta"), scale=0.1, momentum=0.0, decay_rate=0.95, epsilon=1e-8,
                 max_norm=1.0)
-    recs = [SpeechRecognizer(device=gpu_device, params=params, net_config=cfg),
-            SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)]
-    trainers = [Trainer(r, **conf) for r in recs]
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    trainer = Trainer(rec, **conf)
+    rules = OO.TrainingRules(**conf)
+    cur = OrderedDict((k, v.copy()) for k, v in params.items())
     shapes = [(4, 40, 9), (4, 40, 9), (3, 28, 6), (4, 40, 9), (4, 40, 9), (3, 28, 6), (4, 40, 9), (3, 28, 6)]
     for k, (B, T, L) in enumerate(shapes):
         batch = synthetic.make_batch(cfg, B, T, L, seed=90 + k, ragged=True)
-        costs = [float(t.train_step(batch).sum()) for t in trainers]
-        assert abs(costs[0] - costs[1]) <= 2e-4 * abs(costs[1]), (k, costs)
-    assert recs[0]._regions, "no graph region was recorded"
-    states = [s for s in recs[0]._regions.values()]
+        cost = float(trainer.train_step(batch).sum())
+        out, grads = O.OracleRecognizer(cfg, cur, dtype=torch.float64).cost_and_grads(batch)
+        ref = float(out["cost_matrix"].sum())
+        assert abs(cost - ref) <= 2e-4 * abs(ref), (k, cost, ref)
+        # the reference divides the summed cost by the batch size before differentiating (lvsr/main.py:340-345)
+        cur = rules.step(cur, OrderedDict((n, (grads[n] / B).astype(numpy.float32)) for n in cur))
+    assert rec._regions, "no graph region was recorded"
+    states = [s for s in rec._regions.values()]
     assert any(s["seen"] >= 3 for s in states) and not any(s.get("bad") for s in states)
-    a, b = recs[0].get_parameter_values(), recs[1].get_parameter_values()
-    for name in a:
-        scale = max(1e-3, numpy.abs(b[name]).max())
-        assert numpy.abs(a[name] - b[name]).max() / scale < 2e-3, name
+    got = rec.get_parameter_values()
+    for name in got:
+        scale = max(1e-3, numpy.abs(cur[name]).max())
+        assert numpy.abs(got[name] - cur[name]).max() / scale < 2e-3, name
