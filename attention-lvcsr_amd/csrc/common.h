@@ -15,9 +15,11 @@ void lvsr_set_error(const char* fmt, ...);
 int lvsr_check_launch(const char* what);
 // tuning knobs (include/lvsr_hip.h LVSR_KNOB_*; process-wide, part of every cached graph's key through lvsr_knob_bytes)
 int lvsr_knob(int knob);
-// Largest grid of a persistent cluster launch (its work-groups wait for each other, so all of them must be resident at once, one
-// per CU): the device's CU count minus a reserve of 32 for whatever else is running — 224 on MI355X — unless
-// LVSR_KNOB_MAX_CLUSTER_WGS overrides it.
+// Largest grid of a persistent cluster launch with ONE work-group per CU (its work-groups wait for each other, so all of them must
+// be resident at once): the device's CU count (256 on MI355X) — what a cooperative launch would check —, minus
+// LVSR_KNOB_CLUSTER_RESERVE CUs left to other work when the caller shares the device; LVSR_KNOB_MAX_CLUSTER_WGS overrides it.
+// Kernels of which several work-groups fit a CU multiply it by their occupancy (encoder_persist.hip wide_cluster_capacity).
+// Safety does not rest on this number: every wait is bounded and raises the abort word.
 int lvsr_max_cluster_wgs();
 
 #define LVSR_REQUIRE(cond, ...)                 \

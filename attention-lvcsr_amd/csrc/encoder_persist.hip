@@ -174,8 +174,8 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
     // columns, 48 weight registers) instead of 4 of 64 — half the LDS operand traffic per CU and contraction (the contractions
     // are LDS-broadcast bound), twice the CUs: 2.01 / 2.20 instead of 2.13 / 2.38 us per forward / BPTT step of the layer probe,
     // WSJ-base step 17.5 -> 16.7 ms (profiles/r03_persist_probe_wide.txt).  At B = 16 that is 256 work-groups: the limit is what the
-    // device can hold at once — the occupancy the runtime reports for these kernels (two work-groups per CU) times the CUs,
-    // minus the usual reserve — not one work-group per CU.  PF_NARROW keeps clusters of 4.
+    // device can hold at once — the occupancy the runtime reports for these kernels (two work-groups per CU) times the CUs
+    // (lvsr_max_cluster_wgs) — not one work-group per CU.  PF_NARROW keeps clusters of 4.
     if (!(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NARROW) && g.NTH == 512 && g.HP == 256 && 2 * g.rt * 8 <= wide_cluster_capacity()) {
         g.KS = 16; g.KSPLIT = 16; g.UNITS = 32; g.P = 8;
     }
@@ -473,20 +473,20 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
 }
 
 // How many work-groups of the wide (8 per cluster) kernels the device holds at once: occupancy per CU as the runtime computes it
-// from their registers / LDS (2 on MI355X) x (CUs - reserve); a launch at most this large is resident as a whole, which the
+// from their registers / LDS (2 on MI355X) x lvsr_max_cluster_wgs(); a launch at most this large is resident as a whole, which the
 // clusters' mutual waiting needs.  The forward and BPTT kernels of both row counts are asked; the smallest answer counts.
 static int wide_cluster_capacity() {
-    static int cap = -1;
-    if (cap < 0) {
+    static int occ_cached = -1;
+    if (occ_cached < 0) {
         int occ = 1 << 20, n = 0;
         const bool ok = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pfwd_kernel<16, 16, 1, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0 &&
                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pfwd_kernel<16, 16, 2, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0 &&
                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pbwd_kernel<16, 16, 1, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0 &&
                         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, enc_pbwd_kernel<16, 16, 2, false, 512>, 512, 0) == hipSuccess && (occ = min(occ, n)) >= 0;
         if (!ok) { (void)hipGetLastError(); occ = 0; }
-        cap = min(occ, 2) * lvsr_max_cluster_wgs();
+        occ_cached = min(occ, 2);
     }
-    return cap;
+    return occ_cached * lvsr_max_cluster_wgs();
 }
 
 static int persist_flags() { return lvsr_knob(LVSR_KNOB_PERSIST_FLAGS); }

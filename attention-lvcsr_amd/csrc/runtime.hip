@@ -42,10 +42,11 @@ int lvsr_max_cluster_wgs() {
             (void)hipGetLastError();
             cus = 256;
         }
-        v = cus > 64 ? cus - 32 : cus;
+        v = cus;
         cached.store(v, std::memory_order_relaxed);
     }
-    return v;
+    const int reserve = lvsr_knob(LVSR_KNOB_CLUSTER_RESERVE);
+    return reserve > 0 && reserve < v ? v - reserve : v;
 }
 
 // ---- graph cache (LRU, bounded) ----------------------------------------------------------------

@@ -45,8 +45,9 @@ int lvsr_region_end(void* stream, int keep);
 #define LVSR_KNOB_PERSIST_FLAGS 1     /* experiment bits of csrc/persist.h (PF_*): 1 no saved tensors, 2 clusters spread over XCDs, 4 write-through publish, 64 clusters of 4, ... */
 #define LVSR_KNOB_PERSIST_THREADS 2   /* 0 = 512-thread work-groups when a cluster serves <= 2 utterances; 256 = always 256 */
 #define LVSR_KNOB_PHASE_CLOCK 3       /* 1 = work-group 0 of the persistent decoder kernels leaves per-phase times in the workspace header */
-#define LVSR_KNOB_MAX_CLUSTER_WGS 4   /* 0 = device CU count - 32 (224 on MI355X); else the largest grid a cluster launch may have */
-#define LVSR_KNOB_COUNT 5
+#define LVSR_KNOB_MAX_CLUSTER_WGS 4   /* 0 = device CU count (256 on MI355X); else the largest one-work-group-per-CU grid a cluster launch may have */
+#define LVSR_KNOB_CLUSTER_RESERVE 5   /* CUs left free by cluster launches for other work on the device (default 0) */
+#define LVSR_KNOB_COUNT 6
 int lvsr_set_knob(int knob, int value);
 int lvsr_get_knob(int knob);
 

@@ -12,6 +12,7 @@ from lvsr_amd.bricks import Encoder
 
 dev = torch.device("cuda:0")
 lib = native.get()
+lib.knobs_from_env()          # e.g. LVSR_KNOB_MAX_CLUSTER_WGS=256 python tools/probe_persist.py 512 8 1500
 shapes = [(256, 16, 800), (512, 8, 800), (128, 2, 200), (250, 16, 800)]
 if len(sys.argv) >= 4:
     shapes = [tuple(int(v) for v in sys.argv[i:i + 3]) for i in range(1, len(sys.argv) - 2, 3)]
