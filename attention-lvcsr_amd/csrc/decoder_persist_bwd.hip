@@ -507,28 +507,28 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         clk.mark(8);
         // ---- 5. alignment gradient for the previous label, partial over the own positions: behind exchange E
         if (KC > 0 && i > 0) {
-            // thread (s = tid % 256 [+256], half = tid / 256): the own positions tl = half, half + 2, ... whose taps reach s
+            // thread (s = tid % 256 [+256], half = tid / 256): filters k = half, half + 2, ... over ALL own positions.  Straight-line: the
+            // tap index c + t - s is tested instead of bounding the loop per lane (lane-dependent trip counts and the integer
+            // divisions that set them cost more than the taps outside the filter), four accumulators break the FMA chain
             const int cn = a.c, hsel = tid >> 8;
             const float* fls = flt ? dms : a.filters;          // the filters: staged in the dm tile buffer when they fit
             for (int s0 = 0; s0 < Tp; s0 += 256) {
                 const int sx = s0 + (tid & 255);
-                float acc = 0.f;
-                if (sx < Tp && sx >= wi.begin && sx < wi.end) {
-                    // t = tl P + p with |t - sx| <= c:  tl in [lo, hi]
-                    const int tmin = max(sx - cn, 0), tmax = min(sx + cn, Tp - 1);
-                    int lo = (tmin - p + P - 1) / P, hi = (tmax - p) / P;
-                    if (tmin < p) lo = 0;
-                    hi = tmax < p ? -1 : min(hi, nown - 1);
-                    lo += (lo & 1) != hsel;                     // this half's parity
-                    const float* fb = fls + cn + p - sx;         // f[k][c + t - s] = fb[k * FW + tl * P]
-                    for (int tl = lo; tl <= hi; tl += 2) {
-                        const float* dr = dcvs + tl * KCP;
-                        const float* fp = fb + tl * P;
+                float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+                const bool live = sx < Tp && sx >= wi.begin && sx < wi.end;
+                const int base = cn + p - sx;                   // f[k][c + t - s] with t = tl P + p: index base + tl P
+#pragma unroll 4
+                for (int tl = 0; tl < nown; ++tl) {
+                    const int idx = base + tl * P;
+                    const bool ok = live && (unsigned)idx < (unsigned)g.FW;
+                    const float* dr = dcvs + tl * KCP + hsel;
+                    const float* fp = fls + (ok ? idx : 0) + hsel * g.FW;       // clamped: the loads below are unconditional
+                    const float keep = ok ? 1.f : 0.f;                          // (a guarded load serialises behind its check)
 #pragma unroll
-                        for (int k = 0; k < KC; ++k)
-                            if (KC == K || k < K) acc += dr[k] * fp[k * g.FW];
-                    }
+                    for (int kk = 0; kk < (KC + 1) / 2; ++kk)
+                        if (2 * kk + hsel < K) acc4[kk & 3] += (dr[2 * kk] * keep) * fp[2 * kk * g.FW];
                 }
+                const float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
                 if (hsel == 1) r8[tid & 255] = acc;            // (barriers outside any lane-dependent branch: a wave counts once)
                 __syncthreads();
                 if (hsel == 0 && sx < Tp) granule_store(gF + (size_t)p * 512 + sx, epoch, acc + r8[tid & 255], plain);

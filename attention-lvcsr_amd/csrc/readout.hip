@@ -163,6 +163,16 @@ __global__ __launch_bounds__(256) void shallow_fusion_kernel(const float* am, in
     for (int v = lane; v < V; v += 64) o[v] = out_scale * (((am_beta * a[v] - lse_a) + lm_weight * (-l[v] - lse_l)) - lse_t);
 }
 
+// LMEmitter.cost (lvsr/bricks/language_models.py:165-168): cost[r] = -readout[r, label[r]] (* mask[r]); rows whose label is outside
+// [0, V) cost 0
+__global__ __launch_bounds__(256) void select_cost_kernel(const float* x, int ld, const long long* labels, const float* mask, int n, int V,
+                                                          float scale, float* cost) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const long long y = labels[r];
+    const float v = (y >= 0 && y < V) ? x[(size_t)r * ld + y] : 0.f;
+    cost[r] = scale * v * (mask ? mask[r] : 1.f);
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Generation-time readout + emitter of a few rows (beam hypotheses / sampled utterances) in ONE launch:
@@ -431,6 +441,14 @@ int lvsr_softmax_nll(void* stream, const float* logits, int ld, const long long*
     hipLaunchKernelGGL(softmax_nll_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, labels, mask, n, V,
                        cost, dlogits, ldd, scale, neglogp, ldn);
     return lvsr_check_launch("lvsr_softmax_nll");
+}
+
+int lvsr_select_cost(void* stream, const float* x, int ld, const long long* labels, const float* mask, int n, int V, float scale,
+                     float* cost) {
+    LVSR_REQUIRE(x && labels && cost, "lvsr_select_cost: null argument");
+    if (n <= 0) return LVSR_OK;
+    hipLaunchKernelGGL(select_cost_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ld, labels, mask, n, V, scale, cost);
+    return lvsr_check_launch("lvsr_select_cost");
 }
 
 int lvsr_shallow_fusion(void* stream, const float* am, int ld, const float* lm_add, int n, int V, float am_beta,

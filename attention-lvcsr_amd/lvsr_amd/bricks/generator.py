@@ -239,11 +239,49 @@ class SequenceGenerator(object):
         dlogits = ws.get("gen.dlogits", (L * B, d.V))
         lib.call("lvsr_softmax_nll", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V,
                  lib_ptr(cost), lib_ptr(dlogits), d.V, 1.0, None, 0)
+        lm = self.language_model
+        self._cost_has_lm = lm is not None
+        if lm is not None:
+            # SequenceGenerator.evaluate with a language model (sequence_generators.py:286-296): the readout of label i is fused
+            # (ShallowFusionReadout) with the look-ahead costs of the FST state set reached by labels[:i], the emitter is LMEmitter:
+            # cost = -fused[label].  This is what `analyze` reports in the decode driver when `net.lm` is configured.
+            lm_add = self._lm_lookahead(lm, labels, ym, L, B)
+            fused = ws.get("gen.fused", (L * B, d.V))
+            lib.call("lvsr_shallow_fusion", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(lm_add), L * B, d.V, float(lm.am_beta),
+                     float(lm.lm_weight), int(lm.norm[0]), int(lm.norm[1]), int(lm.norm[2]), 1.0, lib_ptr(fused))
+            lib.call("lvsr_select_cost", lib.stream_for(cost), lib_ptr(fused), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V, -1.0,
+                     lib_ptr(cost))
         self.last = dict(weights=W[1:], energies=bufs["EN"], states=S[:L], weighted_averages=WA)
         if save_for_backward:
             self._saved = dict(L=L, B=B, Tp=Tp, A=A, Am=Am, PA=PA, labels=labels, ym=ym, xg=xg, fb=fb, bufs=bufs,
                                fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk, AW_valid=sync is not None)
         return cost
+
+    def _lm_lookahead(self, lm, labels, ym, L, B):
+        """(L*B, V) look-ahead costs `lm_add` of the teacher-forced label sequences: row (i, b) = FSTCostsOp of the state set after
+        labels[:i, b] (LanguageModel.evaluate -> FSTTransition.apply, lvsr/bricks/language_models.py:34-50; masked steps keep the
+        previous state set).  One FST step per label for the whole batch — on the device with a DeviceFSTLanguageModel."""
+        dev = labels.device
+        out = self.ws.get("gen.lm_add", (L, B, self.d.V))
+        st = lm.initial_states(B)
+        on_dev = getattr(lm, "on_device", False)
+        lab = labels if on_dev else labels.cpu().numpy()
+        msk = None if ym is None else (ym if on_dev else ym.cpu().numpy())
+        for i in range(L):
+            out[i].copy_(lm.stage(st, dev))
+            if i + 1 == L:
+                break
+            new = lm.transition(st, lab[i])
+            if msk is not None:
+                if on_dev:
+                    keep = msk[i] > 0
+                    st = {k: torch.where(keep.view(-1, *([1] * (v.dim() - 1))), new[k], st[k]) for k, v in new.items()}
+                else:
+                    keep = msk[i] > 0
+                    st = {k: numpy.where(keep.reshape((-1,) + (1,) * (v.ndim - 1)), new[k], st[k]) for k, v in new.items()}
+            else:
+                st = new
+        return out.view(L * B, self.d.V)
 
     def backward(self):
         """Gradient of sum(cost_matrix) wrt every generator parameter (written to store.g) and wrt `attended`
@@ -251,6 +289,12 @@ class SequenceGenerator(object):
         d, p, g, n, lib, ws = self.d, self.store.p, self.store.g, self.n, self.lib, self.ws
         sv = self._saved
         assert sv is not None, "cost_matrix() must run first"
+        if getattr(self, "_cost_has_lm", False):
+            lm = self.language_model
+            # with the acoustic readout normalised alone and am_beta = 1 the language-model term is a constant of the parameters
+            # and the gradient is the plain one (dlogits of the softmax); the other fusion settings are decode-time options
+            if lm is None or tuple(lm.norm) != (True, False, False) or float(lm.am_beta) != 1.0:
+                raise NotImplementedError("gradient through ShallowFusionReadout is built for normalize_am_weights only (am_beta = 1)")
         L, B, Tp = sv["L"], sv["B"], sv["Tp"]
         bufs, pk = sv["bufs"], sv["pk"]
         nrows = L * B
@@ -548,7 +592,11 @@ def _sampling_methods():
         energies (n,B,T'), costs (n,B))."""
         d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
         if self.language_model is not None:
-            raise NotImplementedError("generate() with a language model is not built (beam search is)")
+            # With a language model the reference's emitter is LMEmitter, whose `emit` returns zeros "that should never be used"
+            # (lvsr/bricks/language_models.py:160-163): free-running generation is not a path of the reference there — beam search
+            # (which picks the outputs itself) and the teacher-forced cost (cost_matrix / analyze, built) are.
+            raise NotImplementedError("generate() with a language model: the reference's LMEmitter.emit returns zeros (not a "
+                                      "sampling path); use beam_search, or cost / analyze for teacher-forced costs")
         N = int(n_steps)
         Tp, B = int(attended.shape[0]), int(attended.shape[1])
         assert batch_size is None or int(batch_size) == B

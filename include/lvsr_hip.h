@@ -382,6 +382,10 @@ int lvsr_topk_smallest(void* stream, const float* costs, int n, int k, long long
  * LMEmitter (costs = -readout, language_models.py:147-184): out_scale = -1 yields the beam-search costs directly. */
 int lvsr_shallow_fusion(void* stream, const float* am, int ld, const float* lm_add, int n, int V, float am_beta,
                         float lm_weight, int norm_am, int norm_lm, int norm_tot, float out_scale, float* out);
+/* LMEmitter.cost (lvsr/bricks/language_models.py:165-168) of teacher-forced labels on fused readouts x (n, V):
+ * cost[r] = scale * x[r, labels[r]] * mask[r] (scale = -1; mask may be NULL). */
+int lvsr_select_cost(void* stream, const float* x, int ld, const long long* labels, const float* mask, int n, int V, float scale,
+                     float* cost);
 
 /* ---- FST language model on the device ---------------------------------------------------
  * Replaces the per-hypothesis Python walks of FSTTransitionOp.perform / FSTCostsOp.perform (lvsr/ops.py:147-169,

@@ -152,7 +152,7 @@ def run_case(name, cfg, B, T, L, ragged, param_seed, batch_seed, scale=1.0, stor
     sys.stdout.flush()
 
 
-def run_lm_case(name, cfg, T, param_seed, fst_seed, beams, lm_kwargs, scale=1.0, utterances=3):
+def run_lm_case(name, cfg, T, param_seed, fst_seed, beams, lm_kwargs, scale=1.0, utterances=3, analyze_labels=0):
     """Beam search WITH shallow fusion through the reference's own bricks (LanguageModel / FSTTransition / FSTCostsOp /
     ShallowFusionReadout, lvsr/bricks/language_models.py, lvsr/ops.py); the PyFST container is the harness stand-in
     (make_scratch.py `fst.py`).  The automaton travels in the fixture as an arc array."""
@@ -200,9 +200,23 @@ def run_lm_case(name, cfg, T, param_seed, fst_seed, beams, lm_kwargs, scale=1.0,
                 results.append(dict(utt=u, settings=bs, outputs=[[int(t) for t in h] for h in o], costs=[float(v) for v in c]))
             except Exception as e:
                 results.append(dict(utt=u, settings=bs, outputs=None, costs=None, error=type(e).__name__))
+    if analyze_labels:
+        # SpeechRecognizer.analyze with the language model attached (recognizer.py:452-494 -> SequenceGenerator.evaluate with
+        # `language_model.evaluate`, sequence_generators.py:286-296: the readout of every label is fused with the look-ahead costs of
+        # the FST state reached by the PREVIOUS labels, the cost is LMEmitter's -readout[label]) — what the decode report of
+        # lvsr/main.py:778-821 prints as groundtruth / recognized cost when `net.lm` is set
+        rng2 = numpy.random.RandomState(7)
+        for u in range(utterances):
+            for j in range(analyze_labels):
+                n = int(rng2.randint(2, 7))
+                y = numpy.concatenate([rng2.randint(0, V - 1, size=n), [cfg.get("eos_label", V - 1) if cfg.get("eos_label") is not None else V - 1]]).astype("int64")
+                a = rec.analyze({"recordings": out["x%d" % u]}, y, y)
+                out["an_u%d_%d_labels" % (u, j)] = y
+                out["an_u%d_%d_cost" % (u, j)] = numpy.asarray(a[0])
+                out["an_u%d_%d_weights" % (u, j)] = numpy.asarray(a[1])
     out["arcs"] = numpy.array(arcs, dtype=numpy.float64)
     out["meta"] = numpy.array(json.dumps(dict(name=name, cfg=cfg, T=T, param_seed=param_seed, scale=scale, lm=lm_kwargs,
-                                              beam=results)))
+                                              beam=results, analyze_labels=int(analyze_labels))))
     numpy.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print("[golden] %s: %s" % (name, [(r["utt"], r.get("error") or [len(h) for h in r["outputs"]][:3]) for r in results]))
     sys.stdout.flush()
@@ -378,6 +392,16 @@ CASES = {
                                 max_decoded_length_scale=3.0), T=800,
         param_seed=10, fst_seed=9, scale=2.0, utterances=2, lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
         beams=[dict(beam_size=16, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")]),
+    # cost / analyze WITH the language model (both weightings of the fusion that the shipped decode scripts use)
+    "tiny_conv_lm_analyze": lambda: run_lm_case(
+        "tiny_conv_lm_analyze", tiny_cfg(dict(type="window_around_median", before=2, after=3), embed_outputs=True), T=14,
+        param_seed=41, fst_seed=5, scale=6.0, utterances=2, lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
+        beams=[dict(beam_size=3, char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost")], analyze_labels=3),
+    "tiny_conv_lm_analyze_tot": lambda: run_lm_case(
+        "tiny_conv_lm_analyze_tot", tiny_cfg(None, embed_outputs=False), T=12,
+        param_seed=43, fst_seed=6, scale=4.0, utterances=2,
+        lm_kwargs=dict(weight=0.8, no_transition_cost=15.0, normalize_am_weights=False, normalize_lm_weights=True, normalize_tot_weights=True, am_beta=0.7),
+        beams=[dict(beam_size=3, char_discount=0.0, round_to_inf=1e9, stop_on="patience")], analyze_labels=3),
     "tiny_conv_generate": lambda: run_generate_case(
         "tiny_conv_generate", tiny_cfg(dict(type="window_around_median", before=1, after=2)), B=3, T=13, n_steps=7,
         param_seed=3, batch_seed=13, scale=2.0),

@@ -183,6 +183,11 @@ def main():
     patch(os.path.join(pkg, "lvsr/bricks/language_models.py"),
           [(r"self\.transition\.pad\(states_dict\.keys\(\), NOT_STATE\)", "self.transition.pad(list(states_dict.keys()), NOT_STATE)"),
            (r"self\.transition\.pad\(states_dict\.values\(\), 0\)", "self.transition.pad(list(states_dict.values()), 0)")], 2)
+    # AdvancedSubtensor.perform indexes with a LIST of index arrays; numpy >= 1.23 reads a list as ONE fancy index on axis 0
+    # (the "non-tuple sequence for multidimensional indexing" deprecation, now removed): a tuple is what numpy 1.x understood
+    # (reached by LMEmitter.cost -> SelectInEachRow, lvsr/bricks/language_models.py:141-168, i.e. `analyze` with a language model)
+    patch(os.path.join(pkg, "theano/tensor/subtensor.py"),
+          [(r"out\[0\] = inputs\[0\]\.__getitem__\(inputs\[1:\]\)", "out[0] = inputs[0].__getitem__(tuple(inputs[1:]))")], 1)
     print("scratch reference at", DST)
     print("run with: THEANO_FLAGS=device=cpu,floatX=float32,cxx=,optimizer_excluding=fusion,"
           "base_compiledir=/tmp/theano_cc PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=%s:%s python3 ..." % (pkg, shims))

@@ -415,3 +415,90 @@ def test_lm_beam_search_matches_the_reference_emulated(device_lm):
 @pytest.mark.parametrize("device_lm", [False, True])
 def test_lm_beam_search_matches_the_reference_gpu(gpu_device, device_lm):
     _lm_beam_vs_reference(gpu_device, None, device_lm)
+
+
+# ---- teacher-forced cost / analyze WITH the language model (SequenceGenerator.evaluate + LanguageModel.evaluate + LMEmitter.cost,
+# libs/blocks/blocks/bricks/sequence_generators.py:286-299, lvsr/bricks/language_models.py:34-50,92-104,165-168) ------------------
+def run_lm_analyze_case(case, device, lib, device_lm):
+    from conftest import load_golden
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    z, meta = load_golden(case)
+    cfg = meta["cfg"]
+    V = cfg["num_phonemes"]
+    rec = SpeechRecognizer(device=device, params=synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"]), lib=lib,
+                           net_config=cfg)
+    f = LM.ArcFST(start=int(z["arcs"][0][0]))
+    for a, b, il, w in z["arcs"]:
+        f.add_arc(int(a), int(b), int(il), float(w))
+    f.isyms = dict([("<eps>", 0)] + [("c%d" % c, c + 1) for c in range(V)])
+    lm_kw = dict(meta["lm"])
+    kw = dict(nn_char_map={"c%d" % c: c for c in range(V)}, weight=lm_kw.pop("weight"), no_transition_cost=lm_kw.pop("no_transition_cost"),
+              am_beta=lm_kw.pop("am_beta", 1.0), normalize_am_weights=lm_kw.pop("normalize_am_weights", True),
+              normalize_lm_weights=lm_kw.pop("normalize_lm_weights", False), normalize_tot_weights=lm_kw.pop("normalize_tot_weights", False))
+    assert not lm_kw
+    rec.set_language_model(LM.DeviceFSTLanguageModel(f, device, lib=rec.lib, **kw) if device_lm else LM.FSTLanguageModel(f, **kw))
+    checked = 0
+    for u in range(8):
+        for j in range(meta["analyze_labels"]):
+            key = "an_u%d_%d_" % (u, j)
+            if key + "labels" not in z.files:
+                continue
+            y = z[key + "labels"]
+            cost, weights, _ = rec.analyze({"recordings": z["x%d" % u]}, y, y)
+            # (scale-6 parameters: label costs up to 135, i.e. logits in the hundreds — a cost near 1 is a float32 difference of
+            # such numbers, hence the absolute tolerance relative to the largest cost of the sequence)
+            assert_allclose(cost, z[key + "cost"], rtol=2e-4, atol=5e-6 * max(1.0, float(z[key + "cost"].max())))
+            assert_allclose(weights, z[key + "weights"], rtol=2e-4, atol=1e-5)
+            checked += 1
+    assert checked >= 6
+    # without the language model the same call gives other costs (the fixture is not vacuous)
+    rec.set_language_model(None)
+    y = z["an_u0_0_labels"]
+    assert numpy.abs(rec.analyze({"recordings": z["x0"]}, y, y)[0] - z["an_u0_0_cost"]).max() > 1e-3
+    return rec
+
+
+@pytest.mark.parametrize("device_lm", [False, True])
+@pytest.mark.parametrize("case", ["tiny_conv_lm_analyze", "tiny_conv_lm_analyze_tot"])
+def test_analyze_with_language_model_matches_the_reference_emulated(case, device_lm):
+    from emu import emu_lib
+    run_lm_analyze_case(case, "cpu", emu_lib(), device_lm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_lm", [False, True])
+@pytest.mark.parametrize("case", ["tiny_conv_lm_analyze", "tiny_conv_lm_analyze_tot"])
+def test_analyze_with_language_model_matches_the_reference_gpu(gpu_device, case, device_lm):
+    run_lm_analyze_case(case, gpu_device, None, device_lm)
+
+
+def test_gradient_with_language_model_is_the_plain_one_for_the_default_fusion():
+    """normalize_am_weights only, am_beta = 1: cost = -log_softmax(readout)[y] - w lm[y]; the second term does not depend on the
+    parameters, so the gradients equal those without the language model; other fusion settings refuse."""
+    from conftest import load_golden
+    from emu import emu_lib
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    z, meta = load_golden("tiny_conv_lm_analyze")
+    cfg = meta["cfg"]
+    V = cfg["num_phonemes"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(cfg, 3, 14, 5, seed=3, ragged=True)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
+    plain = rec.cost_and_gradients(batch).clone()
+    g0 = rec.store.get_grads()
+    f = LM.ArcFST(start=int(z["arcs"][0][0]))
+    for a, b, il, w in z["arcs"]:
+        f.add_arc(int(a), int(b), int(il), float(w))
+    f.isyms = dict([("<eps>", 0)] + [("c%d" % c, c + 1) for c in range(V)])
+    cmap = {"c%d" % c: c for c in range(V)}
+    rec.set_language_model(LM.FSTLanguageModel(f, nn_char_map=cmap, weight=0.5, no_transition_cost=20.0))
+    fused = rec.cost_and_gradients(batch)
+    assert float((fused - plain).abs().max()) > 1e-3
+    g1 = rec.store.get_grads()
+    for k in g0:
+        assert_allclose(g1[k], g0[k], rtol=1e-6, atol=1e-7, err_msg=k)
+    rec.set_language_model(LM.FSTLanguageModel(f, nn_char_map=cmap, weight=0.5, no_transition_cost=20.0, normalize_tot_weights=True))
+    with pytest.raises(NotImplementedError):
+        rec.cost_and_gradients(batch)
