@@ -318,7 +318,10 @@ class DeviceFSTLanguageModel(FSTLanguageModel):
         return {k: v.clone() for k, v in hit.items()}
 
     def transition(self, lm_states, outputs):
-        out = torch.as_tensor(numpy.ascontiguousarray(outputs), dtype=torch.int64).to(self.device).contiguous()
+        if torch.is_tensor(outputs):
+            out = outputs.to(device=self.device, dtype=torch.int64).contiguous()
+        else:
+            out = torch.as_tensor(numpy.ascontiguousarray(outputs), dtype=torch.int64).to(self.device).contiguous()
         return self._step(lm_states["states"].contiguous(), lm_states["weights"].contiguous(), out)
 
     on_device = True

@@ -448,8 +448,9 @@ def run_lm_analyze_case(case, device, lib, device_lm):
             cost, weights, _ = rec.analyze({"recordings": z["x%d" % u]}, y, y)
             # (scale-6 parameters: label costs up to 135, i.e. logits in the hundreds — a cost near 1 is a float32 difference of
             # such numbers, hence the absolute tolerance relative to the largest cost of the sequence)
-            assert_allclose(cost, z[key + "cost"], rtol=2e-4, atol=5e-6 * max(1.0, float(z[key + "cost"].max())))
-            assert_allclose(weights, z[key + "weights"], rtol=2e-4, atol=1e-5)
+            # The alignments: saturated units amplify the 2e-7 of the hardware exp / rcp the GPU kernels use on the chain (common.h)
+            assert_allclose(cost, z[key + "cost"], rtol=5e-4, atol=5e-6 * max(1.0, float(z[key + "cost"].max())))
+            assert_allclose(weights, z[key + "weights"], rtol=1e-3, atol=1e-4)
             checked += 1
     assert checked >= 6
     # without the language model the same call gives other costs (the fixture is not vacuous)
