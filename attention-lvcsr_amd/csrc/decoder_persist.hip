@@ -99,7 +99,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     float* const cp = lds + g.o_cp;       // [PD_NW][16][17] convolution partial tiles
     const int P = g.P, nown = g.nown;
     int b, p;
-    cluster_of_block(P, 0, b, p);
+    if (!cluster_of_block(P, a.B, 0, b, p)) return;                  // (work-groups of the grid's padding)
     const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: conditions on it become scalar branches
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L;
@@ -646,7 +646,7 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     const size_t bytes = 256 + ((size_t)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp) * 8;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(ws, 0, bytes, s);
-        const dim3 grid(a.B * g.P), block(PD_THREADS);
+        const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
         switch (g.KC) {
             case 0: hipLaunchKernelGGL(attdec_pfwd_kernel<0>, grid, block, 0, s, a, w, g, planes, ab); break;
             case 4: hipLaunchKernelGGL(attdec_pfwd_kernel<4>, grid, block, 0, s, a, w, g, planes, ab); break;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const red = lds + g.o_red;
     const int P = g.P, nown = g.nown;
     int b, p;
-    cluster_of_block(P, 0, b, p);
+    if (!cluster_of_block(P, a.B, 0, b, p)) return;                  // (work-groups of the grid's padding)
     const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
@@ -615,7 +615,7 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     u64* planes = (u64*)((char*)ws + 256);
     const size_t bytes = 256 + (size_t)a.B * (PB_NPLANE_SMALL * PD_MAXV + (size_t)g.P * (512 + 256 + 512)) * 8;
     (void)hipMemsetAsync(ws, 0, bytes, s);
-    const dim3 grid(a.B * g.P), block(PD_THREADS);
+    const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
     switch (g.KC) {
         case 0: hipLaunchKernelGGL(attdec_pbwd_kernel<0>, grid, block, 0, s, gb, w, g, planes, ab); break;
         case 4: hipLaunchKernelGGL(attdec_pbwd_kernel<4>, grid, block, 0, s, gb, w, g, planes, ab); break;

@@ -179,7 +179,7 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
     if (!(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NARROW) && g.NTH == 512 && g.HP == 256 && 2 * g.rt * 8 <= wide_cluster_capacity()) {
         g.KS = 16; g.KSPLIT = 16; g.UNITS = 32; g.P = 8;
     }
-    g.grid = 2 * g.rt * g.P;
+    g.grid = cluster_grid(2 * g.rt, g.P, lvsr_knob(LVSR_KNOB_PERSIST_FLAGS));     // (resident: 2 rt P; the padding exits at once)
     g.plane = (long long)g.RB * g.HP;
     return true;
 }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
     const int H = a.H, B = a.B, T = a.T;
     const int rt = (B + RB - 1) / RB;
     int cl, p;
-    cluster_of_block(P, flags, cl, p);
+    if (!cluster_of_block(P, 2 * rt, flags, cl, p)) return;
     const bool save = !(flags & PF_NOSAVE);
     const bool plain = P > 1 && cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
     const int dir = cl / rt, b0 = (cl % rt) * RB;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
     const int H = a.H, B = a.B, T = a.T;
     const int rt = (B + RB - 1) / RB;
     int cl, p;
-    cluster_of_block(P, flags, cl, p);
+    if (!cluster_of_block(P, 2 * rt, flags, cl, p)) return;
     const bool save = !(flags & PF_NOSAVE);
     const bool plain = P > 1 && cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
     const int dir = cl / rt, b0 = (cl % rt) * RB;

@@ -61,11 +61,16 @@ __device__ __forceinline__ bool cluster_shares_xcd(u64* hello, int P, int p, int
     __syncthreads();
     return same_xcd != 0;
 }
-// cluster / member index of a work-group
-__device__ __forceinline__ void cluster_of_block(int P, int flags, int& cl, int& p) {
-    const int b = blockIdx.x, ncl = gridDim.x / P;
-    if (!(flags & PF_SPREAD) && ncl % 8 == 0) { cl = (b % 8) + 8 * (b / (8 * P)); p = (b / 8) % P; }
-    else { cl = b / P; p = b % P; }
+// Launch grid for ncl clusters of P work-groups, and the cluster / member index of a work-group in it.  Work-groups are dealt to
+// the XCDs round-robin (block b on XCD b % 8), so cluster c = (b % 8) + 8 (b / 8P) takes the P blocks of its XCD column: every
+// cluster on ONE XCD for ANY number of clusters — the grid is padded to a multiple of 8 P and the work-groups of the padding
+// (cluster index >= ncl: the reference's batch of 10, a single decoding utterance) return at once.  Returns false for those.
+static inline int cluster_grid(int ncl, int P, int flags) { return (flags & PF_SPREAD) ? ncl * P : ((ncl + 7) / 8) * 8 * P; }
+__device__ __forceinline__ bool cluster_of_block(int P, int ncl, int flags, int& cl, int& p) {
+    const int b = blockIdx.x;
+    if (flags & PF_SPREAD) { cl = b / P; p = b % P; }
+    else { cl = (b % 8) + 8 * (b / (8 * P)); p = (b / 8) % P; }
+    return cl < ncl;
 }
 
 // sum over the KSPLIT adjacent lanes that share a unit; every lane of the group gets the total

@@ -146,7 +146,7 @@ inline void launch(dim3 grid, dim3 block, F&& f) {
     gdim() = grid; bdim() = block;
     int nthreads = block.x * block.y * block.z;
     const unsigned nblocks = grid.x * grid.y * grid.z;
-    if (concurrent_flag() && nblocks > 1 && nblocks <= 64) {
+    if (concurrent_flag() && nblocks > 1 && nblocks <= 256) {      // (cluster grids are padded to multiples of 8 P: most of a large one exits at once)
         std::function<void()> body = f;
         std::vector<std::thread> workers;
         for (unsigned z = 0; z < grid.z; ++z)

@@ -39,13 +39,18 @@ def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, 
 
 # The publish form is chosen per cluster and launch from the work-groups' XCC_ID (persist.h cluster_shares_xcd): plain stores
 # when the members share an XCD, write-through stores otherwise.  HIPEMU_XCDS=8 places block b on "XCD" b % 8 as the MI355X
-# does: clusters whose count is not a multiple of 8 are then numbered consecutively and straddle XCDs (the write-through
-# path); the default places every block on XCD 0 (the plain path).  Both must give the same numbers.
-@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,xcds", [([140], [1], 3, 6, True, 1, 8), ([140, 130], [1, 2], 4, 5, True, 1, 8),
-                                                             ([260], [1], 2, 4, False, 2, 4)])
-def test_persistent_encoder_when_clusters_straddle_xcds(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, xcds):
+# does.  With the default numbering every cluster then sits on one XCD whatever the batch size (padded grid, persist.h
+# cluster_of_block: B = 3 and 5 below leave part of the grid idle) — the plain path; with knob persist_flags = 2 consecutive
+# blocks form a cluster and straddle XCDs — the write-through path.  Both must give the same numbers.
+@pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,xcds,flags", [([140], [1], 3, 6, True, 1, 8, 0), ([140], [1], 3, 6, True, 1, 8, 2),
+                                                                   ([140, 130], [1, 2], 5, 5, True, 1, 8, 0), ([260], [1], 2, 4, False, 2, 4, 2)])
+def test_persistent_encoder_under_xcd_placement(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, xcds, flags):
     monkeypatch.setenv("HIPEMU_XCDS", str(xcds))
-    run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
+    concurrent_lib.set_knob("persist_flags", flags)
+    try:
+        run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
+    finally:
+        concurrent_lib.set_knob("persist_flags", 0)
 
 
 def run_against_oracle_and_step_kernels(lib, Hs, sub, B, T, use_mask):
