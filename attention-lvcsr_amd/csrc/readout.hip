@@ -291,7 +291,15 @@ __global__ __launch_bounds__(256) void readout_step_kernel(lvsr_readout_step_arg
         __syncthreads();
         for (int j = tid, q = 0; j < Pout; j += 256, ++q) r1[j] = v[q];
         __syncthreads();
-        wg_matvec(r1, Pout, a.Wout, a.V, a.bout, lg, part);
+        int cur = Pout;
+        for (int h = 0; h < a.n_hidden; ++h) {            // further post-merge layers: Linear + one-piece activation, via `lg`
+            const int w = a.dimh[h];
+            wg_matvec(r1, cur, a.Wh[h], w, a.bh[h], lg, part);
+            for (int j = tid; j < w; j += 256) r1[j] = a.act == 2 ? fmaxf(lg[j], 0.f) : a.act == 3 ? tanhf(lg[j]) : lg[j];
+            __syncthreads();
+            cur = w;
+        }
+        wg_matvec(r1, cur, a.Wout, a.V, a.bout, lg, part);
         logits = lg;
     }
     if (a.logits) for (int v = tid; v < a.V; v += 256) a.logits[(size_t)r * a.V + v] = logits[v];
@@ -394,6 +402,11 @@ int lvsr_readout_step(void* stream, const lvsr_readout_step_args* args) {
     LVSR_REQUIRE(a.Wout != nullptr || a.P == a.V, "lvsr_readout_step: without a post-merge layer the merge width must be V");
     LVSR_REQUIRE(a.act >= 0 && a.act <= 3 && (a.act != 1 || a.P % 2 == 0), "lvsr_readout_step: bad activation");
     LVSR_REQUIRE(!a.uniforms || a.outputs, "lvsr_readout_step: emit needs an output buffer");
+    LVSR_REQUIRE(a.n_hidden >= 0 && a.n_hidden <= 3 && (a.n_hidden == 0 || (a.Wout && (a.act == 2 || a.act == 3))),
+                 "lvsr_readout_step: further post-merge layers need a one-piece activation and an output layer");
+    for (int h = 0; h < a.n_hidden; ++h)
+        LVSR_REQUIRE(a.Wh[h] && a.bh[h] && a.dimh[h] > 0 && a.dimh[h] <= RS_MAX_P && a.dimh[h] <= RS_MAX_V,
+                     "lvsr_readout_step: bad post-merge layer %d", h);
     hipLaunchKernelGGL(readout_step_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a);
     return lvsr_check_launch("lvsr_readout_step");
 }

@@ -47,9 +47,12 @@ class SequenceGenerator(object):
             Wfi=g + "/fork/fork_inputs.W", bfi=g + "/fork/fork_inputs.b",
             Wfg=g + "/fork/fork_gate_inputs.W", bfg=g + "/fork/fork_gate_inputs.b",
             Wms=g + "/readout/merge/transform_states.W", Wmw=g + "/readout/merge/transform_weighted_averages.W",
-            bpm=g + "/readout/post_merge/bias.b", Wout=g + "/readout/post_merge/mlp/linear_0.W",
-            bout=g + "/readout/post_merge/mlp/linear_0.b", bro=g + "/readout/bias.b",
+            bpm=g + "/readout/post_merge/bias.b", Wout=g + "/readout/post_merge/mlp/linear_%d.W" % len(dims.pm_hidden),
+            bout=g + "/readout/post_merge/mlp/linear_%d.b" % len(dims.pm_hidden), bro=g + "/readout/bias.b",
             table=g + "/readout/lookupfeedback/lookuptable.W")
+        # further post-merge layers (recognizer.py:309-317): linear_0 .. linear_{n-2} with the activation behind each
+        self.pm_hidden = [(g + "/readout/post_merge/mlp/linear_%d.W" % j, g + "/readout/post_merge/mlp/linear_%d.b" % j, w)
+                          for j, w in enumerate(dims.pm_hidden)]
 
     # ---- packed operand copies ------------------------------------------------------------------
     def _packed(self):
@@ -140,6 +143,14 @@ class SequenceGenerator(object):
             return R1, None, R1
         R2 = ws.get("gen.R2" + tag, (nrows, d.Pout))
         lib.call("lvsr_act_fwd", lib.stream_for(R2), ACT_KIND[d.act], lib_ptr(R1), d.P, nrows, d.P, lib_ptr(R2), d.Pout)
+        self._pm_acts = []                       # (input, pre-activation) of every further layer, for the backward pass
+        for j, (wn, bn, width) in enumerate(self.pm_hidden):
+            pre = ws.get("gen.pm_pre%d" % j + tag, (nrows, width))
+            lib.sgemm(R2, p[wn], pre, bias=p[bn])
+            post = ws.get("gen.pm_post%d" % j + tag, (nrows, width))
+            lib.call("lvsr_act_fwd", lib.stream_for(post), ACT_KIND[d.act], lib_ptr(pre), width, nrows, width, lib_ptr(post), width)
+            self._pm_acts.append((R2, pre))
+            R2 = post
         logits = ws.get("gen.logits" + tag, (nrows, d.V))
         lib.sgemm(R2, p[n["Wout"]], logits, bias=p[n["bout"]])
         return R1, R2, logits
@@ -254,7 +265,8 @@ class SequenceGenerator(object):
         self.last = dict(weights=W[1:], energies=bufs["EN"], states=S[:L], weighted_averages=WA)
         if save_for_backward:
             self._saved = dict(L=L, B=B, Tp=Tp, A=A, Am=Am, PA=PA, labels=labels, ym=ym, xg=xg, fb=fb, bufs=bufs,
-                               fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk, AW_valid=sync is not None)
+                               fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk, AW_valid=sync is not None,
+                               pm_acts=list(self._pm_acts))
         return cost
 
     def _lm_lookahead(self, lm, labels, ym, L, B):
@@ -305,8 +317,18 @@ class SequenceGenerator(object):
         if d.post_merge:
             lib.sgemm(R2, dlogits, g[n["Wout"]], transA=True, ws=gws, group=True)
             lib.colsum(dlogits, g[n["bout"]], ws=gws)
-            dR2 = ws.get("gen.dR2", (nrows, d.Pout))
+            dR2 = ws.get("gen.dR2", (nrows, R2.shape[1]))
             lib.sgemm(dlogits, p[n["Wout"]], dR2, transB=True)
+            for j in range(len(self.pm_hidden) - 1, -1, -1):          # the further post-merge layers, last first
+                wn, bn, width = self.pm_hidden[j]
+                xin, pre = sv["pm_acts"][j]
+                dpre = ws.get("gen.pm_dpre%d" % j, (nrows, width))
+                lib.call("lvsr_act_bwd", lib.stream_for(dpre), ACT_KIND[d.act], lib_ptr(pre), width, lib_ptr(dR2), width, nrows, width,
+                         lib_ptr(dpre), width)
+                lib.sgemm(xin, dpre, g[wn], transA=True, ws=gws, group=True)
+                lib.colsum(dpre, g[bn], ws=gws)
+                dR2 = ws.get("gen.pm_dx%d" % j, (nrows, xin.shape[1]))
+                lib.sgemm(dpre, p[wn], dR2, transB=True)
             dR1 = ws.get("gen.dR1", (nrows, d.P))
             lib.call("lvsr_act_bwd", lib.stream_for(dR1), ACT_KIND[d.act], lib_ptr(R1), d.P, lib_ptr(dR2), d.Pout, nrows, d.P,
                      lib_ptr(dR1), d.P)
@@ -764,7 +786,8 @@ def _beam_methods():
             am_beta=lm.am_beta if lm_add is not None else 1.0, lm_weight=lm.lm_weight if lm_add is not None else 0.0,
             norm_am=int(lm.norm[0]) if lm_add is not None else 1, norm_lm=int(lm.norm[1]) if lm_add is not None else 0,
             norm_tot=int(lm.norm[2]) if lm_add is not None else 0, neglogp=neglogp, logits=logits, uniforms=uniforms,
-            outputs=outputs, costs=costs)
+            outputs=outputs, costs=costs, n_hidden=len(self.pm_hidden), Wh=[p[w] for w, _, _ in self.pm_hidden],
+            bh=[p[b] for _, b, _ in self.pm_hidden], dimh=[w for _, _, w in self.pm_hidden])
 
     def beam_costs(self):
         """Pass A of a position: glimpses of the live hypotheses -> readout -> step costs `neglogp` (K,V)

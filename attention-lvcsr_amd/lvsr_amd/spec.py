@@ -85,8 +85,15 @@ def normalize_net_config(cfg):
     if not out["post_merge_dims"]:
         out["post_merge_dims"] = None            # `post_merge_dims: []` (exp/wsj/configs/wsj_small.yaml) = no post-merge (recognizer.py:305 `if post_merge_dims:`)
     if out["post_merge_dims"] is not None:
-        if len(out["post_merge_dims"]) != 1:
-            raise NotImplementedError("only single-layer post_merge_dims is built")
+        out["post_merge_dims"] = [int(v) for v in out["post_merge_dims"]]
+        if len(out["post_merge_dims"]) > 4:
+            raise NotImplementedError("post_merge_dims: at most 4 layers are built")
+        if len(out["post_merge_dims"]) > 1 and out["post_merge_activation"] == "maxout2":
+            # recognizer.py:305-319 builds MLP([act] * (n - 1) + [Identity()], [d // num_pieces for d in dims] + [V]): with Maxout
+            # layer i emits d_{i+1} / pieces^2 values where layer i + 1 expects d_{i+1} / pieces (the source says so itself: "For
+            # deeper Maxout network one has to use the Sequence brick") — the reference's own construction cannot run
+            raise ValueError("post_merge_dims with more than one layer needs a one-piece activation (the reference's Maxout MLP "
+                             "construction is inconsistent beyond one layer, lvsr/bricks/recognizer.py:305-319)")
         if out["post_merge_activation"] not in SUPPORTED_ACTIVATIONS:
             raise ValueError("post_merge_activation must be one of %s" % (SUPPORTED_ACTIVATIONS,))
         if out["post_merge_activation"] == "maxout2" and out["post_merge_dims"][0] % 2:
@@ -124,11 +131,14 @@ class Dims(object):
             self.act = cfg["post_merge_activation"]
             self.pieces = 2 if self.act == "maxout2" else 1
             self.Pout = self.P // self.pieces
+            # further post-merge layers (one-piece activations only): widths of linear_0 .. linear_{n-2}; the last linear maps to V
+            self.pm_hidden = [int(v) for v in cfg["post_merge_dims"][1:]]
         else:
             self.P = self.V
             self.act = "identity"
             self.pieces = 1
             self.Pout = self.V
+            self.pm_hidden = []
         self.post_merge = bool(cfg["post_merge_dims"])
         self.use_states_for_readout = bool(cfg["use_states_for_readout"])
         self.normalizer = cfg["energy_normalizer"] if self.conv else "softmax"
@@ -187,8 +197,10 @@ def parameter_shapes(cfg):
     p[g + "/readout/merge/transform_weighted_averages.W"] = (d.E, d.P)
     if d.post_merge:
         p[g + "/readout/post_merge/bias.b"] = (d.P,)
-        p[g + "/readout/post_merge/mlp/linear_0.W"] = (d.Pout, d.V)
-        p[g + "/readout/post_merge/mlp/linear_0.b"] = (d.V,)
+        widths = [d.Pout] + d.pm_hidden + [d.V]                 # MLP([act] * (n - 1) + [Identity()], ...), recognizer.py:309-317
+        for j in range(len(widths) - 1):
+            p[g + "/readout/post_merge/mlp/linear_%d.W" % j] = (widths[j], widths[j + 1])
+            p[g + "/readout/post_merge/mlp/linear_%d.b" % j] = (widths[j + 1],)
     else:
         p[g + "/readout/bias.b"] = (d.V,)
     if d.embed:

@@ -327,6 +327,10 @@ typedef struct lvsr_readout_step_args {
     float* logits;                        /* (n,V) out, or NULL */
     const float* uniforms;                /* (n) in [0,1): emit, or NULL */
     long long* outputs; float* costs;     /* (n) out: emitted class and its cost (with uniforms) */
+    /* further post-merge layers (post_merge_dims of more than one entry, lvsr/bricks/recognizer.py:309-317): layer h maps the
+     * previous width to dimh[h] (Wh[h] (prev, dimh[h]), bh[h]) and is followed by `act` (2 or 3 only); Wout then has dimh[last] rows */
+    int n_hidden; int dimh[3];
+    const float* Wh[3]; const float* bh[3];
 } lvsr_readout_step_args;
 int lvsr_readout_step(void* stream, const lvsr_readout_step_args* a);
 /* SoftmaxEmitter.emit + cost on given readouts (n,V): outputs[r] = class drawn at uniforms[r], costs[r] = -log p (or NULL) */

@@ -258,7 +258,12 @@ class OracleRecognizer(object):
             r = torch.relu(r)
         elif d.act == "tanh":
             r = torch.tanh(r)
-        return r @ p[g + "/post_merge/mlp/linear_0.W"] + p[g + "/post_merge/mlp/linear_0.b"]
+        # MLP([act] * (n - 1) + [Identity()], [d // pieces for d in post_merge_dims] + [V]) (recognizer.py:309-317)
+        for j in range(len(d.pm_hidden)):
+            r = r @ p[g + "/post_merge/mlp/linear_%d.W" % j] + p[g + "/post_merge/mlp/linear_%d.b" % j]
+            r = torch.relu(r) if d.act == "rectifier" else torch.tanh(r) if d.act == "tanh" else r
+        j = len(d.pm_hidden)
+        return r @ p[g + "/post_merge/mlp/linear_%d.W" % j] + p[g + "/post_merge/mlp/linear_%d.b" % j]
 
     def initial_glimpses(self, B, Tp):
         """content: blocks attention.py:390-393 (zeros); conv: lvsr/bricks/attention.py:215-222 (one-hot at 0)."""

@@ -341,6 +341,11 @@ CASES = {
         "tiny_conv_bottom", tiny_cfg(dict(type="window_around_median", before=2, after=2), bottom_dims=[6, 4],
                                      bottom_activation="rectifier"),
         B=3, T=13, L=5, ragged=True, param_seed=24, batch_seed=33, beam=BEAMS[:1]),
+    # post_merge_dims with TWO entries (MLP([act, Identity], [8, 6, V]) behind Bias + act, recognizer.py:305-319), rectifier
+    "tiny_conv_postmerge2": lambda: run_case(
+        "tiny_conv_postmerge2", tiny_cfg(dict(type="window_around_median", before=2, after=2), post_merge_dims=[8, 6],
+                                         post_merge_activation="rectifier"),
+        B=3, T=13, L=5, ragged=True, param_seed=26, batch_seed=35, beam=BEAMS[:2], analyze=True),
     "tiny_content_embed": lambda: run_case(
         "tiny_content_embed",
         dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",

@@ -56,6 +56,15 @@ def test_unsupported_bricks_raise_not_silently_fall_back():
         spec.from_reference_kwargs(attention_type="nope", **base)                        # recognizer.py:275-277
     with pytest.raises(ValueError):                # the reference's own MLP(1 activation, 2+ layers) raises ValueError, too
         spec.from_reference_kwargs(dims_top=[5], **base)
+    # post_merge_dims: [] = none (exp/wsj/configs/wsj_small.yaml); several entries with a one-piece activation are built; with
+    # Maxout the reference's own MLP construction is inconsistent beyond one layer (recognizer.py:305-319)
+    assert spec.from_reference_kwargs(post_merge_dims=[], **base)["post_merge_dims"] is None
+    two = spec.from_reference_kwargs(post_merge_dims=[12, 6], post_merge_activation=blocks_compat.Rectifier(), **base)
+    shapes = spec.parameter_shapes(two)
+    assert shapes["/recognizer/generator/readout/post_merge/mlp/linear_0.W"] == (12, 6)
+    assert shapes["/recognizer/generator/readout/post_merge/mlp/linear_1.W"] == (6, 10)
+    with pytest.raises(ValueError):
+        spec.from_reference_kwargs(post_merge_dims=[12, 6], post_merge_activation=blocks_compat.Maxout(2), **base)
 
 
 def test_blocks_checkpoint_round_trip(tmp_path):
