@@ -67,11 +67,15 @@ struct Sweep {                       // one sweep of granule loads of a lane: NG
 // the CONSUMER CU's own memory queue").
 // NPL > 1: NPL planes that were published together and lie back to back are swept as one vector; plane p lands in the LDS
 // buffer dst + p * DSTRIDE.
+// NTH = number of SWEEPING threads (the first NTH of the work-group): the 512-thread kernels sweep with waves 0..3 only, so that
+// waves 4..7 can fetch the next step's operands without a global load ever sitting in front of a sweep in a polling wave's
+// in-order memory queue (measured: those loads cost 0.18 / 0.33 us per forward / BPTT step there, tools/probe_persist.py).
 template <int NG1, int HP, int KS, int LDH, int KSPLIT, bool PRIV, int NPL = 1, int DSTRIDE = 0, int NTH = 256>
 __device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float* dst, int* abort_word, int flags = 0) {
     constexpr int NG = NG1 * NPL;
     typedef Sweep<NG, PRIV, NTH> S;
     constexpr int NT = S::NT;
+    if (!PRIV && (int)threadIdx.x >= NTH) return true;              // (wave-uniform: NTH is a multiple of 64)
     const int tid = PRIV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     S a;
     unsigned spins = 0;
@@ -195,6 +199,12 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
     constexpr int NBUF = PRIV ? 4 : 1;
     __shared__ __attribute__((aligned(16))) float hbuf_all[2][NBUF][RB * KSPLIT * LDH];
     float* const hbuf[2] = {hbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], hbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0]};
+    // STAGED (512-thread kernels): waves 0..3 sweep the granules, waves 4..7 fetch the next step's operands (gate inputs, mask)
+    // and hand them over through LDS — a polling wave then issues no other global load (see gather_plane)
+    constexpr bool STAGED = NTH == 512 && P > 1;
+    constexpr int SWEEP = STAGED ? 256 : NTH;
+    constexpr int ITEMS = RB * 3 * UNITS + RB, NLD = (ITEMS + 255) / 256;
+    __shared__ float opnd[STAGED ? ITEMS : 1];
     const int H = a.H, B = a.B, T = a.T;
     const int rt = (B + RB - 1) / RB;
     int cl, p;
@@ -204,6 +214,8 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
     const int dir = cl / rt, b0 = (cl % rt) * RB;
     const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
     const bool junit = j < H;
+    const bool staged = STAGED && !(flags & PF_NOSTAGE);          // (PF_NOSTAGE: the owners fetch their operands themselves, for A/B runs)
+    const bool loader = staged && tid >= 256;
     // ---- this thread's weight slice, in registers for the whole sequence
     f32x2 wr[KS / 2], wu[KS / 2], wc[KS / 2];
     {
@@ -249,12 +261,39 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
         const int row = idx / HP, k = idx % HP;
         hbuf[0][(row * KSPLIT + k / KS) * LDH + (k % KS)] = k < H ? a.h0[dir][k] : 0.f;
     }
+    // (STAGED) what waves 4..7 fetch for scan step `ns`: item idx = ((row * 3 + gate) * UNITS + unit), then the rows' masks
+    auto stage_issue = [&](int ns, float (&dst)[NLD]) {
+        const bool fetch = loader && ns < T && !(flags & PF_NOPREFETCH);
+        const int tn = dir == 0 ? ns : T - 1 - ns;
+#pragma unroll
+        for (int l = 0; l < NLD; ++l) {
+            const int idx = tid - 256 + 256 * l;
+            dst[l] = 0.f;
+            if (fetch && idx < RB * 3 * UNITS) {
+                const int r = idx / (3 * UNITS), gsel = (idx / UNITS) % 3, jj = p * UNITS + idx % UNITS, bb = b0 + r;
+                if (jj < H && bb < B) dst[l] = a.xg[((size_t)tn * B + bb) * 6 * H + dir * 3 * H + gsel * H + jj];
+            } else if (fetch && idx < ITEMS) {
+                const int bb = b0 + idx - RB * 3 * UNITS;
+                dst[l] = (a.mask && bb < B) ? a.mask[(size_t)tn * B + bb] : 1.f;
+            }
+        }
+    };
+    float pf[NLD];
+    if (STAGED) stage_issue(1, pf);                               // (no loads unless `loader`)
     for (int n = 0; n < T; ++n) {
         const int t = dir == 0 ? n : T - 1 - n;
         float xin[NR], gu[NR], gr[NR], m[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) { xin[i] = n_xin[i]; gu[i] = n_gu[i]; gr[i] = n_gr[i]; m[i] = n_m[i]; }
-        if (P > 1 && n > 0 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
+        // waves 4..7: the operands of step n + 2 are issued here; those of step n + 1 (issued a step ago: long landed) are handed
+        // over in front of the second barrier of this step
+        float pf_new[NLD];
+        if (STAGED) stage_issue(n + 2, pf_new);
+        if (P > 1 && n > 0) {
+            const bool ok = (NG <= 256 || staged) ? gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, SWEEP>(gh, (unsigned)n, hbuf[0], abort_word, flags)
+                                                  : gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gh, (unsigned)n, hbuf[0], abort_word, flags);
+            if (!ok) return;
+        }
         gather_fence<PRIV>();
         // ---- reset gate: the only thing the next exchange waits for
         float s[RB], rr[NR], uu[NR];
@@ -283,7 +322,22 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
                 if (rvalid[i] && save) a.u[((size_t)t * B + b0 + r) * 2 * H + dir * H + j] = uu[i];
             }
         }
-        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
+        if (STAGED) {
+            if (loader && n + 1 < T) {
+#pragma unroll
+                for (int l = 0; l < NLD; ++l) {
+                    const int idx = tid - 256 + 256 * l;
+                    if (idx < ITEMS) opnd[idx] = pf[l];
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NLD; ++l) pf[l] = pf_new[l];
+        }
+        if (P > 1) {
+            const bool ok = (NG <= 256 || staged) ? gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, SWEEP>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)
+                                                  : gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags);
+            if (!ok) return;
+        }
         gather_fence<PRIV>();
         // ---- candidate, state update, mask blend
         slice_dot<KS, RB, LDH, KSPLIT>(wc, hbuf[1], q, s, flags);
@@ -306,16 +360,23 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
                 hown[i] = hn;
             }
         }
-        // ---- operands of the next step (independent of the recurrence): in flight during the next hand-off
-        if (n + 1 < T) {
+        // ---- operands of the next step (independent of the recurrence)
+        if (n + 1 < T && !(flags & PF_NOPREFETCH)) {
             const int tn = dir == 0 ? n + 1 : T - 2 - n;
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 if (rvalid[i]) {
-                    const size_t row = (size_t)tn * B + b0 + q + i * KSPLIT;
-                    const float* xr = a.xg + row * 6 * H + dir * 3 * H;
-                    n_xin[i] = xr[j]; n_gu[i] = xr[H + j]; n_gr[i] = xr[2 * H + j];
-                    if (a.mask) n_m[i] = a.mask[row];
+                    const int r = q + i * KSPLIT;
+                    if (staged) {             // handed over by waves 4..7 in front of the second barrier of this step
+                        const int ju = tid / KSPLIT;
+                        n_xin[i] = opnd[(r * 3 + 0) * UNITS + ju]; n_gu[i] = opnd[(r * 3 + 1) * UNITS + ju]; n_gr[i] = opnd[(r * 3 + 2) * UNITS + ju];
+                        n_m[i] = opnd[RB * 3 * UNITS + r];
+                    } else {                  // fetched by the owner itself: in flight during the next hand-off
+                        const size_t row = (size_t)tn * B + b0 + r;
+                        const float* xr = a.xg + row * 6 * H + dir * 3 * H;
+                        n_xin[i] = xr[j]; n_gu[i] = xr[H + j]; n_gr[i] = xr[2 * H + j];
+                        if (a.mask) n_m[i] = a.mask[row];
+                    }
                 }
             }
         }
@@ -425,7 +486,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
             }
         }
         // operands of the next step: in flight during the hand-offs
-        if (n + 1 < T) {
+        if (n + 1 < T && !(flags & PF_NOPREFETCH)) {
 #pragma unroll
             for (int i = 0; i < NR; ++i)
                 if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
