@@ -201,7 +201,10 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
     float* const hbuf[2] = {hbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], hbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0]};
     // STAGED (512-thread kernels): waves 0..3 sweep the granules, waves 4..7 fetch the next step's operands (gate inputs, mask)
     // and hand them over through LDS — a polling wave then issues no other global load (see gather_plane)
-    constexpr bool STAGED = NTH == 512 && P > 1;
+    // (only where the plane fits waves 0..3 with one granule per lane — one utterance per cluster, H <= 256: elsewhere all waves
+    // sweep and the owners fetch their operands themselves; measured with two granules per lane on waves 0..3: B = 32 22.4 vs 21.8 ms
+    // per step, WSJ-deep 67.6 vs 66.6)
+    constexpr bool STAGED = NTH == 512 && P > 1 && NG <= 256;
     constexpr int SWEEP = STAGED ? 256 : NTH;
     constexpr int ITEMS = RB * 3 * UNITS + RB, NLD = (ITEMS + 255) / 256;
     __shared__ float opnd[STAGED ? ITEMS : 1];

@@ -135,6 +135,7 @@ class SequenceGenerator(object):
         """Readout.readout (sequence_generators.py:614-619) + post-merge (recognizer.py:298-320) -> logits."""
         d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
         R1 = ws.get("gen.R1" + tag, (nrows, d.P))
+        self._pm_acts = []                       # (input, pre-activation) of every further post-merge layer, for the backward pass
         bias = p[n["bpm"]] if d.post_merge else p[n["bro"]]
         lib.sgemm(WA2, p[n["Wmw"]], R1, bias=bias)
         if d.use_states_for_readout:
@@ -143,7 +144,6 @@ class SequenceGenerator(object):
             return R1, None, R1
         R2 = ws.get("gen.R2" + tag, (nrows, d.Pout))
         lib.call("lvsr_act_fwd", lib.stream_for(R2), ACT_KIND[d.act], lib_ptr(R1), d.P, nrows, d.P, lib_ptr(R2), d.Pout)
-        self._pm_acts = []                       # (input, pre-activation) of every further layer, for the backward pass
         for j, (wn, bn, width) in enumerate(self.pm_hidden):
             pre = ws.get("gen.pm_pre%d" % j + tag, (nrows, width))
             lib.sgemm(R2, p[wn], pre, bias=p[bn])
