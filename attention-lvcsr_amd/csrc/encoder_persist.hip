@@ -536,6 +536,141 @@ __global__ __launch_bounds__(256) void enc_pbwd_h0_kernel(const float* dh, int B
     (dir == 0 ? out_f : out_b)[j] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Unit-blocked forward kernel (one utterance per cluster): a group of G = 16 U lanes serves U units, lane q of the group keeps the KS
+// rows [q KS, (q+1) KS) of the three weight columns of ALL U units (the same 3 KS U registers as one unit with U KS rows) and reads
+// its slice of the phase vector from LDS ONCE for the U units — the contractions are LDS-broadcast bound, and this divides the
+// operand traffic by U (H = 512: 2 instead of 8 ds_read_b128 per lane and contraction).  The U partial sums are folded with a
+// butterfly over the group's top log2(U) lane bits (each stage halves the values a lane carries) and a 16-lane DPP sum: lane
+// 16 u of the group ends up owning unit u (epilogue, publishing, saved tensors).
+// ---------------------------------------------------------------------------------------------------------------
+template <int KS, int U>
+__device__ __forceinline__ void ub_dot(const f32x2 (&w)[U][KS / 2], const float* buf, int q, float (&out)[U]) {
+    const float4* hv = (const float4*)(buf + q * (KS + 4));
+    f32x2 acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int x = 0; x < KS / 4; ++x) {
+        const float4 h4 = hv[x];
+        const f32x2 lo = {h4.x, h4.y}, hi = {h4.z, h4.w};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc[u] = w[u][2 * x] * lo + acc[u];
+            acc[u] = w[u][2 * x + 1] * hi + acc[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) out[u] = acc[u].x + acc[u].y;
+}
+// the total of value (q >> 4) over the group's lanes, in every lane of row q >> 4
+template <int U>
+__device__ __forceinline__ float ub_fold(const float (&v)[U], int q) {
+    float r;
+    if (U == 4) {
+        const bool up = (q & 32) != 0;
+        const float a0 = (up ? v[2] : v[0]) + __shfl_xor(up ? v[0] : v[2], 32, 64);
+        const float a1 = (up ? v[3] : v[1]) + __shfl_xor(up ? v[1] : v[3], 32, 64);
+        const bool up2 = (q & 16) != 0;
+        r = (up2 ? a1 : a0) + __shfl_xor(up2 ? a0 : a1, 16, 64);
+    } else if (U == 2) {
+        const bool up = (q & 16) != 0;
+        r = (up ? v[1] : v[0]) + __shfl_xor(up ? v[0] : v[1], 16, 64);
+    } else {
+        r = v[0];
+    }
+    return group_sum<16>(r);
+}
+
+template <int KS, int U, int NTH>
+__global__ __launch_bounds__(NTH) void enc_pfwd_ub_kernel(EncFwd a, u64* planes, u64* hello, int* abort_word, int flags) {
+    constexpr int G = 16 * U, HP = KS * G, UNITS = NTH / G * U, P = HP / UNITS, LDH = KS + 4, NG = HP;
+    __shared__ __attribute__((aligned(16))) float hbuf[2][G * LDH];
+    const int H = a.H, B = a.B, T = a.T;
+    int cl, p;
+    if (!cluster_of_block(P, 2 * B, flags, cl, p)) return;
+    const bool save = !(flags & PF_NOSAVE);
+    const bool plain = cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
+    const int dir = cl / B, b = cl % B;
+    const int tid = threadIdx.x, q = tid % G, jb = p * UNITS + (tid / G) * U, k0 = q * KS;
+    // ---- the weight slices of the group's U units, in registers for the whole sequence
+    f32x2 wr[U][KS / 2], wu[U][KS / 2], wc[U][KS / 2];
+    {
+        const float* Whg = a.Whg_p[dir];
+        const float* Whh = a.Whh_p[dir];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u;
+            const size_t jc = (size_t)min(j, H - 1);
+#pragma unroll
+            for (int x = 0; x < KS / 2; ++x) {
+                float v[6];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int k = k0 + 2 * x + e;
+                    const float keep = (j < H && k < H) ? 1.f : 0.f;
+                    const size_t kc = (size_t)min(k, H - 1);
+                    v[e] = Whg[kc * 2 * H + jc] * keep;
+                    v[2 + e] = Whg[kc * 2 * H + H + jc] * keep;
+                    v[4 + e] = Whh[kc * H + jc] * keep;
+                }
+                wu[u][x] = (f32x2){v[0], v[1]}; wr[u][x] = (f32x2){v[2], v[3]}; wc[u][x] = (f32x2){v[4], v[5]};
+            }
+        }
+    }
+    u64* gh = planes + (size_t)cl * 2 * NG;
+    u64* grh = gh + NG;
+    // ---- the owner lane of unit j = jb + (q >> 4): lane 16 (q >> 4) of the group
+    const int j = jb + (q >> 4);
+    const bool own = (q & 15) == 0 && j < H;
+    float hown = own ? a.h0[dir][j] : 0.f, n_xin = 0.f, n_gu = 0.f, n_gr = 0.f, n_m = 1.f;
+    auto fetch = [&](int t) {
+        const size_t row = (size_t)t * B + b;
+        const float* xr = a.xg + row * 6 * H + dir * 3 * H;
+        n_xin = xr[j]; n_gu = xr[H + j]; n_gr = xr[2 * H + j];
+        if (a.mask) n_m = a.mask[row];
+    };
+    if (own) fetch(dir == 0 ? 0 : T - 1);
+    for (int k = tid; k < HP; k += NTH) hbuf[0][(k / KS) * LDH + (k % KS)] = k < H ? a.h0[dir][k] : 0.f;
+    for (int n = 0; n < T; ++n) {
+        const int t = dir == 0 ? n : T - 1 - n;
+        const float xin = n_xin, gu = n_gu, gr = n_gr, m = n_m;
+        if (n > 0 && !gather_plane<NG, HP, KS, LDH, G, false, 1, 0, NTH>(gh, (unsigned)n, hbuf[0], abort_word, flags)) return;
+        __syncthreads();
+        // ---- reset gate: the only thing the next exchange waits for
+        float s[U];
+        ub_dot<KS, U>(wr, hbuf[0], q, s);
+        const float rr = sigmoid_fast(ub_fold<U>(s, q) + gr);
+        const float rh = own ? rr * hown : 0.f;
+        if ((q & 15) == 0) granule_store(grh + min(j, HP - 1), (unsigned)(n + 1), rh, plain);
+        if (own && save) {
+            const size_t o = ((size_t)t * B + b) * 2 * H + dir * H + j;
+            a.r[o] = rr; a.rh[o] = rh;
+        }
+        // ---- update gate, in the shadow of the hand-off
+        ub_dot<KS, U>(wu, hbuf[0], q, s);
+        const float uu = sigmoid_fast(ub_fold<U>(s, q) + gu);
+        if (own && save) a.u[((size_t)t * B + b) * 2 * H + dir * H + j] = uu;
+        if (!gather_plane<NG, HP, KS, LDH, G, false, 1, 0, NTH>(grh, (unsigned)(n + 1), hbuf[1], abort_word, flags)) return;
+        __syncthreads();
+        // ---- candidate, state update, mask blend
+        ub_dot<KS, U>(wc, hbuf[1], q, s);
+        const float cand = tanh_fast(ub_fold<U>(s, q) + xin);
+        float hn = cand * uu + hown * (1.f - uu);
+        hn = m * hn + (1.f - m) * hown;
+        if (!own) hn = 0.f;
+        if ((q & 15) == 0 && n + 1 < T) granule_store(gh + min(j, HP - 1), (unsigned)(n + 1), hn, plain);
+        if (own) {
+            const size_t o = ((size_t)t * B + b) * 2 * H + dir * H + j;
+            if (save) a.c[o] = cand;
+            a.y[o] = hn;
+            if (a.ysub && (t % a.sub) == 0) a.ysub[((size_t)(t / a.sub) * B + b) * 2 * H + dir * H + j] = hn;
+        }
+        hown = hn;
+        if (own && n + 1 < T && !(flags & PF_NOPREFETCH)) fetch(dir == 0 ? n + 1 : T - 2 - n);
+    }
+}
+
 // How many work-groups of the wide (8 per cluster) kernels the device holds at once: occupancy per CU as the runtime computes it
 // from their registers / LDS (2 on MI355X) x lvsr_max_cluster_wgs(); a launch at most this large is resident as a whole, which the
 // clusters' mutual waiting needs.  The forward and BPTT kernels of both row counts are asked; the smallest answer counts.
@@ -572,6 +707,13 @@ extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
 
 template <int KS, int KSPLIT>
 static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64* planes, u64* hello, int* ab, int flags) {
+    if (g.NTH == 512 && g.RB == 1 && g.HP == 512 && !(flags & PF_NOUB)) {
+        // 256 < H <= 512, one utterance per cluster: four units per thread group (2.88 -> 2.37 us per forward step, WSJ-deep layer
+        // probe).  At H <= 256 it measured no gain over the loader-wave kernel (1.78 vs 1.76), and the BPTT counterpart was slower
+        // than the plain kernel at both sizes (3.05 vs 2.90, 2.39 vs 2.22): neither is built.
+        hipLaunchKernelGGL((enc_pfwd_ub_kernel<8, 4, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
+        return;
+    }
     if (g.NTH == 512) {                        // two waves per SIMD: half the k-slice per thread (one or two utterances per cluster)
         if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         else if (g.P == 8 && g.KS == 16) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);

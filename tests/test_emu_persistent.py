@@ -32,7 +32,8 @@ def concurrent_lib(request):
 # H > 256: 16 work-groups (launches of more than 64 work-groups are not run concurrently by the emulator: B and rows chosen so)
 @pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows", [([20], [1], 3, 7, True, 1), ([32, 16], [2, 1], 5, 8, True, 2),
                                                         ([40], [1], 17, 5, False, 8), ([140], [1], 3, 6, True, 1),
-                                                        ([130, 24], [1, 2], 6, 5, True, 4), ([260], [1], 3, 4, True, 2)])
+                                                        ([130, 24], [1, 2], 6, 5, True, 4), ([260], [1], 3, 4, True, 2),
+                                                        ([260], [1], 2, 3, False, 1)])          # rows = 1 at H > 256: the unit-blocked forward kernel
 def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask, rows):
     run_against_oracle_and_step_kernels(concurrent_lib, Hs, sub, B, T, use_mask)
 
