@@ -710,7 +710,7 @@ static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64
     if (g.NTH == 512 && g.RB == 1 && g.HP == 512 && !(flags & PF_NOUB)) {
         // 256 < H <= 512, one utterance per cluster: four units per thread group (2.88 -> 2.37 us per forward step, WSJ-deep layer
         // probe).  At H <= 256 it measured no gain over the loader-wave kernel (1.78 vs 1.76), and the BPTT counterpart was slower
-        // than the plain kernel at both sizes (3.05 vs 2.90, 2.39 vs 2.22): neither is built.
+        // than or equal to the plain kernel at both sizes (2.95 vs 2.90 at H = 512: its contractions are not what bounds it): not built.
         hipLaunchKernelGGL((enc_pfwd_ub_kernel<8, 4, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         return;
     }

@@ -44,7 +44,8 @@ def test_persistent_encoder_matches_oracle_and_step_kernels(concurrent_lib, Hs, 
 # cluster_of_block: B = 3 and 5 below leave part of the grid idle) — the plain path; with knob persist_flags = 2 consecutive
 # blocks form a cluster and straddle XCDs — the write-through path.  Both must give the same numbers.
 @pytest.mark.parametrize("Hs,sub,B,T,use_mask,rows,xcds,flags", [([140], [1], 3, 6, True, 1, 8, 0), ([140], [1], 3, 6, True, 1, 8, 2),
-                                                                   ([140, 130], [1, 2], 5, 5, True, 1, 8, 0), ([260], [1], 2, 4, False, 2, 4, 2)])
+                                                                   pytest.param([140, 130], [1, 2], 5, 5, True, 1, 8, 0, marks=pytest.mark.slow),
+                                                                   ([260], [1], 2, 4, False, 2, 4, 2)])
 def test_persistent_encoder_under_xcd_placement(concurrent_lib, monkeypatch, Hs, sub, B, T, use_mask, rows, xcds, flags):
     monkeypatch.setenv("HIPEMU_XCDS", str(xcds))
     concurrent_lib.set_knob("persist_flags", flags)
