@@ -134,19 +134,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GU (GK / 8)                    // float4 units per thread and operand tile
 #define GLD (GM + 4)
 
-// one 128xGK (or GKx128) operand tile: GK*32 float4 units, GU per thread.  CONTIG_K: element (x,k) at p[x*ld + k].
-template <bool CONTIG_K>
+// one TX x GK (or GK x TX) operand tile (TX = 128 or 64): GK*TX/4 float4 units, TX/32 per thread.  CONTIG_K: element (x,k) at
+// p[x*ld + k].
+template <bool CONTIG_K, int TX>
 __device__ __forceinline__ void gemm_tile_load(const float* __restrict__ p, int ld, int x0, int X, int k0, int kend, bool vec,
-                                               float4 (&r)[GU]) {
+                                               float4 (&r)[TX / 32]) {
 #pragma unroll
-    for (int h = 0; h < GU; ++h) {
+    for (int h = 0; h < TX / 32; ++h) {
         const int u = threadIdx.x + h * 256;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (CONTIG_K) {
-            const int x = x0 + (u & 127), k = k0 + (u >> 7) * 4;
+            const int x = x0 + (u % TX), k = k0 + (u / TX) * 4;
             if (x < X && k < kend) v = ld4g(p + (size_t)x * ld + k, kend - k, vec);
         } else {
-            const int k = k0 + (u >> 5), x = x0 + (u & 31) * 4;
+            const int k = k0 + u / (TX / 4), x = x0 + (u % (TX / 4)) * 4;
             if (k < kend && x < X) v = ld4g(p + (size_t)k * ld + x, X - x, vec);
         }
         r[h] = v;
@@ -155,25 +156,25 @@ __device__ __forceinline__ void gemm_tile_load(const float* __restrict__ p, int 
 // the same tile when it is known to be complete, in bounds and 16-B aligned: straight-line dwordx4 loads.  (The guarded
 // form compiles to exec-masked branches whose results are merged right behind them, i.e. the wave waits for its
 // "prefetch" before it starts the MFMAs of the current tile — measured as exactly half the MFMA rate.)
-template <bool CONTIG_K>
-__device__ __forceinline__ void gemm_tile_load_fast(const float* __restrict__ p, int ld, int x0, int k0, float4 (&r)[GU]) {
+template <bool CONTIG_K, int TX>
+__device__ __forceinline__ void gemm_tile_load_fast(const float* __restrict__ p, int ld, int x0, int k0, float4 (&r)[TX / 32]) {
 #pragma unroll
-    for (int h = 0; h < GU; ++h) {
+    for (int h = 0; h < TX / 32; ++h) {
         const int u = threadIdx.x + h * 256;
-        if (CONTIG_K) r[h] = *(const float4*)(p + (size_t)(x0 + (u & 127)) * ld + k0 + (u >> 7) * 4);
-        else r[h] = *(const float4*)(p + (size_t)(k0 + (u >> 5)) * ld + x0 + (u & 31) * 4);
+        if (CONTIG_K) r[h] = *(const float4*)(p + (size_t)(x0 + (u % TX)) * ld + k0 + (u / TX) * 4);
+        else r[h] = *(const float4*)(p + (size_t)(k0 + u / (TX / 4)) * ld + x0 + (u % (TX / 4)) * 4);
     }
 }
-template <bool CONTIG_K>
-__device__ __forceinline__ void gemm_tile_store(float (*S)[GLD], const float4 (&r)[GU]) {
+template <bool CONTIG_K, int TX>
+__device__ __forceinline__ void gemm_tile_store(float (*S)[TX + 4], const float4 (&r)[TX / 32]) {
 #pragma unroll
-    for (int h = 0; h < GU; ++h) {
+    for (int h = 0; h < TX / 32; ++h) {
         const int u = threadIdx.x + h * 256;
         if (CONTIG_K) {
-            const int x = u & 127, k = (u >> 7) * 4;
+            const int x = u % TX, k = (u / TX) * 4;
             S[k + 0][x] = r[h].x; S[k + 1][x] = r[h].y; S[k + 2][x] = r[h].z; S[k + 3][x] = r[h].w;
         } else {
-            const int k = u >> 5, x = (u & 31) * 4;
+            const int k = u / (TX / 4), x = (u % (TX / 4)) * 4;
             *(float4*)&S[k][x] = r[h];
         }
     }
@@ -188,86 +189,94 @@ __device__ __forceinline__ int gemm_xcd_order(int L, int total) {
     return xcd * per + min(xcd, rem) + (L >> 3);
 }
 
-// one 128x128 output tile (bx, by) of k-chunk / batch member bz
-template <bool TA, bool TB, bool FAST>
-__device__ __forceinline__ void sgemm128_tile(GemmArgs g, int bx, int by, int bz) {
-    __shared__ __attribute__((aligned(16))) float As[2][GK][GLD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK][GLD];
+// one TM x TN output tile (bx, by) of k-chunk / batch member bz.  TM = TN = 128: four waves of 64 x 64 (2 x 2 MFMA 32x32 blocks);
+// TM = TN = 64: four waves of 32 x 32 (one block each) — for outputs of a few hundred 64-tiles that leave most of the chip idle as
+// 128-tiles (the decoder's L*B- and T'*B-row products: 13 x 4 tiles of 128 against 25 x 8 of 64 over 512 resident work-groups)
+template <int TM, int TN, bool TA, bool TB, bool FAST>
+__device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
+    constexpr int MI = TM / 64, NI = TN / 64;                 // MFMA blocks per wave
+    __shared__ __attribute__((aligned(16))) float As[2][GK][TM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][TN + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (g.batch > 1) {
         g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
         bz = 0;
     }
-    const int m0 = by * GM, n0 = bx * GN;
+    const int m0 = by * TM, n0 = bx * TN;
     const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
     const bool vecA = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0);
     const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    float4 ra[GU], rb[GU];
+    float4 ra[TM / 32], rb[TN / 32];
     // A: not transposed -> (m,k) at A[m*lda+k] (contiguous k); transposed -> A[k*lda+m] (contiguous m)
-    const bool inside = FAST && m0 + GM <= g.M && n0 + GN <= g.N;
+    const bool inside = FAST && m0 + TM <= g.M && n0 + TN <= g.N;
     if (inside && kbeg + GK <= kend) {
-        gemm_tile_load_fast<!TA>(g.A, g.lda, m0, kbeg, ra);
-        gemm_tile_load_fast<TB>(g.B, g.ldb, n0, kbeg, rb);
+        gemm_tile_load_fast<!TA, TM>(g.A, g.lda, m0, kbeg, ra);
+        gemm_tile_load_fast<TB, TN>(g.B, g.ldb, n0, kbeg, rb);
     } else {
-        gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
-        gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+        gemm_tile_load<!TA, TM>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
+        gemm_tile_load<TB, TN>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
     }
-    gemm_tile_store<!TA>(As[0], ra);
-    gemm_tile_store<TB>(Bs[0], rb);
+    gemm_tile_store<!TA, TM>(As[0], ra);
+    gemm_tile_store<TB, TN>(Bs[0], rb);
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
         if (more) {
             if (inside && k0 + 2 * GK <= kend) {
-                gemm_tile_load_fast<!TA>(g.A, g.lda, m0, k0 + GK, ra);
-                gemm_tile_load_fast<TB>(g.B, g.ldb, n0, k0 + GK, rb);
+                gemm_tile_load_fast<!TA, TM>(g.A, g.lda, m0, k0 + GK, ra);
+                gemm_tile_load_fast<TB, TN>(g.B, g.ldb, n0, k0 + GK, rb);
             } else {
-                gemm_tile_load<!TA>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
-                gemm_tile_load<TB>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
+                gemm_tile_load<!TA, TM>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
+                gemm_tile_load<TB, TN>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
             }
         }
-        // operand fetch of MFMA step s+1 is issued before the four MFMAs of step s (the scheduler otherwise emits
-        // read -> wait -> 4 MFMA per step and the LDS latency is paid 16 times per k-tile)
+        // operand fetch of MFMA step s+1 is issued before the MFMAs of step s (the scheduler otherwise emits
+        // read -> wait -> MFMAs per step and the LDS latency is paid 16 times per k-tile)
         const int kr0 = lane >> 5, li = lane & 31;
-        float pa[2][2], pb[2][2];
-        pa[0][0] = As[cur][kr0][wm + li]; pa[0][1] = As[cur][kr0][wm + 32 + li];
-        pb[0][0] = Bs[cur][kr0][wn + li]; pb[0][1] = Bs[cur][kr0][wn + 32 + li];
+        float pa[2][MI], pb[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) pa[0][i] = As[cur][kr0][wm + 32 * i + li];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pb[0][j] = Bs[cur][kr0][wn + 32 * j + li];
 #pragma unroll
         for (int s = 0; s < GK / 2; ++s) {
             const int c = s & 1, n = c ^ 1;
             if (s + 1 < GK / 2) {
                 const int kr = 2 * (s + 1) + kr0;
-                pa[n][0] = As[cur][kr][wm + li]; pa[n][1] = As[cur][kr][wm + 32 + li];
-                pb[n][0] = Bs[cur][kr][wn + li]; pb[n][1] = Bs[cur][kr][wn + 32 + li];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) pa[n][i] = As[cur][kr][wm + 32 * i + li];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) pb[n][j] = Bs[cur][kr][wn + 32 * j + li];
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][0], pb[c][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][0], pb[c][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][1], pb[c][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][1], pb[c][1], acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][i], pb[c][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
-            gemm_tile_store<!TA>(As[cur ^ 1], ra);
-            gemm_tile_store<TB>(Bs[cur ^ 1], rb);
+            gemm_tile_store<!TA, TM>(As[cur ^ 1], ra);
+            gemm_tile_store<TB, TN>(Bs[cur ^ 1], rb);
         }
         __syncthreads();
         cur ^= 1;
     }
     // C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -283,6 +292,15 @@ __device__ __forceinline__ void sgemm128_tile(GemmArgs g, int bx, int by, int bz
                     }
                 }
             }
+}
+template <bool TA, bool TB, bool FAST>
+__device__ __forceinline__ void sgemm128_tile(GemmArgs g, int bx, int by, int bz) { sgemm_tile<128, 128, TA, TB, FAST>(g, bx, by, bz); }
+
+template <bool TA, bool TB, bool FAST>
+__global__ __launch_bounds__(256) void lvsr_sgemm64_kernel(GemmArgs g) {
+    const int total = gridDim.x * gridDim.y * gridDim.z;
+    const int t = gemm_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total);
+    sgemm_tile<64, 64, TA, TB, FAST>(g, t % gridDim.x, (t / gridDim.x) % gridDim.y, t / (gridDim.x * gridDim.y));
 }
 
 template <bool TA, bool TB, bool FAST>
@@ -455,14 +473,26 @@ static int sgemm_launch(void* stream, int transA, int transB, int M, int N, int 
     g.A = A; g.B = B; g.C = C; g.bias = bias;
     g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.transA = transA; g.transB = transB;
     g.alpha = alpha; g.beta = beta; g.ksplit = 1; g.kchunk = 0; g.part = nullptr;
-    const bool big = M >= 96 && N >= 96;                      // at least ~one 128x128 tile of real work
-    const int tm = big ? GM : BM, tn = big ? GN : BN, tk = big ? GK : BK;
-    const int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+    // at least ~one 128x128 tile of real work — or a long contraction onto a skinny output (the first layer's 40-row weight
+    // gradient: K = T*B), which the 64-tile kernel with split-K serves better than the small-tile one (107 -> see profiles)
+    const bool big = (M >= 96 && N >= 96) || (min(M, N) >= 32 && max(M, N) >= 256 && K >= 2048);
+    int tm = big ? GM : BM, tn = big ? GN : BN;
+    const int tk = big ? GK : BK;
+    int tiles = ((M + tm - 1) / tm) * ((N + tn - 1) / tn);
+    // fewer 128-tiles than CUs: the same kernel on 64 x 64 tiles (four times the work-groups, four of them resident per CU)
+    // 64 x 64 tiles: always when the 128-tiles would not fill the chip once; up to a few rounds of them when K is
+    // short, where the last, partly filled round costs more than the smaller tile's lower arithmetic intensity
+    // (profiles/r03_gemm_sweep.txt: 6400 x 1536 x 512 122 -> 98 us, 12800 x 512 x 1536 NT 229 -> 200 us; 4096^3 loses 3%).
+    const int mid_max = lvsr_knob(LVSR_KNOB_GEMM_MID_TILES) > 0 ? lvsr_knob(LVSR_KNOB_GEMM_MID_TILES) : 2048;
+    const bool mid = big && batch == 1 && (tiles < 256 || (tiles < mid_max && K <= 2048));
+    if (mid) { tm = 64; tn = 64; tiles = ((M + 63) / 64) * ((N + 63) / 64); }
     g.kchunk = ((K + tk - 1) / tk) * tk;
     if (g.kchunk == 0) g.kchunk = tk;
-    // deterministic split-K when the output is too small to fill 256 CUs and K is long
-    if (ws && tiles < 128 && K >= 1024) {
-        int want = (512 + tiles - 1) / tiles;
+    // deterministic split-K when the output is too small to fill the resident work-group slots (two 128-tiles or four 64-tiles
+    // per CU) and K is long
+    const int slots = mid ? 1024 : 512;
+    if (ws && 2 * tiles <= slots && K >= 1024) {
+        int want = (slots + tiles - 1) / tiles;
         int maxk = K / 256;
         if (want > maxk) want = maxk;
         long long need = (long long)want * M * N * 4;
@@ -487,11 +517,22 @@ static int sgemm_launch(void* stream, int transA, int transB, int M, int N, int 
         if (fast) hipLaunchKernelGGL((lvsr_sgemm128_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, g);    \
         else hipLaunchKernelGGL((lvsr_sgemm128_kernel<TA_, TB_, false>), grid, dim3(256), 0, st, g);        \
     } while (0)
-        if (!transA && !transB) LVSR_GEMM128(false, false);
+#define LVSR_GEMM64(TA_, TB_)                                                                               \
+    do {                                                                                                    \
+        if (fast) hipLaunchKernelGGL((lvsr_sgemm64_kernel<TA_, TB_, true>), grid, dim3(256), 0, st, g);     \
+        else hipLaunchKernelGGL((lvsr_sgemm64_kernel<TA_, TB_, false>), grid, dim3(256), 0, st, g);         \
+    } while (0)
+        if (mid) {
+            if (!transA && !transB) LVSR_GEMM64(false, false);
+            else if (transA && !transB) LVSR_GEMM64(true, false);
+            else if (!transA && transB) LVSR_GEMM64(false, true);
+            else LVSR_GEMM64(true, true);
+        } else if (!transA && !transB) LVSR_GEMM128(false, false);
         else if (transA && !transB) LVSR_GEMM128(true, false);
         else if (!transA && transB) LVSR_GEMM128(false, true);
         else LVSR_GEMM128(true, true);
 #undef LVSR_GEMM128
+#undef LVSR_GEMM64
     }
     if (g.ksplit > 1) {
         int nb = (int)(((size_t)M * N + 255) / 256);

@@ -47,7 +47,8 @@ int lvsr_region_end(void* stream, int keep);
 #define LVSR_KNOB_PHASE_CLOCK 3       /* 1 = work-group 0 of the persistent decoder kernels leaves per-phase times in the workspace header */
 #define LVSR_KNOB_MAX_CLUSTER_WGS 4   /* 0 = device CU count (256 on MI355X); else the largest one-work-group-per-CU grid a cluster launch may have */
 #define LVSR_KNOB_CLUSTER_RESERVE 5   /* CUs left free by cluster launches for other work on the device (default 0) */
-#define LVSR_KNOB_COUNT 6
+#define LVSR_KNOB_GEMM_MID_TILES 6    /* lvsr_sgemm with K <= 2048 uses 64 x 64 tiles when the output has fewer 128 x 128 tiles than this (0 = 2048; 1 = never) */
+#define LVSR_KNOB_COUNT 7
 int lvsr_set_knob(int knob, int value);
 int lvsr_get_knob(int knob);
 

@@ -6,6 +6,7 @@ sys.path[:0] = [REPO, os.path.join(REPO, "attention-lvcsr_amd")]
 import torch
 from lvsr_amd import native
 lib = native.get()
+lib.knobs_from_env()
 dev = torch.device("cuda:0")
 
 
