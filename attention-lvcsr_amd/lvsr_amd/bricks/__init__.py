@@ -91,6 +91,8 @@ class Encoder(object):
         self._pack_cache = {}
         # weight-gradient GEMMs on a second stream: measured SLOWER on MI355X (70.0 vs 66.4 ms per WSJ-base step: the
         # concurrent GEMM work-groups delay the latency-bound step kernels more than the overlap saves), so off by default
+        # (round 3, persistent cluster kernels, groups flushed per layer on the second stream inside the step graph: 16.36 vs
+        # 15.64 ms — the GEMM work-groups sharing the CUs slow the polling clusters by more than the 1.4 ms they hide)
         self.overlap = False        # measured and rejected (comment above); the attribute keeps the second-stream code reachable for probes
         self._side = None
         self._side_pending = False
