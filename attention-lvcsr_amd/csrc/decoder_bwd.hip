@@ -734,20 +734,25 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     memcpy(&g, args, sizeof(g));
     const AttDec& a = g.f;
     if (int rc = attdec_check(a, "lvsr_attdec_bwd")) return rc;
-    LVSR_REQUIRE((a.phases & 3) == 3, "lvsr_attdec_bwd: needs a full forward (phases = 3)");
+    const int parts = (g.parts & 3) ? (g.parts & 3) : 3;
+    LVSR_REQUIRE((a.phases & 3) == 3 || (parts == 1 && (a.phases & 2)) || (parts == 2 && (a.phases & 1)),
+                 "lvsr_attdec_bwd: the forward block does not cover the requested parts");
+    LVSR_REQUIRE(parts == 3 || !(g.AW || g.QR), "lvsr_attdec_bwd: parts and the reassociated glimpse (AW / QR) exclude each other");
+    LVSR_REQUIRE(a.label0 >= 0 && a.label0 < a.L, "lvsr_attdec_bwd: label0 outside [0, L)");
     LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd: contexts must be contiguous (Tp,B,*)");
     hipStream_t s = (hipStream_t)stream;
     const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;
     const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, ntile = (a.Tp + ATT_TT - 1) / ATT_TT, nslice = (a.M + ATT_MS - 1) / ATT_MS;
     auto enqueue = [&]() {
-        for (int i = a.L - 1; i >= 0; --i) {
-            hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
+        for (int i = a.L - 1; i >= a.label0; --i) {
+            if (parts & 1) hipLaunchKernelGGL(attbwd_gru_a_kernel, dim3(ntD, rt), dim3(256), 0, s, g, i);
             if (g.AW && g.QR) {
                 hipLaunchKernelGGL(attbwd_gru_bq_kernel, dim3(ntD * rt + ((a.Tp + 3) / 4) * a.B), dim3(256), 0, s, g, i);
             } else {
-                hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
-                hipLaunchKernelGGL(attbwd_q_kernel, dim3((a.Tp + 3) / 4, a.B), dim3(256), 0, s, g, i);
+                if (parts & 1) hipLaunchKernelGGL(attbwd_gru_b_kernel, dim3(ntE + ntD, rt), dim3(256), 0, s, g, i);
+                if (parts & 2) hipLaunchKernelGGL(attbwd_q_kernel, dim3((a.Tp + 3) / 4, a.B), dim3(256), 0, s, g, i);
             }
+            if (!(parts & 2)) continue;
             const dim3 eg(nslice, a.B, ntile);
             switch ((a.K + 3) / 4) {             // K > 0: handler contractions on the matrix cores, filters padded to a multiple of 4
                 case 0: hipLaunchKernelGGL(attbwd_energy_kernel<0>, eg, dim3(256), 0, s, g, i); break;

@@ -314,12 +314,13 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
     memcpy(&a, args, sizeof(a));
     if (int rc = attdec_check(a, "lvsr_attdec_fwd")) return rc;
     LVSR_REQUIRE((a.phases & 3) != 0, "lvsr_attdec_fwd: phases must select attention and/or GRU");
+    LVSR_REQUIRE(a.label0 >= 0 && a.label0 < a.L, "lvsr_attdec_fwd: label0 outside [0, L)");
     hipStream_t s = (hipStream_t)stream;
     const PreGrid g = attdec_pre_grid(a);
     auto enqueue = [&]() {
-        if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0)
+        if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0 && a.label0 == 0)
             hipLaunchKernelGGL(attdec_pos_kernel, dim3(a.B), dim3(64), 0, s, a, 0);
-        for (int i = 0; i < a.L; ++i) {
+        for (int i = a.label0; i < a.L; ++i) {
             if (g.nmm + g.nconv > 0)
                 hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm + g.nconv), dim3(256), 0, s, a, i);
             if (a.phases & 1) {

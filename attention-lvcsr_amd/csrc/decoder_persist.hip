@@ -635,6 +635,7 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     AttDec a;
     memcpy(&a, args, sizeof(a));
     if (int rc = attdec_check(a, "lvsr_attdec_fwd_persistent")) return rc;
+    LVSR_REQUIRE(a.label0 == 0, "lvsr_attdec_fwd_persistent: runs all labels (label0 must be 0)");
     PdGeom g;
     LVSR_REQUIRE(pd_geom(a, g), "lvsr_attdec_fwd_persistent: configuration outside the persistent kernel's limits "
                  "(lvsr_attdec_persist_ws_bytes returns 0 for it)");

@@ -602,6 +602,7 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     memcpy(&gb, args, sizeof(gb));
     const AttDec& a = gb.f;
     if (int rc = attdec_check(a, "lvsr_attdec_bwd_persistent")) return rc;
+    LVSR_REQUIRE(a.label0 == 0 && (args->parts & 3) % 3 == 0, "lvsr_attdec_bwd_persistent: runs all labels and all parts");
     PbGeom g;
     LVSR_REQUIRE(pb_geom(a, g) && (a.D & 3) == 0, "lvsr_attdec_bwd_persistent: configuration outside the persistent kernel's limits "
                  "(lvsr_attdec_bwd_persist_ws_bytes returns 0 for it)");

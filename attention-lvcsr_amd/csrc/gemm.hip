@@ -416,13 +416,16 @@ __global__ __launch_bounds__(256) void lvsr_copy2d_many_kernel(CopyPack pk) {
     const lvsr_copy_desc& d = pk.d[blockIdx.y];
     const bool vec = ((d.cols | d.lds | d.ldd) & 3) == 0 && ((((size_t)d.src) | ((size_t)d.dst)) & 15) == 0;
     if (d.rows == 1) {                                       // vectors: all blocks share the one row
-        for (int c = blockIdx.x * 256 + threadIdx.x; c < d.cols; c += gridDim.x * 256) d.dst[c] = d.src[c];
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < d.cols; c += gridDim.x * 256)
+            d.dst[c] = d.beta != 0.f ? d.src[c] + d.beta * d.dst[c] : d.src[c];
         return;
     }
     for (int r = blockIdx.x; r < d.rows; r += gridDim.x) {
         const float* s = d.src + (size_t)r * d.lds;
         float* o = d.dst + (size_t)r * d.ldd;
-        if (vec) {
+        if (d.beta != 0.f) {
+            for (int c = threadIdx.x; c < d.cols; c += 256) o[c] = s[c] + d.beta * o[c];
+        } else if (vec) {
             for (int c = threadIdx.x * 4; c < d.cols; c += 1024) *(float4*)(o + c) = *(const float4*)(s + c);
         } else {
             for (int c = threadIdx.x; c < d.cols; c += 256) o[c] = s[c];

@@ -259,13 +259,15 @@ class Lib(object):
                   ptr(ws), (ws.numel() * 4 if ws is not None else 0))
 
     def copy_many(self, pairs):
-        """pairs: [(src, dst)] of equally shaped 1-D / 2-D fp32 tensors with unit inner stride -> one lvsr_copy2d_many launch
-        (per 32 pairs)."""
+        """pairs: [(src, dst)] or [(src, dst, beta)] of equally shaped 1-D / 2-D fp32 tensors with unit inner stride -> one
+        lvsr_copy2d_many launch (per 32 pairs); beta != 0: dst = src + beta * dst."""
         if not pairs:
             return
         cls = self.structs["lvsr_copy_desc"]
         arr = (cls * len(pairs))()
-        for d, (src, dst) in zip(arr, pairs):
+        for d, pair in zip(arr, pairs):
+            src, dst = pair[0], pair[1]
+            d.beta = float(pair[2]) if len(pair) > 2 else 0.0
             assert src.shape == dst.shape and src.dim() in (1, 2) and src.stride(-1) == 1 and dst.stride(-1) == 1
             rows, cols = (1, src.shape[0]) if src.dim() == 1 else (src.shape[0], src.shape[1])
             d.src, d.dst, d.rows, d.cols = src.data_ptr(), dst.data_ptr(), rows, cols

@@ -21,6 +21,7 @@ _DEFAULTS = dict(
     dims_bidir=None,           # [H]*n_layers
     subsample=None,            # [1]*n_layers if None (recognizer.py:237-238)
     dim_dec=None,              # D
+    dec_stack=1,               # number of stacked decoder GRUs (RecurrentStack with skip connections, recognizer.py:250-262)
     dim_matcher=None,          # M; defaults to dim_dec (recognizer.py:224-225)
     attention_type="content",  # 'content' | 'content_and_conv'
     conv_n=None,               # c: filter half width
@@ -57,6 +58,9 @@ def normalize_net_config(cfg):
     out["subsample"] = [int(s) for s in out["subsample"]]
     if len(out["subsample"]) != len(out["dims_bidir"]):
         raise ValueError("subsample and dims_bidir must have the same length")
+    out["dec_stack"] = int(out["dec_stack"])
+    if not 1 <= out["dec_stack"] <= 4:
+        raise NotImplementedError("dec_stack must be between 1 and 4")
     if out["eos_label"] is None:
         out["eos_label"] = out["num_phonemes"] - 1
     if out["dim_matcher"] is None:
@@ -116,6 +120,8 @@ class Dims(object):
         self.n_layers = len(self.Hs)
         self.E = 2 * self.Hs[-1]
         self.D = cfg["dim_dec"]
+        self.n_dec = cfg["dec_stack"]             # decoder GRU layers; the attention and the readout see all their states
+        self.D_tot = self.n_dec * self.D
         self.M = cfg["dim_matcher"]
         self.V = cfg["num_phonemes"]
         self.conv = cfg["attention_type"] == "content_and_conv"
@@ -154,6 +160,31 @@ class Dims(object):
         return T
 
 
+def decoder_layer_names(d, l):
+    """Parameter names of decoder GRU layer `l` (0 = bottom).  One layer: the `transition` brick of AttentionRecurrent.  A stack
+    (recognizer.py:250-262): RecurrentStack renames its children `transition_<l>#<l>`, exposes the sequences / states of layer
+    l > 0 with the suffix `#<l>` (recurrent.py:786-798) — which the generator's Fork, the Distribute of the glimpse, the
+    attention's state transformers and the readout's Merge all pick up as brick names — and feeds layer l from a bias-free
+    Fork `fork_<l>` of the state of layer l - 1 (:823-831).  Names verified against the reference's own parameter dict
+    (oracle/theano_harness/gen_golden.py)."""
+    g = "/recognizer/generator"
+    att = g + "/att_trans/" + ("conv_att" if d.conv else "cont_att")
+    sfx = "" if l == 0 else "#%d" % l
+    if d.n_dec == 1:
+        trans = g + "/att_trans/transition"
+    else:
+        trans = g + "/att_trans/recurrentstack/transition_%d#%d" % (l, l)
+    n = dict(Whh=trans + ".state_to_state", Whg=trans + ".state_to_gates", h0=trans + ".initial_state",
+             Wdi=g + "/att_trans/distribute/fork_inputs%s.W" % sfx, Wdg=g + "/att_trans/distribute/fork_gate_inputs%s.W" % sfx,
+             Wfi=g + "/fork/fork_inputs%s.W" % sfx, bfi=g + "/fork/fork_inputs%s.b" % sfx,
+             Wfg=g + "/fork/fork_gate_inputs%s.W" % sfx, bfg=g + "/fork/fork_gate_inputs%s.b" % sfx,
+             Ws=att + "/state_trans/transform_states%s.W" % sfx, Wms=g + "/readout/merge/transform_states%s.W" % sfx)
+    if l > 0:
+        n["Fi"] = g + "/att_trans/recurrentstack/fork_%d/fork_inputs.W" % l
+        n["Fg"] = g + "/att_trans/recurrentstack/fork_%d/fork_gate_inputs.W" % l
+    return n
+
+
 def parameter_shapes(cfg):
     """name -> shape, names exactly as the reference's Model.get_parameter_dict()."""
     d = Dims(cfg)
@@ -176,24 +207,33 @@ def parameter_shapes(cfg):
     att = g + "/att_trans/" + ("conv_att" if d.conv else "cont_att")
     p[att + "/preprocess.W"] = (d.E, d.M)
     p[att + "/preprocess.b"] = (d.M,)
-    p[att + "/state_trans/transform_states.W"] = (d.D, d.M)
+    for l in range(d.n_dec):
+        p[decoder_layer_names(d, l)["Ws"]] = (d.D, d.M)
     p[att + "/energy_comp/linear.W"] = (d.M, 1)
     if d.energy_bias:
         p[att + "/energy_comp/linear.b"] = (1,)
     if d.conv:
         p[att + "/conv1d.filters"] = (d.K, 2 * d.c + 1)
         p[att + "/handler.W"] = (d.K, d.M)
-    p[g + "/att_trans/distribute/fork_inputs.W"] = (d.E, d.D)
-    p[g + "/att_trans/distribute/fork_gate_inputs.W"] = (d.E, 2 * d.D)
-    p[g + "/att_trans/transition.state_to_state"] = (d.D, d.D)
-    p[g + "/att_trans/transition.state_to_gates"] = (d.D, 2 * d.D)
-    p[g + "/att_trans/transition.initial_state"] = (d.D,)
-    p[g + "/fork/fork_inputs.W"] = (d.FB, d.D)
-    p[g + "/fork/fork_inputs.b"] = (d.D,)
-    p[g + "/fork/fork_gate_inputs.W"] = (d.FB, 2 * d.D)
-    p[g + "/fork/fork_gate_inputs.b"] = (2 * d.D,)
+    for l in range(d.n_dec):
+        n = decoder_layer_names(d, l)
+        p[n["Wdi"]] = (d.E, d.D)
+        p[n["Wdg"]] = (d.E, 2 * d.D)
+        if l > 0:       # fork of the state of the layer below, no bias with skip connections (recurrent.py:823-831)
+            p[n["Fi"]] = (d.D, d.D)
+            p[n["Fg"]] = (d.D, 2 * d.D)
+        p[n["Whh"]] = (d.D, d.D)
+        p[n["Whg"]] = (d.D, 2 * d.D)
+        p[n["h0"]] = (d.D,)
+    for l in range(d.n_dec):
+        n = decoder_layer_names(d, l)
+        p[n["Wfi"]] = (d.FB, d.D)
+        p[n["bfi"]] = (d.D,)
+        p[n["Wfg"]] = (d.FB, 2 * d.D)
+        p[n["bfg"]] = (2 * d.D,)
     if d.use_states_for_readout:
-        p[g + "/readout/merge/transform_states.W"] = (d.D, d.P)
+        for l in range(d.n_dec):
+            p[decoder_layer_names(d, l)["Wms"]] = (d.D, d.P)
     p[g + "/readout/merge/transform_weighted_averages.W"] = (d.E, d.P)
     if d.post_merge:
         p[g + "/readout/post_merge/bias.b"] = (d.P,)
@@ -282,7 +322,7 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
                           bidir=True, subsample=None, dims_top=None, prior=None, conv_n=None,
                           post_merge_activation=None, post_merge_dims=None, dim_matcher=None, embed_outputs=True,
                           dim_output_embedding=None, dec_stack=1, conv_num_filters=1, data_prepend_eos=True,
-                          energy_normalizer=None, max_decoded_length_scale=1, name=None, **kwargs):
+                          energy_normalizer=None, max_decoded_length_scale=1, name=None, **kwargs):  # noqa
     """Map `SpeechRecognizer(**config['net'])` keywords (lvsr/bricks/recognizer.py:176-204) to the net config of
     this package.  Options whose bricks are not built raise NotImplementedError (never a silent fallback)."""
     if kwargs:
@@ -302,8 +342,6 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
         # ValueError when the two counts differ (libs/blocks/blocks/bricks/sequences.py:153-155).  Same error here.
         raise ValueError("dims_top: MLP with 1 activation and %d layers (the reference's own construction fails the same way)"
                          % (len(dims_top) + 1))
-    if dec_stack != 1:
-        raise NotImplementedError("dec_stack > 1 is not built")
     bottom_dims, bottom_act = None, "tanh"
     if bottom is not None:
         bt = dict(bottom)
@@ -322,7 +360,7 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
     else:
         input_dim = input_dims
     cfg = dict(input_dim=input_dim, num_phonemes=num_phonemes, eos_label=eos_label, dims_bidir=dims_bidir,
-               subsample=subsample, dim_dec=dim_dec, dim_matcher=dim_matcher, attention_type=attention_type,
+               subsample=subsample, dim_dec=dim_dec, dec_stack=dec_stack, dim_matcher=dim_matcher, attention_type=attention_type,
                conv_n=conv_n, conv_num_filters=conv_num_filters, prior=prior, energy_normalizer=energy_normalizer,
                post_merge_dims=post_merge_dims, embed_outputs=embed_outputs, dim_output_embedding=dim_output_embedding,
                use_states_for_readout=use_states_for_readout, data_prepend_eos=data_prepend_eos,

@@ -35,7 +35,7 @@ def make_params(cfg, seed=1, scale=1.0):
             v = rng.normal(0.0, 2.0 / numpy.sqrt(shape[0]), shape) * scale * 3.0
         elif name.endswith("lookuptable.W"):
             v = rng.normal(0.0, 1.0, shape) * scale
-        elif name.endswith("fork/fork_inputs.W") or name.endswith("fork/fork_gate_inputs.W"):
+        elif name.split("#")[0].split(".")[0].endswith(("fork/fork_inputs", "fork/fork_gate_inputs")) and name.endswith(".W"):
             # generator fork of a one-hot feedback has fan-in 1 effectively
             fan = 1.0 if "/generator/fork/" in name else shape[0]
             v = rng.normal(0.0, 1.0 / numpy.sqrt(fan), shape) * scale

@@ -79,6 +79,7 @@ int lvsr_sgemm_tn_grouped(void* stream, const lvsr_gemm_desc* descs, int n, floa
 typedef struct lvsr_copy_desc {
     const float* src; float* dst;
     int rows, cols, lds, ldd;
+    float beta;                           /* dst = src + beta * dst (0: plain copy, dst is not read) */
 } lvsr_copy_desc;
 int lvsr_copy2d_many(void* stream, const lvsr_copy_desc* descs, int n);
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]  (bias gradients); ws: optional workspace for the row-split partials */
@@ -196,6 +197,9 @@ typedef struct lvsr_attdec_args {
     float* ep;                            /* (B,ceil(M/32),Tp) partial energies of the match-dim slices */
     const int* step_dev;                  /* optional device word added to step0 (graph-replayed generation: the position
                                              counter of lvsr_beam_select), else NULL */
+    int label0;                           /* lvsr_attdec_fwd / lvsr_attdec_bwd run the steps [label0, L) only (0: all).  A stacked decoder
+                                             (RecurrentStack, lvsr/bricks/recognizer.py:250-262) is driven label by label with one
+                                             block for the attention over the concatenated states and one per GRU layer */
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
@@ -249,6 +253,10 @@ typedef struct lvsr_attdec_bwd_args {
      * per label; DWA is then NOT written: the caller forms DWA = DXG @ [Wdi|Wdg]^T + dWA_r for all labels after the call */
     const float* AW;                      /* (Tp,B,3D) attended @ [fork_inputs.W | fork_gate_inputs.W] */
     const float* QR;                      /* (L,B,Tp) dWA_r[i,b,:] . A[t,b,:] (zeros if dWA_r is NULL) */
+    int parts;                            /* 0 or 3: the whole step; 1: the GRU kernels only (ds -> DXG, DWA, dspart, dsacc; the forward
+                                             block may then have phases = 2); 2: the attention kernels only (DWA, dalp, dsacc -> ds,
+                                             DSW, DCV, dPA, ...; phases = 1).  With parts != 3 the reassociated glimpse (AW / QR) is
+                                             not available */
 } lvsr_attdec_bwd_args;
 int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
 /* The backward walk as ONE persistent launch (csrc/decoder_persist_bwd.hip; same cluster layout and limits as

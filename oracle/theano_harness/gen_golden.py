@@ -58,7 +58,7 @@ def build_reference(cfg, **extra):
         post_merge_activation=ACT[c["post_merge_activation"]]() if c["post_merge_dims"] else None,
         embed_outputs=c["embed_outputs"], dim_output_embedding=c["dim_output_embedding"],
         data_prepend_eos=c["data_prepend_eos"], max_decoded_length_scale=c["max_decoded_length_scale"],
-        name="recognizer")
+        dec_stack=c["dec_stack"], name="recognizer")
     kw.update(extra)
     rec = SpeechRecognizer(**kw)
     rec.weights_init = IsotropicGaussian(0.01)
@@ -346,6 +346,21 @@ CASES = {
         "tiny_conv_postmerge2", tiny_cfg(dict(type="window_around_median", before=2, after=2), post_merge_dims=[8, 6],
                                          post_merge_activation="rectifier"),
         B=3, T=13, L=5, ragged=True, param_seed=26, batch_seed=35, beam=BEAMS[:2], analyze=True),
+    # dec_stack = 2 / 3: RecurrentStack decoder with skip connections (recognizer.py:250-262; wsj_jan_debug.yaml and three more
+    # shipped WSJ configs): the attention and the readout see the states of every layer
+    "tiny_conv_stack2": lambda: run_case(
+        "tiny_conv_stack2", tiny_cfg(dict(type="window_around_median", before=2, after=2), dec_stack=2),
+        B=3, T=13, L=5, ragged=True, param_seed=27, batch_seed=36, beam=BEAMS[:2], analyze=True),
+    "tiny_content_stack3": lambda: run_case(
+        "tiny_content_stack3",
+        dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",
+             post_merge_dims=None, embed_outputs=True, data_prepend_eos=False, dec_stack=3),
+        B=3, T=9, L=4, ragged=True, param_seed=28, batch_seed=37, beam=BEAMS[:1]),
+    "small_conv_stack2": lambda: run_case(
+        "small_conv_stack2", small_cfg(dict(type="expanding", initial_begin=0, initial_end=4, min_speed=0.6, max_speed=2.2),
+                                       dec_stack=2, embed_outputs=True, dim_output_embedding=10),
+        B=5, T=50, L=12, ragged=True, param_seed=29, batch_seed=38,
+        beam=[dict(beam_size=6, char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost")]),
     "tiny_content_embed": lambda: run_case(
         "tiny_content_embed",
         dict(input_dim=5, num_phonemes=6, dims_bidir=[4], dim_dec=5, dim_matcher=6, attention_type="content",

@@ -14,7 +14,8 @@ from lvsr_amd import synthetic
 SMALL_CASES = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_conv_logistic",
                "tiny_conv_relu", "tiny_conv_bottom", "tiny_conv_postmerge2",
                "tiny_content_embed", "tiny_content_relu", "small_conv", "small_conv_median",
-               "small_conv_expanding", "mid_conv_median"]
+               "small_conv_expanding", "mid_conv_median",
+               "tiny_conv_stack2", "tiny_content_stack3", "small_conv_stack2"]
 
 
 def test_conv1d_reference_golden():
