@@ -54,6 +54,26 @@ class SequenceGenerator(object):
         self.pm_hidden = [(g + "/readout/post_merge/mlp/linear_%d.W" % j, g + "/readout/post_merge/mlp/linear_%d.b" % j, w)
                           for j, w in enumerate(dims.pm_hidden)]
 
+    # ---- what a stacked decoder (bricks/generator_stack.py) replaces ----------------------------------------------
+    def _state_width(self):
+        """Width of the `states` the attention and the readout see."""
+        return self.d.D
+
+    def _merge_states_weight(self):
+        """readout/merge/transform_states.W as one (state width, P) matrix."""
+        return self.store.p[self.n["Wms"]]
+
+    def _initial_state(self):
+        return self.store.p[self.n["h0"]]
+
+    def _merge_states_backward(self, S2, dR1, gws):
+        """Gradient of the readout's state source: weight gradient into the store, -> dS_r (rows, state width)."""
+        d, p, g, n, lib, ws = self.d, self.store.p, self.store.g, self.n, self.lib, self.ws
+        lib.sgemm(S2, dR1, g[n["Wms"]], transA=True, ws=gws, group=True)
+        dS_r = ws.get("gen.dS_r", (S2.shape[0], d.D))
+        lib.sgemm(dR1, p[n["Wms"]], dS_r, transB=True)
+        return dS_r
+
     # ---- packed operand copies ------------------------------------------------------------------
     def _packed(self):
         if self._packs is not None and self._packs["version"] == self.store.version and not self.lib.capturing:
@@ -139,7 +159,7 @@ class SequenceGenerator(object):
         bias = p[n["bpm"]] if d.post_merge else p[n["bro"]]
         lib.sgemm(WA2, p[n["Wmw"]], R1, bias=bias)
         if d.use_states_for_readout:
-            lib.sgemm(S2, p[n["Wms"]], R1, beta=1.0)
+            lib.sgemm(S2, self._merge_states_weight(), R1, beta=1.0)
         if not d.post_merge:
             return R1, None, R1
         R2 = ws.get("gen.R2" + tag, (nrows, d.Pout))
@@ -210,6 +230,39 @@ class SequenceGenerator(object):
         labels = outputs.contiguous()
         ym = None if mask is None else mask.contiguous()
         PA = self.preprocess(A)
+        rc = self._forward_recurrent(pk, A, PA, Am, labels, ym, L, B, Tp)
+        bufs, S, W, WA = rc["bufs"], rc["bufs"]["S"], rc["bufs"]["W"], rc["bufs"]["WA"]
+        SW = self._state_width()
+        S2, WA2 = S[:L].view(L * B, SW), WA.view(L * B, d.E)
+        R1, R2, logits = self._readout(S2, WA2, L * B, "")
+        cost = ws.get("gen.cost", (L, B))
+        dlogits = ws.get("gen.dlogits", (L * B, d.V))
+        lib.call("lvsr_softmax_nll", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V,
+                 lib_ptr(cost), lib_ptr(dlogits), d.V, 1.0, None, 0)
+        lm = self.language_model
+        self._cost_has_lm = lm is not None
+        if lm is not None:
+            # SequenceGenerator.evaluate with a language model (sequence_generators.py:286-296): the readout of label i is fused
+            # (ShallowFusionReadout) with the look-ahead costs of the FST state set reached by labels[:i], the emitter is LMEmitter:
+            # cost = -fused[label].  This is what `analyze` reports in the decode driver when `net.lm` is configured.
+            lm_add = self._lm_lookahead(lm, labels, ym, L, B)
+            fused = ws.get("gen.fused", (L * B, d.V))
+            lib.call("lvsr_shallow_fusion", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(lm_add), L * B, d.V, float(lm.am_beta),
+                     float(lm.lm_weight), int(lm.norm[0]), int(lm.norm[1]), int(lm.norm[2]), 1.0, lib_ptr(fused))
+            lib.call("lvsr_select_cost", lib.stream_for(cost), lib_ptr(fused), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V, -1.0,
+                     lib_ptr(cost))
+        self.last = dict(weights=W[1:], energies=bufs["EN"], states=S[:L], weighted_averages=WA)
+        if save_for_backward:
+            self._saved = dict(L=L, B=B, Tp=Tp, A=A, Am=Am, PA=PA, labels=labels, ym=ym, bufs=bufs,
+                               R1=R1, R2=R2, dlogits=dlogits, pk=pk, pm_acts=list(self._pm_acts))
+            self._saved.update(rc["saved"])
+        return cost
+
+    def _forward_recurrent(self, pk, A, PA, Am, labels, ym, L, B, Tp):
+        """The label loop of the teacher-forced pass: fork(feedback(labels)) and the AttentionRecurrent scan
+        (sequence_generators.py:263-277).  -> dict(bufs = the state slots / per-label tensors (S, W, WA, EN, ...), saved =
+        what `_backward_recurrent` needs beyond them)."""
+        d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
         xg = ws.get("gen.xg", (L * B, 3 * d.D))
         fb = ws.get("gen.fb", (L * B, d.FB)) if d.embed else None
         self._feedback_fork(labels.view(-1), L * B, xg, fb)
@@ -243,31 +296,7 @@ class SequenceGenerator(object):
             lib.call("lvsr_attdec_glimpses", lib.stream_for(S), _ct.byref(fwd_args))
         else:
             fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
-        WA = bufs["WA"]
-        S2, WA2 = S[:L].view(L * B, d.D), WA.view(L * B, d.E)
-        R1, R2, logits = self._readout(S2, WA2, L * B, "")
-        cost = ws.get("gen.cost", (L, B))
-        dlogits = ws.get("gen.dlogits", (L * B, d.V))
-        lib.call("lvsr_softmax_nll", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V,
-                 lib_ptr(cost), lib_ptr(dlogits), d.V, 1.0, None, 0)
-        lm = self.language_model
-        self._cost_has_lm = lm is not None
-        if lm is not None:
-            # SequenceGenerator.evaluate with a language model (sequence_generators.py:286-296): the readout of label i is fused
-            # (ShallowFusionReadout) with the look-ahead costs of the FST state set reached by labels[:i], the emitter is LMEmitter:
-            # cost = -fused[label].  This is what `analyze` reports in the decode driver when `net.lm` is configured.
-            lm_add = self._lm_lookahead(lm, labels, ym, L, B)
-            fused = ws.get("gen.fused", (L * B, d.V))
-            lib.call("lvsr_shallow_fusion", lib.stream_for(cost), lib_ptr(logits), d.V, lib_ptr(lm_add), L * B, d.V, float(lm.am_beta),
-                     float(lm.lm_weight), int(lm.norm[0]), int(lm.norm[1]), int(lm.norm[2]), 1.0, lib_ptr(fused))
-            lib.call("lvsr_select_cost", lib.stream_for(cost), lib_ptr(fused), d.V, lib_ptr(labels), lib_ptr(ym), L * B, d.V, -1.0,
-                     lib_ptr(cost))
-        self.last = dict(weights=W[1:], energies=bufs["EN"], states=S[:L], weighted_averages=WA)
-        if save_for_backward:
-            self._saved = dict(L=L, B=B, Tp=Tp, A=A, Am=Am, PA=PA, labels=labels, ym=ym, xg=xg, fb=fb, bufs=bufs,
-                               fields=fields, R1=R1, R2=R2, dlogits=dlogits, pk=pk, AW_valid=sync is not None,
-                               pm_acts=list(self._pm_acts))
-        return cost
+        return dict(bufs=bufs, saved=dict(xg=xg, fb=fb, fields=fields, AW_valid=sync is not None))
 
     def _lm_lookahead(self, lm, labels, ym, L, B):
         """(L*B, V) look-ahead costs `lm_add` of the teacher-forced label sequences: row (i, b) = FSTCostsOp of the state set after
@@ -311,7 +340,7 @@ class SequenceGenerator(object):
         bufs, pk = sv["bufs"], sv["pk"]
         nrows = L * B
         gws = ws.get("gemm_ws", (1 << 22,))
-        S2, WA2 = bufs["S"][:L].view(nrows, d.D), bufs["WA"].view(nrows, d.E)
+        S2, WA2 = bufs["S"][:L].view(nrows, self._state_width()), bufs["WA"].view(nrows, d.E)
         dlogits, R1, R2 = sv["dlogits"], sv["R1"], sv["R2"]
         # ---- readout backward
         if d.post_merge:
@@ -341,10 +370,41 @@ class SequenceGenerator(object):
         lib.sgemm(dR1, p[n["Wmw"]], dWA_r, transB=True)
         dS_r = None
         if d.use_states_for_readout:
-            lib.sgemm(S2, dR1, g[n["Wms"]], transA=True, ws=gws, group=True)
-            dS_r = ws.get("gen.dS_r", (nrows, d.D))
-            lib.sgemm(dR1, p[n["Wms"]], dS_r, transB=True)
-        # ---- recurrent part
+            dS_r = self._merge_states_backward(S2, dR1, gws)
+        rb = self._backward_recurrent(sv, dWA_r, dS_r, gws)
+        accH, accWe, accEb, DCV, dPA, DWA = rb["accH"], rb["accWe"], rb["accEb"], rb["DCV"], rb["dPA"], rb["DWA"]
+        import ctypes
+        st = lib.stream_for(dPA)
+        lib.colsum(accWe, g[n["we"]].view(-1), ws=gws)
+        if d.energy_bias:
+            lib.colsum(accEb, g[n["eb"]], ws=gws)
+        if d.conv:
+            lib.colsum(accH, g[n["handler"]].view(-1), ws=gws)
+            # partial sums per chunk of (label, utterance) rows: at most one chunk per row (large per-GPU batches outgrow gemm_ws)
+            fws = ws.get("gen.filter_ws", (max(1 << 20, L * B * d.K * (2 * d.c + 1)),))
+            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(rb["fwd_args"]), lib_ptr(DCV), lib_ptr(g[n["filters"]]), lib_ptr(fws),
+                     fws.numel() * 4)
+        # ---- attended: preprocess backward + glimpse backward
+        A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
+        lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws, group=True)
+        lib.colsum(dPA2, g[n["bpre"]], ws=gws)
+        dA = ws.get("gen.dA", (Tp, B, d.E))
+        lib.sgemm(dPA2, p[n["Wpre"]], dA.view(Tp * B, d.E), transB=True)
+        W = bufs["W"]
+        # dA[:, b, :] += alpha_b^T (T',L) @ dwa_b (L,E) for every utterance b: one batched launch
+        lib.call("lvsr_sgemm_batched", lib.stream_for(dA), 1, 0, Tp, d.E, L, 1.0, lib_ptr(W[1:]), B * Tp, Tp,
+                 lib_ptr(DWA), B * d.E, d.E, 1.0, lib_ptr(dA), B * d.E, d.E, B)
+        return dA
+
+    def _backward_recurrent(self, sv, dWA_r, dS_r, gws):
+        """Reverse walk over the labels and the weight gradients of the transition, the glimpse distribution, the state
+        transformer and the feedback fork.  -> dict(accH, accWe, accEb: partial sums of the handler / energy vector / energy
+        bias gradients (folded by the caller), DCV, dPA, DWA, fwd_args: the forward argument block of the attention)."""
+        d, p, g, n, lib, ws = self.d, self.store.p, self.store.g, self.n, self.lib, self.ws
+        L, B, Tp = sv["L"], sv["B"], sv["Tp"]
+        bufs, pk = sv["bufs"], sv["pk"]
+        nrows = L * B
+        S2, WA2 = bufs["S"][:L].view(nrows, d.D), bufs["WA"].view(nrows, d.E)
         nslice = (d.M + ATT_MS - 1) // ATT_MS
         ntile = (Tp + 63) // 64
         Kc = max(d.K, 1)
@@ -421,26 +481,7 @@ class SequenceGenerator(object):
                      lib_ptr(g[n["Wfi"]]), d.D, 0.0)
             lib.call("lvsr_scatter_add_rows", st, lib_ptr(dg), 3 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
                      lib_ptr(g[n["Wfg"]]), 2 * d.D, 0.0)
-        lib.colsum(accWe, g[n["we"]].view(-1), ws=gws)
-        if d.energy_bias:
-            lib.colsum(accEb, g[n["eb"]], ws=gws)
-        if d.conv:
-            lib.colsum(accH, g[n["handler"]].view(-1), ws=gws)
-            # partial sums per chunk of (label, utterance) rows: at most one chunk per row (large per-GPU batches outgrow gemm_ws)
-            fws = ws.get("gen.filter_ws", (max(1 << 20, L * B * d.K * (2 * d.c + 1)),))
-            lib.call("lvsr_attdec_filter_grad", st, ctypes.byref(bw.f), lib_ptr(DCV), lib_ptr(g[n["filters"]]), lib_ptr(fws),
-                     fws.numel() * 4)
-        # ---- attended: preprocess backward + glimpse backward
-        A2, dPA2 = sv["A"].view(Tp * B, d.E), dPA.view(Tp * B, d.M)
-        lib.sgemm(A2, dPA2, g[n["Wpre"]], transA=True, ws=gws, group=True)
-        lib.colsum(dPA2, g[n["bpre"]], ws=gws)
-        dA = ws.get("gen.dA", (Tp, B, d.E))
-        lib.sgemm(dPA2, p[n["Wpre"]], dA.view(Tp * B, d.E), transB=True)
-        W = bufs["W"]
-        # dA[:, b, :] += alpha_b^T (T',L) @ dwa_b (L,E) for every utterance b: one batched launch
-        lib.call("lvsr_sgemm_batched", lib.stream_for(dA), 1, 0, Tp, d.E, L, 1.0, lib_ptr(W[1:]), B * Tp, Tp,
-                 lib_ptr(DWA), B * d.E, d.E, 1.0, lib_ptr(dA), B * d.E, d.E, B)
-        return dA
+        return dict(accH=accH, accWe=accWe, accEb=accEb, DCV=DCV, dPA=dPA, DWA=DWA, fwd_args=bw.f)
 
 
 def lib_ptr(t):
@@ -683,11 +724,13 @@ def _beam_methods():
         fin_cap = 2 * K if stop_on == "patience" else K * (max_length + 1)
         Kc = max(d.K, 1)
         pos_needed = d.conv and self._prior()[0] != 0
+        SW = self._state_width()
+        stacked = d.n_dec > 1          # bricks/generator_stack.py: pass B is the attention block and one GRU block per layer
 
         def attbufs(which, phases):
             t = tag + which
             return dict(xg=ws.get("bs.xg" + t, (K, 3 * d.D)) if phases & 2 else None, ymask=None,
-                        S=ws.get("bs.S" + t, (2, K, d.D)), W=ws.get("bs.W" + t, (2, K, Tp)),
+                        S=ws.get("bs.S" + t, (2, K, SW)), W=ws.get("bs.W" + t, (2, K, Tp)),
                         pos=ws.get("bs.pos" + t, (2, K)) if pos_needed else None,
                         WA=ws.get("bs.WA" + t, (1, K, d.E)), EN=ws.get("bs.EN" + t, (1, K, Tp)), ZB=None,
                         sW=ws.get("bs.sW" + t, (1, K, d.M)), CV=ws.get("bs.CV" + t, (1, K, Kc, Tp)) if d.conv else None,
@@ -719,14 +762,18 @@ def _beam_methods():
         # window centres travel with the rows (select / compact move them), so neither pass recomputes slot 0: phases bit 2
         skip_pos = 4 if pos_needed else 0
         fa = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, A_, phases=1 | skip_pos, step0=0, broadcast=True)
-        fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True)
         pos_word = st["ctl"][CTL["pos"]:]
         st["argsA"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fa)
-        st["argsB"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fb_)     # runs after the select kernel moved on: step0 = -1
+        if stacked:
+            st["stepB"] = self._beam_step_blocks(pk, g, K, B_, skip_pos, pos_word, tag)
+        else:
+            fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True)
+            st["argsB"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fb_)     # runs after the select kernel moved on: step0 = -1
         L = st["lm"] or {}
+        host_fork = d.embed or stacked      # the fork of the chosen characters as separate launches of pass B
         st["args"] = lib.make(
             "lvsr_beam_args", K=K, V=d.V, eol=int(eol), ignore_first_eol=int(bool(ignore_first_eol)),
-            stop_on={"patience": 0, "optimistic_future_cost": 1}[stop_on], max_length=int(max_length), fin_cap=fin_cap, D=d.D, Tp=Tp,
+            stop_on={"patience": 0, "optimistic_future_cost": 1}[stop_on], max_length=int(max_length), fin_cap=fin_cap, D=SW, Tp=Tp,
             round_to_inf=float(numpy.float32(min(float(round_to_inf), 3.0e38))), char_discount=float(char_discount),
             ctl=st["ctl"], fctl=st["fctl"], neglogp=st["neglogp"], running=st["running"], live_col=st["live_col"],
             hist_parent=st["hist_parent"], hist_char=st["hist_char"], hist_cost=st["hist_cost"], fin_pos=st["fin_pos"],
@@ -740,8 +787,9 @@ def _beam_methods():
             pos_live=A_["pos"][0] if pos_needed else None, pos_sel=B_["pos"][0] if pos_needed else None,
             pos_new=B_["pos"][1] if pos_needed else None, pos_live_out=A_["pos"][0] if pos_needed else None,
             # one-hot feedback: the fork of the chosen characters is a row gather the select launch does itself
-            fork_xg=None if d.embed else B_["xg"], fork_Wi=None if d.embed else p[n_["Wfi"]], fork_Wg=None if d.embed else p[n_["Wfg"]],
-            fork_bi=None if d.embed else p[n_["bfi"]], fork_bg=None if d.embed else p[n_["bfg"]], fork_rows=0 if d.embed else d.FB)
+            fork_xg=None if host_fork else B_["xg"], fork_Wi=None if host_fork else p[n_["Wfi"]],
+            fork_Wg=None if host_fork else p[n_["Wfg"]], fork_bi=None if host_fork else p[n_["bfi"]],
+            fork_bg=None if host_fork else p[n_["bfg"]], fork_rows=0 if host_fork else d.FB)
         st["readout"] = self._readout_step_args(A_["S"][0], A_["WA"][0], K, neglogp=st["neglogp"],
                                                 lm_add=L.get("add_live") if lm is not None else None)
         # ---- reset: one live hypothesis, replicated over the K rows
@@ -751,7 +799,7 @@ def _beam_methods():
         st["fctl"].copy_(torch.tensor([1000.0, 0.0, 0.0, 0.0]))
         st["running"].zero_()
         st["live_col"].zero_()
-        A_["S"][0].copy_(p[n_["h0"]].unsqueeze(0).expand(K, d.D))
+        A_["S"][0].copy_(self._initial_state().unsqueeze(0).expand(K, SW))
         A_["W"][0].zero_()
         if d.conv:
             A_["W"][0][:, 0] = 1.0
@@ -779,8 +827,9 @@ def _beam_methods():
         d, p, n_ = self.d, self.store.p, self.n
         lm = self.language_model
         return self.lib.make(
-            "lvsr_readout_step_args", S=S2, WA=WA2, lds=int(S2.stride(0)), ldwa=int(WA2.stride(0)), n=n, D=d.D, E=d.E, P=d.P, V=d.V,
-            act=ACT_KIND[d.act] if d.post_merge else 0, Wms=p[n_["Wms"]] if d.use_states_for_readout else None, Wmw=p[n_["Wmw"]],
+            "lvsr_readout_step_args", S=S2, WA=WA2, lds=int(S2.stride(0)), ldwa=int(WA2.stride(0)), n=n, D=self._state_width(), E=d.E,
+            P=d.P, V=d.V, act=ACT_KIND[d.act] if d.post_merge else 0,
+            Wms=self._merge_states_weight() if d.use_states_for_readout else None, Wmw=p[n_["Wmw"]],
             bias1=p[n_["bpm"]] if d.post_merge else p[n_["bro"]], Wout=p[n_["Wout"]] if d.post_merge else None,
             bout=p[n_["bout"]] if d.post_merge else None, lm_add=lm_add,
             am_beta=lm.am_beta if lm_add is not None else 1.0, lm_weight=lm.lm_weight if lm_add is not None else 0.0,
@@ -808,9 +857,12 @@ def _beam_methods():
         transition, then the surviving rows become the new beam."""
         d, lib, st = self.d, self.lib, self._beam
         K, B_ = st["K"], st["B"]
-        if d.embed:          # lookup feedback needs the fork's GEMMs; one-hot feedback was gathered by the select launch
-            self._feedback_fork(st["chars"], K, B_["xg"], st["fb"])
-        lib.call("lvsr_attdec_fwd", lib.stream_for(B_["S"]), ctypes.byref(st["argsB"]), 0)
+        if "stepB" in st:
+            self._beam_step_run(st)
+        else:
+            if d.embed:          # lookup feedback needs the fork's GEMMs; one-hot feedback was gathered by the select launch
+                self._feedback_fork(st["chars"], K, B_["xg"], st["fb"])
+            lib.call("lvsr_attdec_fwd", lib.stream_for(B_["S"]), ctypes.byref(st["argsB"]), 0)
         if st["on_dev_lm"]:
             L, lm = st["lm"], self.language_model
             lib.call("lvsr_fst_lm_step", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),

@@ -43,8 +43,12 @@ class SpeechRecognizer(object):
         self.use_graph = bool(use_graph) and self.device.type == "cuda"
         self.bottom = SpeechBottom(self.d, self.store, self.lib, self.ws)
         self.encoder = Encoder(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph, use_persistent=use_persistent)
-        self.generator = SequenceGenerator(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph,
-                                           use_persistent=use_persistent_decoder)
+        if self.d.n_dec > 1:         # RecurrentStack decoder (recognizer.py:250-262)
+            from .generator_stack import StackedSequenceGenerator as generator_class
+        else:
+            generator_class = SequenceGenerator
+        self.generator = generator_class(self.d, self.store, self.lib, self.ws, use_graph=self.use_graph,
+                                         use_persistent=use_persistent_decoder)
         # hipGraph capture cannot run on the legacy null stream: the hot path owns a side stream
         self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
         self.beam_size = None

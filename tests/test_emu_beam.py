@@ -11,7 +11,7 @@ from lvsr_amd.bricks.recognizer import SpeechRecognizer
 from lvsr_amd.search import CandidateNotFoundError
 
 CASES = ["tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_logistic", "tiny_conv_relu", "tiny_conv_bottom", "tiny_conv_postmerge2", "tiny_content_embed",
-         "tiny_content_relu"]
+         "tiny_content_relu", "tiny_conv_stack2", "tiny_content_stack3"]
 
 
 def run_beam_case(case, device, lib):

@@ -13,7 +13,7 @@ from lvsr_amd.bricks.recognizer import SpeechRecognizer
 
 CASES = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_conv_logistic",
          "tiny_conv_relu", "tiny_conv_bottom", "tiny_conv_postmerge2", "tiny_content_embed",
-         "tiny_content_relu"]
+         "tiny_content_relu", "tiny_conv_stack2", "tiny_content_stack3"]
 
 
 def check_against(rec, cm, z, orc_out, orc_grads, tol=1.0):

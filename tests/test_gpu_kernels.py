@@ -81,7 +81,8 @@ from lvsr_amd.bricks.recognizer import SpeechRecognizer            # noqa: E402
 
 SMALL = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_mean", "tiny_conv_logistic",
          "tiny_conv_relu", "tiny_conv_bottom", "tiny_conv_postmerge2", "tiny_content_embed",
-         "tiny_content_relu", "small_conv", "small_conv_median", "small_conv_expanding", "mid_conv_median"]
+         "tiny_content_relu", "small_conv", "small_conv_median", "small_conv_expanding", "mid_conv_median",
+         "tiny_conv_stack2", "tiny_content_stack3", "small_conv_stack2"]
 
 
 def _setup(meta):
@@ -142,7 +143,8 @@ def test_full_size_configs_vs_reference_golden(gpu_device, case):
 
 # ---- beam search on the GPU vs the hypotheses the reference produced --------------------------------
 @pytest.mark.parametrize("case", ["tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_logistic", "tiny_conv_relu",
-                                  "tiny_conv_bottom", "tiny_conv_postmerge2", "tiny_content_embed", "tiny_content_relu", "small_conv_median"])
+                                  "tiny_conv_bottom", "tiny_conv_postmerge2", "tiny_content_embed", "tiny_content_relu", "small_conv_median",
+                                  "tiny_conv_stack2", "tiny_content_stack3", "small_conv_stack2"])
 def test_beam_search_vs_reference_golden(gpu_device, case):
     """Twice: the first search of a shape runs its positions eagerly / captures the step graph, the second replays it."""
     from test_emu_beam import run_beam_case
