@@ -259,8 +259,11 @@ class StackedSequenceGenerator(SequenceGenerator):
                 if l > 0:       # the fork of the layer below: the tail of this layer's distribution-input gradient
                     lib.copy_many([(bws[l]["DWA"][i][:, E:], bws[l - 1]["ds"], 1.0)])
             # total glimpse gradient (layer 0 wrote its share, incl. the readout's, into DWA); the states' recurrent gradients
-            lib.copy_many([(bws[l]["DWA"][i][:, :E], DWA[i], 1.0) for l in range(1, d.n_dec)]
+            # (one launch per accumulation into DWA[i]: the descriptors of a launch run concurrently)
+            lib.copy_many([(bws[1]["DWA"][i][:, :E], DWA[i], 1.0)]
                           + [(bws[l]["dsacc"], dsacc[:, l * D:(l + 1) * D]) for l in range(d.n_dec)])
+            for l in range(2, d.n_dec):
+                lib.copy_many([(bws[l]["DWA"][i][:, :E], DWA[i], 1.0)])
             bw_att.f.label0, bw_att.f.L = i, i + 1
             lib.call("lvsr_attdec_bwd", stream, ctypes.byref(bw_att), 0)
             lib.copy_many([(ds[:, l * D:(l + 1) * D], bws[l]["ds"]) for l in range(d.n_dec)])

@@ -287,6 +287,8 @@ WORKLOADS = {
     "timit_tiny": (timit_tiny, 2, 200, 40),
     "wsj_base": (wsj_base, 16, 800, 100),
     "wsj_deep": (wsj_deep, 8, 1500, 190),
+    # the WSJ-base network with the two-layer RecurrentStack decoder of exp/wsj/configs/wsj_jan_wsj13v2.yaml (dec_stack: 2)
+    "wsj_stack2": (lambda: dict(wsj_base(), dec_stack=2), 16, 800, 100),
 }
 
 

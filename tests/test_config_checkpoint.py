@@ -46,7 +46,11 @@ def test_unsupported_bricks_raise_not_silently_fall_back():
     ok = spec.from_reference_kwargs(bottom={"bottom_class": blocks_compat.SpeechBottom, "dims": [100],
                                             "activation": blocks_compat.Rectifier()}, **base)
     assert ok["bottom_dims"] == [100] and ok["bottom_activation"] == "rectifier"
-    for bad in (dict(enc_transition=blocks_compat.SimpleRecurrent), dict(dec_stack=2),
+    stacked = spec.from_reference_kwargs(dec_stack=2, **base)          # RecurrentStack decoder (recognizer.py:250-262): built
+    names = spec.parameter_shapes(stacked)
+    assert names["/recognizer/generator/att_trans/recurrentstack/fork_1/fork_gate_inputs.W"] == (8, 16)
+    assert "/recognizer/generator/att_trans/transition.state_to_state" not in names
+    for bad in (dict(enc_transition=blocks_compat.SimpleRecurrent), dict(dec_stack=5),
                 dict(bottom={"bottom_class": blocks_compat.LookupBottom}), dict(bidir=False)):
         kw = dict(base)
         kw.update(bad)
