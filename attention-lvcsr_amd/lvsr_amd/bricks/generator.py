@@ -605,11 +605,12 @@ def _sampling_methods():
         """BaseSequenceGenerator.initial_states (sequence_generators.py:404-422): initial values of the `generate` states:
         states = tiled initial_state (recurrent.py:622-624), outputs = SoftmaxEmitter.initial_outputs (num_phonemes,
         recognizer.py:286), glimpses = initial_glimpses (lvsr/bricks/attention.py:215-222)."""
-        d, p, n_ = self.d, self.store.p, self.n
-        dev = p[n_["h0"]].device
+        d = self.d
+        h0 = self._initial_state()
+        dev = h0.device
         B = int(batch_size)
         Tp = int(attended.shape[0]) if attended is not None else 0
-        out = dict(states=p[n_["h0"]].unsqueeze(0).expand(B, d.D).clone(),
+        out = dict(states=h0.unsqueeze(0).expand(B, self._state_width()).clone(),
                    outputs=torch.full((B,), d.V, dtype=torch.int64, device=dev),
                    weighted_averages=torch.zeros(B, d.E, device=dev), weights=torch.zeros(B, Tp, device=dev))
         if d.conv:

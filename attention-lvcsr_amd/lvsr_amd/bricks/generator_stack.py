@@ -17,6 +17,7 @@ the one-layer GRU kernels with its own state slots and, for l > 0, the "glimpse"
 against the row-concatenated [distribute ; fork_l] weights.  The label loop is driven from here, one label at a time
 (`label0` / `parts` of the argument blocks, include/lvsr_hip.h), a handful of launches per label and layer; inside the training
 step's graph region the loop costs host time only at capture.  The persistent one-launch kernels cover one layer only.
+Built: cost_matrix / backward (training), analyze, the device beam search, generate / sample.
 """
 import ctypes
 
@@ -180,9 +181,18 @@ class StackedSequenceGenerator(SequenceGenerator):
         concatenated state slot i + 1."""
         d, lib = self.d, self.lib
         D, E = d.D, d.E
-        att, layers = blk["att"], blk["layers"]
+        self._run_attention(blk, i, stream)
+        self._run_layers(blk, i, stream)
+
+    def _run_attention(self, blk, i, stream):
+        att = blk["att"]
         att["args"].label0, att["args"].L = i, i + 1
-        lib.call("lvsr_attdec_fwd", stream, ctypes.byref(att["args"]), 0)
+        self.lib.call("lvsr_attdec_fwd", stream, ctypes.byref(att["args"]), 0)
+
+    def _run_layers(self, blk, i, stream):
+        d, lib = self.d, self.lib
+        D, E = d.D, d.E
+        att, layers = blk["att"], blk["layers"]
         for l, lay in enumerate(layers):
             if l > 0:
                 wa_l = lay["bufs"]["WA"][i]
@@ -319,14 +329,52 @@ class StackedSequenceGenerator(SequenceGenerator):
         lib.copy_many([(S[0][:, l * D:(l + 1) * D], lay["bufs"]["S"][0]) for l, lay in enumerate(layers)])
         self._run_step(blk, 0, lib.stream_for(S))
 
+    # ---- free-running generation -----------------------------------------------------------------------------------------
+    def generate(self, n_steps=None, batch_size=None, attended=None, attended_mask=None, uniforms=None, seed=None):
+        """BaseSequenceGenerator.generate (sequence_generators.py:328-377) with the stacked transition; `states` comes back with the
+        layers side by side, (n, B, dec_stack * D)."""
+        d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
+        if self.language_model is not None:
+            raise NotImplementedError("generate() with a language model: the reference's LMEmitter.emit returns zeros (not a "
+                                      "sampling path); use beam_search, or cost / analyze for teacher-forced costs")
+        N = int(n_steps)
+        Tp, B = int(attended.shape[0]), int(attended.shape[1])
+        assert batch_size is None or int(batch_size) == B
+        pk = self._packed()
+        A, Am = attended.contiguous(), attended_mask.contiguous()
+        PA = self.preprocess(A)
+        u = self._uniforms((N, B), uniforms, seed, A.device)
+        Kc = max(d.K, 1)
+        pos_needed = d.conv and self._prior()[0] != 0
+        S = ws.get("sg.S", (N + 1, B, d.D_tot))
+        W = ws.get("sg.W", (N + 1, B, Tp))
+        att_bufs = dict(S=S, W=W, pos=ws.get("sg.pos", (N + 1, B)) if pos_needed else None, WA=ws.get("sg.WA", (N, B, d.E)),
+                        EN=ws.get("sg.EN", (N, B, Tp)), ZB=None, sW=ws.get("sg.sW", (N, B, d.M)),
+                        CV=ws.get("sg.CV", (N, B, Kc, Tp)) if d.conv else None,
+                        ep=ws.get("sg.ep", (B, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
+        blk = self._step_blocks(pk, A, PA, Am, N, B, "sg", att_bufs, None, att_phases=1 | (4 if pos_needed else 0), step0=0,
+                                broadcast=False)
+        first = self.initial_states(B, attended=A)
+        S[0].copy_(first["states"])
+        W[0].copy_(first["weights"])
+        for l, lay in enumerate(blk["layers"]):
+            lay["bufs"]["S"][0].copy_(p[self.nl[l]["h0"]].unsqueeze(0).expand(B, d.D))
+        if pos_needed:
+            att_bufs["pos"][0].zero_()
+        outputs = ws.get("sg.outputs", (N, B), torch.int64)
+        costs = ws.get("sg.costs", (N, B))
+        fb = ws.get("sg.fb", (B, d.FB)) if d.embed else None
+        st = lib.stream_for(S)
+        for t in range(N):
+            self._run_attention(blk, t, st)
+            ra = self._readout_step_args(S[t], att_bufs["WA"][t], B, uniforms=u[t], outputs=outputs[t], costs=costs[t])
+            lib.call("lvsr_readout_step", st, ctypes.byref(ra))
+            self._feedback_forks(outputs[t], B, [lay["bufs"]["xg"][t * B:(t + 1) * B] for lay in blk["layers"]], fb)
+            self._run_layers(blk, t, st)
+        return dict(states=S[1:], outputs=outputs, weighted_averages=att_bufs["WA"], weights=W[1:], energies=att_bufs["EN"],
+                    costs=costs)
+
     # ---- not built for a stack ----------------------------------------------------------------------------------------------
-    def generate(self, *a, **kw):
-        raise NotImplementedError("free-running generate() with dec_stack > 1 is not built (cost, gradients, analyze and beam "
-                                  "search are)")
-
-    def initial_states(self, *a, **kw):
-        raise NotImplementedError("generate() / initial_states() with dec_stack > 1 is not built")
-
     def generation_initial_states(self, n=1):
         raise NotImplementedError("the step-wise generation helpers are one-layer only; dec_stack > 1 decodes through beam_begin / "
                                   "beam_step")

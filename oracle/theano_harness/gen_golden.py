@@ -238,23 +238,30 @@ def run_generate_case(name, cfg, B, T, n_steps, param_seed, batch_seed, scale=1.
         v.set_value(values[k])
     batch = synthetic.make_batch(cfg, B, T, 4, seed=batch_seed, ragged=True)
     generated = rec.get_generate_graph(use_mask=True, n_steps=n_steps)
-    keys = [k for k in ("states", "outputs", "weighted_averages", "weights", "costs") if k in generated]
+    n_dec = spec.normalize_net_config(cfg)["dec_stack"]
+    state_keys = ["states"] + ["states#%d" % l for l in range(1, n_dec)]      # RecurrentStack: one state sequence per layer
+    keys = [k for k in state_keys + ["outputs", "weighted_averages", "weights", "costs"] if k in generated]
     cg = ComputationGraph([generated[k] for k in keys])
     f = theano.function([rec.inputs["recordings"], rec.inputs_mask], cg.outputs, updates=cg.updates)
     res = f(batch["recordings"], batch["recordings_mask"])
     out = dict(zip(keys, res))
     # the reference's readout on (previous states, current glimpses) -> class probabilities of every step
     gen = rec.generator
-    st = tensor.tensor3("st")
+    sts = [tensor.tensor3("st%d" % l) for l in range(n_dec)]
     wa = tensor.tensor3("wa")
     fb = tensor.lmatrix("prev_outputs")
-    readouts = gen.readout.readout(feedback=gen.readout.feedback(fb), states=st, weighted_averages=wa)
-    probs_fn = theano.function([fb, st, wa], gen.readout.emitter.probs(readouts), on_unused_input="ignore")
-    states, outputs = out["states"], out["outputs"]
-    init_state = params["/recognizer/generator/att_trans/transition.initial_state"].get_value()
-    prev_states = numpy.concatenate([numpy.tile(init_state[None, None, :], (1, B, 1)), states[:-1]], axis=0).astype("float32")
+    readouts = gen.readout.readout(feedback=gen.readout.feedback(fb), weighted_averages=wa, **dict(zip(state_keys, sts)))
+    probs_fn = theano.function([fb, wa] + sts, gen.readout.emitter.probs(readouts), on_unused_input="ignore")
+    outputs = out["outputs"]
+    dims = spec.Dims(cfg)
+    prev_states = []
+    for l, k in enumerate(state_keys):
+        init_state = params[spec.decoder_layer_names(dims, l)["h0"]].get_value()
+        prev_states.append(numpy.concatenate([numpy.tile(init_state[None, None, :], (1, B, 1)), out[k][:-1]], axis=0).astype("float32"))
     prev_outputs = numpy.concatenate([numpy.full((1, B), cfg["num_phonemes"], dtype="int64"), outputs[:-1]], axis=0)
-    probs = probs_fn(prev_outputs, prev_states, out["weighted_averages"].astype("float32"))
+    probs = probs_fn(prev_outputs, out["weighted_averages"].astype("float32"), *prev_states)
+    if n_dec > 1:      # the fixture keeps the states of the layers side by side (the layout of lvsr_amd's stacked generator)
+        out["states"] = numpy.concatenate([out.pop(k) if l else out[k] for l, k in enumerate(state_keys)], axis=2)
     uniforms = numpy.zeros(outputs.shape, dtype=numpy.float32)
     for t in range(outputs.shape[0]):
         for b in range(B):
@@ -425,6 +432,9 @@ CASES = {
     "tiny_conv_generate": lambda: run_generate_case(
         "tiny_conv_generate", tiny_cfg(dict(type="window_around_median", before=1, after=2)), B=3, T=13, n_steps=7,
         param_seed=3, batch_seed=13, scale=2.0),
+    "tiny_conv_stack2_generate": lambda: run_generate_case(
+        "tiny_conv_stack2_generate", tiny_cfg(dict(type="window_around_median", before=1, after=2), dec_stack=2), B=3, T=13, n_steps=7,
+        param_seed=27, batch_seed=36, scale=2.0),
     "small_conv_generate": lambda: run_generate_case(
         "small_conv_generate", small_cfg(None), B=4, T=40, n_steps=12, param_seed=7, batch_seed=17, scale=2.0),
     "timit_tiny": lambda: run_case(

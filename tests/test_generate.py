@@ -40,16 +40,16 @@ def run_generate_case(case, device, lib):
     s = rec.sample({"recordings": batch["recordings"][:tl, 0]}, seed=5)
     assert s.shape == (int(tl / rec.max_decoded_length_scale), 1)
     init = rec.generator.initial_states(2, attended=rec.generator.preprocess(torch.zeros(6, 2, rec.d.E, device=rec.device)))
-    assert int(init["outputs"][0]) == cfg["num_phonemes"] and tuple(init["states"].shape) == (2, rec.d.D)
+    assert int(init["outputs"][0]) == cfg["num_phonemes"] and tuple(init["states"].shape) == (2, rec.d.D_tot)
 
 
-@pytest.mark.parametrize("case", ["tiny_conv_generate", "small_conv_generate"])
+@pytest.mark.parametrize("case", ["tiny_conv_generate", "small_conv_generate", "tiny_conv_stack2_generate"])
 def test_generate_emulated(case):
     from emu import emu_lib
     run_generate_case(case, "cpu", emu_lib())
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["tiny_conv_generate", "small_conv_generate"])
+@pytest.mark.parametrize("case", ["tiny_conv_generate", "small_conv_generate", "tiny_conv_stack2_generate"])
 def test_generate_gpu(gpu_device, case):
     run_generate_case(case, gpu_device, None)
