@@ -382,15 +382,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             f32x4 dcva = F32X4_ZERO;
             // dPA[t][b][m] of (r, tile): base of (b, r, tile) uniform, the lane's (t of r = 0, m of tile 0) part one offset
             const unsigned dpaoff = 4u * ((unsigned)(min(tl0 + 4 * g4, nown - 1) * P + p) * (unsigned)(B * M) + (unsigned)(64 * wave + c16));
-            float dpo[4][4];                               // the running dPA of this lane's 16 elements: in flight during the MFMAs
-#pragma unroll
-            for (int tile = 0; tile < 4; ++tile) {
-                const int m = (4 * wave + tile) * 16 + c16;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    dpo[tile][r] = (rowok[r] && m < M) ? pb_ld<float>(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile, dpaoff) : 0.f;
-                }
-            }
 #pragma unroll
             for (int tile = 0; tile < 4; ++tile) {
                 const int m = (4 * wave + tile) * 16 + c16, mc = min(m, M - 1);
@@ -408,7 +399,9 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                     float d = 0.f;
                     if (rowok[r] && m < M) {
                         d = derow[r] * wet[tile] * (1.f - th * th);
-                        pb_st<float>(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile, dpaoff, dpo[tile][r] + d);
+                        // dPA += dm as a no-return L2 atomic: every element belongs to this lane alone (its adds happen in program
+                        // order, label by label: deterministic), and no load has to come back before the store can leave
+                        unsafeAtomicAdd((float*)((char*)(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile) + dpaoff), d);
                         weacc[tile] += derow[r] * th;
                     }
                     dsw[tile] += d;

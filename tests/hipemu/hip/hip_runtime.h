@@ -332,6 +332,7 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 hipemu_mfma_f32_32x32x2f32
 
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+inline float unsafeAtomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline float atomicMax(int* p, int v) { int o = *p; *p = std::max(o, v); return o; }
