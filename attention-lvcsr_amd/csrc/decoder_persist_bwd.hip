@@ -31,8 +31,8 @@ typedef lvsr_attdec_bwd_args AttBwd;
 // per work-group planes: D (512) | E (256) | F (512)
 
 struct PbGeom {
-    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS;
-    int o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
+    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL;
+    int o_ft, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
 };
 
 static int pb_kc(int K) {
@@ -76,6 +76,10 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.o_ws = take(256 * 68);                              // Ws[unit][own column slice] (+4 pad per row)
     g.o_red = take(2 * PD_NW);
     g.o_clk = take(2 * (PD_NPROF + 1));
+    // the location filters, transposed [tap][filter] (row = one 16-byte-aligned vector of KCP floats, zero beyond K): resident
+    // for the whole walk when they fit; else the alignment correlation reads them row-major (staged per label or from L2)
+    g.FTL = g.KCP > 0 && o + g.FW * g.KCP <= PD_LDS_FLOATS;
+    g.o_ft = g.FTL ? take(g.FW * g.KCP) : 0;
     // the AW rows of the own positions are the same for every label: resident in LDS when they fit beside the rest (short
     // contexts), else streamed from L2 per label
     g.AWS = (3 * a.D + 3) / 4 * 4 + 4;
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const WsL = lds + g.o_ws;      // [256][68] transform_states rows x the own 64 match columns
     float* const AWl = lds + g.o_aw;      // AWL: [nown][AWS] rows of AW of the own positions
     float* const red = lds + g.o_red;
+    float* const fT = lds + g.o_ft;       // FTL: [FW][KCP] conv1d.filters, transposed
     const int P = g.P, nown = g.nown;
     int b, p;
     if (!cluster_of_block(P, a.B, 0, b, p)) return;                  // (work-groups of the grid's padding)
@@ -185,6 +190,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
         WsL[kp * 68 + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
     }
+    if (KC > 0 && g.FTL)
+        for (int x = tid; x < a.K * g.FW; x += PD_THREADS) fT[(x % g.FW) * KCP + x / g.FW] = a.filters[x];
     float dsj = junit ? gb.ds[(size_t)b * D + j] : 0.f;            // running gradient wrt the state (caller: zeros + readout part)
     u64* const gA = planes + (size_t)b * (PB_NPLANE_SMALL * PD_MAXV + (size_t)P * (512 + 256 + 512));
     u64* const gB = gA + PD_MAXV;
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 __syncthreads();
             }
         }
-        const bool flt = KC > 0 && K * g.FW <= PD_NW * 16 * 17;
+        const bool flt = KC > 0 && !g.FTL && K * g.FW <= PD_NW * 16 * 17;
         if (flt && i > 0)
             for (int x = tid; x < K * g.FW; x += PD_THREADS) dms[x] = a.filters[x];      // (published by the barriers of exchange D)
         clk.mark(6);
@@ -499,7 +506,40 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         }
         clk.mark(8);
         // ---- 5. alignment gradient for the previous label, partial over the own positions: behind exchange E
-        if (KC > 0 && i > 0) {
+        if (KC > 0 && i > 0 && g.FTL) {
+            // thread (s = tid % 256 [+256], half = tid / 256): ALL filters over the own positions tl = half, half + 2, ...  The
+            // filters of a tap and the dcv of a position are each ONE row of KCP floats in LDS: 2 KCP / 4 vector reads per KCP
+            // multiply-adds (the row-major form below needed two scalar reads per multiply-add and was LDS-issue bound); lanes
+            // step through the tap rows with a 4 KCP-byte stride, which 16-byte reads serve without bank conflicts for KCP = 4, 12
+            const int cn = a.c, hsel = tid >> 8;
+            for (int s0 = 0; s0 < Tp; s0 += 256) {
+                const int sx = s0 + (tid & 255);
+                float acc4[4] = {0.f, 0.f, 0.f, 0.f};
+                const bool live = sx < Tp && sx >= wi.begin && sx < wi.end;
+                const int base = cn + p - sx;                   // f[k][c + t - s] with t = tl P + p: tap base + tl P
+#pragma unroll 2
+                for (int tl = hsel; tl < nown; tl += 2) {
+                    const int idx = base + tl * P;
+                    const bool ok = live && (unsigned)idx < (unsigned)g.FW;
+                    const float4* fr = (const float4*)(fT + (ok ? idx : 0) * KCP);      // clamped: unconditional loads
+                    const float4* dr = (const float4*)(dcvs + tl * KCP);
+                    const float keep = ok ? 1.f : 0.f;
+#pragma unroll
+                    for (int v = 0; v < KCP / 4; ++v) {
+                        const float4 f4 = fr[v], d4 = dr[v];
+                        acc4[0] += (d4.x * keep) * f4.x;
+                        acc4[1] += (d4.y * keep) * f4.y;
+                        acc4[2] += (d4.z * keep) * f4.z;
+                        acc4[3] += (d4.w * keep) * f4.w;
+                    }
+                }
+                const float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                if (hsel == 1) r8[tid & 255] = acc;            // (barriers outside any lane-dependent branch: a wave counts once)
+                __syncthreads();
+                if (hsel == 0 && sx < Tp) granule_store(gF + (size_t)p * 512 + sx, epoch, acc + r8[tid & 255], plain);
+                __syncthreads();
+            }
+        } else if (KC > 0 && i > 0) {
             // thread (s = tid % 256 [+256], half = tid / 256): filters k = half, half + 2, ... over ALL own positions.  Straight-line: the
             // tap index c + t - s is tested instead of bounding the loop per lane (lane-dependent trip counts and the integer
             // divisions that set them cost more than the taps outside the filter), four accumulators break the FMA chain
