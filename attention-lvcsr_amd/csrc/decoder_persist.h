@@ -15,7 +15,7 @@
 #define PD_MAXV 512          // longest exchanged vector
 #define PD_NV (PD_MAXV / PD_THREADS)     // granules per thread and sweep
 #define PD_NW (PD_THREADS / 64)
-#define PD_LDS_FLOATS (39 * 1024 + 512)
+#define PD_LDS_FLOATS (40 * 1024 - 64)      // of the CU's 160 KB
 #define PD_NPLANE 4          // SW | EN | RS | S
 #define PD_NPROF 16
 

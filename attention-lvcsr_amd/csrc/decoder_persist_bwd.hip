@@ -32,7 +32,7 @@ typedef lvsr_attdec_bwd_args AttBwd;
 
 struct PbGeom {
     int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL;
-    int o_ft, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
+    int o_ft, o_nx, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
 };
 
 static int pb_kc(int K) {
@@ -76,6 +76,7 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.o_ws = take(256 * 68);                              // Ws[unit][own column slice] (+4 pad per row)
     g.o_red = take(2 * PD_NW);
     g.o_clk = take(2 * (PD_NPROF + 1));
+    g.o_nx = take(5 * 64);                    // u | r | c | s | dS_readout of the own units for the next label walked
     // the location filters, transposed [tap][filter] (row = one 16-byte-aligned vector of KCP floats, zero beyond K): resident
     // for the whole walk when they fit; else the alignment correlation reads them row-major (staged per label or from L2)
     g.FTL = g.KCP > 0 && o + g.FW * g.KCP <= PD_LDS_FLOATS;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const AWl = lds + g.o_aw;      // AWL: [nown][AWS] rows of AW of the own positions
     float* const red = lds + g.o_red;
     float* const fT = lds + g.o_ft;       // FTL: [FW][KCP] conv1d.filters, transposed
+    float* const nx = lds + g.o_nx;       // [5][64] saved gate values of the own units, fetched one label ahead
     const int P = g.P, nown = g.nown;
     int b, p;
     if (!cluster_of_block(P, a.B, 0, b, p)) return;                  // (work-groups of the grid's padding)
@@ -217,14 +219,29 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const Win wi = attdec_window(a, i);
         // ---- this label's saved values
         float uu, rr, cc, sp, dsr;
-        uu = junit ? pb_ld<float>(a.U + row * D, jb) : 0.f; rr = junit ? pb_ld<float>(a.R + row * D, jb) : 0.f;
-        cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f; sp = junit ? pb_ld<float>(a.S + row * D, jb) : 0.f;
-        dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * D, jb) : 0.f;
-        for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[((size_t)(i + 1) * B + b) * Tp + t];
-        if (KC > 0) {
-            for (int x = tid; x < nown * K; x += PD_THREADS) {
-                const int tl = x / K, k = x % K, t = tl * P + p;
-                cvs[tl * KCP + k] = t < Tp ? a.CV[((row * K) + k) * Tp + t] : 0.f;
+        if (n == 0) {
+            uu = junit ? pb_ld<float>(a.U + row * D, jb) : 0.f; rr = junit ? pb_ld<float>(a.R + row * D, jb) : 0.f;
+            cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f; sp = junit ? pb_ld<float>(a.S + row * D, jb) : 0.f;
+            dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * D, jb) : 0.f;
+        } else {       // fetched into LDS behind the previous label's energy phase (below)
+            uu = junit ? nx[jl] : 0.f; rr = junit ? nx[64 + jl] : 0.f; cc = junit ? nx[128 + jl] : 0.f; sp = junit ? nx[192 + jl] : 0.f;
+            dsr = junit ? nx[256 + jl] : 0.f;
+        }
+        // the alignment row and the convolution features (first used behind exchange B) are fetched by waves 4-7, which poll neither
+        // below (the alignment-gradient gather) nor in exchange A (D <= 256 granules) — a poll issued behind these loads would wait for
+        // them (in-order returns) — and are kept in registers until exchange B is over: nothing on the way waits for their latency
+        float alv[2] = {0.f, 0.f}, cvv[2] = {0.f, 0.f}, swv[2] = {0.f, 0.f};      // swv: the label's transformed states (energy phase)
+        if (tid >= PD_THREADS / 2) {
+            const int t2 = tid - PD_THREADS / 2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int t = t2 + e * (PD_THREADS / 2);
+                if (t < Tp) alv[e] = a.W[((size_t)(i + 1) * B + b) * Tp + t];
+                if (t < M) swv[e] = a.sW[row * M + t];
+                if (KC > 0 && t < nown * K) {
+                    const int tl = t / K, k = t % K, tt = tl * P + p;
+                    if (tt < Tp) cvv[e] = a.CV[((row * K) + k) * Tp + tt];
+                }
             }
         }
         const float ym = a.ymask ? a.ymask[row] : 1.f;
@@ -295,6 +312,15 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 else { dprs[pd_slot(tid - 256, PD_KD)] = v; dgl[2 * D + tid - 256] = v; }
             }
         }
+        if (tid >= PD_THREADS / 2) {
+            const int t2 = tid - PD_THREADS / 2;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int t = t2 + e * (PD_THREADS / 2);
+                if (t < Tp) al[t] = alv[e];
+                if (KC > 0 && t < nown * K) cvs[(t / K) * KCP + t % K] = cvv[e];
+            }
+        }
         __syncthreads();
         clk.mark(3);
         // AW rows of the own positions for q: thread (tl = tid / 16, l16): columns 4 l16 + 64 e.  Issued AFTER exchange B: a sweep of
@@ -357,6 +383,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             }
             des[tid] = de;
         }
+        // the transformed states, staged where dpc | dpu | dpr lay (dead since the q contraction, every wave is past it): the energy
+        // phase opens with them and would otherwise open with their memory latency
+        if (tid >= PD_THREADS / 2) {
+            dgl[tid - PD_THREADS / 2] = swv[0];
+            dgl[tid] = swv[1];
+        }
         __syncthreads();
         if (a.e_bias && tid == 0) {
             float sb = 0.f;
@@ -364,13 +396,20 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             ebacc += sb;
         }
         clk.mark(5);
+        // The saved gate values of the label walked next open that label's chain: fetched at its top, a whole HBM / MALL latency sat
+        // on every label.  They are fetched HERE instead — straight into LDS (global_load_lds: no register lives through the energy
+        // phase, the register-pressure peak of the kernel), one array per wave, and no wave polls before the phase is over (a poll
+        // issued behind them would wait for them: vector-memory results return in order)
+        if (i > 0 && wave < 5 && lane < 32) {
+            const float* arr = wave == 0 ? a.U : wave == 1 ? a.R : wave == 2 ? a.C : wave == 3 ? a.S : gb.dS_r;
+            if (arr) __builtin_amdgcn_global_load_lds(arr + (row - (size_t)B) * D + min(p * PD_UNITS + lane, D - 1), nx + wave * 64, 4, 0, 0);
+        }
         // ---- 3. energies backward on the matrix cores
         float swc[4], dsw[4] = {0.f, 0.f, 0.f, 0.f};
-        const unsigned mwb = 4u * (unsigned)(64 * wave + c16);               // this lane's column of tile 0, bytes
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const int m = (4 * wave + tile) * 16 + c16;
-            swc[tile] = m < M ? C2 * pb_ld<float>(a.sW + row * M + 16 * tile, mwb) : 0.f;
+            swc[tile] = m < M ? C2 * dgl[m] : 0.f;
         }
         float* const dmw = dms + wave * 16 * 17;
         for (int tl0 = 0; tl0 < nown; tl0 += PD_CH) {

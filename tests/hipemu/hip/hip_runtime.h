@@ -333,6 +333,11 @@ inline hipemu_f32x16 hipemu_mfma_f32_32x32x2f32(float a, float b, hipemu_f32x16 
 
 inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 inline float unsafeAtomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
+// global_load_lds_dword: LDS address = wave-uniform base + lane * size
+inline void __builtin_amdgcn_global_load_lds(const void* src, void* dst, unsigned size, unsigned off, unsigned aux) {
+    (void)aux;
+    memcpy((char*)dst + off + (threadIdx.x & 63) * size, src, size);
+}
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v; return o; }
 inline float atomicMax(int* p, int v) { int o = *p; *p = std::max(o, v); return o; }
