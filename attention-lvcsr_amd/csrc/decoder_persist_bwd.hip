@@ -426,6 +426,15 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 derow[r] = rowok[r] ? des[tl] : 0.f;
             }
             f32x4 dcva = F32X4_ZERO;
+            // the convolution features as the A operand of the handler-gradient product: the same for every tile of the round; read
+            // unconditionally (clamped) and masked by a select — a guarded LDS read becomes a branch and serialises behind its check
+            float cva[4];
+#pragma unroll
+            for (int sq = 0; sq < 4; ++sq) {
+                const int tlk = min(tl0 + 4 * sq + g4, nown - 1);
+                const float raw = KC > 0 ? cvs[tlk * KCP + min(c16, KCP - 1)] : 0.f;
+                cva[sq] = (c16 < KCP && tl0 + 4 * sq + g4 < nown) ? raw : 0.f;
+            }
             // dPA[t][b][m] of (r, tile): base of (b, r, tile) uniform, the lane's (t of r = 0, m of tile 0) part one offset
             const unsigned dpaoff = 4u * ((unsigned)(min(tl0 + 4 * g4, nown - 1) * P + p) * (unsigned)(B * M) + (unsigned)(64 * wave + c16));
 #pragma unroll
@@ -438,32 +447,41 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                     for (int sq = 0; sq < NS; ++sq)
                         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], Hb[tile][sq], acc, 0, 0, 0);
                 }
+                // Straight-line: derow is 0 outside the window / beyond the own positions and wet is 0 beyond M, so d needs no guard
+                // and the four tanh chains interleave; only the memory update itself is predicated (an unconditional update with
+                // clamped rows was measured: the 0.0 adds of the masked rows pile up on one address and serialise, 6.9 -> 9.3 us)
+                float dv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float rc = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[r]));
                     const float th = 1.0f - 2.0f * rc;
-                    float d = 0.f;
-                    if (rowok[r] && m < M) {
-                        d = derow[r] * wet[tile] * (1.f - th * th);
-                        // dPA += dm as a no-return L2 atomic: every element belongs to this lane alone (its adds happen in program
-                        // order, label by label: deterministic), and no load has to come back before the store can leave
-                        unsafeAtomicAdd((float*)((char*)(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile) + dpaoff), d);
-                        weacc[tile] += derow[r] * th;
-                    }
-                    dsw[tile] += d;
-                    dmw[(4 * g4 + r) * 17 + c16] = d;
+                    dv[r] = derow[r] * wet[tile] * (1.f - th * th);
+                    weacc[tile] += derow[r] * th;
+                    dsw[tile] += dv[r];
+                    dmw[(4 * g4 + r) * 17 + c16] = dv[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    // dPA += dm as a no-return L2 atomic: every element belongs to this lane alone (its adds happen in program
+                    // order, label by label: deterministic), and no load has to come back before the store can leave
+                    if (rowok[r] && m < M)
+                        unsafeAtomicAdd((float*)((char*)(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile) + dpaoff), dv[r]);
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (KC > 0) {
-                    // dcv[pos][k] += dm[pos][m] handler[k][m];  dH[k][m] += cv[pos][k] dm[pos][m]
+                    // dcv[pos][k] += dm[pos][m] handler[k][m];  dH[k][m] += cv[pos][k] dm[pos][m]: all eight LDS operands first,
+                    // then the eight products back to back
+                    float da[4], db[4];
+#pragma unroll
+                    for (int sq = 0; sq < 4; ++sq) {
+                        da[sq] = dmw[c16 * 17 + 4 * sq + g4];
+                        db[sq] = dmw[(4 * sq + g4) * 17 + c16];
+                    }
                     f32x4 dHt = dH[tile];
 #pragma unroll
                     for (int sq = 0; sq < 4; ++sq) {
-                        const float ht = Ht[tile][sq];
-                        dcva = __builtin_amdgcn_mfma_f32_16x16x4f32(dmw[c16 * 17 + 4 * sq + g4], ht, dcva, 0, 0, 0);
-                        const int tlk = min(tl0 + 4 * sq + g4, nown - 1);
-                        const float cva = (c16 < KCP && tl0 + 4 * sq + g4 < nown) ? cvs[tlk * KCP + min(c16, KCP - 1)] : 0.f;
-                        dHt = __builtin_amdgcn_mfma_f32_16x16x4f32(cva, dmw[(4 * sq + g4) * 17 + c16], dHt, 0, 0, 0);
+                        dcva = __builtin_amdgcn_mfma_f32_16x16x4f32(da[sq], Ht[tile][sq], dcva, 0, 0, 0);
+                        dHt = __builtin_amdgcn_mfma_f32_16x16x4f32(cva[sq], db[sq], dHt, 0, 0, 0);
                     }
                     dH[tile] = dHt;
                 }
