@@ -143,7 +143,7 @@ def gemm_probe(rec, dims, T, B):
             ach = 2.0 * shape[0] * shape[1] * shape[2] / sec / 1e12
             out[name] = dict(shape_mnk=shape, launch_us=sec * 1e6, achieved=ach, frac=ach / PEAK_FP32_MFMA)
     big = out["projection"]
-    return dict(kernel="lvsr_sgemm128_kernel", shape=big["shape_mnk"], launch_us=big["launch_us"], achieved=big["achieved"], unit="TFLOP/s",
+    return dict(kernel="lvsr_sgemm64_kernel", shape=big["shape_mnk"], launch_us=big["launch_us"], achieved=big["achieved"], unit="TFLOP/s",
                 frac=big["frac"], layer_shapes=out)
 
 
