@@ -324,7 +324,7 @@ def from_reference_kwargs(input_dims=None, input_num_chars=None, eos_label=None,
                           bidir=True, subsample=None, dims_top=None, prior=None, conv_n=None,
                           post_merge_activation=None, post_merge_dims=None, dim_matcher=None, embed_outputs=True,
                           dim_output_embedding=None, dec_stack=1, conv_num_filters=1, data_prepend_eos=True,
-                          energy_normalizer=None, max_decoded_length_scale=1, name=None, **kwargs):  # noqa
+                          energy_normalizer=None, max_decoded_length_scale=1, name=None, **kwargs):
     """Map `SpeechRecognizer(**config['net'])` keywords (lvsr/bricks/recognizer.py:176-204) to the net config of
     this package.  Options whose bricks are not built raise NotImplementedError (never a silent fallback)."""
     if kwargs:
