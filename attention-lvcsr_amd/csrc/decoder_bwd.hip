@@ -12,9 +12,9 @@
 
 typedef lvsr_attdec_bwd_args AttBwd;
 
-struct DecDpcSrc {    // A operand: ds * ym * u * (1 - c^2); ds rows ld=D, u,c rows ld=D
+struct DecDpcSrc {    // A operand: ds * ym * u * (1 - c^2); ds rows ld=ldd, u,c rows ld=D
     const float* ds; const float* u; const float* c; const float* mask;
-    int D, nrows; bool vec, fast;
+    int D, ldd, nrows; bool vec, fast;
     template <bool FAST>
     __device__ __forceinline__ float4 get(int i, int k) const {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -22,7 +22,8 @@ struct DecDpcSrc {    // A operand: ds * ym * u * (1 - c^2); ds rows ld=D, u,c r
         else if (i >= nrows || k >= D) return v;
         const float m = mask ? mask[i] : 1.f;
         const size_t o = (size_t)i * D + k;
-        const float4 d4 = FAST ? *(const float4*)(ds + o) : ld4g(ds + o, D - k, vec);
+        const size_t od = (size_t)i * ldd + k;
+        const float4 d4 = FAST ? *(const float4*)(ds + od) : ld4g(ds + od, D - k, vec);
         const float4 u4 = FAST ? *(const float4*)(u + o) : ld4g(u + o, D - k, vec);
         const float4 c4 = FAST ? *(const float4*)(c + o) : ld4g(c + o, D - k, vec);
         v.x = d4.x * m * u4.x * (1.f - c4.x * c4.x);
@@ -42,12 +43,14 @@ __global__ __launch_bounds__(256) void attbwd_gru_a_kernel(AttBwd g, int i) {
     const size_t row = (size_t)i * B + b;
     const float m = (ok && a.ymask) ? a.ymask[row] : 1.f;
     const float uu = ok ? a.U[row * D + j] : 0.f, rr = ok ? a.R[row * D + j] : 0.f, cc = ok ? a.C[row * D + j] : 0.f;
-    const float sp = ok ? a.S[row * D + j] : 0.f;
-    const float dsv = ok ? g.ds[(size_t)b * D + j] : 0.f;
+    const int ldd = g.ds_ld ? g.ds_ld : D;
+    const float sp = ok ? a.S[row * (a.S_ld ? a.S_ld : D) + j] : 0.f;
+    const float dsv = ok ? g.ds[(size_t)b * ldd + j] : 0.f;
     DecDpcSrc src;
-    src.ds = g.ds + (size_t)b0 * D; src.u = a.U + ((size_t)i * B + b0) * D; src.c = a.C + ((size_t)i * B + b0) * D;
+    src.ldd = ldd;
+    src.ds = g.ds + (size_t)b0 * ldd; src.u = a.U + ((size_t)i * B + b0) * D; src.c = a.C + ((size_t)i * B + b0) * D;
     src.mask = a.ymask ? a.ymask + (size_t)i * B + b0 : nullptr; src.D = D; src.nrows = B - b0;
-    src.vec = ((D & 3) == 0) && ((((size_t)src.ds | (size_t)src.u | (size_t)src.c) & 15) == 0);
+    src.vec = ((D & 3) == 0) && ((ldd & 3) == 0) && ((((size_t)src.ds | (size_t)src.u | (size_t)src.c) & 15) == 0);
     src.fast = src.vec && src.nrows > 0 && rb_no_kpad(D);
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
     rb_mm(acc0, acc1, src, g.WhhT_p, D, tile);
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(256) void attbwd_gru_b_kernel(AttBwd g, int i) {
         const float part = ok ? g.dspart[(size_t)b * D + j] : 0.f;
         rb_mm(acc0, acc1, row_src(dx + D, 3 * D, B - b0, 2 * D), g.WhgT_p, 2 * D, tile);
         const float v = rb_reduce(acc0, acc1);
-        if (ok) g.dsacc[(size_t)b * D + j] = part + v;
+        if (ok) g.dsacc[(size_t)b * (g.ds_ld ? g.ds_ld : D) + j] = part + v;
     }
 }
 
@@ -739,6 +742,8 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
                  "lvsr_attdec_bwd: the forward block does not cover the requested parts");
     LVSR_REQUIRE(parts == 3 || !(g.AW || g.QR), "lvsr_attdec_bwd: parts and the reassociated glimpse (AW / QR) exclude each other");
     LVSR_REQUIRE(a.label0 >= 0 && a.label0 < a.L, "lvsr_attdec_bwd: label0 outside [0, L)");
+    LVSR_REQUIRE(parts == 1 || g.ds_ld == 0 || g.ds_ld == a.D, "lvsr_attdec_bwd: ds_ld is for the GRU part alone (parts = 1)");
+    LVSR_REQUIRE(a.S_ld == 0 || a.S_ld >= a.D, "lvsr_attdec_bwd: S_ld < D");
     LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd: contexts must be contiguous (Tp,B,*)");
     hipStream_t s = (hipStream_t)stream;
     const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;

@@ -40,17 +40,18 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
     int blk = blockIdx.x;
     if (blk < g.nmm) {
         const int tileAll = blk % (g.ntS + g.ntG), b0 = (blk / (g.ntS + g.ntG)) * 16;
-        const float* Srow = a.S + ((size_t)i * B + b0) * D;
+        const int ldS = a.S_ld ? a.S_ld : D;
+        const float* Srow = a.S + ((size_t)i * B + b0) * ldS;
         const int b = b0 + (threadIdx.x >> 4);
         f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
         if (tileAll < g.ntS) {
-            rb_mm(acc0, acc1, row_src(Srow, D, B - b0, D), a.Ws_p, D, tileAll);
+            rb_mm(acc0, acc1, row_src(Srow, ldS, B - b0, D), a.Ws_p, D, tileAll);
             const float v = rb_reduce(acc0, acc1);
             const int j = tileAll * 16 + (threadIdx.x & 15);
             if (b < B && j < a.M) a.sW[((size_t)i * B + b) * a.M + j] = v;
         } else {
             const int tile = tileAll - g.ntS;
-            rb_mm(acc0, acc1, row_src(Srow, D, B - b0, D), a.Whg_p, D, tile);
+            rb_mm(acc0, acc1, row_src(Srow, ldS, B - b0, D), a.Whg_p, D, tile);
             const float v = rb_reduce(acc0, acc1);
             const int j = tile * 16 + (threadIdx.x & 15);
             if (b < B && j < 2 * D) a.sg[(size_t)b * 2 * D + j] = v;
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void attdec_gru1_kernel(AttDec a, int i) {
         const int j = tile * 16 + (threadIdx.x & 15);
         const bool ok = b < B && j < 2 * D;
         const float fg = ok ? a.xg[row * 3 * D + D + j] + a.sg[(size_t)b * 2 * D + j] : 0.f;
-        const float sp = (ok && j >= D) ? a.S[row * D + (j - D)] : 0.f;
+        const float sp = (ok && j >= D) ? a.S[row * (a.S_ld ? a.S_ld : D) + (j - D)] : 0.f;
         rb_mm(acc0, acc1, row_src(wa, E, B - b0, E), a.Wdg_p, E, tile);
         const float v = rb_reduce(acc0, acc1);
         if (ok) {
@@ -282,7 +283,8 @@ __global__ __launch_bounds__(256) void attdec_gru2_kernel(AttDec a, int i) {
     const size_t row = (size_t)i * B + b;
     const float xin = ok ? a.xin[(size_t)b * D + j] : 0.f;
     const float uu = ok ? a.U[row * D + j] : 0.f;
-    const float sp = ok ? a.S[row * D + j] : 0.f;
+    const int ldS = a.S_ld ? a.S_ld : D;
+    const float sp = ok ? a.S[row * ldS + j] : 0.f;
     const float m = (ok && a.ymask) ? a.ymask[row] : 1.f;
     f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
     rb_mm(acc0, acc1, row_src(a.RH + ((size_t)i * B + b0) * D, D, B - b0, D), a.Whh_p, D, tile);
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(256) void attdec_gru2_kernel(AttDec a, int i) {
         float sn = cand * uu + sp * (1.f - uu);
         sn = m * sn + (1.f - m) * sp;
         a.C[row * D + j] = cand;
-        a.S[((size_t)(i + 1) * B + b) * D + j] = sn;
+        a.S[((size_t)(i + 1) * B + b) * ldS + j] = sn;
     }
 }
 
@@ -315,6 +317,7 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
     if (int rc = attdec_check(a, "lvsr_attdec_fwd")) return rc;
     LVSR_REQUIRE((a.phases & 3) != 0, "lvsr_attdec_fwd: phases must select attention and/or GRU");
     LVSR_REQUIRE(a.label0 >= 0 && a.label0 < a.L, "lvsr_attdec_fwd: label0 outside [0, L)");
+    LVSR_REQUIRE(a.S_ld == 0 || a.S_ld >= a.D, "lvsr_attdec_fwd: S_ld < D");
     hipStream_t s = (hipStream_t)stream;
     const PreGrid g = attdec_pre_grid(a);
     auto enqueue = [&]() {

@@ -506,7 +506,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int tt = t0 + e * PD_KSPLIT, tc = min(tt, Tp - 1);
-                    av[e] = tt < wi.end ? al[tc] : 0.f;
+                    const float araw = al[tc];                            // (unconditional read + select: a guarded read is a branch)
+                    av[e] = tt < wi.end ? araw : 0.f;
                     const float* rowp = AWs + tc * PD_AWS + jl;
                     vx[e] = rowp[0]; vu[e] = rowp[PD_UNITS]; vr[e] = rowp[2 * PD_UNITS];
                 }
@@ -635,7 +636,7 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     AttDec a;
     memcpy(&a, args, sizeof(a));
     if (int rc = attdec_check(a, "lvsr_attdec_fwd_persistent")) return rc;
-    LVSR_REQUIRE(a.label0 == 0, "lvsr_attdec_fwd_persistent: runs all labels (label0 must be 0)");
+    LVSR_REQUIRE(a.label0 == 0 && (a.S_ld == 0 || a.S_ld == a.D), "lvsr_attdec_fwd_persistent: runs all labels of contiguous state slots (label0 = 0, S_ld = D)");
     PdGeom g;
     LVSR_REQUIRE(pd_geom(a, g), "lvsr_attdec_fwd_persistent: configuration outside the persistent kernel's limits "
                  "(lvsr_attdec_persist_ws_bytes returns 0 for it)");

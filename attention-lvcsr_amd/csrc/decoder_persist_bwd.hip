@@ -488,7 +488,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 __builtin_amdgcn_wave_barrier();
             }
             if (KC > 0) {
-                __syncthreads();                                   // every wave is done with its dm tile: dms becomes the partial buffer
+                // (a wave's dm tile is its own until the fold below: program order within the wave is all that has to be kept here)
+                __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dmw[(4 * g4 + r) * 17 + c16] = dcva[r];
                 __syncthreads();
@@ -692,7 +693,8 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     memcpy(&gb, args, sizeof(gb));
     const AttDec& a = gb.f;
     if (int rc = attdec_check(a, "lvsr_attdec_bwd_persistent")) return rc;
-    LVSR_REQUIRE(a.label0 == 0 && (args->parts & 3) % 3 == 0, "lvsr_attdec_bwd_persistent: runs all labels and all parts");
+    LVSR_REQUIRE(a.label0 == 0 && (args->parts & 3) % 3 == 0 && (a.S_ld == 0 || a.S_ld == a.D) && (args->ds_ld == 0 || args->ds_ld == a.D),
+                 "lvsr_attdec_bwd_persistent: runs all labels and all parts on contiguous states");
     PbGeom g;
     LVSR_REQUIRE(pb_geom(a, g) && (a.D & 3) == 0, "lvsr_attdec_bwd_persistent: configuration outside the persistent kernel's limits "
                  "(lvsr_attdec_bwd_persist_ws_bytes returns 0 for it)");

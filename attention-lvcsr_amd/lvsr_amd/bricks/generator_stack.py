@@ -166,10 +166,12 @@ class StackedSequenceGenerator(SequenceGenerator):
         for l in range(d.n_dec):
             t = "%s.l%d" % (tag, l)
             WA_l = att_bufs["WA"] if l == 0 else ws.get(t + ".WA", (L, B, self._E(l)))
-            bufs = dict(xg=ws.get(t + ".xg", (L * B, 3 * D)), ymask=ym, S=ws.get(t + ".S", (L + 1, B, D)), WA=WA_l,
+            # the layer's states are a column block of the attention block's (L+1, B, n*D) slots: S_ld = n*D in its argument block
+            bufs = dict(xg=ws.get(t + ".xg", (L * B, 3 * D)), ymask=ym, S=att_bufs["S"][:, :, l * D:(l + 1) * D], WA=WA_l,
                         U=ws.get(t + ".U", (L, B, D)), R=ws.get(t + ".R", (L, B, D)), C=ws.get(t + ".C", (L, B, D)),
                         RH=ws.get(t + ".RH", (L, B, D)), sg=ws.get(t + ".sg", (B, 2 * D)), xin=ws.get(t + ".xin", (B, D)))
             fields = self._layer_fields(l, pk, A, PA, Am, L, B, bufs, broadcast)
+            fields["S_ld"] = d.D_tot
             layers.append(dict(bufs=bufs, fields=fields, args=lib.make("lvsr_attdec_args", **fields)))
         fields = self._att_fields(pk, A, PA, Am, L, B, att_bufs, att_phases, step0, broadcast)
         extra = {} if step_dev is None else dict(step_dev=step_dev)
@@ -177,8 +179,8 @@ class StackedSequenceGenerator(SequenceGenerator):
                     layers=layers)
 
     def _run_step(self, blk, i, stream):
-        """Label step i of a block set: glimpses from the concatenated state slot i, then the layers bottom-up, then the new
-        concatenated state slot i + 1."""
+        """Label step i of a block set: glimpses from the concatenated state slot i, then the layers bottom-up, each writing its
+        column block of slot i + 1."""
         d, lib = self.d, self.lib
         D, E = d.D, d.E
         self._run_attention(blk, i, stream)
@@ -199,8 +201,6 @@ class StackedSequenceGenerator(SequenceGenerator):
                 lib.copy_many([(att["bufs"]["WA"][i], wa_l[:, :E]), (layers[l - 1]["bufs"]["S"][i + 1], wa_l[:, E:])])
             lay["args"].label0, lay["args"].L = i, i + 1
             lib.call("lvsr_attdec_fwd", stream, ctypes.byref(lay["args"]), 0)
-        S = att["bufs"]["S"]
-        lib.copy_many([(lay["bufs"]["S"][i + 1], S[i + 1][:, l * D:(l + 1) * D]) for l, lay in enumerate(layers)])
 
     # ---- teacher-forced pass ---------------------------------------------------------------------------------------------
     def _forward_recurrent(self, pk, A, PA, Am, labels, ym, L, B, Tp):
@@ -217,8 +217,6 @@ class StackedSequenceGenerator(SequenceGenerator):
         fb = ws.get("gen.fb", (L * B, d.FB)) if d.embed else None
         self._feedback_forks(labels.view(-1), L * B, [lay["bufs"]["xg"] for lay in blk["layers"]], fb)
         S[0].copy_(self._initial_state().unsqueeze(0).expand(B, d.D_tot))       # initial_state of every layer, tiled
-        for l, lay in enumerate(blk["layers"]):
-            lay["bufs"]["S"][0].copy_(p[self.nl[l]["h0"]].unsqueeze(0).expand(B, D))
         W[0].zero_()
         if d.conv:
             W[0, :, 0] = 1.0
@@ -251,11 +249,12 @@ class StackedSequenceGenerator(SequenceGenerator):
         bws = []
         for l, lay in enumerate(layers):
             t = "gen.l%d" % l
+            # running state gradient and its recurrent part: column blocks of the attention block's (B, n*D) arrays (ds_ld = n*D)
             ent = dict(DXG=ws.get(t + ".DXG", (nrows, 3 * D)), DWA=DWA if l == 0 else ws.get(t + ".DWA", (L, B, self._E(l))),
-                       ds=ws.get(t + ".ds", (B, D), zero=True), dsacc=ws.get(t + ".dsacc", (B, D)))
+                       ds=ds[:, l * D:(l + 1) * D], dsacc=dsacc[:, l * D:(l + 1) * D])
             a = lib.make("lvsr_attdec_bwd_args", WhhT_p=pk["WhhT%d" % l], WhgT_p=pk["WhgT%d" % l], WdT_p=pk["WdT%d" % l],
                          dWA_r=dWA_r if l == 0 else None, DXG=ent["DXG"], DWA=ent["DWA"], ds=ent["ds"],
-                         dspart=ws.get(t + ".dspart", (B, D)), dsacc=ent["dsacc"], parts=1)
+                         dspart=ws.get(t + ".dspart", (B, D)), dsacc=ent["dsacc"], parts=1, ds_ld=DT)
             a.f = lib.make("lvsr_attdec_args", **lay["fields"])
             ent["args"] = a
             bws.append(ent)
@@ -268,15 +267,12 @@ class StackedSequenceGenerator(SequenceGenerator):
                 lib.call("lvsr_attdec_bwd", stream, ctypes.byref(a), 0)
                 if l > 0:       # the fork of the layer below: the tail of this layer's distribution-input gradient
                     lib.copy_many([(bws[l]["DWA"][i][:, E:], bws[l - 1]["ds"], 1.0)])
-            # total glimpse gradient (layer 0 wrote its share, incl. the readout's, into DWA); the states' recurrent gradients
-            # (one launch per accumulation into DWA[i]: the descriptors of a launch run concurrently)
-            lib.copy_many([(bws[1]["DWA"][i][:, :E], DWA[i], 1.0)]
-                          + [(bws[l]["dsacc"], dsacc[:, l * D:(l + 1) * D]) for l in range(d.n_dec)])
-            for l in range(2, d.n_dec):
+            # total glimpse gradient: layer 0 wrote its share, incl. the readout's, into DWA (one launch per accumulation: the
+            # descriptors of a launch run concurrently)
+            for l in range(1, d.n_dec):
                 lib.copy_many([(bws[l]["DWA"][i][:, :E], DWA[i], 1.0)])
             bw_att.f.label0, bw_att.f.L = i, i + 1
             lib.call("lvsr_attdec_bwd", stream, ctypes.byref(bw_att), 0)
-            lib.copy_many([(ds[:, l * D:(l + 1) * D], bws[l]["ds"]) for l in range(d.n_dec)])
         # ---- weight gradients as batched GEMMs over all labels
         Scat2 = att["bufs"]["S"][:L].view(nrows, DT)
         labels_flat = sv["labels"].view(-1)
@@ -286,7 +282,7 @@ class StackedSequenceGenerator(SequenceGenerator):
             dpc, dg = bwl["DXG"][:, :D], bwl["DXG"][:, D:]
             lb = lay["bufs"]
             lib.sgemm(lb["RH"].view(nrows, D), dpc, g[n["Whh"]], transA=True, ws=gws, group=True)
-            lib.sgemm(lb["S"][:L].view(nrows, D), dg, g[n["Whg"]], transA=True, ws=gws, group=True)
+            lib.sgemm(Scat2[:, l * D:(l + 1) * D], dg, g[n["Whg"]], transA=True, ws=gws, group=True)
             WA2 = lb["WA"].view(nrows, self._E(l))
             lib.sgemm(WA2[:, :E], dpc, g[n["Wdi"]], transA=True, ws=gws, group=True)
             lib.sgemm(WA2[:, :E], dg, g[n["Wdg"]], transA=True, ws=gws, group=True)
@@ -326,7 +322,6 @@ class StackedSequenceGenerator(SequenceGenerator):
         S = blk["att"]["bufs"]["S"]
         layers = blk["layers"]
         self._feedback_forks(st["chars"], st["K"], [lay["bufs"]["xg"] for lay in layers], st["fb"])
-        lib.copy_many([(S[0][:, l * D:(l + 1) * D], lay["bufs"]["S"][0]) for l, lay in enumerate(layers)])
         self._run_step(blk, 0, lib.stream_for(S))
 
     # ---- free-running generation -----------------------------------------------------------------------------------------
@@ -357,8 +352,6 @@ class StackedSequenceGenerator(SequenceGenerator):
         first = self.initial_states(B, attended=A)
         S[0].copy_(first["states"])
         W[0].copy_(first["weights"])
-        for l, lay in enumerate(blk["layers"]):
-            lay["bufs"]["S"][0].copy_(p[self.nl[l]["h0"]].unsqueeze(0).expand(B, d.D))
         if pos_needed:
             att_bufs["pos"][0].zero_()
         outputs = ws.get("sg.outputs", (N, B), torch.int64)

@@ -197,6 +197,8 @@ typedef struct lvsr_attdec_args {
     float* ep;                            /* (B,ceil(M/32),Tp) partial energies of the match-dim slices */
     const int* step_dev;                  /* optional device word added to step0 (graph-replayed generation: the position
                                              counter of lvsr_beam_select), else NULL */
+    int S_ld;                             /* row stride of S in floats (0 = D; a slot is B rows): a layer of a stacked decoder keeps its
+                                             states as a column block of the concatenated (L+1,B,n*D) array.  Step kernels only */
     int label0;                           /* lvsr_attdec_fwd / lvsr_attdec_bwd run the steps [label0, L) only (0: all).  A stacked decoder
                                              (RecurrentStack, lvsr/bricks/recognizer.py:250-262) is driven label by label with one
                                              block for the attention over the concatenated states and one per GRU layer */
@@ -253,6 +255,7 @@ typedef struct lvsr_attdec_bwd_args {
      * per label; DWA is then NOT written: the caller forms DWA = DXG @ [Wdi|Wdg]^T + dWA_r for all labels after the call */
     const float* AW;                      /* (Tp,B,3D) attended @ [fork_inputs.W | fork_gate_inputs.W] */
     const float* QR;                      /* (L,B,Tp) dWA_r[i,b,:] . A[t,b,:] (zeros if dWA_r is NULL) */
+    int ds_ld;                            /* row stride of ds and dsacc in floats (0 = D).  Step kernels only */
     int parts;                            /* 0 or 3: the whole step; 1: the GRU kernels only (ds -> DXG, DWA, dspart, dsacc; the forward
                                              block may then have phases = 2); 2: the attention kernels only (DWA, dalp, dsacc -> ds,
                                              DSW, DCV, dPA, ...; phases = 1).  With parts != 3 the reassociated glimpse (AW / QR) is
