@@ -75,8 +75,13 @@ class SequenceGenerator(object):
         return dS_r
 
     # ---- packed operand copies ------------------------------------------------------------------
-    def _packed(self):
+    def _packed(self, packs=True):
+        """The operand copies of the current parameters.  packs=False: only allocate the packed copies (and make the plain
+        concatenations) — the persistent kernels of the teacher-forced pass read the plain weights, so a training step that stays on
+        them never pays the nine pack launches; `_ensure_packs` makes them when a step kernel is about to run."""
         if self._packs is not None and self._packs["version"] == self.store.version and not self.lib.capturing:
+            if packs:
+                self._ensure_packs(self._packs)
             return self._packs
         p, lib, ws, n, d = self.store.p, self.lib, self.ws, self.n, self.d
         ent = dict(version=self.store.version)
@@ -94,9 +99,16 @@ class SequenceGenerator(object):
         wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
         lib.copy_many([(p[n["Wdi"]], wd[:, : d.D]), (p[n["Wdg"]], wd[:, d.D:])])
         pack("WdT", wd, True)
-        lib.pack_many(jobs, use_graph=self.use_graph, cache=self._pack_cache)
+        ent["_jobs"], ent["packed"] = jobs, False
+        if packs:
+            self._ensure_packs(ent)
         self._packs = ent
         return ent
+
+    def _ensure_packs(self, ent):
+        if not ent.get("packed", True):
+            self.lib.pack_many(ent["_jobs"], use_graph=self.use_graph, cache=self._pack_cache)
+            ent["packed"] = True
 
     def _prior(self):
         pr = self.d.cfg["prior"]
@@ -224,7 +236,7 @@ class SequenceGenerator(object):
         d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
         L, B = int(outputs.shape[0]), int(outputs.shape[1])
         Tp = int(attended.shape[0])
-        pk = self._packed()
+        pk = self._packed(packs=False)
         A = attended.contiguous()
         Am = attended_mask.contiguous()
         labels = outputs.contiguous()
@@ -295,6 +307,7 @@ class SequenceGenerator(object):
             lib.call("lvsr_attdec_fwd_persistent", lib.stream_for(S), _ct.byref(fwd_args), _ct.byref(plain), lib_ptr(sync), 0)
             lib.call("lvsr_attdec_glimpses", lib.stream_for(S), _ct.byref(fwd_args))
         else:
+            self._ensure_packs(pk)
             fwd_args = lib.run("lvsr_attdec_fwd", "lvsr_attdec_args", S, self.use_graph, **fields)
         return dict(bufs=bufs, saved=dict(xg=xg, fb=fb, fields=fields, AW_valid=sync is not None))
 
@@ -449,6 +462,7 @@ class SequenceGenerator(object):
             plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
             lib.call("lvsr_attdec_bwd_persistent", lib.stream_for(ds), ctypes.byref(bw), ctypes.byref(plain), lib_ptr(psync))
         else:
+            self._ensure_packs(pk)
             lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
         if reassoc:
             DWA2 = DWA.view(nrows, d.E)

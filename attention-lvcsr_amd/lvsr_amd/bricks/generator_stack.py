@@ -65,7 +65,7 @@ class StackedSequenceGenerator(SequenceGenerator):
         lib.sgemm(dR1, self._merge_states_weight(), dS_r, transB=True)
         return dS_r
 
-    def _packed(self):
+    def _packed(self, packs=True):
         if self._packs is not None and self._packs["version"] == self.store.version and not self.lib.capturing:
             return self._packs
         p, lib, ws, d = self.store.p, self.lib, self.ws, self.d
