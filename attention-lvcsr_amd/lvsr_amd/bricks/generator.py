@@ -421,53 +421,51 @@ class SequenceGenerator(object):
         nslice = (d.M + ATT_MS - 1) // ATT_MS
         ntile = (Tp + 63) // 64
         Kc = max(d.K, 1)
+        import ctypes
         DXG = ws.get("gen.DXG", (nrows, 3 * d.D))
-        DWA = ws.get("gen.DWA", (L, B, d.E))
+        # The glimpse contraction is reassociated (as in the persistent forward): q = DXG . AW + QR — the kernels need no dwa and do
+        # not write DWA; the total gradient wrt the weighted averages is formed after the walk, accumulated onto the readout's share
+        # where it lies: DWA = dWA_r + DXG @ [Wdi | Wdg]^T
+        DWA = dWA_r.view(L, B, d.E)
         DSW = ws.get("gen.DSW", (nrows, d.M))
         DCV = ws.get("gen.DCV", (L, B, Kc, Tp)) if d.conv else None
         dPA = ws.get("gen.dPA", (Tp, B, d.M), zero=True)
-        accH = ws.get("gen.accH", (B * ntile, Kc * d.M), zero=True)
-        accWe = ws.get("gen.accWe", (B * ntile, d.M), zero=True)
-        accEb = ws.get("gen.accEb", (B * ntile, 1), zero=True)
         ds = ws.get("gen.ds", (B, d.D), zero=True)
-        dalp = ws.get("gen.dalp", (B, Kc, Tp), zero=True)
-        bw = lib.make("lvsr_attdec_bwd_args", WhhT_p=pk["WhhT"], WhgT_p=pk["WhgT"], WdT_p=pk["WdT"], WsT_p=pk["WsT"],
-                      dWA_r=dWA_r, dS_r=dS_r, DXG=DXG, DWA=DWA, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe, accEb=accEb,
-                      ds=ds, dalp=dalp, dspart=ws.get("gen.dspart", (B, d.D)), dsacc=ws.get("gen.dsacc", (B, d.D)),
-                      Q=ws.get("gen.Q", (B, Tp)),
-                      dcvp=ws.get("gen.dcvp", (B, nslice, Kc, Tp)) if d.conv else None,
-                      dswp=ws.get("gen.dswp", (B, ntile, d.M)))
-        bw.f = lib.make("lvsr_attdec_args", **sv["fields"])
-        import ctypes
-        reassoc = True
-        if reassoc:
-            # the glimpse contraction reassociated (as in the persistent forward): q = DXG . AW + QR, one launch less per label
-            wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
-            AW = ws.get("gen.AW", (Tp * B, 3 * d.D))
-            if not sv.get("AW_valid"):
-                lib.sgemm(sv["A"].view(Tp * B, d.E), wd, AW)
-            QR = ws.get("gen.QR", (L, B, Tp))
-            lib.call("lvsr_sgemm_batched", lib.stream_for(QR), 0, 1, L, Tp, d.E, 1.0, lib_ptr(dWA_r), B * d.E, d.E,
-                     lib_ptr(sv["A"]), B * d.E, d.E, 0.0, lib_ptr(QR), B * Tp, Tp, B)
-            bw.AW, bw.QR = AW.data_ptr(), QR.data_ptr()
-        psync = self._persistent_bwd_ws(bw.f) if reassoc else None
+        wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
+        AW = ws.get("gen.AW", (Tp * B, 3 * d.D))
+        if not sv.get("AW_valid"):
+            lib.sgemm(sv["A"].view(Tp * B, d.E), wd, AW)
+        QR = ws.get("gen.QR", (L, B, Tp))
+        lib.call("lvsr_sgemm_batched", lib.stream_for(QR), 0, 1, L, Tp, d.E, 1.0, lib_ptr(dWA_r), B * d.E, d.E,
+                 lib_ptr(sv["A"]), B * d.E, d.E, 0.0, lib_ptr(QR), B * Tp, Tp, B)
+        fwd_args = lib.make("lvsr_attdec_args", **sv["fields"])
+        psync = self._persistent_bwd_ws(fwd_args)
         if psync is not None:
             # the whole reverse walk as one persistent launch (csrc/decoder_persist_bwd.hip); its handler / energy-vector / bias
-            # gradient partials come one row per work-group
+            # gradient partials come one row per work-group — written, not accumulated: nothing but dPA and ds to clear
             P = (d.D + 31) // 32
-            accH = ws.get("gen.accH_p", (B * P, Kc * d.M), zero=True)
-            accWe = ws.get("gen.accWe_p", (B * P, d.M), zero=True)
-            accEb = ws.get("gen.accEb_p", (B * P, 1), zero=True)
-            bw.accH, bw.accWe, bw.accEb = accH.data_ptr(), accWe.data_ptr(), accEb.data_ptr()
+            accH = ws.get("gen.accH_p", (B * P, Kc * d.M))
+            accWe = ws.get("gen.accWe_p", (B * P, d.M))
+            accEb = ws.get("gen.accEb_p", (B * P, 1))
+            bw = lib.make("lvsr_attdec_bwd_args", dS_r=dS_r, DXG=DXG, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe, accEb=accEb,
+                          ds=ds, AW=AW, QR=QR)
+            bw.f = fwd_args
             plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
             lib.call("lvsr_attdec_bwd_persistent", lib.stream_for(ds), ctypes.byref(bw), ctypes.byref(plain), lib_ptr(psync))
         else:
             self._ensure_packs(pk)
+            accH = ws.get("gen.accH", (B * ntile, Kc * d.M), zero=True)
+            accWe = ws.get("gen.accWe", (B * ntile, d.M), zero=True)
+            accEb = ws.get("gen.accEb", (B * ntile, 1), zero=True)
+            bw = lib.make("lvsr_attdec_bwd_args", WhhT_p=pk["WhhT"], WhgT_p=pk["WhgT"], WdT_p=pk["WdT"], WsT_p=pk["WsT"],
+                          dWA_r=dWA_r, dS_r=dS_r, DXG=DXG, DWA=DWA, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe, accEb=accEb,
+                          ds=ds, dalp=ws.get("gen.dalp", (B, Kc, Tp), zero=True), dspart=ws.get("gen.dspart", (B, d.D)),
+                          dsacc=ws.get("gen.dsacc", (B, d.D)), Q=ws.get("gen.Q", (B, Tp)),
+                          dcvp=ws.get("gen.dcvp", (B, nslice, Kc, Tp)) if d.conv else None,
+                          dswp=ws.get("gen.dswp", (B, ntile, d.M)), AW=AW, QR=QR)
+            bw.f = fwd_args
             lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
-        if reassoc:
-            DWA2 = DWA.view(nrows, d.E)
-            DWA2.copy_(dWA_r)
-            lib.sgemm(DXG, wd, DWA2, transB=True, beta=1.0)
+        lib.sgemm(DXG, wd, dWA_r, transB=True, beta=1.0)
         # ---- weight gradients as batched GEMMs over all steps
         dpc, dg = DXG[:, : d.D], DXG[:, d.D:]
         RH2 = bufs["RH"].view(nrows, d.D)
@@ -495,7 +493,7 @@ class SequenceGenerator(object):
                      lib_ptr(g[n["Wfi"]]), d.D, 0.0)
             lib.call("lvsr_scatter_add_rows", st, lib_ptr(dg), 3 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
                      lib_ptr(g[n["Wfg"]]), 2 * d.D, 0.0)
-        return dict(accH=accH, accWe=accWe, accEb=accEb, DCV=DCV, dPA=dPA, DWA=DWA, fwd_args=bw.f)
+        return dict(accH=accH, accWe=accWe, accEb=accEb, DCV=DCV, dPA=dPA, DWA=DWA, fwd_args=fwd_args)
 
 
 def lib_ptr(t):
