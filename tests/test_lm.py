@@ -83,7 +83,7 @@ CFG = dict(input_dim=5, num_phonemes=6, dims_bidir=[4, 3], subsample=[1, 2], dim
            max_decoded_length_scale=1)
 
 
-def run_fused_beam(device, lib, device_lm=False):
+def run_fused_beam(device, lib, device_lm=False, CFG=CFG):
     from oracle import lvsr_oracle as O
     from lvsr_amd import synthetic
     from lvsr_amd.bricks.recognizer import SpeechRecognizer
@@ -116,9 +116,18 @@ def test_beam_search_with_shallow_fusion_emulated():
     run_fused_beam("cpu", emu_lib())
 
 
+def test_beam_search_with_shallow_fusion_and_a_stacked_decoder_emulated():
+    """dec_stack = 2 (RecurrentStack decoder) under shallow fusion, host and device language model: the fused readout and the beam
+    kernels see the states of both layers side by side."""
+    from emu import emu_lib
+    run_fused_beam("cpu", emu_lib(), CFG=dict(CFG, dec_stack=2))
+    run_fused_beam("cpu", emu_lib(), device_lm=True, CFG=dict(CFG, dec_stack=2))
+
+
 @pytest.mark.gpu
 def test_beam_search_with_shallow_fusion_gpu(gpu_device):
     run_fused_beam(gpu_device, None)
+    run_fused_beam(gpu_device, None, device_lm=True, CFG=dict(CFG, dec_stack=2))
 
 
 # ---- device-side FST walk (lvsr_fst_lm_step) vs the host walk ------------------------------------------------------
