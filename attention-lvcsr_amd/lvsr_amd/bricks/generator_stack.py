@@ -16,7 +16,9 @@ state with the row-concatenated transformers) and the readout this is the one-la
 the one-layer GRU kernels with its own state slots and, for l > 0, the "glimpse" [weighted_averages | new state of layer l-1]
 against the row-concatenated [distribute ; fork_l] weights.  The label loop is driven from here, one label at a time
 (`label0` / `parts` of the argument blocks, include/lvsr_hip.h), a handful of launches per label and layer; inside the training
-step's graph region the loop costs host time only at capture.  The persistent one-launch kernels cover one layer only.
+step's graph region the loop costs host time only at capture.  A layer's state slots and running state gradient are
+column blocks of the concatenated arrays (`S_ld` / `ds_ld`), worked on in place.  The persistent one-launch kernels cover one
+layer only.
 Built: cost_matrix / backward (training), analyze, the device beam search, generate / sample.
 """
 import ctypes
@@ -181,8 +183,6 @@ class StackedSequenceGenerator(SequenceGenerator):
     def _run_step(self, blk, i, stream):
         """Label step i of a block set: glimpses from the concatenated state slot i, then the layers bottom-up, each writing its
         column block of slot i + 1."""
-        d, lib = self.d, self.lib
-        D, E = d.D, d.E
         self._run_attention(blk, i, stream)
         self._run_layers(blk, i, stream)
 
@@ -193,7 +193,7 @@ class StackedSequenceGenerator(SequenceGenerator):
 
     def _run_layers(self, blk, i, stream):
         d, lib = self.d, self.lib
-        D, E = d.D, d.E
+        E = d.E
         att, layers = blk["att"], blk["layers"]
         for l, lay in enumerate(layers):
             if l > 0:
@@ -204,8 +204,7 @@ class StackedSequenceGenerator(SequenceGenerator):
 
     # ---- teacher-forced pass ---------------------------------------------------------------------------------------------
     def _forward_recurrent(self, pk, A, PA, Am, labels, ym, L, B, Tp):
-        d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
-        D = d.D
+        d, lib, ws = self.d, self.lib, self.ws
         Kc = max(d.K, 1)
         S = ws.get("gen.S", (L + 1, B, d.D_tot))
         W = ws.get("gen.W", (L + 1, B, Tp))
@@ -317,8 +316,7 @@ class StackedSequenceGenerator(SequenceGenerator):
                                  broadcast=True, step_dev=pos_word)
 
     def _beam_step_run(self, st):
-        d, lib, blk = self.d, self.lib, st["stepB"]
-        D = d.D
+        lib, blk = self.lib, st["stepB"]
         S = blk["att"]["bufs"]["S"]
         layers = blk["layers"]
         self._feedback_forks(st["chars"], st["K"], [lay["bufs"]["xg"] for lay in layers], st["fb"])
@@ -328,7 +326,7 @@ class StackedSequenceGenerator(SequenceGenerator):
     def generate(self, n_steps=None, batch_size=None, attended=None, attended_mask=None, uniforms=None, seed=None):
         """BaseSequenceGenerator.generate (sequence_generators.py:328-377) with the stacked transition; `states` comes back with the
         layers side by side, (n, B, dec_stack * D)."""
-        d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
+        d, lib, ws = self.d, self.lib, self.ws
         if self.language_model is not None:
             raise NotImplementedError("generate() with a language model: the reference's LMEmitter.emit returns zeros (not a "
                                       "sampling path); use beam_search, or cost / analyze for teacher-forced costs")
