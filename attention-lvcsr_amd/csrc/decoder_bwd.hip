@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void attbwd_gru_bq_kernel(AttBwd g, int i) {
     float q = 0.f;
     if (t >= w.begin && t < w.end) {
         const float* dx = g.DXG + ((size_t)i * B + b) * G;
-        const float* ar = g.AW + ((size_t)t * B + b) * G;
+        const float* ar = g.AW + ((size_t)t * B + b) * (g.AW_ld ? g.AW_ld : G);
         const bool vec = ((G & 3) == 0) && ((((size_t)ar | (size_t)dx) & 15) == 0);
         float4 x[4], y[4];
 #pragma unroll

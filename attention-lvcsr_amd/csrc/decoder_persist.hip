@@ -186,7 +186,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     }
     for (int x = tid; x < Tp * 3 * PD_UNITS; x += PD_THREADS) {
         const int t = x / (3 * PD_UNITS), gcol = x % (3 * PD_UNITS), gate = gcol / PD_UNITS, unit = p * PD_UNITS + gcol % PD_UNITS;
-        AWs[t * PD_AWS + gcol] = unit < D ? w.AW[((size_t)t * B + b) * 3 * D + (size_t)gate * D + unit] : 0.f;
+        AWs[t * PD_AWS + gcol] = unit < D ? w.AW[((size_t)t * B + b) * (w.AW_ld ? w.AW_ld : 3 * D) + (size_t)gate * D + unit] : 0.f;
     }
     __syncthreads();
     for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[(size_t)b * Tp + t];

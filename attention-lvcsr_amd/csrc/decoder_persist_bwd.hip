@@ -131,6 +131,9 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L, G3 = 3 * a.D;
+    // AW rows are read 16 bytes at a time: row stride AWld (a multiple of 4, the host pads when 3D is not), columns up to G3p;
+    // the gradient vector they are contracted with is zero beyond 3D
+    const int AWld = w.AW_ld ? w.AW_ld : G3, G3p = (G3 + 3) & ~3;
     const int j = p * PD_UNITS + jl;
     const bool junit = j < D;
     const float C2 = 2.885390081777927f;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     if (g.AWL)
         for (int x = tid; x < nown * G3; x += PD_THREADS) {
             const int tl = x / G3, col = x % G3, t = tl * P + p;
-            AWl[tl * g.AWS + col] = t < Tp ? w.AW[((size_t)t * B + b) * G3 + col] : 0.f;
+            AWl[tl * g.AWS + col] = t < Tp ? w.AW[((size_t)t * B + b) * AWld + col] : 0.f;
         }
     for (int x = tid; x < 256 * 64; x += PD_THREADS) {
         const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
@@ -328,12 +331,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         // last as long as they do
         const int qtl = tid >> 4, l16 = tid & 15, qt = qtl * P + p;
         const bool qok = qtl < nown && qt < Tp && qt >= wi.begin && qt < wi.end;
-        const unsigned awoff = 4u * ((unsigned)min(qt, Tp - 1) * (unsigned)(B * G3) + 4u * l16);
+        const unsigned awoff = 4u * ((unsigned)min(qt, Tp - 1) * (unsigned)(B * AWld) + 4u * l16);
         float4 awv[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
             const int col = 4 * l16 + 64 * e;
-            awv[e] = (!g.AWL && qok && col + 3 < G3) ? pb_ld<float4>(w.AW + (size_t)b * G3 + 64 * e, awoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            awv[e] = (!g.AWL && qok && col < G3p) ? pb_ld<float4>(w.AW + (size_t)b * AWld + 64 * e, awoff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         const float dsacc = part + pd_dot<PD_KD>(whu, dpus, q) + pd_dot<PD_KD>(whr, dprs, q);
         clk.mark(11);
@@ -343,8 +346,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
 #pragma unroll
             for (int e = 0; e < 12; ++e) {
                 const int col = 4 * l16 + 64 * e;                 // columns [0,D) dpc, [D,2D) dpu, [2D,3D) dpr: dgl is laid out the same
-                const float4 dg = (col + 3 < G3) ? *(const float4*)(dgl + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 aw = !g.AWL ? awv[e] : (qok && col + 3 < G3) ? *(const float4*)(AWl + qtl * g.AWS + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 dg = (col < G3p) ? *(const float4*)(dgl + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 aw = !g.AWL ? awv[e] : (qok && col < G3p) ? *(const float4*)(AWl + qtl * g.AWS + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 s0 += aw.x * dg.x + aw.y * dg.y;
                 s1 += aw.z * dg.z + aw.w * dg.w;
             }
@@ -683,7 +686,6 @@ extern "C" long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* ar
     memcpy(&a, args, sizeof(a));
     PbGeom g;
     if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pb_geom(a, g)) return 0;
-    if ((a.D & 3) != 0) return 0;
     return 256 + (long long)a.B * (PB_NPLANE_SMALL * PD_MAXV + (long long)g.P * (512 + 256 + 512)) * 8;
 }
 
@@ -696,7 +698,9 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     LVSR_REQUIRE(a.label0 == 0 && (args->parts & 3) % 3 == 0 && (a.S_ld == 0 || a.S_ld == a.D) && (args->ds_ld == 0 || args->ds_ld == a.D),
                  "lvsr_attdec_bwd_persistent: runs all labels and all parts on contiguous states");
     PbGeom g;
-    LVSR_REQUIRE(pb_geom(a, g) && (a.D & 3) == 0, "lvsr_attdec_bwd_persistent: configuration outside the persistent kernel's limits "
+    LVSR_REQUIRE((plain->AW_ld ? plain->AW_ld : 3 * a.D) % 4 == 0 && (plain->AW_ld == 0 || plain->AW_ld >= 3 * a.D),
+                 "lvsr_attdec_bwd_persistent: the rows of AW must be a multiple of 4 floats apart (pad them: AW_ld)");
+    LVSR_REQUIRE(pb_geom(a, g), "lvsr_attdec_bwd_persistent: configuration outside the persistent kernel's limits "
                  "(lvsr_attdec_bwd_persist_ws_bytes returns 0 for it)");
     LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd_persistent: contexts must be contiguous (Tp,B,*)");
     LVSR_REQUIRE(plain->Ws && plain->Whg && plain->Whh && plain->AW && gb.QR && gb.DXG && gb.DSW && gb.dPA && gb.ds && gb.accWe,

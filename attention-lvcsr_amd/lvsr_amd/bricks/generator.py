@@ -66,6 +66,13 @@ class SequenceGenerator(object):
     def _initial_state(self):
         return self.store.p[self.n["h0"]]
 
+    def _AW(self, Tp, B):
+        """Buffer of AW = attended @ [fork_inputs.W | fork_gate_inputs.W]: (T'*B, 3D) with the rows a multiple of 4 floats apart (the
+        persistent backward reads them 16 bytes at a time; D = 250 of the wsj_paper configs gives 750 columns).  -> (view, row stride);
+        the padding columns are never written and never contribute (the vector they meet is zero there)."""
+        ld = (3 * self.d.D + 3) // 4 * 4
+        return self.ws.get("gen.AW", (Tp * B, ld))[:, : 3 * self.d.D], ld
+
     def _merge_states_backward(self, S2, dR1, gws):
         """Gradient of the readout's state source: weight gradient into the store, -> dS_r (rows, state width)."""
         d, p, g, n, lib, ws = self.d, self.store.p, self.store.g, self.n, self.lib, self.ws
@@ -301,9 +308,9 @@ class SequenceGenerator(object):
             fwd_args = lib.make("lvsr_attdec_args", **fields)
             # gate inputs of the glimpse, reassociated: AW = attended @ [fork_inputs.W | fork_gate_inputs.W] once per batch
             wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
-            AW = ws.get("gen.AW", (Tp * B, 3 * d.D))
+            AW, AW_ld = self._AW(Tp, B)
             lib.sgemm(A.view(Tp * B, d.E), wd, AW)
-            plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
+            plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW, AW_ld=AW_ld)
             lib.call("lvsr_attdec_fwd_persistent", lib.stream_for(S), _ct.byref(fwd_args), _ct.byref(plain), lib_ptr(sync), 0)
             lib.call("lvsr_attdec_glimpses", lib.stream_for(S), _ct.byref(fwd_args))
         else:
@@ -432,7 +439,7 @@ class SequenceGenerator(object):
         dPA = ws.get("gen.dPA", (Tp, B, d.M), zero=True)
         ds = ws.get("gen.ds", (B, d.D), zero=True)
         wd = ws.get("gen.Wd_cat", (d.E, 3 * d.D))
-        AW = ws.get("gen.AW", (Tp * B, 3 * d.D))
+        AW, AW_ld = self._AW(Tp, B)
         if not sv.get("AW_valid"):
             lib.sgemm(sv["A"].view(Tp * B, d.E), wd, AW)
         QR = ws.get("gen.QR", (L, B, Tp))
@@ -448,9 +455,9 @@ class SequenceGenerator(object):
             accWe = ws.get("gen.accWe_p", (B * P, d.M))
             accEb = ws.get("gen.accEb_p", (B * P, 1))
             bw = lib.make("lvsr_attdec_bwd_args", dS_r=dS_r, DXG=DXG, DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe, accEb=accEb,
-                          ds=ds, AW=AW, QR=QR)
+                          ds=ds, AW=AW, QR=QR, AW_ld=AW_ld)
             bw.f = fwd_args
-            plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW)
+            plain = lib.make("lvsr_attdec_plain", Ws=p[n["Ws"]], Whg=p[n["Whg"]], Whh=p[n["Whh"]], AW=AW, AW_ld=AW_ld)
             lib.call("lvsr_attdec_bwd_persistent", lib.stream_for(ds), ctypes.byref(bw), ctypes.byref(plain), lib_ptr(psync))
         else:
             self._ensure_packs(pk)
@@ -462,7 +469,7 @@ class SequenceGenerator(object):
                           ds=ds, dalp=ws.get("gen.dalp", (B, Kc, Tp), zero=True), dspart=ws.get("gen.dspart", (B, d.D)),
                           dsacc=ws.get("gen.dsacc", (B, d.D)), Q=ws.get("gen.Q", (B, Tp)),
                           dcvp=ws.get("gen.dcvp", (B, nslice, Kc, Tp)) if d.conv else None,
-                          dswp=ws.get("gen.dswp", (B, ntile, d.M)), AW=AW, QR=QR)
+                          dswp=ws.get("gen.dswp", (B, ntile, d.M)), AW=AW, QR=QR, AW_ld=AW_ld)
             bw.f = fwd_args
             lib.call("lvsr_attdec_bwd", lib.stream_for(ds), ctypes.byref(bw), int(self.use_graph))
         lib.sgemm(DXG, wd, dWA_r, transB=True, beta=1.0)

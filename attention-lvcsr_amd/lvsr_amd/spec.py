@@ -282,6 +282,17 @@ def wsj_deep():
                 embed_outputs=False, data_prepend_eos=False)
 
 
+def wsj_paper():
+    """The README-recommended model (exp/wsj/configs/wsj_paper7.yaml and its parent chain): 4 x 250 BiGRU on
+    123-dimensional features (fbank + deltas), 250-unit decoder and matcher, ONE location filter of 201 taps, rectifier post-merge,
+    embedded feedback, window_around_median(100, 100); trained with batch_size 10."""
+    return dict(input_dim=123, num_phonemes=33, dims_bidir=[250] * 4, subsample=[1, 1, 2, 2], dim_dec=250, dim_matcher=250,
+                attention_type="content_and_conv", conv_n=100, conv_num_filters=1,
+                prior=dict(type="window_around_median", before=100, after=100),
+                post_merge_dims=[250], post_merge_activation="rectifier", embed_outputs=True, data_prepend_eos=False,
+                max_decoded_length_scale=3.0)
+
+
 WORKLOADS = {
     # name: (net config factory, B, T, L)
     "timit_tiny": (timit_tiny, 2, 200, 40),
@@ -289,6 +300,7 @@ WORKLOADS = {
     "wsj_deep": (wsj_deep, 8, 1500, 190),
     # the WSJ-base network with the two-layer RecurrentStack decoder of exp/wsj/configs/wsj_jan_wsj13v2.yaml (dec_stack: 2)
     "wsj_stack2": (lambda: dict(wsj_base(), dec_stack=2), 16, 800, 100),
+    "wsj_paper": (wsj_paper, 10, 800, 100),
 }
 
 

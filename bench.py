@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: encoder+attention+decoder TRAINING frames/sec on WSJ-shape synthetic fbank batches.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wsj_base|wsj_deep|wsj_stack2|timit_tiny|wsj_decode]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wsj_base|wsj_deep|wsj_stack2|wsj_paper|timit_tiny|wsj_decode]
                     [--scaling weak|strong] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 

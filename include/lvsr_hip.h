@@ -220,6 +220,8 @@ typedef struct lvsr_attdec_plain {
     const float* Whg;                     /* transition.state_to_gates (D,2D) */
     const float* Whh;                     /* transition.state_to_state (D,D) */
     const float* AW;                      /* (T',B,3D) attended @ [distribute/fork_inputs.W | distribute/fork_gate_inputs.W] */
+    int AW_ld;                            /* row stride of AW in floats (0 = 3D).  lvsr_attdec_bwd_persistent reads the rows 16 bytes at a
+                                             time: it needs AW_ld % 4 == 0 (pad the rows when 3D is not a multiple of 4, e.g. D = 250) */
 } lvsr_attdec_plain;
 long long lvsr_attdec_persist_ws_bytes(const lvsr_attdec_args* a);
 int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* a, const lvsr_attdec_plain* w, void* ws, int use_graph);
@@ -255,6 +257,7 @@ typedef struct lvsr_attdec_bwd_args {
      * per label; DWA is then NOT written: the caller forms DWA = DXG @ [Wdi|Wdg]^T + dWA_r for all labels after the call */
     const float* AW;                      /* (Tp,B,3D) attended @ [fork_inputs.W | fork_gate_inputs.W] */
     const float* QR;                      /* (L,B,Tp) dWA_r[i,b,:] . A[t,b,:] (zeros if dWA_r is NULL) */
+    int AW_ld;                            /* row stride of AW in floats (0 = 3D) */
     int ds_ld;                            /* row stride of ds and dsacc in floats (0 = D).  Step kernels only */
     int parts;                            /* 0 or 3: the whole step; 1: the GRU kernels only (ds -> DXG, DWA, dspart, dsacc; the forward
                                              block may then have phases = 2); 2: the attention kernels only (DWA, dalp, dsacc -> ds,

@@ -449,12 +449,17 @@ CASES = {
     "wsj_stack2": lambda: run_case(
         "wsj_stack2", dict(spec.wsj_base(), dec_stack=2), B=16, T=800, L=100, ragged=False, param_seed=13, batch_seed=1234,
         scale=0.7, store_full=False),
+    # the README-recommended model at full size (exp/wsj/configs/wsj_paper7.yaml chain: 4 x 250 BiGRU on 123 features, D = M = 250,
+    # one location filter, rectifier post-merge, embedded feedback, batch 10) with the expanding prior of its pre-training stage
+    "wsj_paper": lambda: run_case(
+        "wsj_paper", dict(spec.wsj_paper(), prior=dict(type="expanding", initial_begin=0, initial_end=40, min_speed=1.2, max_speed=2.2)),
+        B=10, T=800, L=100, ragged=False, param_seed=15, batch_seed=1234, store_full=False),
     "wsj_deep": lambda: run_case(
         "wsj_deep", spec.wsj_deep(), B=8, T=1500, L=190, ragged=False, param_seed=11, batch_seed=1234,
         store_full=False),
 }
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "wsj_stack2", "mid_conv_lm_decode", "wsj_decode_full")]
+    which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "wsj_stack2", "wsj_paper", "mid_conv_lm_decode", "wsj_decode_full")]
     for k in which:
         CASES[k]()

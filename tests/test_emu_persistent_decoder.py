@@ -53,11 +53,11 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
     rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=meta["cfg"])
     cm = rec.cost_and_gradients(batch)
     assert engaged(rec), "persistent decoder did not engage"
-    # the backward kernel serves at most 32 attended positions per work-group (the long case has 75: step kernels there) and
-    # decoder widths that are a multiple of 4 (16-byte loads of the gate-gradient vector)
+    # the backward kernel serves at most 32 attended positions per work-group (the long case has 75: step kernels there); decoder
+    # widths that are not a multiple of 4 (D = 5 here, 250 in the wsj_paper configs) run with padded AW rows
     P = (rec.d.D + 31) // 32
     bwd = any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs)
-    assert bwd == ((rec.generator._saved["Tp"] + P - 1) // P <= 32 and rec.d.D % 4 == 0), "persistent decoder backward engaged / did not engage"
+    assert bwd == ((rec.generator._saved["Tp"] + P - 1) // P <= 32), "persistent decoder backward engaged / did not engage"
     rec.generator.check_persistent()
     # the long case accumulates more float32 rounding per element (tests/test_oracle_golden.py TOL); the north-star bars inside
     # check_against (cost sum 1e-4 relative, identical alignment argmax against the reference golden) are the same for all

@@ -120,10 +120,11 @@ def test_recognizer_vs_reference_golden(gpu_device, case, use_graph):
             assert_allclose(got[str(name)] / scale, ref / scale, rtol=0, atol=1e-3 if long_case else 2e-4, err_msg=str(name))
 
 
-@pytest.mark.parametrize("case", ["timit_tiny", "wsj_base", "wsj_deep", "wsj_stack2"])
+@pytest.mark.parametrize("case", ["timit_tiny", "wsj_base", "wsj_deep", "wsj_stack2", "wsj_paper"])
 def test_full_size_configs_vs_reference_golden(gpu_device, case):
     """BASELINE.json configs[0], configs[1] and configs[3] at full size against the reference's outputs (fingerprints);
-    wsj_stack2 = configs[1] with the two-layer stacked decoder of the wsj_jan_* configs."""
+    wsj_stack2 = configs[1] with the two-layer stacked decoder of the wsj_jan_* configs; wsj_paper = the README-recommended model
+    (250-unit layers: a decoder width that is not a multiple of 4)."""
     z, meta = load_golden(case)
     params, batch = _setup(meta)
     rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"])

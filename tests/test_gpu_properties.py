@@ -118,6 +118,33 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
         assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 2e-3
 
 
+def test_persistent_decoder_at_the_paper_width(gpu_device):
+    """The README-recommended model (wsj_paper7: 250-unit BiGRUs, decoder and matcher, one location filter) has a decoder width that
+    is not a multiple of 4: the persistent reverse walk reads its AW rows 16 bytes at a time and runs there with padded rows
+    (`lvsr_attdec_plain.AW_ld`).  Persistent kernels against the step kernels: costs, alignments, every gradient."""
+    from lvsr_amd import spec
+    cfg = dict(spec.wsj_paper(), prior=None)              # expanding prior: no window centres, the two paths differ by rounding only
+    params = synthetic.make_params(cfg, seed=21, scale=0.7)
+    batch = synthetic.make_batch(cfg, 6, 400, 40, seed=22, ragged=True)
+    out = {}
+    for persistent in (True, False):
+        rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg, use_persistent_decoder=persistent)
+        cm = rec.cost_and_gradients(batch).cpu().numpy()
+        torch.cuda.synchronize()
+        rec.generator.check_persistent()
+        assert any(k[0] == "gen.sync" for k in rec.ws._bufs) == persistent, "persistent decoder engaged / did not engage"
+        assert any(k[0] == "gen.sync_bwd" for k in rec.ws._bufs) == persistent, "persistent decoder backward engaged / did not engage"
+        out[persistent] = (cm, rec.generator.last["weights"].cpu().numpy(), rec.store.get_grads())
+    (cm_p, w_p, g_p), (cm_s, w_s, g_s) = out[True], out[False]
+    assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
+    assert_allclose(cm_p, cm_s, rtol=1e-3, atol=1e-3)
+    assert (w_p.argmax(axis=2) == w_s.argmax(axis=2)).all()
+    assert_allclose(w_p, w_s, rtol=1e-3, atol=1e-6)
+    for k in g_s:
+        scale = max(1e-3, numpy.abs(g_s[k]).max())
+        assert numpy.abs(g_p[k] - g_s[k]).max() / scale < 2e-3, k
+
+
 def test_shard_gradients_add_up_to_the_batch_gradient(gpu_device, setup):
     """The data-parallel invariant behind the single all-reduce: grad(sum over all utterances) = sum over shards r::N."""
     s = setup

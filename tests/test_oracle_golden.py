@@ -139,7 +139,7 @@ def test_beam_search_vs_reference(case):
             assert_allclose(w, z["analyze%d_weights" % bi], rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("case", ["timit_tiny", "wsj_stack2"])
+@pytest.mark.parametrize("case", ["timit_tiny", "wsj_stack2", "wsj_paper"])
 def test_full_size_config_vs_reference(case):
     z, meta = load_golden(case)
     orc, batch = _oracle_for(meta, torch.float32)
