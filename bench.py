@@ -233,6 +233,8 @@ def main(backend=None):
     ap.add_argument("--workload", default="wsj_base")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (weak) / global batch (strong) override")
+    ap.add_argument("--frames", type=int, default=None, help="frames per utterance override (labels scale along unless --labels)")
+    ap.add_argument("--labels", type=int, default=None, help="labels per utterance override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (configs[4] sample) of the default line")
     ap.add_argument("--decode-utterances", type=int, default=32)
@@ -276,6 +278,11 @@ def main(backend=None):
     factory, B0, T, L = backend.workloads[args.workload] if args.workload in backend.workloads else spec.WORKLOADS[args.workload]
     cfg = factory()
     dims = spec.Dims(cfg)
+    if args.frames:          # length sweeps: longer utterances leave the persistent decoder kernels' limits
+        L = args.labels or max(1, L * args.frames // T)
+        T = args.frames
+    elif args.labels:
+        L = args.labels
     if args.scaling == "weak":
         B = args.batch or B0
         global_batch = B * world
