@@ -4,6 +4,8 @@
   python build.py            -> hipcc --offload-arch=gfx950  => ../lvsr_amd/liblvsr_hip.so   (product)
   python build.py --emu      -> host clang++ + tests/hipemu  => tests/hipemu/liblvsr_emu.so  (TEST ONLY:
                                 same sources on CPU fibers, see tests/hipemu/hip/hip_runtime.h)
+  python build.py --probes   -> hipcc -DLVSR_PROBES          => tools/probes/liblvsr_hip_probes.so  (MEASUREMENT ONLY: the
+                                timing ablations of csrc/persist.h that produce wrong results; tools/probe_persist.py)
 """
 import glob
 import os
@@ -15,6 +17,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 SRCS = sorted(glob.glob(os.path.join(HERE, "*.hip")))
 HDRS = sorted(glob.glob(os.path.join(HERE, "*.h"))) + sorted(glob.glob(os.path.join(REPO, "include", "*.h")))
 OUT = os.path.join(os.path.dirname(HERE), "lvsr_amd", "liblvsr_hip.so")
+PROBES_OUT = os.path.join(REPO, "tools", "probes", "liblvsr_hip_probes.so")
 EMU_OUT = os.path.join(REPO, "tests", "hipemu", "liblvsr_emu.so")
 EMU_INC = os.path.join(REPO, "tests", "hipemu")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
@@ -27,12 +30,13 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, probes=False):
     deps = SRCS + HDRS + [os.path.abspath(__file__)]
+    OUT = PROBES_OUT if probes else globals()["OUT"]
     if not force and not _stale(OUT, deps):
         return OUT
     objs = []
-    bdir = os.path.join(HERE, "build")
+    bdir = os.path.join(HERE, "build_probes" if probes else "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for s in SRCS:
@@ -43,6 +47,8 @@ def build(force=False, verbose=False):
                    "-I", os.path.join(REPO, "include"), "-c", s, "-o", o]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            if probes:
+                cmd.insert(1, "-DLVSR_PROBES")
             procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
         if p.wait() != 0:
@@ -79,4 +85,4 @@ if __name__ == "__main__":
     if "--emu" in sys.argv:
         print(build_emu(force))
     else:
-        print(build(force, verbose="--verbose" in sys.argv))
+        print(build(force, verbose="--verbose" in sys.argv, probes="--probes" in sys.argv))

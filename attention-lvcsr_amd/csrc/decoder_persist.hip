@@ -645,9 +645,9 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     hipStream_t s = (hipStream_t)stream;
     int* ab = (int*)ws;
     u64* planes = (u64*)((char*)ws + 256);
-    const size_t bytes = 256 + ((size_t)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp) * 8;
+    const size_t bytes = ((size_t)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp) * 8;
     auto enqueue = [&]() {
-        (void)hipMemsetAsync(ws, 0, bytes, s);
+        (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
         const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
         switch (g.KC) {
             case 0: hipLaunchKernelGGL(attdec_pfwd_kernel<0>, grid, block, 0, s, a, w, g, planes, ab); break;

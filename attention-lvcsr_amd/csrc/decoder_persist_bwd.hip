@@ -710,8 +710,8 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     hipStream_t s = (hipStream_t)stream;
     int* ab = (int*)ws;
     u64* planes = (u64*)((char*)ws + 256);
-    const size_t bytes = 256 + (size_t)a.B * (PB_NPLANE_SMALL * PD_MAXV + (size_t)g.P * (512 + 256 + 512)) * 8;
-    (void)hipMemsetAsync(ws, 0, bytes, s);
+    const size_t bytes = (size_t)a.B * (PB_NPLANE_SMALL * PD_MAXV + (size_t)g.P * (512 + 256 + 512)) * 8;
+    (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
     const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
     switch (g.KC) {
         case 0: hipLaunchKernelGGL(attdec_pbwd_kernel<0>, grid, block, 0, s, gb, w, g, planes, ab); break;

@@ -702,7 +702,10 @@ extern "C" long long lvsr_bigru_persist_ws_bytes(int B, int H) {
     if (B <= 0 || H <= 0) return 0;
     // sized for one utterance per cluster (the largest number of clusters) so LVSR_PERSIST_ROWS cannot outgrow it
     if (!persist_geom(B, H, g)) return 0;
-    return 256 + (long long)2 * (B + 16) * 4 * g.HP * 8 + 8 * 1024;     // abort word + 4 planes per (direction, utterance) + XCC_ID granules
+    // abort word + 4 planes per (direction, utterance) + one XCC_ID granule per work-group of the largest grid any knob setting
+    // can ask for (one utterance per cluster, 16 work-groups per cluster, padded to a multiple of 8 clusters)
+    const long long hello = (long long)cluster_grid(2 * B, 16, 0) * 8;
+    return 256 + (long long)2 * (B + 16) * 4 * g.HP * 8 + (hello > 8 * 1024 ? hello : 8 * 1024);
 }
 
 template <int KS, int KSPLIT>
@@ -758,11 +761,14 @@ int lvsr_bigru_fwd_persistent(hipStream_t s, const EncFwd& a0, int use_graph) {
     int* ab = (int*)a.sync_ws;
     u64* planes = (u64*)((char*)a.sync_ws + 256);
     u64* hello = planes + (size_t)2 * g.rt * 2 * g.plane;          // one {1, XCC_ID} granule per work-group, behind the planes
-    const size_t bytes = 256 + (size_t)2 * g.rt * 2 * g.plane * 8 + (size_t)g.grid * 8;
+    const size_t bytes = (size_t)2 * g.rt * 2 * g.plane * 8 + (size_t)g.grid * 8;
     if (a.sub == 1) a.ysub = nullptr;
     const int flags = persist_flags();
     auto enqueue = [&]() {
-        (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
+        // planes and XCC_ID granules only: the abort word (first 256 bytes) is STICKY — no launch clears it, so a cluster that gave
+        // up in the forward pass of a step is still reported after the backward pass (which shares this workspace) and after any
+        // number of replayed steps; the host clears it when it has raised (Encoder.check_persistent)
+        (void)hipMemsetAsync(planes, 0, bytes, s);
         switch (g.KSPLIT / (g.NTH / 256)) {
             case 2: launch_fwd<64, 2>(s, a, g, planes, hello, ab, flags); break;
             case 4: launch_fwd<64, 4>(s, a, g, planes, hello, ab, flags); break;
@@ -783,12 +789,12 @@ int lvsr_bigru_bwd_persistent(hipStream_t s, const EncBwd0& a, int use_graph) {
     int* ab = (int*)a.sync_ws;
     u64* planes = (u64*)((char*)a.sync_ws + 256);
     u64* hello = planes + (size_t)2 * g.rt * 4 * g.plane;
-    const size_t bytes = 256 + (size_t)2 * g.rt * 4 * g.plane * 8 + (size_t)g.grid * 8;
+    const size_t bytes = (size_t)2 * g.rt * 4 * g.plane * 8 + (size_t)g.grid * 8;
     const int Bp = ((a.B + 15) / 16) * 16;
     float* dh = a.dh_ws;
     const int flags = persist_flags();
     auto enqueue = [&]() {
-        (void)hipMemsetAsync(a.sync_ws, 0, bytes, s);
+        (void)hipMemsetAsync(planes, 0, bytes, s);          // not the abort word: sticky until the host has seen it (see the forward)
         switch (g.KSPLIT / (g.NTH / 256)) {
             case 2: launch_bwd<64, 2>(s, a, g, planes, hello, ab, dh, Bp, flags); break;
             case 4: launch_bwd<64, 4>(s, a, g, planes, hello, ab, dh, Bp, flags); break;

@@ -14,20 +14,31 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // members exchange their XCC_ID once, and only a cluster that shares an XCD publishes with plain stores (the granules then
 // live in the XCD's L2, which the members' sc1 polls read: 0.91 instead of 1.33 us per exchange, profiles/r03_hop_probe.txt);
 // any other cluster keeps write-through (sc1) stores, which are correct under every placement.
-// Experiment switches (flags argument of the kernels): 1 = do not write the saved tensors (timing only, results unusable
-// for BPTT), 2 = consecutive blocks form a cluster instead (members spread over the XCDs), 4 = write-through stores even
-// when the cluster shares an XCD (the round-2 hand-off)
-#define PF_NOSAVE 1
+// Kernel-variant switches (flags argument of the kernels; LVSR_KNOB_PERSIST_FLAGS): every one of them computes the SAME results —
+// 2 = consecutive blocks form a cluster instead (members spread over the XCDs), 4 = write-through stores even when the cluster
+// shares an XCD (the round-2 hand-off), ...
 #define PF_SPREAD 2
 #define PF_SC1 4
-#define PF_NOWAIT 8      // ablation: take whatever the first sweep returns (wrong results; what the step costs without hand-off waits)
-#define PF_NODOT 16      // ablation: skip the contractions (wrong results; what the hand-offs cost alone)
 #define PF_NARROW 64     // encoder, 128 < H <= 256: clusters of 4 work-groups (64 units each) instead of 8 — see persist_geom
-#define PF_NOPREFETCH 128   // ablation: do not fetch the next step's operands (wrong results; what those loads cost in front of the sweeps)
 #define PF_NOSTAGE 256      // forward kernel: no loader waves (every owner lane fetches its next operands itself, the round-2 form)
 #define PF_NOUB 2048        // forward kernel at 256 < H <= 512: one unit per lane group instead of four (see enc_pfwd_ub_kernel)
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
                          // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue
+// Timing ablations that produce WRONG results (what a step costs without its waits / contractions / operand fetches / saved
+// tensors).  They exist only in a probe build of the library (`python csrc/build.py --probes` -> liblvsr_hip_probes.so, for
+// tools/probe_persist.py): in the product build the bits are 0, the branches fold away and lvsr_set_knob refuses them.
+#ifdef LVSR_PROBES
+#define PF_NOSAVE 1
+#define PF_NOWAIT 8
+#define PF_NODOT 16
+#define PF_NOPREFETCH 128
+#else
+#define PF_NOSAVE 0
+#define PF_NOWAIT 0
+#define PF_NODOT 0
+#define PF_NOPREFETCH 0
+#endif
+#define PF_WRONG_RESULT_BITS (1 | 8 | 16 | 128)
 // plain = true: a store without cache-policy bits (wavefront-scope atomic = global_store_dwordx2; NOT a volatile store, which
 // is emitted as flat_store sc0 sc1): it is visible to the other CUs of the SAME XCD once it reaches the XCD's L2 (the vector
 // L1 is write-through) — only for granules whose every reader was verified to share the XCD.

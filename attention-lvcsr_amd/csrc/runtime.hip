@@ -1,5 +1,6 @@
 // Error reporting + small runtime utilities of the C-ABI library (see include/lvsr_hip.h).
 #include "common.h"
+#include "persist.h"
 #include "graph_cache.h"
 #include <list>
 #include <mutex>
@@ -177,6 +178,11 @@ int lvsr_graph_count(void) {
 const char* lvsr_last_error(void) { return g_err; }
 int lvsr_set_knob(int knob, int value) {
     LVSR_REQUIRE(knob >= 0 && knob < LVSR_KNOB_COUNT, "lvsr_set_knob: unknown knob %d", knob);
+#ifndef LVSR_PROBES
+    LVSR_REQUIRE(knob != LVSR_KNOB_PERSIST_FLAGS || (value & PF_WRONG_RESULT_BITS) == 0,
+                 "lvsr_set_knob: persist_flags %d contains timing-ablation bits (1, 8, 16, 128: wrong results); they exist only in the "
+                 "probe build of the library (csrc/build.py --probes)", value);
+#endif
     g_knobs[knob].store(value, std::memory_order_relaxed);
     return LVSR_OK;
 }

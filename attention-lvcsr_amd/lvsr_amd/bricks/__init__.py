@@ -6,7 +6,6 @@ All arithmetic happens in the C-ABI library (lvsr_sgemm / lvsr_bigru_fwd / lvsr_
 torch is used for buffers and views only.
 """
 import contextlib
-import os
 
 import torch
 
@@ -75,9 +74,6 @@ class Encoder(object):
         otherwise two step kernels per time step."""
         # needs co-resident work-groups: the GPU, or the emulator with concurrent work-groups switched on (tests)
         can = not lib.is_emulator or lib.emulates_concurrency()
-        env = os.environ.get("LVSR_PERSISTENT")
-        if use_persistent is None and env is not None:
-            use_persistent = env == "1"
         self.persist_auto = use_persistent is None
         self.use_persistent = can and (not lib.is_emulator if use_persistent is None else bool(use_persistent))
         self.d = dims
@@ -187,10 +183,14 @@ class Encoder(object):
         return self.ws.get("enc%d.sync" % i, ((nbytes + 3) // 4,), torch.int32)
 
     def check_persistent(self):
-        """After a synchronisation point: raise if a persistent kernel gave up waiting for its cluster."""
+        """After a synchronisation point: raise if a persistent kernel gave up waiting for its cluster.  The abort word is sticky
+        (no launch clears it: a forward cluster that gave up is still reported after the backward pass and after replayed steps, and
+        every later launch on the workspace leaves at once); it is cleared here, when the failure has been reported."""
         for k, t in self.ws._bufs.items():
             if k[0].startswith("enc") and k[0].endswith(".sync") and int(t[0]) != 0:
-                raise RuntimeError("persistent BiGRU kernel aborted (a work-group of the cluster was not scheduled)")
+                t[:64].zero_()
+                raise RuntimeError("persistent BiGRU kernel aborted (a work-group of the cluster was not scheduled); results since "
+                                   "the last check are invalid")
 
     def apply(self, input_, mask=None, save_for_backward=True):
         """input_ (T,B,F) fp32, mask (T,B) fp32 or None -> encoded (T',B,2H_last), encoded_mask (T',B)."""
@@ -276,7 +276,7 @@ class Encoder(object):
             # critical path first: the gradient wrt this layer's input is what the next (lower) layer's recurrence waits for
             if dx is not None:      # the concatenated copy the forward pass of this step made (parameters have not moved since)
                 lib.sgemm(dxg2, self._cats[i]["W"], dx.view(T * B, I), transB=True)
-            # weight gradients are off the critical path; with LVSR_OVERLAP=1 they go to a second stream and overlap the next
+            # weight gradients are off the critical path; with `self.overlap = True` they go to a second stream and overlap the next
             # layer's recurrence (see __init__ for why this is not the default)
             with self._side_stream() as side_ws:
                 for di, direction in enumerate(("forward", "backward")):

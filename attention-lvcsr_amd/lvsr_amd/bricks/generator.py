@@ -31,7 +31,8 @@ class SequenceGenerator(object):
         self.lib = lib
         self.ws = workspace
         self.use_graph = use_graph
-        self.use_persistent = use_persistent      # None: LVSR_DEC_PERSISTENT / auto (persistent label loop when available)
+        self.use_persistent = use_persistent      # None: auto (persistent label loop and reverse walk when available), True / False: forced on / off
+        self.use_persistent_bwd = None            # None: follows use_persistent; False: step kernels for the reverse walk only (probes)
         self._packs = None
         self._pack_cache = {}
         self._gen_cache = {}
@@ -197,9 +198,9 @@ class SequenceGenerator(object):
     # ---- persistent label loop -------------------------------------------------------------------
     def _persistent_ws(self, fields):
         """Workspace of the persistent decoder kernel for this argument block, or None when the step kernels run: the
-        configuration is outside the kernel's limits (lvsr_attdec_persist_ws_bytes == 0), LVSR_DEC_PERSISTENT=0, or — on the
+        configuration is outside the kernel's limits (lvsr_attdec_persist_ws_bytes == 0), `use_persistent=False`, or — on the
         CPU emulator — its work-groups are not run concurrently."""
-        mode = os.environ.get("LVSR_DEC_PERSISTENT", "auto") if self.use_persistent is None else ("1" if self.use_persistent else "0")
+        mode = "auto" if self.use_persistent is None else ("1" if self.use_persistent else "0")
         if mode == "0":
             return None
         import ctypes as _ct
@@ -214,12 +215,11 @@ class SequenceGenerator(object):
         return self.ws.get("gen.sync", ((nbytes + 3) // 4,), torch.int32)
 
     def _persistent_bwd_ws(self, fwd_args):
-        """Workspace of the persistent backward kernel, or None (LVSR_DEC_BWD_PERSISTENT=0, outside its limits, or — on the CPU
+        """Workspace of the persistent backward kernel, or None (`use_persistent` / `use_persistent_bwd` False, outside its limits, or — on the CPU
         emulator — work-groups not run concurrently)."""
         # Default since round 3: 33.4 us per label against 41.5 for the four step kernels (profiles/r03_decoder_bwd_persist_probe.txt),
         # WSJ-base step 18.3 -> 17.4 ms.
-        mode = os.environ.get("LVSR_DEC_BWD_PERSISTENT", "auto")
-        if self.use_persistent is False or mode == "0":
+        if self.use_persistent is False or self.use_persistent_bwd is False:
             return None
         import ctypes as _ct
         nbytes = int(self.lib._lvsr_attdec_bwd_persist_ws_bytes(_ct.byref(fwd_args)))
@@ -233,7 +233,9 @@ class SequenceGenerator(object):
         """After a synchronisation point: raise if the persistent decoder kernel gave up waiting for its cluster."""
         for k, buf in self.ws._bufs.items():
             if k[0] in ("gen.sync", "gen.sync_bwd") and int(buf[0]) != 0:
-                raise RuntimeError("persistent decoder kernel aborted (a work-group of a cluster was not scheduled)")
+                buf[:16].zero_()          # sticky abort word (no launch clears it): cleared once reported
+                raise RuntimeError("persistent decoder kernel aborted (a work-group of a cluster was not scheduled); results since "
+                                   "the last check are invalid")
 
     # ---- teacher-forced cost ---------------------------------------------------------------------
     def cost_matrix(self, outputs, mask=None, attended=None, attended_mask=None, save_for_backward=True):

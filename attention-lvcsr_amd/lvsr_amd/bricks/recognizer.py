@@ -188,25 +188,69 @@ class SpeechRecognizer(object):
         with self._on_stream():
             # the small weight-gradient products of decoder and encoder (recurrent matrices, readout, ...) are collected and
             # run as ONE grouped launch at the end: alone none of them fills the chip
-            grouped = True
-            if grouped:
-                self.lib.begin_group()
+            self.lib.begin_group()
             d_encoded = self.generator.backward()
+            self._backward_encoder(d_encoded)
+
+    def _backward_decoder(self):
+        """The decoder's half of backward() with a grouped launch of its own: afterwards every gradient under
+        /recognizer/generator is final (the tail of the flat gradient buffer, `decoder_bucket()`).  -> d_encoded."""
+        with self._on_stream():
+            self.lib.begin_group()
+            d_encoded = self.generator.backward()
+            self.lib.flush_group(self.ws.get("gemm_ws.grouped", (1 << 26,)))
+            return d_encoded
+
+    def _backward_encoder(self, d_encoded):
+        """Encoder (and bottom) half of backward(); flushes the pending grouped launch (opens one if none is pending)."""
+        with self._on_stream():
+            if getattr(self.lib, "_group", None) is None:
+                self.lib.begin_group()
             d_bottom = self.encoder.backward(d_encoded, need_input_grad=bool(self.d.bottom_dims))
-            if grouped:
-                self.lib.flush_group(self.ws.get("gemm_ws.grouped", (1 << 26,)))
+            self.lib.flush_group(self.ws.get("gemm_ws.grouped", (1 << 26,)))
             self.encoder.finish_backward()
             if self.d.bottom_dims:
                 self.bottom.backward(d_bottom)
 
-    def cost_and_gradients(self, batch, tail=None, tail_key=None, region=True):
+    def decoder_bucket(self):
+        """(offset, count) of the decoder's gradients in the flat buffers: the parameters under /recognizer/generator are laid out
+        behind everything else (spec.parameter_shapes), so they form one contiguous tail."""
+        offs = self.store.offsets
+        first = min(o for k, (o, n) in offs.items() if k.startswith("/recognizer/generator"))
+        assert all(k.startswith("/recognizer/generator") == (o >= first) for k, (o, n) in offs.items()), "decoder parameters are not a tail"
+        return first, self.store.flat.numel() - first
+
+    def cost_and_gradients(self, batch, tail=None, tail_key=None, region=True, between=None):
         """One training forward+backward on a batch dict in the reference's layout.
         Returns the cost matrix (L,B) on the device; gradients of its sum are in self.store.grad.
         `tail` (optional callable, described by the hashable `tail_key`) enqueues more work behind the backward pass — the
-        optimiser step — inside the same graph region: the whole step is then ONE hipGraph launch per minibatch shape."""
+        optimiser step — inside the same graph region: the whole step is then ONE hipGraph launch per minibatch shape.
+        `between` (optional callable, data parallelism with overlapped exchange): called — eagerly, outside any graph region — when
+        the decoder's gradients are final and before the encoder's backward pass is enqueued; the step is then TWO graph regions
+        (forward + decoder backward | encoder backward [+ tail])."""
         with self._on_stream():
             x, xm, y, ym = self._stage(batch["recordings"], batch.get("recordings_mask"), batch["labels"],
                                        batch.get("labels_mask"))
+            shape_key = (tuple(x.shape), tuple(y.shape), xm is None, ym is None)
+            volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
+                        self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
+            plain = region and self.use_graph and not self.encoder.overlap
+            if between is not None:
+                def first_half():
+                    cm = self._forward(x, xm, y, ym)
+                    return cm, self._backward_decoder()
+
+                cm, d_encoded = self.lib.region(self, ("train_step_fwd_dec",) + shape_key, x, enabled=plain, volatile=volatile).run(first_half)
+                between()
+
+                def second_half():
+                    self._backward_encoder(d_encoded)
+                    if tail is not None:
+                        tail()
+                    return True
+                vol2 = volatile + (d_encoded.data_ptr(), self.ws.generation)
+                self.lib.region(self, ("train_step_enc",) + shape_key + (tail_key,), x, enabled=plain, volatile=vol2).run(second_half)
+                return cm
 
             def enqueue():
                 cm = self._forward(x, xm, y, ym)
@@ -214,10 +258,7 @@ class SpeechRecognizer(object):
                 if tail is not None:
                     tail()
                 return cm
-            key = ("train_step", tuple(x.shape), tuple(y.shape), xm is None, ym is None, tail_key)
-            volatile = (x.data_ptr(), y.data_ptr(), 0 if xm is None else xm.data_ptr(), 0 if ym is None else ym.data_ptr(),
-                        self.ws.generation, self.store.flat.data_ptr(), self.store.grad.data_ptr())
-            plain = region and self.use_graph and not self.encoder.overlap
+            key = ("train_step",) + shape_key + (tail_key,)
             return self.lib.region(self, key, x, enabled=plain, volatile=volatile).run(enqueue)
 
     # ---- analyze (recognizer.py:452-494) -----------------------------------------------------------

@@ -21,11 +21,10 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "lvsr_
 # Measured on MI355X / ROCm 7.2 (WSJ-base step): when the host keeps submitting work while a 1600-node time-loop graph
 # replays, the graph's kernels run ~25 % slower (6.2 -> 8.0 us per encoder step); blocking the host until the graph has
 # drained gives 57.3 ms per step instead of 66.4 (sync BEFORE the launch: 58.6; a dedicated graph stream: 71 — both removed).  Default on.
-_SYNC_AFTER_GRAPH = os.environ.get("LVSR_SYNC_AFTER_GRAPH", "1") == "1"
-
-# Whole-step graph regions (lvsr_region_begin/end): one hipGraph launch per training step.  LVSR_STEP_GRAPH=0 keeps the
-# per-layer time-loop graphs with eager launches between them.
-_STEP_GRAPH = os.environ.get("LVSR_STEP_GRAPH", "1") == "1"
+# `Lib.sync_after_graph` (constructor argument, default True).
+#
+# Whole-step graph regions (lvsr_region_begin/end): one hipGraph launch per training step.  `Lib.step_graph = False` (constructor
+# argument `step_graph`) keeps the per-layer time-loop graphs with eager launches between them.
 
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double,
             "long long": ctypes.c_longlong, "char": ctypes.c_char}
@@ -127,14 +126,16 @@ def _addr(v):
 
 
 class Lib(object):
-    def __init__(self, path=DEFAULT_LIB):
+    def __init__(self, path=DEFAULT_LIB, sync_after_graph=True, step_graph=True):
+        self.sync_after_graph = bool(sync_after_graph)
+        self.step_graph = bool(step_graph)
         if not os.path.exists(path):
             raise NativeError(
                 "HIP extension %s not found: build it with `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950). There is no fallback path." % path)
         self.path = path
         self._dll = ctypes.CDLL(path)
-        self.is_emulator = os.path.basename(path) != os.path.basename(DEFAULT_LIB)
+        self.is_emulator = hasattr(self._dll, "hipemu_set_concurrent")      # tests/hipemu build of the same sources (CPU fibers)
         self._gstream = None
         self.capturing = False          # inside a Region capture: no host synchronisation, no nested graphs
         self.structs, self.functions = parse_header()
@@ -198,13 +199,17 @@ class Lib(object):
     def get_knob(self, name):
         return int(self._lvsr_get_knob(name if isinstance(name, int) else self.knobs[name.upper()]))
 
-    def knobs_from_env(self, environ=None):
-        """For the tools under tools/: LVSR_KNOB_<NAME>=<int> in the environment -> set_knob.  The library itself never reads
-        the environment and the product never calls this."""
-        environ = os.environ if environ is None else environ
+    def set_knobs(self, settings):
+        """settings: {knob name: int} or an iterable of "name=value" strings (the --knob arguments of bench.py and tools/);
+        knobs that are not named are reset to 0."""
+        if not isinstance(settings, dict):
+            settings = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in settings)
+        unknown = [k for k in settings if k.upper() not in self.knobs]
+        if unknown:
+            raise NativeError("unknown knob(s) %s (include/lvsr_hip.h LVSR_KNOB_*: %s)" % (unknown, sorted(k.lower() for k in self.knobs)))
+        low = {k.upper(): int(v) for k, v in settings.items()}
         for name in self.knobs:
-            v = environ.get("LVSR_KNOB_" + name)
-            self.set_knob(name, int(v) if v not in (None, "") else 0)
+            self.set_knob(name, low.get(name, 0))
 
     # ---- thin typed wrappers -----------------------------------------------------------------
     # ---- grouped weight-gradient products ---------------------------------------------------------
@@ -318,8 +323,8 @@ class Lib(object):
         return a
 
     def after_graph(self, ref_tensor, steps):
-        """Block the host until a long time-loop graph has drained (see _SYNC_AFTER_GRAPH above)."""
-        if _SYNC_AFTER_GRAPH and ref_tensor.is_cuda and steps >= 16 and not self.capturing:
+        """Block the host until a long time-loop graph has drained (see the measurement at the top of this file)."""
+        if self.sync_after_graph and ref_tensor.is_cuda and steps >= 16 and not self.capturing:
             torch.cuda.current_stream(ref_tensor.device).synchronize()
 
     def region(self, owner, key, ref_tensor, enabled=True, volatile=(), drain=True):
@@ -347,7 +352,7 @@ class Region(object):
     seen the body runs eagerly (so every workspace exists), the second time it is captured, afterwards replayed; a changed
     `volatile` part (workspace generation: buffers were re-allocated) re-captures without another eager pass.  A capture during
     which the caching allocator handed out memory is dropped (a replay would write to memory it does not own) and the key
-    is enqueued again eagerly, and stays eager.  Disabled on the emulator / CPU tensors, with LVSR_STEP_GRAPH=0, and inside another region."""
+    is enqueued again eagerly, and stays eager.  Disabled on the emulator / CPU tensors, with `lib.step_graph = False`, and inside another region."""
     def __init__(self, lib, owner, key, ref, enabled, volatile=(), drain=True):
         self.lib, self.ref = lib, ref
         self.drain = drain          # block the host until a replay has drained (long time-loop regions); False: short regions
@@ -355,7 +360,7 @@ class Region(object):
             owner._region_token, owner._regions = lib.unique_token(), {}
         soft = repr((owner._region_token, key)).encode()
         self.kb = soft + b"|" + repr(volatile).encode()
-        self.enabled = bool(enabled) and _STEP_GRAPH and ref.is_cuda and not lib.is_emulator and not lib.capturing
+        self.enabled = bool(enabled) and lib.step_graph and ref.is_cuda and not lib.is_emulator and not lib.capturing
         self.state = "eager"
         self.slot = owner._regions.setdefault(soft, dict(seen=0, result=None)) if self.enabled else dict(seen=0, result=None)
 

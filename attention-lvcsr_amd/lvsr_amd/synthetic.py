@@ -16,11 +16,14 @@ def _rng_for(name, seed):
     return numpy.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
 
 
-def make_params(cfg, seed=1, scale=1.0):
+def make_params(cfg, seed=1, scale=1.0, scales=None):
     """Parameters by reference name.  Fan-in scaled Gaussians so activations are O(1) and attention /
     gates are far from their trivial fixed points (a near-zero init would hide indexing bugs).
 
     `scale` multiplies every weight matrix; biases and initial states ~ N(0, 0.3) / N(0, 0.2).
+    `scales`: optional {substring of the parameter name: factor}, applied on top of `scale` to every parameter (biases and
+    initial states too) whose name contains the substring — the per-group conditioning of the full-size fixtures
+    (tools/probes/wsj_conditioning_search.py); several matching substrings multiply.
     """
     out = {}
     for name, shape in parameter_shapes(cfg).items():
@@ -41,6 +44,9 @@ def make_params(cfg, seed=1, scale=1.0):
             v = rng.normal(0.0, 1.0 / numpy.sqrt(fan), shape) * scale
         else:
             v = rng.normal(0.0, 1.0 / numpy.sqrt(shape[0]), shape) * scale
+        for key, factor in (scales or {}).items():
+            if key in name:
+                v = v * factor
         out[name] = numpy.ascontiguousarray(v, dtype=numpy.float32)
     return out
 

@@ -21,7 +21,8 @@ def _is_weight(name):
 class Trainer(object):
     def __init__(self, recognizer, gradient_threshold=None, rules=("momentum",), scale=0.1, momentum=0.0,
                  decay_rate=0.95, epsilon=1e-8, max_norm=0.0, max_norm_exclude_lookup=False, nonfinite_scaler=0.0,
-                 burn_in_steps=0, adaptive_clipping=None, process_group=None, distributed=None):
+                 burn_in_steps=0, adaptive_clipping=None, process_group=None, distributed=None, dp_region=True,
+                 overlap_allreduce=False):
         """Keywords = `training:` / `regularization:` keys of the reference's config (lvsr/main.py:480-519).
         `adaptive_clipping`: None, True or dict(decay_rate=0.998, burnin_period=500) — the AdaptiveClipping extension the
         reference's `train()` always installs on top of `gradient_threshold` (lvsr/main.py:616-619)."""
@@ -70,8 +71,14 @@ class Trainer(object):
         self.world = torch.distributed.get_world_size(process_group) if distributed else 1
         self.rank = torch.distributed.get_rank(process_group) if distributed else 0
         # data parallel: forward + backward of a minibatch shape replay as ONE hipGraph launch, the all-reduce and the fused
-        # optimiser follow eagerly on the same stream (LVSR_DP_REGION=0: per-layer graphs + eager launches instead)
-        self.dp_region = os.environ.get("LVSR_DP_REGION", "1") == "1"
+        # optimiser follow eagerly on the same stream (dp_region=False: per-layer graphs + eager launches instead)
+        self.dp_region = bool(dp_region)
+        # overlap_allreduce: two buckets instead of one — the decoder's gradients (the tail of the flat buffer, final when the decoder's
+        # reverse walk is over) are reduced on the communication stream WHILE the encoder's BPTT runs, the encoder's after it
+        # (SURVEY.md 2.3 C1).  Off by default: it cannot be measured on the one-GPU boxes this was developed on, the exchange is
+        # ~2 % of a step, and a collective's work-groups share the CUs with latency-bound cluster kernels whose work-groups must
+        # all be resident (what concurrent GEMMs did to them is in bricks/__init__.py: slower, not faster).
+        self.overlap_allreduce = bool(overlap_allreduce)
         self._comm = None
 
     @classmethod
@@ -130,7 +137,11 @@ class Trainer(object):
         stream has meanwhile entered hipGraph capture (hipErrorCapturedEvent kills the process: tools/probes/
         nccl_capture_probe.py) — the compute stream captures the next minibatch shape's graph, the communication stream
         never captures."""
-        g = self.rec.store.grad
+        self._all_reduce(self.rec.store.grad)
+
+    def _all_reduce(self, g, wait=True):
+        """Sum all-reduce of (a slice of) the flat gradient buffer; wait=False leaves the compute stream un-ordered behind it
+        (the caller joins later with `_join_comm`): the exchange then overlaps whatever the compute stream does next."""
         if not g.is_cuda:
             torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.group)
             return
@@ -140,7 +151,12 @@ class Trainer(object):
         self._comm.wait_stream(cur)
         with torch.cuda.stream(self._comm):
             torch.distributed.all_reduce(g, op=torch.distributed.ReduceOp.SUM, group=self.group)
-        cur.wait_stream(self._comm)
+        if wait:
+            cur.wait_stream(self._comm)
+
+    def _join_comm(self, ref):
+        if ref.is_cuda and self._comm is not None:
+            torch.cuda.current_stream(ref.device).wait_stream(self._comm)
 
     def apply_gradients(self, global_batch_size):
         rec, st = self.rec, self.rec.store
@@ -164,6 +180,20 @@ class Trainer(object):
                 n = torch.tensor([B_local], dtype=torch.int64, device=self.rec.store.grad.device)
                 torch.distributed.all_reduce(n, op=torch.distributed.ReduceOp.SUM, group=self.group)
                 global_batch_size = int(n[0])
+            if self.overlap_allreduce:
+                rec, st = self.rec, self.rec.store
+                off, cnt = rec.decoder_bucket()
+
+                def reduce_decoder_bucket():
+                    with rec._on_stream():
+                        self._all_reduce(st.grad[off: off + cnt], wait=False)
+                cm = rec.cost_and_gradients(batch, region=self.dp_region, between=reduce_decoder_bucket)
+                with rec._on_stream():
+                    self._all_reduce(st.grad[:off], wait=False)
+                    self._join_comm(st.grad)
+                    self._enqueue_optimizer(global_batch_size)
+                    st.version += 1
+                return cm
             cm = self.rec.cost_and_gradients(batch, region=self.dp_region)
             self.apply_gradients(global_batch_size)
             return cm

@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, overlap=False):
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [here, os.path.dirname(here), os.path.join(os.path.dirname(here), "attention-lvcsr_amd")]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -39,7 +39,7 @@ def _worker(rank, world, port, out_dir):
     from lvsr_amd.training import Trainer
     params = synthetic.make_params(CFG, seed=31)
     rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=CFG)
-    tr = Trainer(rec, **RULES)
+    tr = Trainer(rec, overlap_allreduce=overlap, **RULES)          # overlap: two buckets, decoder gradients reduced before the encoder's BPTT
     assert tr.distributed and tr.world == world and tr.rank == rank
     costs = []
     for step in range(2):
@@ -52,9 +52,10 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_two_rank_step_matches_single_process(tmp_path, overlap):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), overlap), nprocs=world, join=True)
     r0 = numpy.load(str(tmp_path / "rank0.npz"))
     r1 = numpy.load(str(tmp_path / "rank1.npz"))
     names = [k for k in r0.files if k not in ("costs", "norm")]

@@ -45,7 +45,7 @@ def run_decode_case(device, lib, device_lm, utterances=None, fixture="mid_conv_l
     z, meta = load_golden(fixture)
     cfg = meta["cfg"]
     V = cfg["num_phonemes"]
-    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
     rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=cfg)
     fst, cmap = _fst_from_arcs(z["arcs"], V)
     kw = dict(nn_char_map=cmap, **meta["lm"])
@@ -62,8 +62,12 @@ def run_decode_case(device, lib, device_lm, utterances=None, fixture="mid_conv_l
                 rec.beam_search({"recordings": x}, **s)
             continue
         outs, costs = rec.beam_search({"recordings": x}, **s)
-        n = sum(1 for h in r["outputs"] if len(h) <= stable)
-        assert n >= 1 and all(len(h) <= stable for h in r["outputs"][:n])
+        if stable is None:          # the WHOLE ranked list: same number of hypotheses, every one token for token, every cost
+            n = len(r["outputs"])
+            assert len(outs) == n, "utterance %d: %d hypotheses, the reference has %d" % (r["utt"], len(outs), n)
+        else:
+            n = sum(1 for h in r["outputs"] if len(h) <= stable)
+            assert n >= 1 and all(len(h) <= stable for h in r["outputs"][:n])
         assert outs[:n] == r["outputs"][:n], "utterance %d" % r["utt"]           # the ranked hypotheses, token for token
         assert_allclose(costs[:n], r["costs"][:n], rtol=1e-4, atol=1e-4)
         checked += n
@@ -77,6 +81,40 @@ def test_full_size_wsj_decode_matches_the_reference_gpu(gpu_device, device_lm):
     rec = run_decode_case(gpu_device, None, device_lm, fixture="wsj_decode_full", stable=FULL_STABLE_LENGTH, min_checked=8)
     if device_lm:
         run_decode_case(gpu_device, None, True, fixture="wsj_decode_full", stable=FULL_STABLE_LENGTH, min_checked=8)     # replayed step graph
+
+
+# Round 4: the same decode on a WELL-CONDITIONED full-size fixture (tests/golden/wsj_decode_full2.npz, gen_golden.py
+# `wsj_decode_full2`): per-group parameter scales (contractive recurrences, sharper energies: gen_golden.WSJ_COND_DECODE, found with
+# tools/probes/wsj_conditioning_search.py) on which the reference, the float32 oracle and the float64 oracle agree on the WHOLE ranked
+# list — 172 / 9 / 12 finished hypotheses of up to 117 characters for the three utterances, costs within 4e-6 relative.  Here the
+# entire list is compared: its length, every hypothesis token for token, every cost to 1e-4 — north_star's "bit-exact indices".
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_lm", [True, False])
+def test_full_size_wsj_decode_whole_list_matches_the_reference_gpu(gpu_device, device_lm):
+    rec = run_decode_case(gpu_device, None, device_lm, fixture="wsj_decode_full2", stable=None, min_checked=193)
+    if device_lm:
+        run_decode_case(gpu_device, None, True, fixture="wsj_decode_full2", stable=None, min_checked=193)     # replayed step graph
+        assert rec._beam_search.last_stats["positions"] > 0
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_oracles_reproduce_the_whole_list_of_the_well_conditioned_decode(dtype):
+    """Both precisions of the torch restatement against wsj_decode_full2: the whole ranked list (~1 minute per utterance)."""
+    import torch
+    from oracle import lvsr_oracle as O, lm_oracle as LO
+    z, meta = load_golden("wsj_decode_full2")
+    cfg = meta["cfg"]
+    V = cfg["num_phonemes"]
+    orc = O.OracleRecognizer(cfg, synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta["scales"]),
+                             dtype=getattr(torch, dtype))
+    arcs = [(int(a), int(b), int(il), float(w)) for a, b, il, w in z["arcs"]]
+    lm = dict(dense=LO.DenseFST(arcs, arcs[0][0], V), remap={c: c + 1 for c in range(V)}, **meta["lm"])
+    for r in meta["beam"]:
+        s = dict(r["settings"])
+        outs, costs = orc.beam_search(z["x%d" % r["utt"]], s.pop("beam_size"), lm=lm, **s)
+        assert outs == r["outputs"]
+        assert_allclose(costs, r["costs"], rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.slow

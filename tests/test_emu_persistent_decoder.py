@@ -2,8 +2,6 @@
 label loop forward, one for the reverse walk; a cluster of work-groups per utterance exchanging phase vectors through
 {epoch,value} granules) on the emulator with concurrent work-groups, against the float64 oracle and the reference goldens:
 costs, alignments and every gradient."""
-import os
-
 import numpy
 import pytest
 import torch
@@ -21,18 +19,10 @@ from test_emu_recognizer import check_against
 def concurrent_lib():
     lib = emu_lib()
     lib._dll.hipemu_set_concurrent(1)
-    old = {k: os.environ.get(k) for k in ("LVSR_DEC_PERSISTENT", "LVSR_DEC_BWD_PERSISTENT")}
-    os.environ["LVSR_DEC_PERSISTENT"] = "1"
-    os.environ["LVSR_DEC_BWD_PERSISTENT"] = "1"          # the backward kernel is opt-in (see generator._persistent_bwd_ws)
     try:
         yield lib
     finally:
         lib._dll.hipemu_set_concurrent(0)
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
 
 
 def engaged(rec):
@@ -50,7 +40,7 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
     batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
     orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float64)
     out, grads = orc.cost_and_grads(batch)
-    rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=meta["cfg"])
+    rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=meta["cfg"], use_persistent_decoder=True)
     cm = rec.cost_and_gradients(batch)
     assert engaged(rec), "persistent decoder did not engage"
     # the backward kernel serves at most 32 attended positions per work-group (the long case has 75: step kernels there); decoder
@@ -77,7 +67,7 @@ def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K,
     batch = synthetic.make_batch(cfg, 3, 13, 5, seed=12, ragged=True)
     orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
     out, grads = orc.cost_and_grads(batch)
-    rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=cfg)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=concurrent_lib, net_config=cfg, use_persistent_decoder=True)
     cm = rec.cost_and_gradients(batch)
     assert engaged(rec) and any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs), "persistent decoder (forward and backward) did not engage"
     rec.generator.check_persistent()

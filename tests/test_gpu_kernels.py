@@ -86,7 +86,7 @@ SMALL = ["tiny_conv_expanding", "tiny_conv_nowindow", "tiny_conv_median", "tiny_
 
 
 def _setup(meta):
-    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
     batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"],
                                  ragged=meta["ragged"])
     return params, batch
@@ -120,16 +120,23 @@ def test_recognizer_vs_reference_golden(gpu_device, case, use_graph):
             assert_allclose(got[str(name)] / scale, ref / scale, rtol=0, atol=1e-3 if long_case else 2e-4, err_msg=str(name))
 
 
-@pytest.mark.parametrize("case", ["timit_tiny", "wsj_base", "wsj_deep", "wsj_stack2", "wsj_paper"])
-def test_full_size_configs_vs_reference_golden(gpu_device, case):
+@pytest.mark.parametrize("case,persistent_decoder", [("timit_tiny", None), ("wsj_base", None), ("wsj_deep", None), ("wsj_stack2", None),
+                                                     ("wsj_paper", None), ("wsj_base_median", True), ("wsj_base_median", False)])
+def test_full_size_configs_vs_reference_golden(gpu_device, case, persistent_decoder):
     """BASELINE.json configs[0], configs[1] and configs[3] at full size against the reference's outputs (fingerprints);
     wsj_stack2 = configs[1] with the two-layer stacked decoder of the wsj_jan_* configs; wsj_paper = the README-recommended model
-    (250-unit layers: a decoder width that is not a multiple of 4)."""
+    (250-unit layers: a decoder width that is not a multiple of 4); wsj_base_median (round 4) = configs[1] under
+    window_around_median(10, 100), the prior the shipped models train with (wsj_paper.yaml:7-10, lvsr/bricks/attention.py:138-157),
+    on well-conditioned parameter scales (gen_golden.WSJ_COND_TRAIN): every one of the 100 x 16 alignment argmax, the cost matrix
+    and the gradient fingerprints of the reference, through the persistent decoder kernels AND through the step kernels."""
     z, meta = load_golden(case)
     params, batch = _setup(meta)
-    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"])
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=meta["cfg"], use_persistent_decoder=persistent_decoder)
     cm = rec.cost_and_gradients(batch)
     torch.cuda.synchronize()
+    rec.generator.check_persistent()
+    if persistent_decoder is not None:
+        assert any(k[0] == "gen.sync" for k in rec.ws._bufs) == persistent_decoder, "persistent decoder engaged / did not engage"
     cmn = cm.cpu().numpy()
     assert abs(cmn.sum() - z["cost_sum"]) / abs(z["cost_sum"]) < 1e-4
     assert_allclose(cmn, z["cost_matrix"], rtol=1e-3, atol=1e-4)

@@ -71,51 +71,45 @@ def test_persistent_cluster_kernels_agree_with_step_kernels(gpu_device, setup):
         assert numpy.abs(g[k] - s["grads"][k]).max() / scale < 2e-3, k
 
 
-@pytest.mark.parametrize("prior", [None, dict(type="window_around_median", before=20, after=60),
+# Well-conditioned parameter scales for the window priors (oracle/theano_harness/gen_golden.py WSJ_COND_TRAIN, found with
+# tools/probes/wsj_conditioning_search.py): contractive recurrences and sharp energies, on which the float32 and float64 oracles agree on
+# every alignment argmax and to 7e-8 on the summed cost — so two float32 implementations can be compared on ALL labels.  (With
+# plain scale-1 random weights the label loop amplifies rounding ~1.7x per label and a window centre, a step function of the
+# alignment, flips somewhere after ~30 labels: round 3 could only compare the first 8 labels there.)
+WSJ_COND_TRAIN = {"transition.state_to": 0.3, "gatedrecurrent.state_to": 0.5, "energy_comp": 2.0, "handler": 2.0, "transform_states": 0.3}
+
+
+@pytest.mark.parametrize("prior", [None, dict(type="window_around_median", before=10, after=100),
                                    dict(type="window_around_mean", before=30, after=40)])
 def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
-    """The persistent label loop (csrc/decoder_persist.hip) against the five-launches-per-label forward, full WSJ-base size,
-    expanding and window_around_* priors: costs, alignments and — through the tensors it saves for the backward pass — every
-    gradient.  The two differ by float32 rounding only (order of additions, the reassociated glimpse)."""
+    """The persistent label loop (csrc/decoder_persist.hip) and reverse walk (csrc/decoder_persist_bwd.hip) against the step kernels
+    (five + four launches per label), full WSJ-base size, expanding and window_around_* priors: costs, alignments of ALL labels and
+    every gradient.  The two differ by float32 rounding only (order of additions, the reassociated glimpse)."""
     s = setup
     cfg = dict(s["cfg"])
+    params = s["params"]
     if prior is not None:
         cfg["prior"] = prior
+        params = synthetic.make_params(cfg, seed=13, scale=1.0, scales=WSJ_COND_TRAIN)
     out = {}
-    import os
-    # the persistent reverse walk (csrc/decoder_persist_bwd.hip) is the default and takes part
-    pbwd = True
     for persistent in (True, False):
-        rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=cfg, use_persistent_decoder=persistent)
+        rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg, use_persistent_decoder=persistent)
         cm = rec.cost_and_gradients(s["batch"]).cpu().numpy()
         torch.cuda.synchronize()
         rec.generator.check_persistent()
         assert any(k[0] == "gen.sync" for k in rec.ws._bufs) == persistent, "persistent decoder engaged / did not engage"
-        assert any(k[0] == "gen.sync_bwd" for k in rec.ws._bufs) == (persistent and pbwd), "persistent decoder backward engaged / did not engage"
+        assert any(k[0] == "gen.sync_bwd" for k in rec.ws._bufs) == persistent, "persistent decoder backward engaged / did not engage"
         out[persistent] = (cm, rec.generator.last["weights"].cpu().numpy(), rec.generator.last["weighted_averages"].cpu().numpy(),
                            rec.store.get_grads())
     (cm_p, w_p, wa_p, g_p), (cm_s, w_s, wa_s, g_s) = out[True], out[False]
-    if prior is None:
-        assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
-        assert_allclose(cm_p, cm_s, rtol=1e-3, atol=1e-3)
-        assert (w_p.argmax(axis=2) == w_s.argmax(axis=2)).all()
-        assert_allclose(w_p, w_s, rtol=1e-3, atol=1e-6)
-        assert_allclose(wa_p, wa_s, rtol=1e-3, atol=1e-5)
-        for k in g_s:
-            scale = max(1e-3, numpy.abs(g_s[k]).max())
-            assert numpy.abs(g_p[k] - g_s[k]).max() / scale < 2e-3, k
-    else:
-        # With random weights of this size the label loop amplifies rounding: the two forwards agree to float32 rounding at label 0
-        # (energies to 3e-6) and drift apart by ~1.7x per label (tools/probes/pd_diff_probe.py); a window centre is a step
-        # function of the alignment, so after ~30 labels one of them flips and single labels differ.  What can be asserted at
-        # this size: the first labels tightly, the summed cost loosely — the float32 and float64 ORACLES themselves differ by 1.1e-3
-        # in the summed cost on this network (tools/probes/wsj_train_conditioning.py), so 2e-3 is what "the same computation" means
-        # here.  (Exact parity of the window_around_* path is pinned by the reference goldens — tests/test_gpu_kernels.py,
-        # tests/test_emu_persistent_decoder.py — and at full size by tests/test_decode_golden.py's wsj_decode_full.)
-        assert_allclose(cm_p[:8], cm_s[:8], rtol=1e-4, atol=1e-4)
-        assert_allclose(w_p[:8], w_s[:8], rtol=2e-3, atol=1e-5)
-        assert (w_p[:8].argmax(axis=2) == w_s[:8].argmax(axis=2)).all()
-        assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 2e-3
+    assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
+    assert_allclose(cm_p, cm_s, rtol=1e-3, atol=1e-3)
+    assert (w_p.argmax(axis=2) == w_s.argmax(axis=2)).all()
+    assert_allclose(w_p, w_s, rtol=2e-3, atol=2e-6)
+    assert_allclose(wa_p, wa_s, rtol=2e-3, atol=1e-5)
+    for k in g_s:
+        scale = max(1e-3, numpy.abs(g_s[k]).max())
+        assert numpy.abs(g_p[k] - g_s[k]).max() / scale < 2e-3, k
 
 
 def test_persistent_decoder_at_the_paper_width(gpu_device):

@@ -77,7 +77,7 @@ def test_gru_masked_sequence_and_bidirectional_reference_semantics():
 
 
 def _oracle_for(meta, dtype):
-    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
     batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"],
                                  ragged=meta["ragged"])
     return O.OracleRecognizer(meta["cfg"], params, dtype=dtype), batch
@@ -139,7 +139,10 @@ def test_beam_search_vs_reference(case):
             assert_allclose(w, z["analyze%d_weights" % bi], rtol=1e-4, atol=2e-6)
 
 
-@pytest.mark.parametrize("case", ["timit_tiny", "wsj_stack2", "wsj_paper"])
+# wsj_base_median (round 4): WSJ-base under window_around_median(10, 100) — the prior the shipped models train with — on the
+# well-conditioned parameter scales of gen_golden.WSJ_COND_TRAIN: ALL 100 x 16 alignment argmax of the reference, its cost matrix
+# and gradient fingerprints (the float32 and float64 restatements agree with each other and with the reference there)
+@pytest.mark.parametrize("case", ["timit_tiny", "wsj_stack2", "wsj_paper", "wsj_base_median"])
 def test_full_size_config_vs_reference(case):
     z, meta = load_golden(case)
     orc, batch = _oracle_for(meta, torch.float32)

@@ -4,8 +4,10 @@ Usage: python tools/pmc_summary.py [--json out.json --tag wsj_base] db1 [db2 ...
 --json writes the record bench.py reads (profiles/r03_pmc_bench.json): per kernel "<name>@<tag>"
   hbm_bytes_per_launch = 2 * FETCH_SIZE + WRITE_SIZE in bytes (rocprofv3 reports KiB; FETCH_SIZE on gfx950 counts 64 B per
   128-B request of a wide coalesced read, MI355X_MICROARCH.md "HBM": doubled as prescribed; WRITE_SIZE uncorrected),
-  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, valu_busy = SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES (per-SE aggregates
-  as rocprofv3 sums them; ratios of the same aggregation)."""
+  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES (per-SE aggregates as rocprofv3 sums them; ratio of the same aggregation),
+  valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES and wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES: both numerator and denominator
+  are quad-cycles summed over the waves (MI355X_MICROARCH.md), so these ARE fractions — of the time a wave is resident, how much it
+  issues vector-ALU instructions / waits.  (Round 3 divided by SQ_BUSY_CYCLES, which is not per wave: 1.88 was not a fraction.)"""
 import collections, json, re, sqlite3, sys
 
 argv = sys.argv[1:]
@@ -68,15 +70,15 @@ if json_out:
         if mean.get("SQ_BUSY_CYCLES"):
             if "SQ_VALU_MFMA_BUSY_CYCLES" in mean:
                 rec["mfma_busy"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / mean["SQ_BUSY_CYCLES"]
+        if mean.get("SQ_WAVE_CYCLES"):
             if "SQ_ACTIVE_INST_VALU" in mean:
-                rec["valu_busy"] = mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_BUSY_CYCLES"]
+                rec["valu_busy"] = mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_WAVE_CYCLES"]
+            if "SQ_WAIT_ANY" in mean:
+                rec["wait_frac"] = mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"]
         out["%s@%s" % (base, tag)] = rec
-    # stamp: the record is valid for the kernel sources it was measured on (bench.py refuses it otherwise)
-    import hashlib, os
-    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "attention-lvcsr_amd", "csrc")
-    h = hashlib.sha256()
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(csrc, f), "rb").read())
-    out["__stamp__"] = dict(csrc_sha256=h.hexdigest()[:16])
+    # stamp: the record is valid for the sources of the ENCODER cluster kernels it is read for (bench.py refuses it otherwise)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_sha
+    out["__stamp__"] = dict(csrc_sha256=csrc_sha())
     json.dump(out, open(json_out, "w"), indent=1, sort_keys=True)

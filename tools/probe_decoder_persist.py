@@ -22,9 +22,8 @@ PH = ["S gather", "A: sW/sg dots + publish", "SW gather", "B: energies", "EN gat
       "conv (SW shadow)", "centre scan (RS shadow)", "centres + window", "RS gather", "E: candidate", "  conv: operands + MFMA", "  conv: partials + barrier", "  conv: fold + store"]
 ref = None
 for mode, prof in (("0", "0"), ("1", "0"), ("1", "1")):
-    os.environ["LVSR_DEC_PERSISTENT"] = mode
     native.get().set_knob("phase_clock", int(prof))
-    rec = SpeechRecognizer(device="cuda:0", params=params, net_config=cfg)
+    rec = SpeechRecognizer(device="cuda:0", params=params, net_config=cfg, use_persistent_decoder=(mode == "1"))
     gen = rec.generator
     x = torch.from_numpy(batch["recordings"]).cuda(); xm = torch.from_numpy(batch["recordings_mask"]).cuda()
     y = torch.from_numpy(batch["labels"]).cuda(); ym = torch.from_numpy(batch["labels_mask"]).cuda()

@@ -19,10 +19,10 @@ PH = ["loads + publish dpc + alignment-gradient gather", "A gather", "drh, publi
 from lvsr_amd import native
 # (persistent?, phase clock?): the step kernels, then the persistent kernel without / with the phase clock of work-group 0
 for mode, prof in (("0", "0"), ("1", "0"), ("1", "1")):
-    os.environ["LVSR_DEC_BWD_PERSISTENT"] = mode
     native.get().set_knob("phase_clock", int(prof))
     rec = SpeechRecognizer(device="cuda:0", params=params, net_config=cfg)
     gen = rec.generator
+    gen.use_persistent_bwd = mode == "1"          # "0": the four step kernels per label for the reverse walk
     x = torch.from_numpy(batch["recordings"]).cuda(); xm = torch.from_numpy(batch["recordings_mask"]).cuda()
     y = torch.from_numpy(batch["labels"]).cuda(); ym = torch.from_numpy(batch["labels_mask"]).cuda()
     enc, em = rec.encoder.apply(x, xm)

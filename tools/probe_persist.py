@@ -11,8 +11,14 @@ from lvsr_amd.params import ParameterStore, Workspace
 from lvsr_amd.bricks import Encoder
 
 dev = torch.device("cuda:0")
-lib = native.get()
-lib.knobs_from_env()          # e.g. LVSR_KNOB_MAX_CLUSTER_WGS=256 python tools/probe_persist.py 512 8 1500
+# The ablation variants below (flags 1, 8, 16, 128: wrong results, timing only) exist only in the probe build of the library
+# (python attention-lvcsr_amd/csrc/build.py --probes -> tools/probes/liblvsr_hip_probes.so); the product library refuses them.
+PROBES = os.path.join(REPO, "tools", "probes", "liblvsr_hip_probes.so")
+lib = native.Lib(PROBES) if os.path.exists(PROBES) else native.get()
+ABLATIONS = lib is not native._default
+BASE_KNOBS = [a for a in sys.argv[1:] if "=" in a]          # e.g. python tools/probe_persist.py max_cluster_wgs=256 512 8 1500
+sys.argv = [a for a in sys.argv if "=" not in a]
+lib.set_knobs(BASE_KNOBS)
 shapes = [(256, 16, 800), (512, 8, 800), (128, 2, 200), (250, 16, 800)]
 if len(sys.argv) >= 4:
     shapes = [tuple(int(v) for v in sys.argv[i:i + 3]) for i in range(1, len(sys.argv) - 2, 3)]
@@ -36,6 +42,8 @@ for (H, B, T) in shapes:
     stream = torch.cuda.Stream()
     ref = None
     for name, persistent, rows, flags, *more in variants:
+        if flags and int(flags) & (1 | 8 | 16 | 128) and not ABLATIONS:
+            continue
         for k, v in (("persist_rows", rows), ("persist_flags", flags), ("persist_threads", more[0] if more else None)):
             lib.set_knob(k, int(v or 0))
         enc = Encoder(spec.Dims(cfg), store, lib, Workspace(dev), use_graph=True, use_persistent=persistent)
