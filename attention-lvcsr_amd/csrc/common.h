@@ -59,6 +59,14 @@ __device__ __forceinline__ float lvsr_dpp_half_mirror(float v) {
 __device__ __forceinline__ float lvsr_dpp_mirror(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x140, 0xf, 0xf, true));   // row_mirror
 }
+// v + the value of the lane 16 away inside each half of the wave (lanes 0-31, 32-63): v_permlane16_swap_b32 (gfx950) exchanges the
+// odd rows of its first operand with the even rows of its second; with both = v the two results are [r0 r0 r2 r2] and [r1 r1 r3 r3]
+// (r = rows of 16 lanes), whose sum is the pair total in every lane — the fifth step of a 32-lane fold without the LDS crossbar
+__device__ __forceinline__ float lvsr_swap16_sum(float v) {
+    const unsigned b = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float lvsr_dpp_row_ror4(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), 0x124, 0xf, 0xf, true));   // row_ror:4
 }

@@ -4,11 +4,6 @@
 #include "persist.h"
 
 #define PD_THREADS 512       // two waves per SIMD: with one, every LDS / transcendental latency of the energy phase is exposed
-#define PD_KSPLIT 16
-#define PD_UNITS 32          // decoder units per work-group
-#define PD_KD 16             // state rows per thread
-#define PD_MC 2              // transform_states columns per lane group
-#define PD_AWS (3 * PD_UNITS + 4)   // LDS row stride of the AW slice: +4 words spreads the 8 position lanes of a unit over the banks
 #define PD_CH 16             // attended positions per energy round (8 per half of the work-group)
 #define PD_EG 2              // positions whose chains are written interleaved in the energy phase (registers: 12 per position)
 #define PD_MP 256            // match-column pairs (m, m + 256): one per thread of a half
@@ -18,6 +13,44 @@
 #define PD_LDS_FLOATS (40 * 1024 - 64)      // of the CU's 160 KB
 #define PD_NPLANE 4          // SW | EN | RS | S
 #define PD_NPROF 16
+#define PD_MAXP 32           // work-groups per cluster at most (XCC_ID granules per utterance)
+
+// Cluster shapes.  A cluster of P = ceil(D / UNITS) work-groups serves one utterance; thread (unit jl = tid / KSPLIT, slice q =
+// tid % KSPLIT) keeps KD rows of its unit's state columns and of MC transform_states columns in registers (UNITS * KSPLIT = 512
+// threads, KSPLIT * KD >= D, P * MC * UNITS >= M).
+//   PdShape<32, 16, 2>  clusters of  8 at D = 256 (round 3): 128 of the 256 CUs at B = 16, T' <= ~216 / 224 (LDS budget)
+//   PdShape<16,  8, 2>  clusters of 16 at D = 256 (round 4): all 256 CUs at B = 16; half the positions, gate columns, match
+//                       columns and state rows per work-group: one energy round of 16 positions instead of two, half the
+//                       alignment correlation, T' <= ~440
+//   PdShape<16, 16, 1>  clusters of up to 32 for 256 < D <= 512 (round 4: WSJ-deep's decoder, B = 8 on all 256 CUs)
+template <int UNITS_, int KD_, int MC_>
+struct PdShape {
+    static constexpr int UNITS = UNITS_, KSPLIT = PD_THREADS / UNITS_, KD = KD_, MC = MC_;
+    static constexpr int DMAX = KSPLIT * KD_;                 // widest decoder
+    // LDS row stride of the AW slice [x | u | r][UNITS]: lanes q = 0..KSPLIT-1 of a unit read consecutive rows — an odd stride
+    // (KSPLIT = 32) spreads them over all banks; +4 words for KSPLIT = 16 (the round-3 layout)
+    static constexpr int AWS = UNITS_ == 32 ? 3 * UNITS_ + 4 : 3 * UNITS_ + 1;
+};
+typedef PdShape<32, 16, 2> PdShape8;
+typedef PdShape<16, 8, 2> PdShape16;
+typedef PdShape<16, 16, 1> PdShape32;
+
+// Which shape serves (B, D, M): LVSR_KNOB_DEC_CLUSTER 0 = clusters of 16 at D <= 256 when B * ceil(D/16) work-groups fit the chip
+// (one per CU), else clusters of 8; 8 / 16 force one of the two (the kernels refuse what does not fit).  D > 256: PdShape32.
+// -> 0 / 1 / 2 (PdShape8 / 16 / 32) or -1; fills units, ksplit, kd, mc, P.
+struct PdPick { int shape, UNITS, KSPLIT, KD, MC, AWS, P; };
+static inline bool pd_pick(int B, int D, int M, PdPick& k, bool allow16 = true) {
+    auto set = [&](int shape, int U, int KD, int MC, int AWS) {
+        k.shape = shape; k.UNITS = U; k.KSPLIT = PD_THREADS / U; k.KD = KD; k.MC = MC; k.AWS = AWS; k.P = (D + U - 1) / U;
+        return M <= k.P * MC * U && k.P <= PD_MAXP && B * k.P <= lvsr_max_cluster_wgs();
+    };
+    if (D > PdShape32::DMAX) return false;
+    if (D > PdShape8::DMAX) return set(2, PdShape32::UNITS, PdShape32::KD, PdShape32::MC, PdShape32::AWS);
+    const int want = lvsr_knob(LVSR_KNOB_DEC_CLUSTER);
+    if (want != 8 && allow16 && set(1, PdShape16::UNITS, PdShape16::KD, PdShape16::MC, PdShape16::AWS)) return true;
+    if (want == 16) return false;          // (allow16 = false: the caller found that clusters of 16 do not fit its LDS budget)
+    return set(0, PdShape8::UNITS, PdShape8::KD, PdShape8::MC, PdShape8::AWS);
+}
 
 __host__ __device__ __forceinline__ int pd_slot(int k, int KX) { return (k / KX) * (KX + 4) + (k % KX); }
 
@@ -70,7 +103,7 @@ __device__ __forceinline__ bool pd_gather(const u64* g, int n, unsigned epoch, i
 }
 
 // sum_x w[x] * v[q][x] over this thread's row slice of a sliced LDS vector, folded over the lanes of the unit
-template <int KX>
+template <int KX, int KSPLIT>
 __device__ __forceinline__ float pd_dot(const f32x2 (&w)[KX / 2], const float* buf, int q) {
     const float4* hv = (const float4*)(buf + q * (KX + 4));
     f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
@@ -81,7 +114,7 @@ __device__ __forceinline__ float pd_dot(const f32x2 (&w)[KX / 2], const float* b
         a0 = w[2 * x] * lo + a0;
         a1 = w[2 * x + 1] * hi + a1;
     }
-    return group_sum<PD_KSPLIT>((a0.x + a1.x) + (a0.y + a1.y));
+    return group_sum<KSPLIT>((a0.x + a1.x) + (a0.y + a1.y));
 }
 
 // v[x] (x < 8) -> sum over the 64 lanes of the wave; lane l ends with the total of value index 4*bit5(l) + 2*bit4(l) + bit3(l):

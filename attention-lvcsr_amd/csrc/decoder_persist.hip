@@ -27,15 +27,16 @@
 //
 // Same results as decoder_fwd.hip up to float32 rounding (order of additions; the reassociated glimpse); it writes every tensor
 // the backward pass reads (sW, CV, EN, ZB, W, U, R, C, RH, S, pos; WA through lvsr_attdec_glimpses).  Limits (else the caller
-// uses the step kernels): D <= 256, M <= 512, T' <= 512, M <= 64 P with P = ceil(D/32), B P <= 224 work-groups, conv filter
-// width <= 256, the LDS budget below (T' <= ~205 at WSJ-base dims).  With the window_around_* priors the window centres of
+// uses the step kernels): D <= 512, M <= 512, T' <= 512, M <= MC UNITS P and B P <= the device's CUs for the cluster shape
+// (decoder_persist.h PdShape: clusters of 8 / 16 work-groups at D <= 256, up to 32 at D <= 512), conv filter width <= 256, the LDS
+// budget below (T' <= ~216 with clusters of 8, ~440 with clusters of 16 at WSJ-base dims).  With the window_around_* priors the window centres of
 // all utterances bound the window: one more (B-granule) exchange per label, between all clusters.
 #include "decoder_persist.h"
 #include <stdlib.h>
 #include <string.h>
 
 struct PdGeom {
-    int P, nown, nownp, KC, KCP, FW, prof, RL;
+    int P, nown, nownp, KC, KCP, FW, prof, RL, shape;
     int o_pa, o_a, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, o_sw, Bp, total;
 };
 
@@ -47,14 +48,15 @@ static int pd_kc(int K) {
     return -1;
 }
 
-static bool pd_geom(const AttDec& a, PdGeom& g) {
+static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true) {
     if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
-    if (a.D > PD_KSPLIT * PD_KD || a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
+    if (a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
     g.KC = pd_kc(a.K);
     if (g.KC < 0) return false;
     g.KCP = (g.KC + 3) / 4 * 4;
-    g.P = (a.D + PD_UNITS - 1) / PD_UNITS;
-    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > lvsr_max_cluster_wgs()) return false;
+    PdPick k;
+    if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
+    g.P = k.P; g.shape = k.shape;
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
     g.FW = 2 * a.c + 1;
@@ -64,12 +66,13 @@ static bool pd_geom(const AttDec& a, PdGeom& g) {
     g.RL = (g.nown + 3) / 4 * 4;
     if (g.RL % 32 == 0) g.RL += 4;          // transposed table [m][RL] of the MFMA energy path: row stride off the bank period
     g.o_pa = take((g.KC > 0 ? g.RL : g.nown) * a.M + 64);
-    g.o_a = take(a.Tp * PD_AWS);
+    g.o_a = take(a.Tp * k.AWS);
     g.o_cv = take(g.nownp * (g.KCP > 0 ? g.KCP : 4));
     take(256);                               // the convolution reads up to 255 floats below `al` (and c + 16 P above) unclamped
     g.o_al = take(a.Tp);
-    g.o_sv = take(PD_KSPLIT * (PD_KD + 4));
-    g.o_rs = take(PD_KSPLIT * (PD_KD + 4));
+    take(max(0, g.nownp * g.P + a.c + 4 - a.Tp));      // (... and up to nownp P + c above its start)
+    g.o_sv = take(k.KSPLIT * (k.KD + 4));
+    g.o_rs = take(k.KSPLIT * (k.KD + 4));
     g.o_xw = take(PD_NW * PD_CH);
     g.o_sw = take(PD_THREADS);
     g.o_red = take(3 * PD_NW);
@@ -79,12 +82,14 @@ static bool pd_geom(const AttDec& a, PdGeom& g) {
     g.o_cp = take(PD_NW * 16 * 17);
     g.total = o;
     g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);         // phase clock of work-group 0 (tools/probe_decoder_persist.py); costs ~1 us per label
+    if (o > PD_LDS_FLOATS && k.shape == 1 && allow16) return pd_geom(a, g, false);      // clusters of 8 instead, if they fit
     return o <= PD_LDS_FLOATS;
 }
 
-template <int KC>
+template <int KC, class SH>
 __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_attdec_plain w, PdGeom g, u64* planes, int* abort_word) {
     constexpr int KCP = (KC + 3) / 4 * 4;
+    constexpr int PD_UNITS = SH::UNITS, PD_KSPLIT = SH::KSPLIT, PD_KD = SH::KD, PD_MC = SH::MC, PD_AWS = SH::AWS;
     __shared__ __attribute__((aligned(16))) float lds[PD_LDS_FLOATS];
     float* const PAs = lds + g.o_pa;      // [nown][M]   own positions (t = tl*P + p) of the preprocessed attended
     float* const AWs = lds + g.o_a;       // [T'][PD_AWS] own gate columns of AW: [x | u | r][32 units]
@@ -198,8 +203,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     u64* const gS = gSW + 3 * PD_MAXV;
     u64* const gPOS = planes + (size_t)B * PD_NPLANE * PD_MAXV;      // [2][Bp], shared by all clusters
     // plain stores for the exchanges INSIDE the cluster when its work-groups share an XCD (persist.h); the window centres travel
-    // between clusters and stay write-through.  The XCC_ID granules use the unused upper half of the S plane (D <= 256).
-    const bool plain = cluster_shares_xcd(gS + 256, P, p, abort_word);
+    // between clusters and stay write-through.  The XCC_ID granules: PD_MAXP per utterance behind the window centres.
+    const bool plain = cluster_shares_xcd(gPOS + 2 * g.Bp + (size_t)b * PD_MAXP, P, p, abort_word);
     const bool winprior = K > 0 && a.prior_type != 0;
     const bool pos_wave = p == P - 1 && wave == PD_NW - 1;           // the wave that derives this utterance's window centre
     __syncthreads();
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         {
             float sw[PD_MC];
 #pragma unroll
-            for (int c = 0; c < PD_MC; ++c) sw[c] = pd_dot<PD_KD>(wsw[c], sv, q);
+            for (int c = 0; c < PD_MC; ++c) sw[c] = pd_dot<PD_KD, PD_KSPLIT>(wsw[c], sv, q);
             if (q < PD_MC) {
                 const int m = (p * PD_MC + q) * PD_UNITS + jl;
                 float mine = sw[0];
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 }
             }
         }
-        const float gu = pd_dot<PD_KD>(whu, sv, q), gr = pd_dot<PD_KD>(whr, sv, q);
+        const float gu = pd_dot<PD_KD, PD_KSPLIT>(whu, sv, q), gr = pd_dot<PD_KD, PD_KSPLIT>(whr, sv, q);
         clk.mark(1);
         // in the shadow of the transformed-state exchange: this label's window centres (published by every cluster during its
         // previous label) and the location convolution of the previous alignment
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         __syncthreads();
         clk.mark(10);
         // ---- phase E: candidate, state update, label-mask blend
-        const float cand = tanh_fast(xin + pd_dot<PD_KD>(whc, rsv, q));
+        const float cand = tanh_fast(xin + pd_dot<PD_KD, PD_KSPLIT>(whc, rsv, q));
         float sn = cand * uu + sj * (1.f - uu);
         sn = ym * sn + (1.f - ym) * sj;
         if (!junit) sn = 0.f;
@@ -627,7 +632,7 @@ extern "C" long long lvsr_attdec_persist_ws_bytes(const lvsr_attdec_args* args) 
     memcpy(&a, args, sizeof(a));
     PdGeom g;
     if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pd_geom(a, g)) return 0;
-    return 256 + ((long long)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp) * 8;
+    return 256 + ((long long)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp + (long long)a.B * PD_MAXP) * 8;
 }
 
 extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* args, const lvsr_attdec_plain* plain, void* ws,
@@ -645,21 +650,29 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     hipStream_t s = (hipStream_t)stream;
     int* ab = (int*)ws;
     u64* planes = (u64*)((char*)ws + 256);
-    const size_t bytes = ((size_t)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp) * 8;
+    const size_t bytes = ((size_t)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp + (size_t)a.B * PD_MAXP) * 8;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
         const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
-        switch (g.KC) {
-            case 0: hipLaunchKernelGGL(attdec_pfwd_kernel<0>, grid, block, 0, s, a, w, g, planes, ab); break;
-            case 4: hipLaunchKernelGGL(attdec_pfwd_kernel<4>, grid, block, 0, s, a, w, g, planes, ab); break;
-            case 10: hipLaunchKernelGGL(attdec_pfwd_kernel<10>, grid, block, 0, s, a, w, g, planes, ab); break;
-            default: hipLaunchKernelGGL(attdec_pfwd_kernel<16>, grid, block, 0, s, a, w, g, planes, ab); break;
+#define PD_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pfwd_kernel<KCV, SHAPE>), grid, block, 0, s, a, w, g, planes, ab)
+#define PD_LAUNCH_KC(SHAPE)                       \
+        switch (g.KC) {                           \
+            case 0: PD_LAUNCH(0, SHAPE); break;   \
+            case 4: PD_LAUNCH(4, SHAPE); break;   \
+            case 10: PD_LAUNCH(10, SHAPE); break; \
+            default: PD_LAUNCH(16, SHAPE); break; \
         }
+        if (g.shape == 0) { PD_LAUNCH_KC(PdShape8) }
+        else if (g.shape == 1) { PD_LAUNCH_KC(PdShape16) }
+        else { PD_LAUNCH_KC(PdShape32) }
+#undef PD_LAUNCH_KC
+#undef PD_LAUNCH
     };
     GraphKey key("attdec_pfwd");
     key.add(&a, sizeof(a));
     key.add(&w, sizeof(w));
     key.add(&ws, sizeof(ws));
     key.add(&g.prof, sizeof(g.prof));
+    key.add(&g.shape, sizeof(g.shape));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd_persistent");
 }

@@ -1,6 +1,7 @@
 // Persistent attention-decoder BACKWARD for gfx950: one launch for the reverse walk over the labels instead of four per label.
-// Same cluster layout as the forward (decoder_persist.hip): P = ceil(D/32) work-groups of 512 threads serve ONE utterance,
-// work-group p owns decoder units [32p, 32p+32), attended positions t = p mod P and match columns [64p, 64p+64).
+// Same cluster layout as the forward (decoder_persist.hip, decoder_persist.h PdShape): P = ceil(D/UNITS) work-groups of 512 threads
+// serve ONE utterance, work-group p owns decoder units [UNITS p, UNITS p + UNITS), attended positions t = p mod P and match columns
+// [MS p, MS p + MS), MS = MC UNITS (clusters of 8: 32 units / 64 columns; of 16: 16 / 32; of up to 32 at D <= 512: 16 / 16).
 //
 // Per label i = L-1 .. 0 (math as decoder_bwd.hip; AW / QR as its reassociated form):
 //   1. GRU:      dsn = ym ds; dpc = dsn u (1-c^2); dpu = dsn (c-s) u (1-u)                          (own units, elementwise)
@@ -27,11 +28,13 @@
 
 typedef lvsr_attdec_bwd_args AttBwd;
 
-#define PB_NPLANE_SMALL 3           // A (dpc) | B (dpu, dpr: 2 x 256, packed as 512) | C (q)        : PD_MAXV granules each
-// per work-group planes: D (512) | E (256) | F (512)
+// granule planes of an utterance: A (dpc: 512) | B (dpu | dpr: 2 x 512) | C (q: 512) | XCC_ID granules (64), then per work-group
+// D (dsW partials: 512) | E (state-gradient contributions: 512) | F (alignment-gradient partials: 512)
+#define PB_SMALL (4 * PD_MAXV + 64)
+#define PB_PERWG (3 * 512)
 
 struct PbGeom {
-    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL;
+    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL;
     int o_ft, o_nx, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
 };
 
@@ -42,17 +45,23 @@ static int pb_kc(int K) {
     return -1;
 }
 
-static bool pb_geom(const AttDec& a, PbGeom& g) {
+static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true) {
     if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
-    if (a.D > PD_KSPLIT * PD_KD || a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
+    if (a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
     g.KC = pb_kc(a.K);
     if (g.KC < 0) return false;
     g.KCP = (g.KC + 3) / 4 * 4;
-    g.P = (a.D + PD_UNITS - 1) / PD_UNITS;
-    if (a.M > g.P * PD_MC * PD_UNITS || a.B * g.P > lvsr_max_cluster_wgs()) return false;
+    PdPick k;
+    if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
+    g.P = k.P; g.shape = k.shape;
+    const int DP = k.KSPLIT * k.KD > 256 ? 512 : 256, MS = k.MC * k.UNITS;      // padded decoder width of the exchanges, match columns per work-group
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
-    if (g.nown > 32) return false;            // the q / alignment-gradient phases map one 16-lane group / one granule row per own position
+    // the q phase maps one lane group (16 lanes at D <= 256, 32 above) per own position, the alignment-gradient gather one granule
+    // row of NTL positions per source work-group (P NTL <= 512 threads)
+    if (g.nown > (DP == 256 ? 32 : 16)) return allow16 && k.shape == 1 ? pb_geom(a, g, false) : false;
+    g.NTL = (g.nown <= 16 || DP == 512) ? 16 : 32;
+    if (g.P * g.NTL > PD_THREADS) return false;
     g.FW = 2 * a.c + 1;
     g.RL = (g.nown + 3) / 4 * 4;
     if (g.RL % 32 == 0) g.RL += 4;
@@ -65,15 +74,15 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.o_q = take(a.Tp);
     g.o_des = take(g.nownp);
     g.o_dalp = take(32);                      // one slot per own position (nown <= 32)
-    g.o_dgl = take(3 * PD_KSPLIT * PD_KD);
-    g.o_dpc = take(PD_KSPLIT * (PD_KD + 4));
-    g.o_dpu = take(PD_KSPLIT * (PD_KD + 4));
-    g.o_dpr = take(PD_KSPLIT * (PD_KD + 4));
+    g.o_dgl = take(3 * DP);
+    g.o_dpc = take(k.KSPLIT * (k.KD + 4));
+    g.o_dpu = take(k.KSPLIT * (k.KD + 4));
+    g.o_dpr = take(k.KSPLIT * (k.KD + 4));
     g.o_dms = take(PD_NW * 16 * 17);
-    g.o_r8 = take(8 * 64);
-    g.o_r8b = take(8 * 32);
+    g.o_r8 = take(512);
+    g.o_r8b = take(512);
     g.o_dsw = take(64);
-    g.o_ws = take(256 * 68);                              // Ws[unit][own column slice] (+4 pad per row)
+    g.o_ws = take(DP * (MS + 4));                         // Ws[unit][own column slice] (+4 pad per row)
     g.o_red = take(2 * PD_NW);
     g.o_clk = take(2 * (PD_NPROF + 1));
     g.o_nx = take(5 * 64);                    // u | r | c | s | dS_readout of the own units for the next label walked
@@ -88,6 +97,7 @@ static bool pb_geom(const AttDec& a, PbGeom& g) {
     g.o_aw = g.AWL ? take(g.nown * g.AWS) : 0;
     g.total = o;
     g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);
+    if (o > PD_LDS_FLOATS && k.shape == 1 && allow16) return pb_geom(a, g, false);      // clusters of 8 instead, if they fit
     return o <= PD_LDS_FLOATS;
 }
 
@@ -98,9 +108,16 @@ __device__ __forceinline__ T pb_ld(const void* sbase, unsigned voff) { return *(
 template <class T>
 __device__ __forceinline__ void pb_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
 
-template <int KC>
+template <int KC, class SH>
 __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr_attdec_plain w, PbGeom g, u64* planes, int* abort_word) {
     constexpr int KCP = (KC + 3) / 4 * 4;
+    constexpr int PD_UNITS = SH::UNITS, PD_KSPLIT = SH::KSPLIT, PD_KD = SH::KD;
+    constexpr int DP = SH::DMAX > 256 ? 512 : 256;        // padded decoder width: planes A / B / E, rows of the Ws slice
+    constexpr int PMAX = DP / PD_UNITS;                    // work-groups per cluster at most (8 / 16 / 32)
+    constexpr int MS = SH::MC * PD_UNITS;                  // match columns per work-group (64 / 32 / 16): PMAX MS = 512
+    constexpr int TPU = PD_THREADS / DP;                   // threads per unit in the Ws^T contribution (2 / 1)
+    constexpr int QL = DP == 256 ? 16 : 32;                // lanes per own position in the q contraction: 12 float4 of the 3 D columns each
+    constexpr int NB = 2 * DP / PD_THREADS;                // granules per thread in exchange B (dpu | dpr)
     constexpr int NS = KCP / 4 > 0 ? KCP / 4 : 1;
     const AttDec& a = gb.f;
     __shared__ __attribute__((aligned(16))) float lds[PD_LDS_FLOATS];
@@ -116,10 +133,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const dpus = lds + g.o_dpu;
     float* const dprs = lds + g.o_dpr;
     float* const dms = lds + g.o_dms;     // [PD_NW][16][17] dm tile of a wave; later the cross-wave dcv partials
-    float* const r8 = lds + g.o_r8;       // [8][64]
-    float* const r8b = lds + g.o_r8b;     // [8][32]
-    float* const dsws = lds + g.o_dsw;    // [64] dsW of the own column slice
-    float* const WsL = lds + g.o_ws;      // [256][68] transform_states rows x the own 64 match columns
+    float* const r8 = lds + g.o_r8;       // [PMAX][MS] / [PMAX][UNITS]: gathered partials of exchanges D / E
+    float* const r8b = lds + g.o_r8b;     // [PMAX][NTL]: gathered partials of exchange F
+    float* const dsws = lds + g.o_dsw;    // [MS] dsW of the own column slice
+    float* const WsL = lds + g.o_ws;      // [DP][MS + 4] transform_states rows x the own match columns
     float* const AWl = lds + g.o_aw;      // AWL: [nown][AWS] rows of AW of the own positions
     float* const red = lds + g.o_red;
     float* const fT = lds + g.o_ft;       // FTL: [FW][KCP] conv1d.filters, transposed
@@ -191,20 +208,20 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             const int tl = x / G3, col = x % G3, t = tl * P + p;
             AWl[tl * g.AWS + col] = t < Tp ? w.AW[((size_t)t * B + b) * AWld + col] : 0.f;
         }
-    for (int x = tid; x < 256 * 64; x += PD_THREADS) {
-        const int kp = x >> 6, mm = x & 63, m = p * 64 + mm;
-        WsL[kp * 68 + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
+    for (int x = tid; x < DP * MS; x += PD_THREADS) {
+        const int kp = x / MS, mm = x % MS, m = p * MS + mm;
+        WsL[kp * (MS + 4) + mm] = (kp < D && m < M) ? w.Ws[(size_t)kp * M + m] : 0.f;
     }
     if (KC > 0 && g.FTL)
         for (int x = tid; x < a.K * g.FW; x += PD_THREADS) fT[(x % g.FW) * KCP + x / g.FW] = a.filters[x];
     float dsj = junit ? gb.ds[(size_t)b * D + j] : 0.f;            // running gradient wrt the state (caller: zeros + readout part)
-    u64* const gA = planes + (size_t)b * (PB_NPLANE_SMALL * PD_MAXV + (size_t)P * (512 + 256 + 512));
-    u64* const gB = gA + PD_MAXV;
-    u64* const gC = gA + 2 * PD_MAXV;
-    u64* const gD = gA + 3 * PD_MAXV;                 // [P][512]
-    u64* const gE = gD + (size_t)P * 512;             // [P][256]
-    u64* const gF = gE + (size_t)P * 256;             // [P][512]
-    const bool plain = cluster_shares_xcd(gA + 256, P, p, abort_word);     // XCC_ID granules: the unused upper half of plane A (D <= 256)
+    u64* const gA = planes + (size_t)b * (PB_SMALL + (size_t)P * PB_PERWG);
+    u64* const gB = gA + PD_MAXV;                     // [2][DP]
+    u64* const gC = gA + 3 * PD_MAXV;
+    u64* const gD = gA + PB_SMALL;                    // [P][512]
+    u64* const gE = gD + (size_t)P * 512;             // [P][512] (DP used)
+    u64* const gF = gE + (size_t)P * 512;             // [P][512]
+    const bool plain = cluster_shares_xcd(gA + 4 * PD_MAXV, P, p, abort_word);
     __syncthreads();
     PdClock clk;
     clk.start(g.prof != 0 && blockIdx.x == 0 && tid == 0, lds + g.o_clk);
@@ -256,8 +273,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         if (q == 0 && junit) granule_store(gA + j, epoch, dpc, plain);
         // gradient wrt the alignment this label produced: gathered from the partial correlations of the previous iteration
         if (n > 0 && KC > 0) {
-            const int src = tid >> 5, tl = tid & 31, t = tl * P + p;
-            const bool mine = tid < 8 * 32 && src < P && tl < nown && t < Tp;
+            const int src = tid / g.NTL, tl = tid % g.NTL, t = tl * P + p;
+            const bool mine = src < P && tl < nown && t < Tp;
             // (granules of positions this work-group does not own are not waited for: sweep only the valid ones)
             u64 wv = (u64)epoch << 32;
             unsigned spins = 0;
@@ -269,7 +286,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                     if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 }
             }
-            if (tid < 8 * 32) r8b[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+            r8b[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
         }
         clk.mark(0);
         {
@@ -278,41 +295,50 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             if (tid < D) { dpcs[pd_slot(tid, PD_KD)] = v[0]; dgl[tid] = v[0]; }
         }
         __syncthreads();
-        if (n > 0 && KC > 0 && tid < 32) {
+        if (n > 0 && KC > 0 && tid < g.NTL) {
             float s = 0.f;
-#pragma unroll
-            for (int src = 0; src < 8; ++src) s += r8b[src * 32 + tid];
+            for (int src = 0; src < P; ++src) s += r8b[src * g.NTL + tid];
             dalp[tid] = s;
         }
         clk.mark(1);
-        const float drh = pd_dot<PD_KD>(whh, dpcs, q);
+        const float drh = pd_dot<PD_KD, PD_KSPLIT>(whh, dpcs, q);
         const float dpr = junit ? drh * sp * rr * (1.f - rr) : 0.f;
         part += drh * rr;
         if (q == 0 && junit) {
             granule_store(gB + j, epoch, dpu, plain);
-            granule_store(gB + 256 + j, epoch, dpr, plain);
+            granule_store(gB + DP + j, epoch, dpr, plain);
             float* dx = gb.DXG + row * G3;
             pb_st<float>(dx, jb, dpc); pb_st<float>(dx + D, jb, dpu); pb_st<float>(dx + 2 * D, jb, dpr);
         }
         clk.mark(2);
         // ---- 2. gates
         {
-            u64 wv = (u64)epoch << 32;
+            // granule g = tid + 512 e of the 2 DP of the plane: [dpu | dpr]
+            u64 wv[NB];
             unsigned spins = 0;
-            const int src = tid < 256 ? tid : 256 + (tid - 256);
-            const bool mine = (tid < 256 ? tid : tid - 256) < D;
             for (;;) {
-                if (mine) wv = __hip_atomic_load(gB + src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
+                bool ok = true;
+#pragma unroll
+                for (int e = 0; e < NB; ++e) {
+                    const int gi = tid + e * PD_THREADS;
+                    wv[e] = (u64)epoch << 32;
+                    if (gi % DP < D) wv[e] = __hip_atomic_load(gB + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(wv[e] >> 32) == epoch;
+                }
+                if (__all(ok)) break;
                 if (((++spins) & 127u) == 0u) {
                     if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
                     if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 }
             }
-            if (mine) {
-                const float v = __uint_as_float((unsigned)wv);
-                if (tid < 256) { dpus[pd_slot(tid, PD_KD)] = v; dgl[D + tid] = v; }
-                else { dprs[pd_slot(tid - 256, PD_KD)] = v; dgl[2 * D + tid - 256] = v; }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int gi = tid + e * PD_THREADS, u = gi % DP;
+                if (u < D) {
+                    const float v = __uint_as_float((unsigned)wv[e]);
+                    if (gi < DP) { dpus[pd_slot(u, PD_KD)] = v; dgl[D + u] = v; }
+                    else { dprs[pd_slot(u, PD_KD)] = v; dgl[2 * D + u] = v; }
+                }
             }
         }
         if (tid >= PD_THREADS / 2) {
@@ -329,30 +355,30 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         // AW rows of the own positions for q: thread (tl = tid / 16, l16): columns 4 l16 + 64 e.  Issued AFTER exchange B: a sweep of
         // the exchange would queue behind them in this wave's memory pipeline (loads return in order) and the exchange would
         // last as long as they do
-        const int qtl = tid >> 4, l16 = tid & 15, qt = qtl * P + p;
+        const int qtl = tid / QL, l16 = tid % QL, qt = qtl * P + p;
         const bool qok = qtl < nown && qt < Tp && qt >= wi.begin && qt < wi.end;
         const unsigned awoff = 4u * ((unsigned)min(qt, Tp - 1) * (unsigned)(B * AWld) + 4u * l16);
         float4 awv[12];
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
-            const int col = 4 * l16 + 64 * e;
-            awv[e] = (!g.AWL && qok && col < G3p) ? pb_ld<float4>(w.AW + (size_t)b * AWld + 64 * e, awoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int col = 4 * l16 + 4 * QL * e;
+            awv[e] = (!g.AWL && qok && col < G3p) ? pb_ld<float4>(w.AW + (size_t)b * AWld + 4 * QL * e, awoff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        const float dsacc = part + pd_dot<PD_KD>(whu, dpus, q) + pd_dot<PD_KD>(whr, dprs, q);
+        const float dsacc = part + pd_dot<PD_KD, PD_KSPLIT>(whu, dpus, q) + pd_dot<PD_KD, PD_KSPLIT>(whr, dprs, q);
         clk.mark(11);
         {
             // q of the own positions
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
             for (int e = 0; e < 12; ++e) {
-                const int col = 4 * l16 + 64 * e;                 // columns [0,D) dpc, [D,2D) dpu, [2D,3D) dpr: dgl is laid out the same
+                const int col = 4 * l16 + 4 * QL * e;             // columns [0,D) dpc, [D,2D) dpu, [2D,3D) dpr: dgl is laid out the same
                 const float4 dg = (col < G3p) ? *(const float4*)(dgl + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 aw = !g.AWL ? awv[e] : (qok && col < G3p) ? *(const float4*)(AWl + qtl * g.AWS + col) : make_float4(0.f, 0.f, 0.f, 0.f);
                 s0 += aw.x * dg.x + aw.y * dg.y;
                 s1 += aw.z * dg.z + aw.w * dg.w;
             }
             clk.mark(12);
-            float qs = group_sum<16>(s0 + s1);
+            float qs = group_sum<QL>(s0 + s1);
             if (qok) qs += gb.QR[row * Tp + qt] + (KC > 0 ? dalp[qtl] : 0.f);
             else qs = 0.f;
             if (l16 == 0 && qtl < nown && qt < Tp) granule_store(gC + qt, epoch, qs, plain);
@@ -403,7 +429,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         // on every label.  They are fetched HERE instead — straight into LDS (global_load_lds: no register lives through the energy
         // phase, the register-pressure peak of the kernel), one array per wave, and no wave polls before the phase is over (a poll
         // issued behind them would wait for them: vector-memory results return in order)
-        if (i > 0 && wave < 5 && lane < 32) {
+        if (i > 0 && wave < 5 && lane < PD_UNITS) {
             const float* arr = wave == 0 ? a.U : wave == 1 ? a.R : wave == 2 ? a.C : wave == 3 ? a.S : gb.dS_r;
             if (arr) __builtin_amdgcn_global_load_lds(arr + (row - (size_t)B) * D + min(p * PD_UNITS + lane, D - 1), nx + wave * 64, 4, 0, 0);
         }
@@ -522,12 +548,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             if (g4 == 0) granule_store(gD + (size_t)p * 512 + (4 * wave + tile) * 16 + c16, epoch, dsw[tile], plain);
         }
         {
-            const int src = tid >> 6, mm = tid & 63;
-            const bool mine = src < P && p * 64 + mm < M;
+            const int src = tid / MS, mm = tid % MS;
+            const bool mine = src < P && p * MS + mm < M;
             u64 wv = (u64)epoch << 32;
             unsigned spins = 0;
             for (;;) {
-                if (mine) wv = __hip_atomic_load(gD + (size_t)src * 512 + p * 64 + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (mine) wv = __hip_atomic_load(gD + (size_t)src * 512 + p * MS + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
                 if (((++spins) & 127u) == 0u) {
                     if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
@@ -537,33 +563,35 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
         }
         __syncthreads();
-        if (tid < 64) {
+        if (tid < MS) {
             float s = 0.f;
 #pragma unroll
-            for (int src = 0; src < 8; ++src) s += r8[src * 64 + tid];
+            for (int src = 0; src < PMAX; ++src) s += r8[src * MS + tid];          // (rows of absent work-groups hold zeros)
             dsws[tid] = s;
-            if (p * 64 + tid < M) gb.DSW[row * M + p * 64 + tid] = s;
+            if (p * MS + tid < M) gb.DSW[row * M + p * MS + tid] = s;
         }
         __syncthreads();
         clk.mark(7);
         {
-            // contribution of the own column slice to ALL units: thread (k' = tid / 2, half) takes 32 of the 64 columns
-            const float4* dv = (const float4*)(dsws + (tid & 1) * 32);
-            float4 wreg[8];
+            // contribution of the own column slice to ALL units: thread (unit k' = tid / TPU, part tid % TPU) takes MS / TPU columns
+            constexpr int NC = MS / TPU, NC4 = NC / 4;
+            const int ku = tid / TPU, part = tid % TPU;
+            const float4* dv = (const float4*)(dsws + part * NC);
+            float4 wreg[NC4];
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                wreg[x] = *(const float4*)(WsL + (tid >> 1) * 68 + (tid & 1) * 32 + 4 * x);
+            for (int x = 0; x < NC4; ++x) {
+                wreg[x] = *(const float4*)(WsL + ku * (MS + 4) + part * NC + 4 * x);
             }
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
+            for (int x = 0; x < NC4; ++x) {
                 const float4 d4 = dv[x], w4 = wreg[x];
                 s0 += d4.x * w4.x + d4.y * w4.y;
                 s1 += d4.z * w4.z + d4.w * w4.w;
             }
             float s = s0 + s1;
-            s += lvsr_dpp_quad_xor1(s);
-            if ((tid & 1) == 0 && (tid >> 1) < D) granule_store(gE + (size_t)p * 256 + (tid >> 1), epoch, s, plain);
+            if (TPU == 2) s += lvsr_dpp_quad_xor1(s);
+            if (part == 0 && ku < D) granule_store(gE + (size_t)p * 512 + ku, epoch, s, plain);
         }
         clk.mark(8);
         // ---- 5. alignment gradient for the previous label, partial over the own positions: behind exchange E
@@ -631,25 +659,25 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         }
         clk.mark(9);
         {
-            const int src = tid >> 5, uu_ = tid & 31;
-            const bool mine = tid < 256 && src < P && p * 32 + uu_ < D;
+            const int src = tid / PD_UNITS, uu_ = tid % PD_UNITS;
+            const bool mine = tid < DP && src < P && p * PD_UNITS + uu_ < D;
             u64 wv = (u64)epoch << 32;
             unsigned spins = 0;
             for (;;) {
-                if (mine) wv = __hip_atomic_load(gE + (size_t)src * 256 + p * 32 + uu_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (mine) wv = __hip_atomic_load(gE + (size_t)src * 512 + p * PD_UNITS + uu_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
                 if (((++spins) & 127u) == 0u) {
                     if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
                     if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
                 }
             }
-            if (tid < 256) r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+            if (tid < DP) r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
         }
         __syncthreads();
         {
             float s = 0.f;
 #pragma unroll
-            for (int src = 0; src < 8; ++src) s += r8[src * 32 + jl];
+            for (int src = 0; src < PMAX; ++src) s += r8[src * PD_UNITS + jl];
             dsj = junit ? dsacc + s : 0.f;
         }
         __syncthreads();
@@ -686,7 +714,16 @@ extern "C" long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* ar
     memcpy(&a, args, sizeof(a));
     PbGeom g;
     if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pb_geom(a, g)) return 0;
-    return 256 + (long long)a.B * (PB_NPLANE_SMALL * PD_MAXV + (long long)g.P * (512 + 256 + 512)) * 8;
+    return 256 + (long long)a.B * (PB_SMALL + (long long)g.P * PB_PERWG) * 8;
+}
+
+extern "C" int lvsr_attdec_bwd_persist_clusters(const lvsr_attdec_args* args) {
+    if (args == nullptr) return 0;
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    PbGeom g;
+    if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pb_geom(a, g)) return 0;
+    return g.P;
 }
 
 extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_args* args, const lvsr_attdec_plain* plain, void* ws) {
@@ -710,14 +747,21 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     hipStream_t s = (hipStream_t)stream;
     int* ab = (int*)ws;
     u64* planes = (u64*)((char*)ws + 256);
-    const size_t bytes = (size_t)a.B * (PB_NPLANE_SMALL * PD_MAXV + (size_t)g.P * (512 + 256 + 512)) * 8;
+    const size_t bytes = (size_t)a.B * (PB_SMALL + (size_t)g.P * PB_PERWG) * 8;
     (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
     const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
-    switch (g.KC) {
-        case 0: hipLaunchKernelGGL(attdec_pbwd_kernel<0>, grid, block, 0, s, gb, w, g, planes, ab); break;
-        case 4: hipLaunchKernelGGL(attdec_pbwd_kernel<4>, grid, block, 0, s, gb, w, g, planes, ab); break;
-        case 10: hipLaunchKernelGGL(attdec_pbwd_kernel<10>, grid, block, 0, s, gb, w, g, planes, ab); break;
-        default: hipLaunchKernelGGL(attdec_pbwd_kernel<16>, grid, block, 0, s, gb, w, g, planes, ab); break;
+#define PB_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pbwd_kernel<KCV, SHAPE>), grid, block, 0, s, gb, w, g, planes, ab)
+#define PB_LAUNCH_KC(SHAPE)                       \
+    switch (g.KC) {                               \
+        case 0: PB_LAUNCH(0, SHAPE); break;       \
+        case 4: PB_LAUNCH(4, SHAPE); break;       \
+        case 10: PB_LAUNCH(10, SHAPE); break;     \
+        default: PB_LAUNCH(16, SHAPE); break;     \
     }
+    if (g.shape == 0) { PB_LAUNCH_KC(PdShape8) }
+    else if (g.shape == 1) { PB_LAUNCH_KC(PdShape16) }
+    else { PB_LAUNCH_KC(PdShape32) }
+#undef PB_LAUNCH_KC
+#undef PB_LAUNCH
     return lvsr_check_launch("lvsr_attdec_bwd_persistent");
 }

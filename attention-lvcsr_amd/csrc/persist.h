@@ -94,5 +94,6 @@ __device__ __forceinline__ float group_sum(float v) {
     if (KSPLIT >= 4) v += lvsr_dpp_quad_xor2(v);
     if (KSPLIT >= 8) v += lvsr_dpp_half_mirror(v);          // all DPP: the lane groups are aligned to their size
     if (KSPLIT >= 16) v += lvsr_dpp_mirror(v);
+    if (KSPLIT >= 32) v = lvsr_swap16_sum(v);
     return v;
 }

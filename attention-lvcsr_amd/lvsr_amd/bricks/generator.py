@@ -452,7 +452,7 @@ class SequenceGenerator(object):
         if psync is not None:
             # the whole reverse walk as one persistent launch (csrc/decoder_persist_bwd.hip); its handler / energy-vector / bias
             # gradient partials come one row per work-group — written, not accumulated: nothing but dPA and ds to clear
-            P = (d.D + 31) // 32
+            P = int(lib._lvsr_attdec_bwd_persist_clusters(ctypes.byref(fwd_args)))        # work-groups per utterance of the launch
             accH = ws.get("gen.accH_p", (B * P, Kc * d.M))
             accWe = ws.get("gen.accWe_p", (B * P, d.M))
             accEb = ws.get("gen.accEb_p", (B * P, 1))

@@ -49,7 +49,8 @@ int lvsr_region_end(void* stream, int keep);
 #define LVSR_KNOB_MAX_CLUSTER_WGS 4   /* 0 = device CU count (256 on MI355X); else the largest one-work-group-per-CU grid a cluster launch may have */
 #define LVSR_KNOB_CLUSTER_RESERVE 5   /* CUs left free by cluster launches for other work on the device (default 0) */
 #define LVSR_KNOB_GEMM_MID_TILES 6    /* lvsr_sgemm with K <= 2048 uses 64 x 64 tiles when the output has fewer 128 x 128 tiles than this (0 = 2048; 1 = never) */
-#define LVSR_KNOB_COUNT 7
+#define LVSR_KNOB_DEC_CLUSTER 7       /* persistent decoder at D <= 256: 0 = clusters of 16 work-groups per utterance when they fit the chip, else 8; 8 / 16 = only that */
+#define LVSR_KNOB_COUNT 8
 int lvsr_set_knob(int knob, int value);
 int lvsr_get_knob(int knob);
 
@@ -206,7 +207,8 @@ typedef struct lvsr_attdec_args {
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
-/* The same label loop as ONE persistent launch (csrc/decoder_persist.hip): a cluster of ceil(D/32) work-groups per utterance
+/* The same label loop as ONE persistent launch (csrc/decoder_persist.hip): a cluster of P work-groups per utterance (P =
+ * ceil(D/16) when B * P fits the device's CUs, else ceil(D/32), at D <= 256; ceil(D/16) <= 32 at D <= 512; LVSR_KNOB_DEC_CLUSTER)
  * keeps the decoder's state weights in registers and the utterance's contexts in LDS for the whole sequence and exchanges four
  * phase vectors per label through {epoch,value} granules.  Same semantics, inputs and saved tensors as lvsr_attdec_fwd with
  * phases = 3 (the scratch fields sg / xin / ep are not used), except that
@@ -269,9 +271,10 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
 /* The backward walk as ONE persistent launch (csrc/decoder_persist_bwd.hip; same cluster layout and limits as
  * lvsr_attdec_fwd_persistent).  Takes the plain weights and AW of lvsr_attdec_plain, and in the argument block: QR (required),
  * dS_r, DXG, DSW, DCV, dPA, ds as lvsr_attdec_bwd; accH / accWe / accEb hold ONE ROW PER WORK-GROUP here — (B*P, K*M), (B*P, M),
- * (B*P) with P = ceil(D/32) — written, not accumulated.  DWA is not written (see AW / QR above); dalp, dspart, dsacc, Q, dcvp,
+ * (B*P) with P = lvsr_attdec_bwd_persist_clusters(args), the work-groups per utterance — written, not accumulated.  DWA is not written (see AW / QR above); dalp, dspart, dsacc, Q, dcvp,
  * dswp and the packed weights are not used.  lvsr_attdec_bwd_persist_ws_bytes: workspace size, 0 = not available. */
 long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* a);
+int lvsr_attdec_bwd_persist_clusters(const lvsr_attdec_args* a);      /* work-groups per utterance the launch will use (0 = not available) */
 int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_args* a, const lvsr_attdec_plain* w, void* ws);
 /* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block; ws: scratch of at least
  * ceil(L*B / R) * K * (2c+1) floats with R = min(4, 8192 / (K*Tp)) rows per work-group (L*B*K*(2c+1) floats always suffice) */

@@ -268,6 +268,20 @@ inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
     return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
 }
 #define __builtin_amdgcn_mov_dpp hipemu_mov_dpp
+// v_permlane16_swap_b32 vdst, src0 (gfx950): the odd rows (16 lanes) of vdst are exchanged with the even rows of src0;
+// -> {new vdst, new src0}
+struct hipemu_u32x2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };
+inline hipemu_u32x2 __builtin_amdgcn_permlane16_swap(unsigned vdst, unsigned src0, bool, bool) {
+    const int l = hipemu::lane_id();
+    const bool odd = ((l >> 4) & 1) != 0;
+    // lane in an odd row: its vdst <- src0 of the lane 16 below; lane in an even row: its src0 <- vdst of the lane 16 above
+    const unsigned from_src_below = (unsigned)hipemu::shfl_generic<long long, long long>((long long)src0, odd ? l - 16 : l);
+    const unsigned from_dst_above = (unsigned)hipemu::shfl_generic<long long, long long>((long long)vdst, odd ? l : l + 16);
+    hipemu_u32x2 r;
+    r.v[0] = odd ? from_src_below : vdst;
+    r.v[1] = odd ? src0 : from_dst_above;
+    return r;
+}
 // v_readlane_b32: the value lane `src` holds, for every lane (all lanes of the wave must reach the call)
 inline int hipemu_readlane(int v, int src) { return (int)hipemu::shfl_generic<long long, long long>(v, src); }
 #define __builtin_amdgcn_readlane hipemu_readlane

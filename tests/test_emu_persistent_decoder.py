@@ -15,13 +15,17 @@ from lvsr_amd.bricks.recognizer import SpeechRecognizer
 from test_emu_recognizer import check_against
 
 
-@pytest.fixture
-def concurrent_lib():
+# both cluster shapes of decoder_persist.h that serve D <= 256: knob dec_cluster 0 = clusters of ceil(D/16) work-groups (16 units
+# each, 32 lanes per unit: the v_permlane16_swap fold), 8 = ceil(D/32) work-groups (32 units each)
+@pytest.fixture(params=[0, 8], ids=["units16", "units32"])
+def concurrent_lib(request):
     lib = emu_lib()
     lib._dll.hipemu_set_concurrent(1)
+    lib.set_knob("dec_cluster", request.param)
     try:
         yield lib
     finally:
+        lib.set_knob("dec_cluster", 0)
         lib._dll.hipemu_set_concurrent(0)
 
 
@@ -45,9 +49,10 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
     assert engaged(rec), "persistent decoder did not engage"
     # the backward kernel serves at most 32 attended positions per work-group (the long case has 75: step kernels there); decoder
     # widths that are not a multiple of 4 (D = 5 here, 250 in the wsj_paper configs) run with padded AW rows
-    P = (rec.d.D + 31) // 32
+    Tp, fits = rec.generator._saved["Tp"], lambda units: -(-rec.generator._saved["Tp"] // -(-rec.d.D // units)) <= 32
+    expect = fits(32) if concurrent_lib.get_knob("dec_cluster") == 8 else (fits(16) or fits(32))       # (clusters of 8 are the fallback)
     bwd = any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs)
-    assert bwd == ((rec.generator._saved["Tp"] + P - 1) // P <= 32), "persistent decoder backward engaged / did not engage"
+    assert bwd == expect, "persistent decoder backward engaged / did not engage"
     rec.generator.check_persistent()
     # the long case accumulates more float32 rounding per element (tests/test_oracle_golden.py TOL); the north-star bars inside
     # check_against (cost sum 1e-4 relative, identical alignment argmax against the reference golden) are the same for all
@@ -58,8 +63,12 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
 
 # the backward kernel's filter-count instantiations (K <= 4 / 10 / 16) and matcher widths that are / are not a multiple of 4
 # (16-byte vs element loads of the transform_states rows), clusters of one and two work-groups
-@pytest.mark.parametrize("K,M,D", [(5, 12, 8), (7, 10, 36), (3, 7, 36), pytest.param(12, 9, 8, marks=pytest.mark.slow)])
+# (3, 40, 264): a decoder wider than 256 units — PdShape32, clusters of ceil(D/16) = 17 work-groups, planes A / B / E 512 wide,
+# 32 lanes per position in the q contraction (WSJ-deep's decoder shape in miniature)
+@pytest.mark.parametrize("K,M,D", [(5, 12, 8), (7, 10, 36), (3, 7, 36), (3, 40, 264), pytest.param(12, 9, 8, marks=pytest.mark.slow)])
 def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K, M, D):
+    if D > 256 and concurrent_lib.get_knob("dec_cluster") == 8:
+        pytest.skip("one cluster shape above 256 units")
     _, meta = load_golden("tiny_conv_median")
     cfg = dict(meta["cfg"])
     cfg.update(conv_num_filters=K, dim_matcher=M, dim_dec=D)

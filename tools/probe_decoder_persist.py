@@ -10,6 +10,9 @@ from lvsr_amd import spec, synthetic
 from lvsr_amd import native
 from lvsr_amd.bricks.recognizer import SpeechRecognizer
 
+KNOBS = [a for a in sys.argv[1:] if "=" in a]          # e.g. dec_cluster=8 (include/lvsr_hip.h LVSR_KNOB_*)
+sys.argv = [a for a in sys.argv if "=" not in a]
+native.get().set_knobs(KNOBS)
 name = sys.argv[1] if len(sys.argv) > 1 else "wsj_base"
 prior = sys.argv[2] if len(sys.argv) > 2 else None
 factory, B, T, L = spec.WORKLOADS[name]

@@ -6,9 +6,13 @@ import os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "attention-lvcsr_amd"))
 import numpy, torch
+from lvsr_amd import native
 from lvsr_amd import spec, synthetic
 from lvsr_amd.bricks.recognizer import SpeechRecognizer
 
+KNOBS = [a for a in sys.argv[1:] if "=" in a]          # e.g. dec_cluster=8 (include/lvsr_hip.h LVSR_KNOB_*)
+sys.argv = [a for a in sys.argv if "=" not in a]
+native.get().set_knobs(KNOBS)
 name = sys.argv[1] if len(sys.argv) > 1 else "wsj_base"
 factory, B, T, L = spec.WORKLOADS[name]
 cfg = factory()

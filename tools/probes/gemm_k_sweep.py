@@ -6,7 +6,7 @@ sys.path[:0] = [REPO, os.path.join(REPO, "attention-lvcsr_amd")]
 import torch
 from lvsr_amd import native
 lib = native.get()
-lib.knobs_from_env()
+lib.set_knobs([a for a in sys.argv[1:] if "=" in a]); sys.argv = [a for a in sys.argv if "=" not in a]
 dev = torch.device("cuda:0")
 
 
