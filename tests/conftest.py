@@ -18,6 +18,8 @@ def pytest_configure(config):
 
 def pytest_addoption(parser):
     parser.addoption("--runslow", action="store_true", default=False, help="also run the tests marked slow")
+    parser.addoption("--knob", action="append", default=[], metavar="NAME=INT",
+                     help="run the GPU tests under a kernel variant (include/lvsr_hip.h LVSR_KNOB_*), e.g. --knob dec_cluster=8")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -45,12 +47,13 @@ def load_golden(name):
 
 
 @pytest.fixture(scope="session")
-def gpu_device():
+def gpu_device(request):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    # A/B runs of the GPU suite under a kernel variant: LVSR_KNOB_<NAME>=<int> (tools/r3*.sh); nothing set = the defaults
-    if any(k.startswith("LVSR_KNOB_") for k in os.environ):
+    # A/B runs of the GPU suite under a kernel variant: `pytest --knob dec_cluster=8 ...`; nothing given = the defaults
+    knobs = request.config.getoption("--knob")
+    if knobs:
         from lvsr_amd import native
-        native.get().knobs_from_env()
+        native.get().set_knobs(knobs)
     return torch.device("cuda:0")
