@@ -120,6 +120,13 @@ def test_recognizer_vs_reference_golden(gpu_device, case, use_graph):
             assert_allclose(got[str(name)] / scale, ref / scale, rtol=0, atol=1e-3 if long_case else 2e-4, err_msg=str(name))
 
 
+# Fingerprint = (norm, sum, dot with a fixed random direction) of a gradient tensor; sum and dot are cancellation residues far below
+# the norm, so their absolute tolerance is a fraction of the NORM.  wsj_base_median: the backward chain through 100 labels under a
+# window prior has a conditioning of its own — the float32 and float64 oracles differ by 5e-4 of a tensor's maximum there, the
+# reference and the float32 oracle by up to 9e-4 on the norms (gen_golden.py WSJ_COND_TRAIN) — hence 2e-3 of the norm for it.
+FP_ATOL = {"wsj_base_median": 2e-3}
+
+
 @pytest.mark.parametrize("case,persistent_decoder", [("timit_tiny", None), ("wsj_base", None), ("wsj_deep", None), ("wsj_stack2", None),
                                                      ("wsj_paper", None), ("wsj_base_median", True), ("wsj_base_median", False)])
 def test_full_size_configs_vs_reference_golden(gpu_device, case, persistent_decoder):
@@ -147,7 +154,7 @@ def test_full_size_configs_vs_reference_golden(gpu_device, case, persistent_deco
     got = rec.store.get_grads()
     for name, fp in zip(z["grad_names"], z["grad_fp"]):
         mine = synthetic.fingerprint(str(name), got[str(name)])
-        assert_allclose(mine, fp, rtol=2e-3, atol=2e-4 * max(1.0, fp[0]), err_msg=str(name))
+        assert_allclose(mine, fp, rtol=2e-3, atol=FP_ATOL.get(case, 2e-4) * max(1.0, fp[0]), err_msg=str(name))
 
 
 # ---- beam search on the GPU vs the hypotheses the reference produced --------------------------------
