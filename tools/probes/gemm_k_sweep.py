@@ -38,3 +38,16 @@ for n in (2048, 4096):
 run(12800, 1536, 512); run(12800, 1536, 40); run(6400, 1536, 512)
 run(12800, 512, 1536, tB=True); run(12800, 512, 512, tB=True); run(12800, 40, 1536, tB=True)
 run(512, 1536, 12800, tA=True); run(512, 1536, 6400, tA=True); run(40, 1536, 12800, tA=True)
+# sustained: the layer's projection for ~4 s back to back — what the clocks settle at under continuous fp32 MFMA load (the cool-chip
+# figures above are 20 launches = 4 ms)
+if "sustained" in sys.argv:
+    M, N, K = 12800, 1536, 512
+    A, Bm, C = torch.randn(M, K, device=dev), torch.randn(K, N, device=dev), torch.empty(M, N, device=dev)
+    for chunk in range(8):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2500):
+            lib.sgemm(A, Bm, C)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 2500
+        print("sustained chunk %d (2500 launches): %7.1f us  %6.1f TFLOP/s" % (chunk, us, 2.0 * M * N * K / us / 1e6), flush=True)
