@@ -142,7 +142,20 @@ def gemm_probe(rec, dims, T, B):
             sec = e0.elapsed_time(e1) * 1e-3 / 20
             ach = 2.0 * shape[0] * shape[1] * shape[2] / sec / 1e12
             out[name] = dict(shape_mnk=shape, launch_us=sec * 1e6, achieved=ach, frac=ach / PEAK_FP32_MFMA)
+    # the projection again: 300 launches back to back on the recognizer's stream, then on the default stream (is the figure above a
+    # property of the kernel, of the 20-launch burst, or of the stream?)
+    diag = {}
+    for tag, stream in (("rec_stream_x300", rec.stream), ("default_stream_x300", torch.cuda.default_stream(dev))):
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(300):
+                calls[0][1]()
+            e1.record(stream)
+            e1.synchronize()
+            diag[tag] = e0.elapsed_time(e1) * 1e3 / 300
     big = out["projection"]
+    big["diagnostics_us"] = diag
     return dict(kernel="lvsr_sgemm64_kernel", shape=big["shape_mnk"], launch_us=big["launch_us"], achieved=big["achieved"], unit="TFLOP/s",
                 frac=big["frac"], layer_shapes=out)
 
