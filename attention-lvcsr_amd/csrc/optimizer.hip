@@ -45,7 +45,11 @@ __global__ __launch_bounds__(256) void opt_norm_kernel(Opt o, int nparts) {
     s = blk_sum256(s, red);
     if (threadIdx.x == 0) {
         const float norm = sqrtf(s);
-        double* cs = o.clip_state;
+        // guard: a cluster kernel of this step gave up -> gradients are garbage: skip the step altogether (scratch[3] tells the
+        // kernels behind this one, and the host)
+        const bool skip = o.guard && o.guard[0] != 0.f;
+        o.scratch[3] = skip ? 1.f : 0.f;
+        double* cs = skip ? nullptr : o.clip_state;
         const float thr = cs ? (float)cs[0] : o.clip_threshold;        // Theano shared floatX
         o.scratch[0] = norm;
         o.scratch[1] = (thr > 0.f && !(norm < thr)) ? thr / norm : 1.f;
@@ -73,6 +77,7 @@ __global__ __launch_bounds__(256) void opt_norm_kernel(Opt o, int nparts) {
 
 // clipping multiplier, Scale, BasicMomentum, AdaDelta -> step
 __global__ __launch_bounds__(256) void opt_rules_kernel(Opt o) {
+    if (o.scratch[3] != 0.f) return;                                   // guarded step: rule state untouched
     const float mult = o.scratch[1];
     if (blockIdx.x == 0)
         for (int sgi = threadIdx.x; sgi < o.nseg; sgi += 256) o.segflag[sgi] = 0;
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(64 * MAXNORM_GROUPS) void opt_maxnorm_kernel(Opt o)
     __shared__ float red[MAXNORM_GROUPS][64];
     const long long* seg = o.segments + 4 * (long long)blockIdx.y;
     const long long off = seg[0], rows = seg[1], cols = seg[2], flags = seg[3];
-    if (!(flags & 1)) return;
+    if (!(flags & 1) || o.scratch[3] != 0.f) return;
     const long long j = (long long)blockIdx.x * 64 + (threadIdx.x & 63);
     if ((long long)blockIdx.x * 64 >= cols) return;
     const int g = threadIdx.x >> 6;
@@ -135,6 +140,7 @@ __global__ __launch_bounds__(256) void opt_finite_kernel(Opt o) {
     __shared__ float red[4];
     const long long* seg = o.segments + 4 * (long long)blockIdx.y;
     const long long off = seg[0], n = seg[1] * seg[2];
+    if (o.scratch[3] != 0.f) return;
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += o.step[off + i];
     s = blk_sum256(s, red);
@@ -145,12 +151,32 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(Opt o) {
     const long long* seg = o.segments + 4 * (long long)blockIdx.y;
     const long long off = seg[0], n = seg[1] * seg[2];
     const int bad = o.remove_not_finite ? o.segflag[blockIdx.y] : 0;
+    if (o.scratch[3] != 0.f) return;                                   // guarded step
     if (o.clip_state && o.scratch[2] != 0.f) return;                   // BurnIn: the step is multiplied by zero
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
         const float p = o.param[off + i];
         const float s = bad ? (1.f - o.nonfinite_scaler) * p : o.step[off + i];
         o.param[off + i] = p - s;
     }
+}
+
+struct GuardPack { const int* w[16]; int n; };
+__global__ void guard_collect_kernel(GuardPack pk, float* out) {
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        for (int i = 0; i < pk.n; ++i)
+            if (pk.w[i] && __hip_atomic_load(pk.w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++bad;
+        out[0] = (float)bad;
+    }
+}
+
+extern "C" int lvsr_guard_collect(void* stream, const int* const* words, int n, float* out) {
+    LVSR_REQUIRE(n >= 0 && n <= 16 && out && (n == 0 || words), "lvsr_guard_collect: at most 16 words");
+    GuardPack pk;
+    pk.n = n;
+    for (int i = 0; i < 16; ++i) pk.w[i] = i < n ? words[i] : nullptr;
+    hipLaunchKernelGGL(guard_collect_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pk, out);
+    return lvsr_check_launch("lvsr_guard_collect");
 }
 
 extern "C" int lvsr_opt_step(void* stream, const lvsr_opt_args* args) {

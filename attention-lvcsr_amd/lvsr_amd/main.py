@@ -115,9 +115,14 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                 continue
             gbs = batch.pop("global_batch_size", None)
             cm = trainer.train_step(batch, global_batch_size=gbs)
+            if trainer.step_was_skipped():
+                # a persistent cluster kernel gave up waiting for its partners (its work-groups were not all resident: the device is
+                # shared): the optimiser skipped the step on the device — on every rank, the flag travels with the gradients.  Go on
+                # with the step kernels and run the batch again.
+                trainer.recover()
+                log.append(dict(iterations_done=iterations, persistent_kernels_aborted=True))
+                cm = trainer.train_step(batch, global_batch_size=gbs)
             iterations += 1
-            rec.encoder.check_persistent()
-            rec.generator.check_persistent()          # (the row below synchronises anyway) a cluster that gave up -> raise
             row = dict(iterations_done=iterations, epochs_done=epoch, train_cost=float(cm.sum()) / int(batch["labels"].shape[1]),
                        total_gradient_norm=trainer.gradient_norm(), gradient_norm_threshold=trainer.gradient_threshold())
             costs.append(row["train_cost"])

@@ -56,7 +56,11 @@ class ParameterStore(object):
         self.offsets = offs
         self.version = 0          # bumped whenever parameter values change (packed copies key on it)
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        # the gradient bucket of data parallelism = [4 guard floats | gradients]: element 0 carries "a persistent cluster kernel of
+        # this step gave up" (lvsr_guard_collect) through the all-reduce, so every rank skips such a step together (lvsr_opt_args.guard)
+        self.grad_bucket = torch.zeros(total + 4, dtype=torch.float32, device=self.device)
+        self.guard = self.grad_bucket[:1]
+        self.grad = self.grad_bucket[4:]
         self.p = OrderedDict((k, self.flat[o:o + n].view(self.shapes[k])) for k, (o, n) in offs.items())
         self.g = OrderedDict((k, self.grad[o:o + n].view(self.shapes[k])) for k, (o, n) in offs.items())
         if values is not None:

@@ -13,6 +13,8 @@ import os
 import numpy
 import torch
 
+from .native import ptr
+
 
 def _is_weight(name):
     return name.endswith(".W") or name.endswith("state_to_state") or name.endswith("state_to_gates")
@@ -122,13 +124,37 @@ class Trainer(object):
         """L2 norm of the (scaled, all-reduced) gradient of the last step: the reference's `total_gradient_norm`."""
         return float(self.scratch[0])
 
+    def _enqueue_guard(self):
+        """Behind the backward pass: store.guard[0] = number of persistent cluster launches of this step that gave up waiting (the
+        abort words in front of their workspaces).  The optimiser skips the step on the device when it is non-zero; under data
+        parallelism the word is the first element of the gradient bucket, so every rank sees the sum and skips together."""
+        rec, st, lib = self.rec, self.rec.store, self.rec.lib
+        words = [t for k, t in rec.ws._bufs.items() if k[0] in ("gen.sync", "gen.sync_bwd") or (k[0].startswith("enc") and k[0].endswith(".sync"))]
+        arr = (ctypes.c_void_p * 16)(*[t.data_ptr() for t in words[:16]])
+        lib.call("lvsr_guard_collect", lib.stream_for(st.flat), arr, min(len(words), 16), ptr(st.guard))
+
     def _enqueue_optimizer(self, global_batch_size):
         st, lib = self.rec.store, self.rec.lib
         a = lib.make("lvsr_opt_args", param=st.flat, grad=st.grad, velocity=self.velocity, ms_step=self.ms_step,
                      ms_dx=self.ms_dx, step=self.step_buf, segments=self.segments, segflag=self.segflag,
                      scratch=self.scratch, n=st.flat.numel(), nseg=int(self.segments.shape[0]), max_cols=self.max_cols,
-                     grad_scale=1.0 / float(global_batch_size), clip_state=self.clip_state, **self.conf)
+                     grad_scale=1.0 / float(global_batch_size), clip_state=self.clip_state, guard=st.guard, **self.conf)
         lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
+
+    def step_was_skipped(self):
+        """After a step (synchronises): did the optimiser skip it because a persistent cluster kernel gave up (lvsr_opt_args.guard)?"""
+        return float(self.scratch[3]) != 0.0
+
+    def recover(self):
+        """Call when step_was_skipped(): clear the abort words, put encoder and decoder on their step kernels for the rest of the run
+        (a cluster launch needs all its work-groups resident at once — something else is using the device's CUs) and tell the
+        caller to run the batch again.  Parameters and rule state are untouched by the skipped step."""
+        rec = self.rec
+        for k, t in rec.ws._bufs.items():
+            if k[0] in ("gen.sync", "gen.sync_bwd") or (k[0].startswith("enc") and k[0].endswith(".sync")):
+                t[:16].zero_()
+        rec.encoder.use_persistent, rec.encoder.persist_auto = False, False
+        rec.generator.use_persistent = False
 
     def _all_reduce_gradients(self):
         """ONE collective per step over the flat gradient bucket (sum); RCCL over xGMI when the tensors are on GPUs.
@@ -137,7 +163,7 @@ class Trainer(object):
         stream has meanwhile entered hipGraph capture (hipErrorCapturedEvent kills the process: tools/probes/
         nccl_capture_probe.py) — the compute stream captures the next minibatch shape's graph, the communication stream
         never captures."""
-        self._all_reduce(self.rec.store.grad)
+        self._all_reduce(self.rec.store.grad_bucket)          # [guard | gradients]
 
     def _all_reduce(self, g, wait=True):
         """Sum all-reduce of (a slice of) the flat gradient buffer; wait=False leaves the compute stream un-ordered behind it
@@ -161,6 +187,7 @@ class Trainer(object):
     def apply_gradients(self, global_batch_size):
         rec, st = self.rec, self.rec.store
         with rec._on_stream():
+            self._enqueue_guard()
             if self.distributed:
                 self._all_reduce_gradients()
             self._enqueue_optimizer(global_batch_size)
@@ -189,7 +216,8 @@ class Trainer(object):
                         self._all_reduce(st.grad[off: off + cnt], wait=False)
                 cm = rec.cost_and_gradients(batch, region=self.dp_region, between=reduce_decoder_bucket)
                 with rec._on_stream():
-                    self._all_reduce(st.grad[:off], wait=False)
+                    self._enqueue_guard()
+                    self._all_reduce(st.grad_bucket[: 4 + off], wait=False)          # [guard | encoder gradients]
                     self._join_comm(st.grad)
                     self._enqueue_optimizer(global_batch_size)
                     st.version += 1
@@ -199,6 +227,9 @@ class Trainer(object):
             return cm
         gbs = global_batch_size if global_batch_size is not None else B_local
         tail_key = ("opt", self._token, float(gbs), tuple(sorted(self.conf.items())))
-        cm = self.rec.cost_and_gradients(batch, tail=lambda: self._enqueue_optimizer(gbs), tail_key=tail_key)
+        def tail():
+            self._enqueue_guard()
+            self._enqueue_optimizer(gbs)
+        cm = self.rec.cost_and_gradients(batch, tail=tail, tail_key=tail_key)
         self.rec.store.version += 1
         return cm

@@ -324,8 +324,16 @@ typedef struct lvsr_opt_args {
     double* clip_state;
     int adaptive_clipping, adaptive_burnin;
     float adaptive_decay, pad1;
+    /* Guard (NULL = off): a device float that must be 0 for the step to be applied.  Non-zero — a persistent cluster kernel of this
+     * step gave up waiting (lvsr_guard_collect below; under data parallelism the word rides in front of the gradient bucket, so
+     * after the all-reduce every rank sees the same value) — and the whole step is skipped on the device: parameters, rule state,
+     * adaptive-clipping statistics and burn-in counter stay as they are; scratch[3] = 1 reports it (else 0). */
+    const float* guard;
 } lvsr_opt_args;
 int lvsr_opt_step(void* stream, const lvsr_opt_args* a);
+/* *out = number of non-zero words among words[0..n) (n <= 16 device int pointers; NULL entries are skipped): the abort words of the
+ * persistent cluster launches of a step (first int of their workspaces), collected behind the backward pass. */
+int lvsr_guard_collect(void* stream, const int* const* words, int n, float* out);
 
 /* Generation-time readout + emitter of n rows in one launch (one work-group per row):
  * Readout.readout (libs/blocks/blocks/bricks/sequence_generators.py:614-619) with the post-merge stack of

@@ -85,3 +85,50 @@ def run_against_oracle_and_step_kernels(lib, Hs, sub, B, T, use_mask):
         if "/encoder/" in name:
             scale = max(1e-3, numpy.abs(g_s[name]).max())
             assert numpy.abs(g_p[name] - g_s[name]).max() / scale < 2e-5, name
+
+
+def test_step_of_an_aborted_cluster_is_skipped_on_the_device_and_recovered():
+    """A persistent cluster kernel that gives up waiting raises the (sticky) abort word of its workspace; lvsr_guard_collect carries
+    it into the guard word in front of the gradient bucket and lvsr_opt_step skips the whole step on the device: parameters, rule
+    state and clipping statistics unchanged.  Trainer.recover() then puts the run on the step kernels; the batch run again gives
+    the update of an undisturbed step."""
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    from lvsr_amd.training import Trainer
+    lib = emu_lib()
+    lib._dll.hipemu_set_concurrent(1)
+    lib.set_knob("persist_rows", 1)
+    try:
+        cfg = dict(input_dim=6, num_phonemes=6, dims_bidir=[140], subsample=[1], dim_dec=4, dim_matcher=7,
+                   attention_type="content", post_merge_dims=None, embed_outputs=True)
+        params = synthetic.make_params(cfg, seed=3)
+        batch = synthetic.make_batch(cfg, 2, 5, 3, seed=5, ragged=True)
+        rules = dict(gradient_threshold=5.0, rules=("momentum", "adadelta"), scale=0.5, decay_rate=0.9, epsilon=1e-6, max_norm=1.0,
+                     adaptive_clipping=True)
+        # reference: the same two steps without any disturbance, on the step kernels
+        ref = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=cfg, use_persistent=False, use_persistent_decoder=False)
+        tr_ref = Trainer(ref, distributed=False, **rules)
+        tr_ref.train_step(batch)
+        tr_ref.train_step(batch)
+        rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=cfg, use_persistent=True, use_persistent_decoder=False)
+        tr = Trainer(rec, distributed=False, **rules)
+        tr.train_step(batch)
+        assert not tr.step_was_skipped() and any(k[0] == "enc0.sync" for k in rec.ws._bufs)
+        before = rec.store.get_values()
+        state = {k: v.copy() for k, v in tr.state_dict().items() if k != "layout"}
+        [t for k, t in rec.ws._bufs.items() if k[0] == "enc0.sync"][0][0] = 1          # "a work-group of the cluster was never scheduled"
+        tr.train_step(batch)
+        assert tr.step_was_skipped()
+        for k, v in rec.store.get_values().items():
+            assert (v == before[k]).all(), "a skipped step changed %s" % k
+        for k, v in tr.state_dict().items():
+            if k != "layout":
+                assert (numpy.asarray(v) == state[k]).all(), "a skipped step changed the optimiser's %s" % k
+        tr.recover()
+        tr.train_step(batch)                     # the batch again, on the step kernels
+        assert not tr.step_was_skipped() and not rec.encoder.use_persistent
+        got, want = rec.store.get_values(), ref.store.get_values()
+        for k in want:
+            assert_allclose(got[k], want[k], rtol=2e-4, atol=2e-6, err_msg=k)
+    finally:
+        lib._dll.hipemu_set_concurrent(0)
+        lib.set_knob("persist_rows", 0)

@@ -10,7 +10,7 @@ for what in "$@"; do
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 4 $O/pytest.log;;
     newtests) timeout 900 python -m pytest tests -m gpu -x -q -k "wsj_base_median or whole_list or persistent_decoder or wsj_deep or wsj_paper or stack2" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -n 6 $O/pytest_new.log;;
     bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step')}, d.get('sustained'), d.get('strong'), d.get('fbank',{}).get('lvsr_fbank'), d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
-    quick) timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; python -c "import json;d=json.load(open('$O/quick.json'));print('wsj_base', d['ms_per_step'], d['value'])"; tail -n 2 $O/quick.err;;
+    quick) timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; python -c "import json;d=json.load(open('$O/quick.json'));print('wsj_base', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 2 $O/quick.err;;
     quick8) timeout 300 python bench.py --steps 20 --warmup 5 $B --knob dec_cluster=8 > $O/quick8.json 2> $O/quick8.err; python -c "import json;d=json.load(open('$O/quick8.json'));print('wsj_base clusters of 8', d['ms_per_step'], d['value'])"; tail -n 2 $O/quick8.err;;
     dec) for k in dec_cluster=0 dec_cluster=8; do timeout 300 python tools/probe_decoder_persist.py wsj_base $k > $O/dec_fwd_$k.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base $k > $O/dec_bwd_$k.txt 2>&1; echo "== $k"; grep -v "^    " $O/dec_fwd_$k.txt | tail -n 4; grep -v "^    " $O/dec_bwd_$k.txt | tail -n 4; done;;
     decmed) timeout 300 python tools/probe_decoder_persist.py wsj_base median > $O/dec_fwd_median.txt 2>&1; grep -v "^    " $O/dec_fwd_median.txt | tail -n 4;;
@@ -22,6 +22,8 @@ for what in "$@"; do
     batches) for b in 10 32 64 128; do timeout 300 python bench.py --steps 8 --warmup 2 --batch $b $B > $O/batch_$b.json 2> $O/batch_$b.err; python -c "import json;d=json.load(open('$O/batch_$b.json'));print('batch $b', d['ms_per_step'], d['value'])"; tail -n 1 $O/batch_$b.err; done;;
     gemm) timeout 400 python tools/probes/gemm_k_sweep.py sustained > $O/gemm_k_sweep.txt 2>&1; tail -n 22 $O/gemm_k_sweep.txt;;
     prof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 $B > $R/$O/prof.log 2>&1; cd $R; ls $O/prof | head; python tools/rocpd_stats.py $O/prof/*/*.db > $O/kernel_stats.md 2>> $O/prof.log || python tools/rocpd_stats.py $O/prof/*.db > $O/kernel_stats.md 2>> $O/prof.log; head -n 30 $O/kernel_stats.md;;
+    enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
+    knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
     *) echo "unknown item $what";;
   esac
 done
