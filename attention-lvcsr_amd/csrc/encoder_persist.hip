@@ -101,36 +101,6 @@ __device__ __forceinline__ bool gather_plane(const u64* g, unsigned epoch, float
     }
     return true;
 }
-// The BPTT kernel's first exchange carries TWO values per unit (dpre_c, dpre_u).  Published as a granule PAIR (16 bytes, side by
-// side) they are swept with one 16-byte load per lane: the NG pairs of a plane by NG <= 256 lanes = waves 0..3, which leaves waves
-// 4..7 free to fetch the next step's operands — as in the forward kernel — without a load of theirs ever standing in front of a poll
-// (round 3 swept the two planes as 2 NG granules with all eight waves and measured every loader-wave variant slower).
-template <int NG, int HP, int KS, int LDH, int KSPLIT>
-__device__ __forceinline__ bool gather_pairs(const u64* g, unsigned epoch, float* dst0, float* dst1, int* abort_word) {
-    const int tid = (int)threadIdx.x;
-    if (tid >= 256) return true;                                   // (wave-uniform)
-    const bool mine = tid < NG;
-    u64 w0 = (u64)epoch << 32, w1 = (u64)epoch << 32;
-    unsigned spins = 0;
-    for (;;) {
-        if (mine) lvsr_granule_pair_load(g + 2 * (size_t)tid, w0, w1);
-        if (__all((unsigned)(w0 >> 32) == epoch && (unsigned)(w1 >> 32) == epoch)) break;
-        ++spins;
-        if ((spins & 127u) == 0u) {
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (spins > PERSIST_SPIN_LIMIT) {
-                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-    if (mine) {
-        const int row = tid / HP, k = tid % HP, at = (row * KSPLIT + k / KS) * LDH + (k % KS);
-        dst0[at] = __uint_as_float((unsigned)w0);
-        dst1[at] = __uint_as_float((unsigned)w1);
-    }
-    return true;
-}
 // A cluster of ONE work-group (H <= 128) has nobody to hand anything to: the phase vector goes straight into the LDS operand
 // buffer and the hand-off is a work-group barrier.
 template <int KS, int LDH, int KSPLIT>
@@ -437,12 +407,6 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;
     constexpr int NBUF = PRIV ? 4 : 1;
-    // STAGED (512-thread kernels whose plane fits waves 0..3 with one PAIR per lane — one utterance per cluster, H <= 256): dpre_c and
-    // dpre_u travel as granule pairs swept by waves 0..3 (gather_pairs), waves 4..7 fetch the next step's operands (saved gates, the
-    // previous state, dy, mask) and hand them over through LDS: a polling wave issues no other global load
-    constexpr bool STAGED = NTH == 512 && P > 1 && NG <= 256;
-    constexpr int ITEMS = RB * 5 * UNITS + RB, NLD = (ITEMS + 255) / 256;
-    __shared__ float opnd[STAGED ? ITEMS : 1];
     __shared__ __attribute__((aligned(16))) float vbuf_all[3][NBUF][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
     float* const vbuf[3] = {vbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], vbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0],
                             vbuf_all[2][PRIV ? (threadIdx.x >> 6) : 0]};
@@ -455,8 +419,6 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
     const int dir = cl / rt, b0 = (cl % rt) * RB;
     const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
     const bool junit = j < H;
-    const bool staged = STAGED && !(flags & PF_NOSTAGE_BWD);      // (PF_NOSTAGE_BWD: the owners fetch their operands themselves, for A/B runs)
-    const bool loader = staged && tid >= 256;
     f32x2 wa[KS / 2], wbu[KS / 2], wbr[KS / 2];
     {
         const float* Whg = a.WhgT_p[dir];     // persistent mode: PLAIN (H,2H) / (H,H) weights, rows read in place
@@ -477,9 +439,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
             wa[x] = (f32x2){v[0], v[1]}; wbu[x] = (f32x2){v[2], v[3]}; wbr[x] = (f32x2){v[4], v[5]};
         }
     }
-    // dpre_c, then dpre_u right behind it: published together, swept together; STAGED: interleaved instead — granule pair (c, u) of
-    // (row, unit) at 2 (row HP + unit)
-    u64* gc = planes + (size_t)cl * 4 * NG;
+    u64* gc = planes + (size_t)cl * 4 * NG;        // dpre_c, then dpre_u right behind it: published together, swept together
     u64* gu = gc + NG;
     u64* gr = gc + 2 * NG;                         // dpre_r
     const int t_first = dir == 0 ? T - 1 : 0;
@@ -502,40 +462,9 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
         n_u[i] = n_c[i] = n_r[i] = n_hp[i] = n_dy[i] = 0.f; n_m[i] = 1.f;
         if (rvalid[i]) prefetch(t_first, i);
     }
-    // (STAGED) what waves 4..7 fetch for walk step `ns`: item idx = ((row * 5 + which) * UNITS + unit) with which = u | c | r | previous
-    // state | dy of the previous state's time step; then the rows' masks
-    auto stage_issue = [&](int ns, float (&dst)[NLD]) {
-        const bool fetch = loader && ns < T;
-        const int tn = dir == 0 ? T - 1 - ns : ns, tpn = dir == 0 ? tn - 1 : tn + 1;
-#pragma unroll
-        for (int l = 0; l < NLD; ++l) {
-            const int idx = tid - 256 + 256 * l;
-            dst[l] = 0.f;
-            if (fetch && idx < RB * 5 * UNITS) {
-                const int r = idx / (5 * UNITS), which = (idx / UNITS) % 5, jj = p * UNITS + idx % UNITS, bb = b0 + r;
-                if (jj < H && bb < B) {
-                    const size_t o = ((size_t)tn * B + bb) * 2 * H + dir * H + jj;
-                    if (which == 0) dst[l] = a.u[o];
-                    else if (which == 1) dst[l] = a.c[o];
-                    else if (which == 2) dst[l] = a.r[o];
-                    else if (which == 3) dst[l] = (tpn < 0 || tpn >= T) ? a.h0[dir][jj] : a.y[((size_t)tpn * B + bb) * 2 * H + dir * H + jj];
-                    else dst[l] = pb_dy_at(a, tpn, bb, dir, jj);
-                }
-            } else if (fetch && idx < ITEMS) {
-                const int bb = b0 + idx - RB * 5 * UNITS;
-                dst[l] = (a.mask && bb < B) ? a.mask[(size_t)tn * B + bb] : 1.f;
-            }
-        }
-    };
-    float pf[NLD];
-    if (STAGED) stage_issue(1, pf);                               // (no loads unless `loader`)
     for (int n = 0; n < T; ++n) {
         const int t = dir == 0 ? T - 1 - n : n;
         float uu[NR], cc[NR], rr[NR], hp[NR], part[NR];
-        // waves 4..7: the operands of step n + 2 are issued here; those of step n + 1 (issued a step ago) are handed over in front
-        // of the second barrier of this step
-        float pf_new[NLD];
-        if (STAGED) stage_issue(n + 2, pf_new);
         // ---- everything of this step that depends on dh elementwise only; publish dpre_c and dpre_u
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
@@ -548,9 +477,6 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
                 if (P == 1) {
                     lds_publish<KS, LDH, KSPLIT>(vbuf[0], r, j, dpc);
                     lds_publish<KS, LDH, KSPLIT>(vbuf[1], r, j, dpu);
-                } else if (STAGED) {
-                    granule_store(gc + 2 * ((size_t)r * HP + j), (unsigned)(n + 1), dpc, plain);
-                    granule_store(gc + 2 * ((size_t)r * HP + j) + 1, (unsigned)(n + 1), dpu, plain);
                 } else {
                     granule_store(gc + (size_t)r * HP + j, (unsigned)(n + 1), dpc, plain);
                     granule_store(gu + (size_t)r * HP + j, (unsigned)(n + 1), dpu, plain);
@@ -562,15 +488,13 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
                 }
             }
         }
-        // operands of the next step: in flight during the hand-offs (fetched by the owner lanes unless waves 4..7 do it)
-        if (!staged && n + 1 < T && !(flags & PF_NOPREFETCH)) {
+        // operands of the next step: in flight during the hand-offs
+        if (n + 1 < T && !(flags & PF_NOPREFETCH)) {
 #pragma unroll
             for (int i = 0; i < NR; ++i)
                 if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
         }
-        if (STAGED) {
-            if (!gather_pairs<NG, HP, KS, LDH, KSPLIT>(gc, (unsigned)(n + 1), vbuf[0], vbuf[1], abort_word)) return;
-        } else if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 2, NBUF * RB * KSPLIT * LDH, NTH>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 2, NBUF * RB * KSPLIT * LDH, NTH>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
         gather_fence<PRIV>();
         float s[RB], vu[RB];
         slice_dot<KS, RB, LDH, KSPLIT>(wa, vbuf[0], q, s);                     // d(r*h)
@@ -588,40 +512,13 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
         }
         // ---- dpre_u @ Whg[:, :H]^T in the shadow of the hand-off (dpre_u came in with dpre_c's sweep)
         slice_dot<KS, RB, LDH, KSPLIT>(wbu, vbuf[1], q, vu);
-        if (STAGED) {
-            if (loader && n + 1 < T) {
-#pragma unroll
-                for (int l = 0; l < NLD; ++l) {
-                    const int idx = tid - 256 + 256 * l;
-                    if (idx < ITEMS) opnd[idx] = pf[l];
-                }
-            }
-#pragma unroll
-            for (int l = 0; l < NLD; ++l) pf[l] = pf_new[l];
-        }
-        if (P > 1) {
-            const bool ok = STAGED ? gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, 256>(gr, (unsigned)(n + 1), vbuf[2], abort_word)
-                                   : gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gr, (unsigned)(n + 1), vbuf[2], abort_word);
-            if (!ok) return;
-        }
+        if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gr, (unsigned)(n + 1), vbuf[2], abort_word)) return;
         gather_fence<PRIV>();
         slice_dot<KS, RB, LDH, KSPLIT>(wbr, vbuf[2], q, s);
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int r = q + i * KSPLIT;
             if (r < RB) dh[i] = rvalid[i] ? part[i] + pick_row<RB, KSPLIT>(vu, q, i) + pick_row<RB, KSPLIT>(s, q, i) : 0.f;
-        }
-        // (STAGED) the operands of the next step, handed over by waves 4..7 in front of the barrier above
-        if (staged && n + 1 < T) {
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                if (rvalid[i]) {
-                    const int r = q + i * KSPLIT, ju = tid / KSPLIT;
-                    n_u[i] = opnd[(r * 5 + 0) * UNITS + ju]; n_c[i] = opnd[(r * 5 + 1) * UNITS + ju]; n_r[i] = opnd[(r * 5 + 2) * UNITS + ju];
-                    n_hp[i] = opnd[(r * 5 + 3) * UNITS + ju]; n_dy[i] = opnd[(r * 5 + 4) * UNITS + ju];
-                    n_m[i] = opnd[RB * 5 * UNITS + r];
-                }
-            }
         }
     }
 #pragma unroll

@@ -21,7 +21,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PF_SC1 4
 #define PF_NARROW 64     // encoder, 128 < H <= 256: clusters of 4 work-groups (64 units each) instead of 8 — see persist_geom
 #define PF_NOSTAGE 256      // forward kernel: no loader waves (every owner lane fetches its next operands itself, the round-2 form)
-#define PF_NOSTAGE_BWD 512   // BPTT kernel: no loader waves (the owners fetch their next operands themselves; granule pairs are kept)
 #define PF_NOUB 2048        // forward kernel at 256 < H <= 512: one unit per lane group instead of four (see enc_pfwd_ub_kernel)
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
                          // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue
@@ -48,18 +47,6 @@ __device__ __forceinline__ void granule_store(u64* p, unsigned epoch, float v, b
     if (plain) __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Two granules that lie side by side (16-byte aligned) with ONE request: global_load_dwordx4 with the cache policy of the 8-byte
-// relaxed agent-scope atomic load (sc1).  Each 8-byte half carries its own epoch, so nothing rests on the 16 bytes being read
-// atomically.  (The test emulator supplies its own version: tests/hipemu/hip/hip_runtime.h.)
-#ifndef LVSR_GRANULE_PAIR_LOAD
-__device__ __forceinline__ void lvsr_granule_pair_load(const u64* p, u64& a, u64& b) {
-    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
-    u32x4_ v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-    a = ((u64)v[1] << 32) | (u64)v[0];
-    b = ((u64)v[3] << 32) | (u64)v[2];
-}
-#endif
 // Do the P work-groups of this cluster run on one XCD?  Member p publishes its XCC_ID (hardware register 20, bits 3:0) as a
 // write-through granule {1, id} into hello[p] (zeroed by the launch's memset node) and wave 0 polls the P slots; every member
 // sees the same P values, so the answer is uniform over the cluster.  Called once per launch by all threads (it contains a

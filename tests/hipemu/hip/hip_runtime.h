@@ -247,12 +247,6 @@ template <typename T, typename V> inline void hipemu_atomic_store(T* p, V v) { _
 template <typename T> inline T hipemu_atomic_load(const T* p) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 #define __hip_atomic_store(p, v, order, scope) hipemu_atomic_store(p, v)
 #define __hip_atomic_load(p, order, scope) hipemu_atomic_load(p)
-// persist.h lvsr_granule_pair_load (global_load_dwordx4 sc1 in the product): two relaxed atomic loads here
-#define LVSR_GRANULE_PAIR_LOAD 1
-inline void lvsr_granule_pair_load(const unsigned long long* p, unsigned long long& a, unsigned long long& b) {
-    a = __atomic_load_n(p, __ATOMIC_SEQ_CST);
-    b = __atomic_load_n(p + 1, __ATOMIC_SEQ_CST);
-}
 inline void __builtin_amdgcn_s_sleep(int) { hipemu::yield(); }
 inline void __builtin_amdgcn_sched_barrier(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::wave_barrier(); }      // lanes are fibers here, not lock-step
