@@ -121,20 +121,17 @@ __device__ __forceinline__ float pd_dot(const f32x2 (&w)[KX / 2], const float* b
 // every stage halves the values a lane carries (10 shuffles instead of 8 x 6)
 __device__ __forceinline__ float pd_butterfly8(float (&v)[8]) {
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-        const int half = 4 >> s, off = 32 >> s;
-        const bool up = (lane & off) != 0;
-#pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            if (x < half) {
-                const float keep = up ? v[x + half] : v[x];
-                const float send = up ? v[x] : v[x + half];
-                v[x] = keep + __shfl_xor(send, off, 64);
-            }
-        }
-    }
-    float r = v[0];
+    // (named scalars and explicit selects: written as `up ? v[x + half] : v[x]` on the array, the compiler turned the lane-dependent
+    // choice into a dynamically indexed private array — 48 bytes of scratch per lane in the content-only kernel)
+    const bool up0 = (lane & 32) != 0, up1 = (lane & 16) != 0, up2 = (lane & 8) != 0;
+    const float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
+    const float b0 = (up0 ? a4 : a0) + __shfl_xor(up0 ? a0 : a4, 32, 64);
+    const float b1 = (up0 ? a5 : a1) + __shfl_xor(up0 ? a1 : a5, 32, 64);
+    const float b2 = (up0 ? a6 : a2) + __shfl_xor(up0 ? a2 : a6, 32, 64);
+    const float b3 = (up0 ? a7 : a3) + __shfl_xor(up0 ? a3 : a7, 32, 64);
+    const float c0 = (up1 ? b2 : b0) + __shfl_xor(up1 ? b0 : b2, 16, 64);
+    const float c1 = (up1 ? b3 : b1) + __shfl_xor(up1 ? b1 : b3, 16, 64);
+    float r = (up2 ? c1 : c0) + __shfl_xor(up2 ? c0 : c1, 8, 64);
     r += lvsr_dpp_quad_xor1(r);
     r += lvsr_dpp_quad_xor2(r);
     r += lvsr_dpp_half_mirror(r);

@@ -22,6 +22,15 @@ for what in "$@"; do
     batches) for b in 10 32 64 128; do timeout 300 python bench.py --steps 8 --warmup 2 --batch $b $B > $O/batch_$b.json 2> $O/batch_$b.err; python -c "import json;d=json.load(open('$O/batch_$b.json'));print('batch $b', d['ms_per_step'], d['value'])"; tail -n 1 $O/batch_$b.err; done;;
     gemm) timeout 400 python tools/probes/gemm_k_sweep.py sustained > $O/gemm_k_sweep.txt 2>&1; tail -n 22 $O/gemm_k_sweep.txt;;
     prof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 $B > $R/$O/prof.log 2>&1; cd $R; ls $O/prof | head; python tools/rocpd_stats.py $O/prof/*/*.db > $O/kernel_stats.md 2>> $O/prof.log || python tools/rocpd_stats.py $O/prof/*.db > $O/kernel_stats.md 2>> $O/prof.log; head -n 30 $O/kernel_stats.md;;
+    pmc) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+         for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY"; do
+           n=$(echo $c | cut -d" " -f1)
+           timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/$O/pmc_$n -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-graph $B > $R/$O/pmc_$n.log 2>&1; echo "pmc $n rc=$?"
+         done
+         cd $R; python tools/pmc_summary.py --json $O/pmc_bench.json --tag wsj_base $(find $O/pmc_* -name "*.db") > $O/pmc_bench_wsj_base.md 2>> $O/pmc_FETCH_SIZE.log; head -n 12 $O/pmc_bench_wsj_base.md | cut -c1-260; python -c "import json;d=json.load(open('$O/pmc_bench.json'));print({k:v for k,v in d.items() if 'enc_p' in k or k=='__stamp__'})";;
+    timeline) python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>&1; head -n 24 $O/timeline.txt;;
+    decode) timeout 900 python bench.py --workload wsj_decode > $O/decode.json 2> $O/decode.err; echo "decode rc=$?"; cut -c1-600 $O/decode.json; tail -n 2 $O/decode.err;;
+    smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log;;
     enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
     knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
     *) echo "unknown item $what";;
