@@ -39,6 +39,10 @@ def engaged(rec):
                                   "tiny_content_embed", "small_conv",
                                   pytest.param("mid_conv_median", marks=pytest.mark.slow)])
 def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
+    # the fallback shape (clusters of ceil(D/32)) runs the cases with more than one work-group per cluster and one one-work-group
+    # case; priors / normalisers / attention types do not depend on the cluster shape (each case costs 1-2 minutes here)
+    if concurrent_lib.get_knob("dec_cluster") == 8 and case not in ("tiny_conv_median", "small_conv"):
+        pytest.skip("cluster-shape independent case: run with the default shape only")
     z, meta = load_golden(case)
     params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
     batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
@@ -67,8 +71,8 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
 # 32 lanes per position in the q contraction (WSJ-deep's decoder shape in miniature)
 @pytest.mark.parametrize("K,M,D", [(5, 12, 8), (7, 10, 36), (3, 7, 36), (3, 40, 264), pytest.param(12, 9, 8, marks=pytest.mark.slow)])
 def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K, M, D):
-    if D > 256 and concurrent_lib.get_knob("dec_cluster") == 8:
-        pytest.skip("one cluster shape above 256 units")
+    if concurrent_lib.get_knob("dec_cluster") == 8 and (K, M, D) != (7, 10, 36):
+        pytest.skip("the fallback cluster shape runs one of these cases (two work-groups per cluster)")
     _, meta = load_golden("tiny_conv_median")
     cfg = dict(meta["cfg"])
     cfg.update(conv_num_filters=K, dim_matcher=M, dim_dec=D)
