@@ -192,15 +192,18 @@ __device__ __forceinline__ int gemm_xcd_order(int L, int total) {
 // one TM x TN output tile (bx, by) of k-chunk / batch member bz.  TM = TN = 128: four waves of 64 x 64 (2 x 2 MFMA 32x32 blocks);
 // TM = TN = 64: four waves of 32 x 32 (one block each) — for outputs of a few hundred 64-tiles that leave most of the chip idle as
 // 128-tiles (the decoder's L*B- and T'*B-row products: 13 x 4 tiles of 128 against 25 x 8 of 64 over 512 resident work-groups)
-// `pout` != nullptr: the raw accumulators of k range [kbeg, kend) go to pout[(m - pm0) * pld + (n - pn0)] (split-K: the chunk's (M, N)
-// plane; stream-K: a 64 x 64 slot of the work-group) instead of through the epilogue into C.
 template <int TM, int TN, bool TA, bool TB, bool FAST>
-__device__ __forceinline__ void sgemm_tile_core(const GemmArgs& g, int bx, int by, int kbeg, int kend, float* pout, long long pld, int pm0, int pn0) {
+__device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
     constexpr int MI = TM / 64, NI = TN / 64;                 // MFMA blocks per wave
     __shared__ __attribute__((aligned(16))) float As[2][GK][TM + 4];
     __shared__ __attribute__((aligned(16))) float Bs[2][GK][TN + 4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (g.batch > 1) {
+        g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
+        bz = 0;
+    }
     const int m0 = by * TM, n0 = bx * TN;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
     const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
     const bool vecA = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0);
     const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
@@ -279,8 +282,8 @@ __device__ __forceinline__ void sgemm_tile_core(const GemmArgs& g, int bx, int b
                 const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int n = n0 + wn + j * 32 + (lane & 31);
                 if (m < g.M && n < g.N) {
-                    if (pout) {
-                        pout[(size_t)(m - pm0) * pld + (n - pn0)] = acc[i][j][r];
+                    if (g.ksplit > 1) {
+                        g.part[((size_t)bz * g.M + m) * g.N + n] = acc[i][j][r];
                     } else {
                         float v = g.alpha * acc[i][j][r];
                         if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
@@ -290,15 +293,6 @@ __device__ __forceinline__ void sgemm_tile_core(const GemmArgs& g, int bx, int b
                 }
             }
 }
-template <int TM, int TN, bool TA, bool TB, bool FAST>
-__device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
-    if (g.batch > 1) {
-        g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
-        bz = 0;
-    }
-    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
-    sgemm_tile_core<TM, TN, TA, TB, FAST>(g, bx, by, kbeg, kend, g.ksplit > 1 ? g.part + (size_t)bz * g.M * g.N : nullptr, g.N, 0, 0);
-}
 template <bool TA, bool TB, bool FAST>
 __device__ __forceinline__ void sgemm128_tile(GemmArgs g, int bx, int by, int bz) { sgemm_tile<128, 128, TA, TB, FAST>(g, bx, by, bz); }
 
@@ -307,59 +301,6 @@ __global__ __launch_bounds__(256) void lvsr_sgemm64_kernel(GemmArgs g) {
     const int total = gridDim.x * gridDim.y * gridDim.z;
     const int t = gemm_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total);
     sgemm_tile<64, 64, TA, TB, FAST>(g, t % gridDim.x, (t / gridDim.x) % gridDim.y, t / (gridDim.x * gridDim.y));
-}
-
-// ---- stream-K over the resident work-group slots (64 x 64 tiles) ---------------------------------------------------------------
-// A product whose tiles fill a fractional number of rounds of the 1 024 resident work-groups (four per CU) leaves the last round
-// partly empty: 12 800 x 512 x 1 536 = 1 600 tiles = 1.56 rounds runs as long as 2.  Here the launch has exactly G work-groups and
-// the tiles' k-iterations (tiles x ceil(K/32) of them) are dealt out evenly: work-group w takes iterations [w I / G, (w+1) I / G) —
-// the tail of one tile, whole tiles, the head of another.  Whole tiles go through the epilogue as usual; the (at most two) partial
-// segments of a work-group are written raw into its two 64 x 64 slots of the workspace, and lvsr_sgemm64_streamk_fixup adds the
-// segments of every shared tile in work-group order (fixed: deterministic) and applies the epilogue.
-__device__ __forceinline__ long long sk_begin(long long w, long long I, int G) { return w * I / G; }
-
-template <bool TA, bool TB, bool FAST>
-__global__ __launch_bounds__(256) void lvsr_sgemm64_streamk_kernel(GemmArgs g, int tiles_x, int tiles, int kiters, float* part) {
-    const int G = gridDim.x;
-    const int w = gemm_xcd_order(blockIdx.x, G);          // consecutive ranges (tiles sharing an operand panel) on one XCD
-    const long long I = (long long)tiles * kiters;
-    const long long it0 = sk_begin(w, I, G), it1 = sk_begin(w + 1, I, G);
-    long long it = it0;
-    while (it < it1) {
-        const int tile = (int)(it / kiters), kb = (int)(it % kiters);
-        const int ke = (int)min((long long)kiters, kb + (it1 - it));
-        const bool full = kb == 0 && ke == kiters;
-        const int bx = tile % tiles_x, by = tile / tiles_x;
-        float* pout = full ? nullptr : part + ((size_t)w * 2 + (it == it0 ? 0 : 1)) * (64 * 64);
-        sgemm_tile_core<64, 64, TA, TB, FAST>(g, bx, by, kb * GK, min(g.K, ke * GK), pout, 64, by * 64, bx * 64);
-        it += ke - kb;
-    }
-}
-
-// one work-group per tile: a tile with a single contributor was written by it; else fold the contributors' slots in order
-__global__ __launch_bounds__(256) void lvsr_sgemm64_streamk_fixup(GemmArgs g, int tiles_x, int tiles, int kiters, int G, const float* part) {
-    const int t = blockIdx.x;
-    const long long I = (long long)tiles * kiters, lo = (long long)t * kiters, hi = lo + kiters;
-    int wf = (int)(lo * G / I), wl = (int)((hi - 1) * G / I);
-    while (wf > 0 && sk_begin(wf, I, G) > lo) --wf;                       // first work-group whose range reaches into the tile
-    while (wf + 1 < G && sk_begin(wf + 1, I, G) <= lo) ++wf;
-    while (wl + 1 < G && sk_begin(wl + 1, I, G) < hi) ++wl;               // last one that starts inside it
-    while (wl > wf && sk_begin(wl, I, G) >= hi) --wl;
-    if (wl == wf) return;
-    const int bx = t % tiles_x, by = t / tiles_x;
-    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
-        const int m = by * 64 + e / 64, n = bx * 64 + e % 64;
-        if (m >= g.M || n >= g.N) continue;
-        float s = 0.f;
-        for (int w = wf; w <= wl; ++w) {
-            const int slot = sk_begin(w, I, G) >= lo ? 0 : 1;             // the segment holds the start of w's range: its first, else its last
-            s += part[((size_t)w * 2 + slot) * (64 * 64) + e];
-        }
-        float v = g.alpha * s;
-        if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
-        if (g.bias) v += g.bias[n];
-        g.C[(size_t)m * g.ldc + n] = v;
-    }
 }
 
 template <bool TA, bool TB, bool FAST>
@@ -569,30 +510,6 @@ static int sgemm_launch(void* stream, int transA, int transB, int M, int N, int 
     }
     dim3 grid((N + tn - 1) / tn, (M + tm - 1) / tm, batch > 1 ? batch : g.ksplit);
     hipStream_t st = (hipStream_t)stream;
-    // stream-K (64-tile products without split-K whose tiles fill a fractional number of rounds of the resident slots): needs a
-    // workspace of 2 slots per work-group (32 MB for the 1 024 of an MI355X)
-    const int kiters = (K + GK - 1) / GK;
-    const int SK_G = 4 * lvsr_max_cluster_wgs();
-    const double rounds = (double)tiles / SK_G;
-    const bool streamk = mid && g.ksplit == 1 && ws && lvsr_knob(LVSR_KNOB_GEMM_STREAMK) != 1 && tiles >= SK_G / 2 &&
-                         (long long)tiles * kiters >= 8LL * SK_G && ws_bytes >= (long long)SK_G * 2 * 64 * 64 * 4 &&
-                         rounds / ceil(rounds) < 0.97;
-    if (streamk) {
-        const bool fast = (lda & 3) == 0 && (ldb & 3) == 0 && (((size_t)A) & 15) == 0 && (((size_t)B) & 15) == 0;
-        const int tiles_x = (N + 63) / 64;
-#define LVSR_GEMM_SK(TA_, TB_)                                                                                                     \
-    do {                                                                                                                            \
-        if (fast) hipLaunchKernelGGL((lvsr_sgemm64_streamk_kernel<TA_, TB_, true>), dim3(SK_G), dim3(256), 0, st, g, tiles_x, tiles, kiters, ws);   \
-        else hipLaunchKernelGGL((lvsr_sgemm64_streamk_kernel<TA_, TB_, false>), dim3(SK_G), dim3(256), 0, st, g, tiles_x, tiles, kiters, ws);       \
-    } while (0)
-        if (!transA && !transB) LVSR_GEMM_SK(false, false);
-        else if (transA && !transB) LVSR_GEMM_SK(true, false);
-        else if (!transA && transB) LVSR_GEMM_SK(false, true);
-        else LVSR_GEMM_SK(true, true);
-#undef LVSR_GEMM_SK
-        hipLaunchKernelGGL(lvsr_sgemm64_streamk_fixup, dim3(tiles), dim3(256), 0, st, g, tiles_x, tiles, kiters, SK_G, ws);
-        return lvsr_check_launch("lvsr_sgemm(stream-K)");
-    }
     if (!big) {
         hipLaunchKernelGGL(lvsr_sgemm_kernel, grid, dim3(256), 0, st, g);
     } else {

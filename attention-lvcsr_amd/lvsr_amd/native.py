@@ -254,20 +254,8 @@ class Lib(object):
         lda = A.stride(0) if lda is None else lda
         ldb = B.stride(0) if ldb is None else ldb
         ldc = C.stride(0) if ldc is None else ldc
-        if ws is None and M * N >= (1 << 21) and C.is_cuda:
-            ws = self._streamk_ws(C)
         self.call("lvsr_sgemm", self.stream_for(C), int(transA), int(transB), M, N, K, alpha, ptr(A), lda, ptr(B), ldb,
                   beta, ptr(C), ldc, ptr(bias), ptr(ws), (ws.numel() * 4 if ws is not None else 0))
-
-    def _streamk_ws(self, ref):
-        """The stream-K slots of lvsr_sgemm (two 64 x 64 partial tiles per resident work-group: 32 MB on an MI355X) for products that
-        come without a workspace: one buffer per (device, stream) — launches of one stream are ordered, streams never share one."""
-        key = (ref.device.index, torch.cuda.current_stream(ref.device).cuda_stream)
-        cache = self.__dict__.setdefault("_sk_ws", {})
-        t = cache.get(key)
-        if t is None:
-            t = cache[key] = torch.empty(8 << 20, dtype=torch.float32, device=ref.device)
-        return t
 
     def colsum(self, X, out, beta=0.0, M=None, N=None, ldx=None, ws=None):
         M = X.shape[0] if M is None else M

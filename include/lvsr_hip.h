@@ -50,15 +50,12 @@ int lvsr_region_end(void* stream, int keep);
 #define LVSR_KNOB_CLUSTER_RESERVE 5   /* CUs left free by cluster launches for other work on the device (default 0) */
 #define LVSR_KNOB_GEMM_MID_TILES 6    /* lvsr_sgemm with K <= 2048 uses 64 x 64 tiles when the output has fewer 128 x 128 tiles than this (0 = 2048; 1 = never) */
 #define LVSR_KNOB_DEC_CLUSTER 7       /* persistent decoder at D <= 256: 0 = clusters of 16 work-groups per utterance when they fit the chip, else 8; 8 / 16 = only that */
-#define LVSR_KNOB_GEMM_STREAMK 8      /* 1 = lvsr_sgemm never deals k-iterations over the resident slots (stream-K); 0 = when a workspace is given and the tiles fill a fractional number of rounds */
-#define LVSR_KNOB_COUNT 9
+#define LVSR_KNOB_COUNT 8
 int lvsr_set_knob(int knob, int value);
 int lvsr_get_knob(int knob);
 
 /* ---- dense helpers (Linear bricks: libs/blocks/blocks/bricks/simple.py:59-76) ------------------ */
-/* C[M,N] = alpha*op(A)[M,K]*op(B)[K,N] + beta*C + bias[N]; fp32 MFMA; ws: optional workspace — split-K partials of the
- * weight-gradient shapes, or (>= 32 MB on an MI355X) the stream-K slots of products whose 64 x 64 tiles fill a fractional number of
- * rounds of the resident work-groups; results do not depend on it bit for bit only up to float32 summation order */
+/* C[M,N] = alpha*op(A)[M,K]*op(B)[K,N] + beta*C + bias[N]; fp32 MFMA; ws: optional split-K workspace */
 int lvsr_sgemm(void* stream, int transA, int transB, int M, int N, int K, float alpha, const float* A, int lda,
                const float* B, int ldb, float beta, float* C, int ldc, const float* bias, float* ws,
                long long ws_bytes);

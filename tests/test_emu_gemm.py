@@ -48,38 +48,6 @@ def test_sgemm128_strided_and_splitk():
     assert_allclose(C.numpy(), (A.double().T @ Bm.double()).numpy(), rtol=1e-4, atol=1e-4)
 
 
-# stream-K (csrc/gemm.hip lvsr_sgemm64_streamk_kernel): the k-iterations of all 64 x 64 tiles dealt out evenly over the resident
-# work-group slots; knob max_cluster_wgs = 2 makes that 8 slots, so that small products take the path: ranges that end inside a tile,
-# span several tiles, lie inside one tile; ragged edges, every layout, aligned (unguarded loads) and misaligned operands
-@pytest.mark.parametrize("transA,transB", [(False, False), (True, False), (False, True), (True, True)])
-@pytest.mark.parametrize("M,N,K,pad", [(200, 130, 200, 0), (256, 192, 256, 0), (130, 200, 330, 3), (192, 128, 2048, 0)])
-def test_sgemm_streamk(transA, transB, M, N, K, pad):
-    lib = emu_lib()
-    rng = numpy.random.RandomState(3)
-    lib.set_knob("max_cluster_wgs", 2)
-    try:
-        Af = torch.tensor(rng.normal(size=((K, M + pad) if transA else (M, K + pad))), dtype=torch.float32)
-        Bf = torch.tensor(rng.normal(size=((N, K + pad) if transB else (K, N + pad))), dtype=torch.float32)
-        A = Af[:, pad:] if pad else Af
-        Bm = Bf[:, pad:] if pad else Bf
-        C0 = torch.tensor(rng.normal(size=(M, N)), dtype=torch.float32)
-        bias = torch.tensor(rng.normal(size=(N,)), dtype=torch.float32)
-        ref = 0.5 * ((A.T if transA else A).double() @ (Bm.T if transB else Bm).double()) + 2.0 * C0.double() + bias.double()
-        out = {}
-        for streamk in (0, 1):
-            lib.set_knob("gemm_streamk", 1 - streamk)
-            C = C0.clone()
-            ws = torch.full((8 * 2 * 64 * 64 + 64,), float("nan"))
-            lib.sgemm(A, Bm, C, transA=transA, transB=transB, alpha=0.5, beta=2.0, bias=bias, ws=ws)
-            assert_allclose(C.numpy(), ref.numpy(), rtol=1e-4, atol=2e-4)          # (float32 accumulation over up to 2048 terms)
-            out[streamk] = (C, bool(torch.isnan(ws).all()))
-        assert not out[1][1], "stream-K did not engage"
-        assert out[0][1] or K >= 1024, "stream-K engaged with the knob off"          # (K >= 1024: plain split-K uses the workspace then)
-    finally:
-        lib.set_knob("max_cluster_wgs", 0)
-        lib.set_knob("gemm_streamk", 0)
-
-
 def test_colsum_and_transpose():
     lib = emu_lib()
     rng = numpy.random.RandomState(2)

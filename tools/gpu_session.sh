@@ -34,7 +34,6 @@ for what in "$@"; do
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          for st in 1 8; do timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decprof$st -o dec -- python $R/tools/bench_decode.py --utts 8 --streams $st > $R/$O/decprof$st.log 2>&1; done
          cd $R; for st in 1 8; do python tools/rocpd_stats.py $(find $O/decprof$st -name "*.db" | head -n 1) > $O/decode_kernel_stats_$st.md 2>&1; tail -n 2 $O/decprof$st.log | cut -c1-400; head -n 34 $O/decode_kernel_stats_$st.md | cut -c1-150; done;;
-    gemmsk) for k in gemm_streamk=1 gemm_streamk=0; do timeout 400 python tools/probes/gemm_k_sweep.py $k > $O/gemm_$k.txt 2>&1; echo "== $k"; grep -E "M= 12800 N= 1536 K=   512|M=  6400 N= 1536|tB=1 M= 12800 N=  512|M= 32768|M= 16384|M=  8192|4096 N= 4096" $O/gemm_$k.txt; done;;
     enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
     knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
     *) echo "unknown item $what";;
