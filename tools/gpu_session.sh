@@ -34,6 +34,7 @@ for what in "$@"; do
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          for st in 1 8; do timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decprof$st -o dec -- python $R/tools/bench_decode.py --utts 8 --streams $st > $R/$O/decprof$st.log 2>&1; done
          cd $R; for st in 1 8; do python tools/rocpd_stats.py $(find $O/decprof$st -name "*.db" | head -n 1) > $O/decode_kernel_stats_$st.md 2>&1; tail -n 2 $O/decprof$st.log | cut -c1-400; head -n 34 $O/decode_kernel_stats_$st.md | cut -c1-150; done;;
+    profb:*) bb=${what#profb:}; cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/profb$bb -o bench -- python $R/bench.py --steps 6 --warmup 2 --batch $bb $B > $R/$O/profb$bb.log 2>&1; cd $R; python tools/rocpd_timeline.py $(find $O/profb$bb -name "*.db" | head -n 1) > $O/timeline_b$bb.txt 2>&1; head -n 12 $O/timeline_b$bb.txt; python tools/rocpd_stats.py $(find $O/profb$bb -name "*.db" | head -n 1) > $O/kernel_stats_b$bb.md 2>&1; head -n 9 $O/kernel_stats_b$bb.md | cut -c1-140;;
     enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
     knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
     *) echo "unknown item $what";;
