@@ -12,6 +12,7 @@
 #define PD_NW (PD_THREADS / 64)
 #define PD_LDS_FLOATS (40 * 1024 - 64)      // of the CU's 160 KB
 #define PD_NPLANE 4          // SW | EN | RS | S
+#define PD_NPLANE_STACK 7    // two-layer launch: + SW1 | RS1 | S1 of the layer-1 cluster
 #define PD_NPROF 16
 #define PD_MAXP 32           // work-groups per cluster at most (XCC_ID granules per utterance)
 

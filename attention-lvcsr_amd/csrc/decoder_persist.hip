@@ -37,7 +37,7 @@
 
 struct PdGeom {
     int P, nown, nownp, KC, KCP, FW, prof, RL, shape;
-    int o_pa, o_a, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, o_sw, Bp, total;
+    int o_pa, o_a, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, o_sw, o_s0, Bp, total;
 };
 
 
@@ -48,14 +48,20 @@ static int pd_kc(int K) {
     return -1;
 }
 
-static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true) {
+// stack: the two-layer launch (lvsr_attdec_fwd_persistent_stack2): clusters of 8 (PdShape8), two of them per utterance
+static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true, bool stack = false) {
     if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
     if (a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
     g.KC = pd_kc(a.K);
     if (g.KC < 0) return false;
     g.KCP = (g.KC + 3) / 4 * 4;
     PdPick k;
-    if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
+    if (stack) {
+        if (a.D > PdShape8::DMAX) return false;
+        k.shape = 0; k.UNITS = PdShape8::UNITS; k.KSPLIT = PdShape8::KSPLIT; k.KD = PdShape8::KD; k.MC = PdShape8::MC; k.AWS = PdShape8::AWS;
+        k.P = (a.D + k.UNITS - 1) / k.UNITS;
+        if (a.M > k.P * k.MC * k.UNITS || a.B * 2 * k.P > lvsr_max_cluster_wgs()) return false;
+    } else if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
     g.P = k.P; g.shape = k.shape;
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
@@ -73,6 +79,7 @@ static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true) {
     take(max(0, g.nownp * g.P + a.c + 4 - a.Tp));      // (... and up to nownp P + c above its start)
     g.o_sv = take(k.KSPLIT * (k.KD + 4));
     g.o_rs = take(k.KSPLIT * (k.KD + 4));
+    g.o_s0 = stack ? take(k.KSPLIT * (k.KD + 4)) : 0;      // (layer-1 cluster of the two-layer launch: the new state of layer 0)
     g.o_xw = take(PD_NW * PD_CH);
     g.o_sw = take(PD_THREADS);
     g.o_red = take(3 * PD_NW);
@@ -82,12 +89,246 @@ static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true) {
     g.o_cp = take(PD_NW * 16 * 17);
     g.total = o;
     g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);         // phase clock of work-group 0 (tools/probe_decoder_persist.py); costs ~1 us per label
-    if (o > PD_LDS_FLOATS && k.shape == 1 && allow16) return pd_geom(a, g, false);      // clusters of 8 instead, if they fit
+    if (o > PD_LDS_FLOATS && k.shape == 1 && allow16 && !stack) return pd_geom(a, g, false);      // clusters of 8 instead, if they fit
     return o <= PD_LDS_FLOATS;
 }
 
-template <int KC, class SH>
-__global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_attdec_plain w, PdGeom g, u64* planes, int* abort_word) {
+typedef lvsr_attdec_stack2 PdStack;
+
+// The layer-1 cluster of the two-layer launch (see lvsr_attdec_fwd_persistent_stack2 in lvsr_hip.h).  Work-group p of it owns units
+// [UNITS p, UNITS p + UNITS) of layer 1; thread (unit, q) keeps its row slice of the layer's three recurrent columns, of the three
+// fork_1 columns (input: the NEW state of layer 0) and of MC transform_states#1 columns.  Per label: own-state gate sums -> the
+// label's energies (plane EN of the main cluster) -> softmax (repeated here: cheaper than a hop) -> glimpse part of the gate inputs
+// from the AW1 slice in LDS -> new state of layer 0 (plane S of the main cluster) -> fork_1 sums -> r*s exchange -> candidate ->
+// new state (plane S1) -> its transformed part for the NEXT label's energies (plane SW1, which the main cluster adds to its own).
+template <class SH>
+__device__ __forceinline__ void pd_stack_layer1(const AttDec& a, const PdGeom& g, const PdStack& k2, float* lds, u64* planes, int* abort_word,
+                                                int b, int p) {
+    constexpr int PD_UNITS = SH::UNITS, PD_KSPLIT = SH::KSPLIT, PD_KD = SH::KD, PD_MC = SH::MC, PD_AWS = SH::AWS;
+    float* const sv0 = lds + g.o_s0;      // new state of layer 0, sliced
+    float* const AWs = lds + g.o_a;       // [T'][PD_AWS] own gate columns of AW1
+    float* const al = lds + g.o_al;
+    float* const sv = lds + g.o_sv;       // own state (layer 1), sliced
+    float* const rsv = lds + g.o_rs;
+    float* const red = lds + g.o_red;
+    float* const posv = lds + g.o_pos;
+    const int P = g.P;
+    const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L;
+    const int SLD = a.S_ld ? a.S_ld : 2 * D, FLD = k2.F1_ld ? k2.F1_ld : 3 * D;
+    const int j = p * PD_UNITS + jl;
+    const bool junit = j < D;
+    f32x2 wsw[PD_MC][PD_KD / 2], whu[PD_KD / 2], whr[PD_KD / 2], whc[PD_KD / 2], wfx[PD_KD / 2], wfu[PD_KD / 2], wfr[PD_KD / 2];
+    {
+        const size_t jc = (size_t)min(j, D - 1);
+#pragma unroll
+        for (int x = 0; x < PD_KD / 2; ++x) {
+            float v[6][2], s2[PD_MC][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = q * PD_KD + 2 * x + e;
+                const size_t kc = (size_t)min(k, D - 1);
+                const float keep = (junit && k < D) ? 1.f : 0.f;
+                v[0][e] = k2.Whg1[kc * 2 * D + jc] * keep;
+                v[1][e] = k2.Whg1[kc * 2 * D + D + jc] * keep;
+                v[2][e] = k2.Whh1[kc * D + jc] * keep;
+                v[3][e] = k2.F1[kc * FLD + jc] * keep;
+                v[4][e] = k2.F1[kc * FLD + D + jc] * keep;
+                v[5][e] = k2.F1[kc * FLD + 2 * D + jc] * keep;
+#pragma unroll
+                for (int c = 0; c < PD_MC; ++c) {
+                    const int m = (p * PD_MC + c) * PD_UNITS + jl;
+                    s2[c][e] = k2.Ws1[kc * M + (size_t)min(m, M - 1)] * ((m < M && k < D) ? 1.f : 0.f);
+                }
+            }
+            whu[x] = (f32x2){v[0][0], v[0][1]}; whr[x] = (f32x2){v[1][0], v[1][1]}; whc[x] = (f32x2){v[2][0], v[2][1]};
+            wfx[x] = (f32x2){v[3][0], v[3][1]}; wfu[x] = (f32x2){v[4][0], v[4][1]}; wfr[x] = (f32x2){v[5][0], v[5][1]};
+#pragma unroll
+            for (int c = 0; c < PD_MC; ++c) wsw[c][x] = (f32x2){s2[c][0], s2[c][1]};
+        }
+    }
+    const float am = tid < Tp ? a.Am[(size_t)tid * a.Am_ts + (size_t)b * a.Am_bs] : 0.f;
+    const float eb = a.e_bias ? a.e_bias[0] : 0.f;
+    for (int x = tid; x < g.total - g.o_cv; x += PD_THREADS) lds[g.o_cv + x] = 0.f;
+    const int AWL = k2.AW1_ld ? k2.AW1_ld : 3 * D;
+    for (int x = tid; x < Tp * 3 * PD_UNITS; x += PD_THREADS) {
+        const int t = x / (3 * PD_UNITS), gcol = x % (3 * PD_UNITS), gate = gcol / PD_UNITS, unit = p * PD_UNITS + gcol % PD_UNITS;
+        AWs[t * PD_AWS + gcol] = unit < D ? k2.AW1[((size_t)t * B + b) * AWL + (size_t)gate * D + unit] : 0.f;
+    }
+    __syncthreads();
+    for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[(size_t)b * Tp + t];
+    for (int k = tid; k < D; k += PD_THREADS) sv[pd_slot(k, PD_KD)] = a.S[(size_t)b * SLD + D + k];
+    float sj = junit ? a.S[(size_t)b * SLD + D + j] : 0.f;
+    u64* const base = planes + (size_t)b * PD_NPLANE_STACK * PD_MAXV;
+    u64* const gEN = base + PD_MAXV;
+    u64* const gS0 = base + 3 * PD_MAXV;
+    u64* const gSW1 = base + 4 * PD_MAXV;
+    u64* const gRS1 = base + 5 * PD_MAXV;
+    u64* const gS1 = base + 6 * PD_MAXV;
+    u64* const gPOS = planes + (size_t)B * PD_NPLANE_STACK * PD_MAXV;
+    const bool plain = cluster_shares_xcd(gPOS + 2 * g.Bp + (size_t)b * PD_MAXP, 2 * P, P + p, abort_word);
+    const bool winprior = K > 0 && a.prior_type != 0;
+    __syncthreads();
+    bool pos_given = false;
+    if (winprior && (a.phases & 4)) {
+        for (int x = tid; x < B; x += PD_THREADS) posv[x] = a.pos[x];
+        pos_given = true;
+        __syncthreads();
+    }
+    // transformed part of the initial state: what the main cluster's first energies wait for
+    {
+        float sw[PD_MC];
+#pragma unroll
+        for (int c = 0; c < PD_MC; ++c) sw[c] = pd_dot<PD_KD, PD_KSPLIT>(wsw[c], sv, q);
+        if (q < PD_MC) {
+            const int m = (p * PD_MC + q) * PD_UNITS + jl;
+            float mine = sw[0];
+#pragma unroll
+            for (int c = 1; c < PD_MC; ++c) mine = q == c ? sw[c] : mine;
+            if (m < M) granule_store(gSW1 + m, 1u, mine, plain);
+        }
+    }
+    for (int i = 0; i < L; ++i) {
+        const unsigned epoch = (unsigned)(i + 1);
+        const size_t row = (size_t)i * B + b;
+        const int tid = lvsr_unhoisted((int)threadIdx.x), q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
+        const int j = p * PD_UNITS + jl;
+        const bool junit = j < D;
+        const float* xr = k2.xg1 + row * 3 * D;
+        const float fx = junit ? xr[j] : 0.f, fu = junit ? xr[D + j] : 0.f, fr = junit ? xr[2 * D + j] : 0.f;
+        const float ym = a.ymask ? a.ymask[row] : 1.f;
+        const float gu = pd_dot<PD_KD, PD_KSPLIT>(whu, sv, q), gr = pd_dot<PD_KD, PD_KSPLIT>(whr, sv, q);
+        if (winprior && !(i == 0 && pos_given)) {
+            float v[PD_NV];
+            if (!pd_gather(gPOS + (i & 1) * g.Bp, B, epoch, abort_word, v)) return;
+#pragma unroll
+            for (int x = 0; x < PD_NV; ++x)
+                if (tid + x * PD_THREADS < B) posv[(i & 1) * g.Bp + tid + x * PD_THREADS] = v[x];
+            __syncthreads();
+        }
+        const Win wi = winprior ? pd_window(a, i, posv + (i & 1) * g.Bp) : attdec_window(a, i);
+        float amk = am;
+        if (winprior) {
+            const float pb = posv[(i & 1) * g.Bp + b];
+            const float lo = floorf(pb - (float)a.p0), hi = ceilf(pb + (float)a.p1), tf = (float)tid;
+            amk *= (tf > lo && tf < hi) ? 1.f : 0.f;
+        }
+        // ---- the label's alignment: the main cluster's energies, normalised here as there (decoder_persist.hip phase C)
+        float eg[PD_NV];
+        if (!pd_gather(gEN, Tp, epoch, abort_word, eg)) return;
+        {
+            const int t = tid;
+            const bool inw = t < Tp && t >= wi.begin && t < wi.end;
+            const float e = inw ? eg[0] + eb : 0.f;
+            const float wmx = wave_max_dpp(inw ? e : -3.0e38f);
+            const float wany = wave_max_dpp((inw && 1.f - amk == 0.f) ? 1.f : 0.f);
+            if (lane == 0) { red[wave] = wmx; red[PD_NW + wave] = wany; }
+            __syncthreads();
+            float mx = red[0], anyone = red[PD_NW];
+#pragma unroll
+            for (int x = 1; x < PD_NW; ++x) { mx = fmaxf(mx, red[x]); anyone = fmaxf(anyone, red[PD_NW + x]); }
+            float u = 0.f;
+            if (inw) {
+                if (a.normalizer == 0) u = __expf(e - mx) * amk;
+                else if (a.normalizer == 1) u = sigmoidf_(e) * amk;
+                else u = fmaxf(e / 1000.f, 0.f) * amk;
+            }
+            const float wsm = wave_sum_dpp(u);
+            if (lane == 0) red[2 * PD_NW + wave] = wsm;
+            __syncthreads();
+            float ssum = 0.f;
+#pragma unroll
+            for (int x = 0; x < PD_NW; ++x) ssum += red[2 * PD_NW + x];
+            const float Z = ssum + (anyone > 0.f ? 0.f : 1.f);
+            if (t < Tp) al[t] = inw ? u / Z : 0.f;
+        }
+        __syncthreads();
+        // ---- glimpse part of the gate inputs: sum_t alpha_t AW1[t] over the window (as phase D of the main kernel)
+        float gx, gu2, gr2;
+        {
+            float x0 = 0.f, x1 = 0.f, u0 = 0.f, u1 = 0.f, r0 = 0.f, r1 = 0.f;
+            for (int t0 = wi.begin + q; t0 < wi.end; t0 += 4 * PD_KSPLIT) {
+                float av[4], vx[4], vu[4], vr[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int tt = t0 + e * PD_KSPLIT, tc = min(tt, Tp - 1);
+                    const float araw = al[tc];
+                    av[e] = tt < wi.end ? araw : 0.f;
+                    const float* rowp = AWs + tc * PD_AWS + jl;
+                    vx[e] = rowp[0]; vu[e] = rowp[PD_UNITS]; vr[e] = rowp[2 * PD_UNITS];
+                }
+                x0 += av[0] * vx[0]; u0 += av[0] * vu[0]; r0 += av[0] * vr[0];
+                x1 += av[1] * vx[1]; u1 += av[1] * vu[1]; r1 += av[1] * vr[1];
+                x0 += av[2] * vx[2]; u0 += av[2] * vu[2]; r0 += av[2] * vr[2];
+                x1 += av[3] * vx[3]; u1 += av[3] * vu[3]; r1 += av[3] * vr[3];
+            }
+            gr2 = group_sum<PD_KSPLIT>(r0 + r1);
+            gx = group_sum<PD_KSPLIT>(x0 + x1); gu2 = group_sum<PD_KSPLIT>(u0 + u1);
+        }
+        // ---- fork_1 of the new state of layer 0
+        {
+            float v[PD_NV];
+            if (!pd_gather(gS0, D, epoch, abort_word, v)) return;
+#pragma unroll
+            for (int x = 0; x < PD_NV; ++x)
+                if (tid + x * PD_THREADS < D) sv0[pd_slot(tid + x * PD_THREADS, PD_KD)] = v[x];
+        }
+        __syncthreads();
+        const float ar = pd_dot<PD_KD, PD_KSPLIT>(wfr, sv0, q);
+        const float rr = sigmoid_fast(fr + gr + gr2 + ar);
+        const float rs = junit ? rr * sj : 0.f;
+        if (q == 0 && junit) {
+            granule_store(gRS1 + j, epoch, rs, plain);
+            k2.R1[row * D + j] = rr;
+            k2.RH1[row * D + j] = rs;
+        }
+        const float uu = sigmoid_fast(fu + gu + gu2 + pd_dot<PD_KD, PD_KSPLIT>(wfu, sv0, q));
+        const float xin = fx + gx + pd_dot<PD_KD, PD_KSPLIT>(wfx, sv0, q);
+        if (q == 0 && junit) k2.U1[row * D + j] = uu;
+        {
+            float v[PD_NV];
+            if (!pd_gather(gRS1, D, epoch, abort_word, v)) return;
+#pragma unroll
+            for (int x = 0; x < PD_NV; ++x)
+                if (tid + x * PD_THREADS < D) rsv[pd_slot(tid + x * PD_THREADS, PD_KD)] = v[x];
+        }
+        __syncthreads();
+        const float cand = tanh_fast(xin + pd_dot<PD_KD, PD_KSPLIT>(whc, rsv, q));
+        float sn = cand * uu + sj * (1.f - uu);
+        sn = ym * sn + (1.f - ym) * sj;
+        if (!junit) sn = 0.f;
+        if (q == 0 && junit) {
+            if (i + 1 < L) granule_store(gS1 + j, epoch, sn, plain);
+            k2.C1[row * D + j] = cand;
+            a.S[((size_t)(i + 1) * B + b) * SLD + D + j] = sn;
+        }
+        sj = sn;
+        if (i + 1 < L) {
+            // the whole new state of this layer: operand of the next label's gate sums, and of the transformed part the main
+            // cluster's next energies wait for
+            float v[PD_NV];
+            if (!pd_gather(gS1, D, epoch, abort_word, v)) return;
+#pragma unroll
+            for (int x = 0; x < PD_NV; ++x)
+                if (tid + x * PD_THREADS < D) sv[pd_slot(tid + x * PD_THREADS, PD_KD)] = v[x];
+            __syncthreads();
+            float sw[PD_MC];
+#pragma unroll
+            for (int c = 0; c < PD_MC; ++c) sw[c] = pd_dot<PD_KD, PD_KSPLIT>(wsw[c], sv, q);
+            if (q < PD_MC) {
+                const int m = (p * PD_MC + q) * PD_UNITS + jl;
+                float mine = sw[0];
+#pragma unroll
+                for (int c = 1; c < PD_MC; ++c) mine = q == c ? sw[c] : mine;
+                if (m < M) granule_store(gSW1 + m, epoch + 1u, mine, plain);
+            }
+        }
+    }
+}
+
+template <int KC, class SH, bool STACK = false>
+__global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_attdec_plain w, PdGeom g, u64* planes, int* abort_word, PdStack k2) {
     constexpr int KCP = (KC + 3) / 4 * 4;
     constexpr int PD_UNITS = SH::UNITS, PD_KSPLIT = SH::KSPLIT, PD_KD = SH::KD, PD_MC = SH::MC, PD_AWS = SH::AWS;
     __shared__ __attribute__((aligned(16))) float lds[PD_LDS_FLOATS];
@@ -104,10 +345,15 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     float* const cp = lds + g.o_cp;       // [PD_NW][16][17] convolution partial tiles
     const int P = g.P, nown = g.nown;
     int b, p;
-    if (!cluster_of_block(P, a.B, 0, b, p)) return;                  // (work-groups of the grid's padding)
+    if (!cluster_of_block(STACK ? 2 * P : P, a.B, 0, b, p)) return;  // (work-groups of the grid's padding)
+    if (STACK && p >= P) {            // the second cluster of the utterance: layer 1 of the stack
+        pd_stack_layer1<SH>(a, g, k2, lds, planes, abort_word, b, p - P);
+        return;
+    }
     const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // wave-uniform: conditions on it become scalar branches
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L;
+    const int SLD = a.S_ld ? a.S_ld : D;          // row stride of the state slots (two-layer launch: 2 D, this layer in front)
     const int j = p * PD_UNITS + jl;
     const bool junit = j < D;
     // ---- weights of this thread, in registers for the whole sequence (clamped addresses, zeroed afterwards: straight-line loads)
@@ -195,16 +441,18 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     }
     __syncthreads();
     for (int t = tid; t < Tp; t += PD_THREADS) al[t] = a.W[(size_t)b * Tp + t];
-    for (int k = tid; k < D; k += PD_THREADS) sv[pd_slot(k, PD_KD)] = a.S[(size_t)b * D + k];
-    float sj = junit ? a.S[(size_t)b * D + j] : 0.f;
-    u64* const gSW = planes + (size_t)b * PD_NPLANE * PD_MAXV;
+    for (int k = tid; k < D; k += PD_THREADS) sv[pd_slot(k, PD_KD)] = a.S[(size_t)b * SLD + k];
+    float sj = junit ? a.S[(size_t)b * SLD + j] : 0.f;
+    constexpr int NPL = STACK ? PD_NPLANE_STACK : PD_NPLANE;
+    u64* const gSW = planes + (size_t)b * NPL * PD_MAXV;
     u64* const gEN = gSW + PD_MAXV;
     u64* const gRS = gSW + 2 * PD_MAXV;
     u64* const gS = gSW + 3 * PD_MAXV;
-    u64* const gPOS = planes + (size_t)B * PD_NPLANE * PD_MAXV;      // [2][Bp], shared by all clusters
+    u64* const gSW1 = gSW + 4 * PD_MAXV;                             // (two-layer launch) layer 1's part of the transformed state
+    u64* const gPOS = planes + (size_t)B * NPL * PD_MAXV;            // [2][Bp], shared by all clusters
     // plain stores for the exchanges INSIDE the cluster when its work-groups share an XCD (persist.h); the window centres travel
     // between clusters and stay write-through.  The XCC_ID granules: PD_MAXP per utterance behind the window centres.
-    const bool plain = cluster_shares_xcd(gPOS + 2 * g.Bp + (size_t)b * PD_MAXP, P, p, abort_word);
+    const bool plain = cluster_shares_xcd(gPOS + 2 * g.Bp + (size_t)b * PD_MAXP, STACK ? 2 * P : P, p, abort_word);
     const bool winprior = K > 0 && a.prior_type != 0;
     const bool pos_wave = p == P - 1 && wave == PD_NW - 1;           // the wave that derives this utterance's window centre
     __syncthreads();
@@ -322,7 +570,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
                 for (int c = 1; c < PD_MC; ++c) mine = q == c ? sw[c] : mine;
                 if (m < M) {
                     granule_store(gSW + m, epoch, mine, plain);
-                    a.sW[row * M + m] = mine;
+                    if (!STACK) a.sW[row * M + m] = mine;
                 }
             }
         }
@@ -360,6 +608,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         if (!pd_gather(gSW, M, epoch, abort_word, swv)) return;
         // thread tid received granule tid; the energy phase wants columns mp and mp + 256 in one thread: through LDS.  The
         // barrier also publishes the convolution features
+        if (STACK) {          // + the layer-1 cluster's part (from that layer's state before this label); saved: the total
+            float sw1[PD_NV];
+            if (!pd_gather(gSW1, M, epoch, abort_word, sw1)) return;
+            swv[0] += sw1[0];
+            if (p == 0 && tid < M) a.sW[row * M + tid] = swv[0];
+        }
         swst[tid] = swv[0];
         __syncthreads();
         clk.mark(2);
@@ -564,9 +818,9 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
         sn = ym * sn + (1.f - ym) * sj;
         if (!junit) sn = 0.f;
         if (q == 0 && junit) {
-            if (i + 1 < L) granule_store(gS + j, epoch, sn, plain);
+            if (STACK || i + 1 < L) granule_store(gS + j, epoch, sn, plain);          // (the layer-1 cluster needs the last one too)
             a.C[row * D + j] = cand;
-            a.S[((size_t)(i + 1) * B + b) * D + j] = sn;
+            a.S[((size_t)(i + 1) * B + b) * SLD + j] = sn;
         }
         sj = sn;
         clk.mark(11);
@@ -654,7 +908,7 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     auto enqueue = [&]() {
         (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
         const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
-#define PD_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pfwd_kernel<KCV, SHAPE>), grid, block, 0, s, a, w, g, planes, ab)
+#define PD_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pfwd_kernel<KCV, SHAPE, false>), grid, block, 0, s, a, w, g, planes, ab, PdStack())
 #define PD_LAUNCH_KC(SHAPE)                       \
         switch (g.KC) {                           \
             case 0: PD_LAUNCH(0, SHAPE); break;   \
@@ -675,4 +929,50 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     key.add(&g.prof, sizeof(g.prof));
     key.add(&g.shape, sizeof(g.shape));
     return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd_persistent");
+}
+
+extern "C" long long lvsr_attdec_stack2_persist_ws_bytes(const lvsr_attdec_args* args) {
+    if (args == nullptr) return 0;
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    PdGeom g;
+    if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pd_geom(a, g, false, true)) return 0;
+    return 256 + ((long long)a.B * PD_NPLANE_STACK * PD_MAXV + 2 * g.Bp + (long long)a.B * PD_MAXP) * 8;
+}
+
+extern "C" int lvsr_attdec_fwd_persistent_stack2(void* stream, const lvsr_attdec_args* args, const lvsr_attdec_plain* plain,
+                                                 const lvsr_attdec_stack2* l1, void* ws, int use_graph) {
+    LVSR_REQUIRE(args != nullptr && plain != nullptr && l1 != nullptr && ws != nullptr, "lvsr_attdec_fwd_persistent_stack2: null argument");
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    if (int rc = attdec_check(a, "lvsr_attdec_fwd_persistent_stack2")) return rc;
+    LVSR_REQUIRE(a.label0 == 0 && a.S_ld >= 2 * a.D, "lvsr_attdec_fwd_persistent_stack2: runs all labels; the state slots hold both layers side by side (S_ld >= 2 D)");
+    PdGeom g;
+    LVSR_REQUIRE(pd_geom(a, g, false, true), "lvsr_attdec_fwd_persistent_stack2: configuration outside the kernel's limits "
+                 "(lvsr_attdec_stack2_persist_ws_bytes returns 0 for it)");
+    LVSR_REQUIRE(plain->Ws && plain->Whg && plain->Whh && plain->AW, "lvsr_attdec_fwd_persistent_stack2: plain weights of layer 0 missing");
+    LVSR_REQUIRE(l1->Whg1 && l1->Whh1 && l1->Ws1 && l1->F1 && l1->AW1 && l1->xg1 && l1->U1 && l1->R1 && l1->C1 && l1->RH1,
+                 "lvsr_attdec_fwd_persistent_stack2: layer-1 block incomplete");
+    const lvsr_attdec_plain w = *plain;
+    const PdStack k2 = *l1;
+    hipStream_t s = (hipStream_t)stream;
+    int* ab = (int*)ws;
+    u64* planes = (u64*)((char*)ws + 256);
+    const size_t bytes = ((size_t)a.B * PD_NPLANE_STACK * PD_MAXV + 2 * g.Bp + (size_t)a.B * PD_MAXP) * 8;
+    auto enqueue = [&]() {
+        (void)hipMemsetAsync(planes, 0, bytes, s);
+        const dim3 grid(cluster_grid(a.B, 2 * g.P, 0)), block(PD_THREADS);
+        switch (g.KC) {
+            case 0: hipLaunchKernelGGL((attdec_pfwd_kernel<0, PdShape8, true>), grid, block, 0, s, a, w, g, planes, ab, k2); break;
+            case 4: hipLaunchKernelGGL((attdec_pfwd_kernel<4, PdShape8, true>), grid, block, 0, s, a, w, g, planes, ab, k2); break;
+            case 10: hipLaunchKernelGGL((attdec_pfwd_kernel<10, PdShape8, true>), grid, block, 0, s, a, w, g, planes, ab, k2); break;
+            default: hipLaunchKernelGGL((attdec_pfwd_kernel<16, PdShape8, true>), grid, block, 0, s, a, w, g, planes, ab, k2); break;
+        }
+    };
+    GraphKey key("attdec_pfwd_stack2");
+    key.add(&a, sizeof(a));
+    key.add(&w, sizeof(w));
+    key.add(&k2, sizeof(k2));
+    key.add(&ws, sizeof(ws));
+    return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd_persistent_stack2");
 }

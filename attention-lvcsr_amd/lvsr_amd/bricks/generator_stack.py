@@ -35,6 +35,9 @@ class StackedSequenceGenerator(SequenceGenerator):
     def __init__(self, dims, store, lib, workspace, use_graph=True, use_persistent=None):
         super(StackedSequenceGenerator, self).__init__(dims, store, lib, workspace, use_graph=use_graph, use_persistent=False)
         assert dims.n_dec > 1
+        # the teacher-forced label loop of a TWO-layer stack as one persistent launch (csrc/decoder_persist.hip, two clusters per
+        # utterance): None = when the configuration fits, True / False = forced on / off.  The reverse walk stays on the step kernels.
+        self.use_persistent_stack = use_persistent
         self.nl = [decoder_layer_names(dims, l) for l in range(dims.n_dec)]
         for k in _LAYER_KEYS:          # the one-layer names do not exist here: nothing may fall back to them
             self.n.pop(k, None)
@@ -220,9 +223,54 @@ class StackedSequenceGenerator(SequenceGenerator):
         if d.conv:
             W[0, :, 0] = 1.0
         stream = lib.stream_for(S)
-        for i in range(L):
-            self._run_step(blk, i, stream)
+        if not self._forward_persistent_stack2(blk, att_bufs, A, PA, Am, L, B, Tp, stream):
+            for i in range(L):
+                self._run_step(blk, i, stream)
         return dict(bufs=att_bufs, saved=dict(blk=blk, fb=fb))
+
+    def _forward_persistent_stack2(self, blk, att_bufs, A, PA, Am, L, B, Tp, stream):
+        """The label loop of a two-layer stack as ONE persistent launch (lvsr_attdec_fwd_persistent_stack2: per utterance a cluster
+        for the attention + layer 0 and one for layer 1), writing everything the step-kernel reverse walk reads: state slots of
+        both layers, alignments, energies, transformed states, convolution features, the gates of both layers; the glimpses and
+        layer 1's distribution input [glimpse | new state of layer 0] are filled in behind it.  -> False when it does not apply."""
+        d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
+        if d.n_dec != 2 or self.use_persistent_stack is False or (lib.is_emulator and not lib.emulates_concurrency()):
+            if self.use_persistent_stack:
+                raise ValueError("persistent stacked decoder requested but not available (two layers, concurrent work-groups)")
+            return False
+        D, E = d.D, d.E
+        l0, l1 = blk["layers"]
+        n0, n1 = self.nl
+        kind, pp = self._prior()
+        f = dict(Tp=Tp, B=B, L=L, E=E, D=D, M=d.M, K=d.K, c=d.c, prior_type=kind, step0=0, phases=3, p0=pp[0], p1=pp[1], p2=pp[2],
+                 p3=pp[3], A=A, PA=PA, Am=Am, w_e=p[self.n["we"]], normalizer=NORMALIZER_KIND[d.normalizer],
+                 e_bias=p[self.n["eb"]] if d.energy_bias else None, filters=p[self.n["filters"]] if d.conv else None,
+                 handler=p[self.n["handler"]] if d.conv else None, S_ld=d.D_tot)
+        f.update(self._strides(B, False))
+        f.update({k: v for k, v in att_bufs.items() if k != "ep"})
+        f.update(xg=l0["bufs"]["xg"], ymask=l0["bufs"]["ymask"], U=l0["bufs"]["U"], R=l0["bufs"]["R"], C=l0["bufs"]["C"], RH=l0["bufs"]["RH"])
+        args = lib.make("lvsr_attdec_args", **f)
+        nbytes = int(lib._lvsr_attdec_stack2_persist_ws_bytes(ctypes.byref(args)))
+        if nbytes == 0:
+            if self.use_persistent_stack:
+                raise ValueError("persistent stacked decoder requested but the configuration is outside the kernel's limits")
+            return False
+        sync = ws.get("gen.sync", ((nbytes + 3) // 4,), torch.int32)
+        cats = self._cats()
+        wd0, wd1 = ws.get("gen.Wd_cat0", (E, 3 * D)), ws.get("gen.Wd_cat1", (E + D, 3 * D))
+        AW0, AW1 = ws.get("gen.AW0", (Tp * B, 3 * D)), ws.get("gen.AW1", (Tp * B, 3 * D))
+        A2 = A.view(Tp * B, E)
+        lib.sgemm(A2, wd0, AW0)
+        lib.sgemm(A2, wd1[:E], AW1)
+        plain = lib.make("lvsr_attdec_plain", Ws=p[n0["Ws"]], Whg=p[n0["Whg"]], Whh=p[n0["Whh"]], AW=AW0, AW_ld=0)
+        b1 = l1["bufs"]
+        st2 = lib.make("lvsr_attdec_stack2", Whg1=p[n1["Whg"]], Whh1=p[n1["Whh"]], Ws1=p[n1["Ws"]], F1=wd1[E:], AW1=AW1, xg1=b1["xg"],
+                       U1=b1["U"], R1=b1["R"], C1=b1["C"], RH1=b1["RH"], F1_ld=0, AW1_ld=0)
+        lib.call("lvsr_attdec_fwd_persistent_stack2", stream, ctypes.byref(args), ctypes.byref(plain), ctypes.byref(st2), lib_ptr(sync), 0)
+        lib.call("lvsr_attdec_glimpses", stream, ctypes.byref(args))
+        WA1 = b1["WA"].view(L * B, E + D)
+        lib.copy_many([(att_bufs["WA"].view(L * B, E), WA1[:, :E]), (att_bufs["S"][1:].reshape(L * B, d.D_tot)[:, :D], WA1[:, E:])])
+        return True
 
     def _backward_recurrent(self, sv, dWA_r, dS_r, gws):
         d, p, g, lib, ws = self.d, self.store.p, self.store.g, self.lib, self.ws

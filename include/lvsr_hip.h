@@ -228,6 +228,25 @@ typedef struct lvsr_attdec_plain {
 } lvsr_attdec_plain;
 long long lvsr_attdec_persist_ws_bytes(const lvsr_attdec_args* a);
 int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* a, const lvsr_attdec_plain* w, void* ws, int use_graph);
+/* The label loop of a TWO-layer stacked decoder (RecurrentStack with skip connections, lvsr/bricks/recognizer.py:250-262;
+ * libs/blocks/blocks/bricks/recurrent.py:677-950) as one persistent launch: per utterance one cluster of 8 work-groups runs the
+ * attention and layer 0 exactly as lvsr_attdec_fwd_persistent does, a second cluster of 8 runs layer 1 — glimpse part of its gate
+ * inputs from AW1 and the alignment (it repeats the softmax), fork of the NEW state of layer 0, its own recurrence — and hands the
+ * layer-1 part of the transformed state (s1 . transform_states#1) back for the next label's energies.  `a` / `w`: the block of
+ * layer 0 (D = width of ONE layer; S = (L+1, B, 2D) slots with S_ld = 2D, layer l in columns [l D, (l+1) D); xg, U, R, C, RH, the
+ * plain weights and AW of layer 0); sW receives the transformed state of BOTH layers.  WA: lvsr_attdec_glimpses afterwards. */
+typedef struct lvsr_attdec_stack2 {
+    const float* Whg1; const float* Whh1; /* transition#1 state_to_gates (D,2D), state_to_state (D,D) */
+    const float* Ws1;                     /* state_trans/transform_states#1.W (D,M) */
+    const float* F1;                      /* recurrentstack/fork_1: [fork_inputs.W | fork_gate_inputs.W] (D,3D), row stride F1_ld */
+    const float* AW1;                     /* (T',B,3D) attended @ [distribute/fork_inputs#1.W | fork_gate_inputs#1.W], row stride AW1_ld */
+    const float* xg1;                     /* (L,B,3D) fork#1(feedback) incl. biases */
+    float* U1; float* R1; float* C1; float* RH1;      /* (L,B,D) saved for the backward pass */
+    int F1_ld, AW1_ld;                    /* 0 = 3D */
+} lvsr_attdec_stack2;
+long long lvsr_attdec_stack2_persist_ws_bytes(const lvsr_attdec_args* a);      /* 0 = not available (then: the step kernels) */
+int lvsr_attdec_fwd_persistent_stack2(void* stream, const lvsr_attdec_args* a, const lvsr_attdec_plain* w,
+                                      const lvsr_attdec_stack2* l1, void* ws, int use_graph);
 /* WA[l,b,:] = sum_t W[l+1,b,t] * A[t,b,:] for l in [0,L) (compute_weighted_averages, libs/blocks/blocks/bricks/attention.py:236-256) */
 int lvsr_attdec_glimpses(void* stream, const lvsr_attdec_args* a);
 

@@ -85,3 +85,25 @@ def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K,
     assert engaged(rec) and any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs), "persistent decoder (forward and backward) did not engage"
     rec.generator.check_persistent()
     check_against(rec, cm, None, out, grads)
+
+
+# dec_stack = 2: the label loop of the two-layer stack as one persistent launch (lvsr_attdec_fwd_persistent_stack2: a cluster for
+# the attention + layer 0 and one for layer 1 per utterance); the reverse walk stays on the step kernels.  Costs, alignments and
+# every gradient against the reference's goldens / the float64 oracle.
+@pytest.mark.parametrize("case", ["tiny_conv_stack2", "small_conv_stack2"])
+def test_persistent_two_layer_stack_against_oracle_and_golden(case):
+    lib = emu_lib()
+    lib._dll.hipemu_set_concurrent(1)
+    try:
+        z, meta = load_golden(case)
+        params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+        batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+        orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float64)
+        out, grads = orc.cost_and_grads(batch)
+        rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=meta["cfg"], use_persistent_decoder=True)
+        cm = rec.cost_and_gradients(batch)
+        assert engaged(rec), "persistent stacked decoder did not engage"
+        rec.generator.check_persistent()
+        check_against(rec, cm, z, out, grads)
+    finally:
+        lib._dll.hipemu_set_concurrent(0)
