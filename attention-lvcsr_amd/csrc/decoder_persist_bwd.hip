@@ -32,6 +32,10 @@ typedef lvsr_attdec_bwd_args AttBwd;
 // D (dsW partials: 512) | E (state-gradient contributions: 512) | F (alignment-gradient partials: 512)
 #define PB_SMALL (4 * PD_MAXV + 64)
 #define PB_PERWG (3 * 512)
+// two-layer launch (lvsr_attdec_bwd_persistent_stack2): + A1 (512) | B1 (2 x 512) | X0 (512: fork_1 part of layer 0's state gradient)
+// | Q1 (512: layer 1's share of the glimpse gradient) behind the small planes, and a fourth per-work-group plane E1
+#define PB_STACK_EXTRA (5 * PD_MAXV)
+#define PB_PERWG_STACK (4 * 512)
 
 struct PbGeom {
     int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL;
@@ -45,21 +49,26 @@ static int pb_kc(int K) {
     return -1;
 }
 
-static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true) {
+static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack = false) {
     if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
     if (a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
     g.KC = pb_kc(a.K);
     if (g.KC < 0) return false;
     g.KCP = (g.KC + 3) / 4 * 4;
     PdPick k;
-    if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
+    if (stack) {          // two clusters of 8 per utterance (PdShape8)
+        if (a.D > PdShape8::DMAX || (3 * a.D) % 4 != 0) return false;
+        k.shape = 0; k.UNITS = PdShape8::UNITS; k.KSPLIT = PdShape8::KSPLIT; k.KD = PdShape8::KD; k.MC = PdShape8::MC; k.AWS = PdShape8::AWS;
+        k.P = (a.D + k.UNITS - 1) / k.UNITS;
+        if (a.M > k.P * k.MC * k.UNITS || a.B * 2 * k.P > lvsr_max_cluster_wgs()) return false;
+    } else if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
     g.P = k.P; g.shape = k.shape;
     const int DP = k.KSPLIT * k.KD > 256 ? 512 : 256, MS = k.MC * k.UNITS;      // padded decoder width of the exchanges, match columns per work-group
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
     // the q phase maps one lane group (16 lanes at D <= 256, 32 above) per own position, the alignment-gradient gather one granule
     // row of NTL positions per source work-group (P NTL <= 512 threads)
-    if (g.nown > (DP == 256 ? 32 : 16)) return allow16 && k.shape == 1 ? pb_geom(a, g, false) : false;
+    if (g.nown > (DP == 256 ? 32 : 16)) return allow16 && k.shape == 1 && !stack ? pb_geom(a, g, false) : false;
     g.NTL = (g.nown <= 16 || DP == 512) ? 16 : 32;
     if (g.P * g.NTL > PD_THREADS) return false;
     g.FW = 2 * a.c + 1;
@@ -97,7 +106,7 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true) {
     g.o_aw = g.AWL ? take(g.nown * g.AWS) : 0;
     g.total = o;
     g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);
-    if (o > PD_LDS_FLOATS && k.shape == 1 && allow16) return pb_geom(a, g, false);      // clusters of 8 instead, if they fit
+    if (o > PD_LDS_FLOATS && k.shape == 1 && allow16 && !stack) return pb_geom(a, g, false);      // clusters of 8 instead, if they fit
     return o <= PD_LDS_FLOATS;
 }
 
@@ -108,8 +117,232 @@ __device__ __forceinline__ T pb_ld(const void* sbase, unsigned voff) { return *(
 template <class T>
 __device__ __forceinline__ void pb_st(void* sbase, unsigned voff, T v) { *(T*)((char*)sbase + voff) = v; }
 
-template <int KC, class SH>
-__global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr_attdec_plain w, PbGeom g, u64* planes, int* abort_word) {
+typedef lvsr_attdec_stack2 PbStack;
+
+// The layer-1 cluster of the two-layer reverse walk (lvsr_attdec_bwd_persistent_stack2).  Per label, in walk order: this layer's GRU
+// backward (exchanges A1: dpc1, B1: dpu1 | dpr1 inside the cluster) -> X0: the fork_1 part of layer 0's state gradient,
+// [dpc1 | dpu1 | dpr1] . F1[unit, :], which the main cluster adds before ITS GRU step of the label -> Q1: this layer's share of the
+// glimpse gradient for the own positions, [dpc1 | dpu1 | dpr1] . AW1[t] (the main cluster adds it to its q) -> wait for the main
+// cluster's dsW partials of the label (plane D) -> the transform_states#1 part of this layer's state gradient (exchange E1).
+template <class SH>
+__device__ __forceinline__ void pb_stack_layer1(const AttBwd& gb, const PbGeom& g, const PbStack& k2, float* lds, u64* gbase, int* abort_word,
+                                                int b, int p) {
+    constexpr int PD_UNITS = SH::UNITS, PD_KSPLIT = SH::KSPLIT, PD_KD = SH::KD;
+    constexpr int DP = 256, PMAX = DP / PD_UNITS, MS = SH::MC * PD_UNITS, TPU = PD_THREADS / DP, QL = 16, NB = 2 * DP / PD_THREADS;
+    const AttDec& a = gb.f;
+    float* const dgl = lds + g.o_dgl;
+    float* const dpcs = lds + g.o_dpc;
+    float* const dpus = lds + g.o_dpu;
+    float* const dprs = lds + g.o_dpr;
+    float* const r8 = lds + g.o_r8;
+    float* const dsws = lds + g.o_dsw;
+    float* const WsL = lds + g.o_ws;
+    const int P = g.P, nown = g.nown;
+    const int tid0 = threadIdx.x;
+    const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, L = a.L, G3 = 3 * a.D;
+    const int SLD = a.S_ld ? a.S_ld : 2 * D, DSL = gb.ds_ld ? gb.ds_ld : 2 * D;
+    const int AWld = k2.AW1_ld ? k2.AW1_ld : G3, FLD = k2.F1_ld ? k2.F1_ld : G3, G3p = (G3 + 3) & ~3;
+    f32x2 whh[PD_KD / 2], whu[PD_KD / 2], whr[PD_KD / 2], wfx[PD_KD / 2], wfu[PD_KD / 2], wfr[PD_KD / 2];
+    {
+        const int q = tid0 & (PD_KSPLIT - 1), j = p * PD_UNITS + tid0 / PD_KSPLIT;
+        const bool junit = j < D;
+        const size_t jc = (size_t)min(j, D - 1);
+#pragma unroll
+        for (int x = 0; x < PD_KD / 2; ++x) {
+            float v[6][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = q * PD_KD + 2 * x + e;
+                const size_t kc = (size_t)min(k, D - 1);
+                const float keep = (junit && k < D) ? 1.f : 0.f;
+                v[0][e] = k2.Whh1[jc * D + kc] * keep;
+                v[1][e] = k2.Whg1[jc * 2 * D + kc] * keep;
+                v[2][e] = k2.Whg1[jc * 2 * D + D + kc] * keep;
+                v[3][e] = k2.F1[jc * FLD + kc] * keep;                // row `unit` of fork_1: [to x | to u | to r] of layer 1's units k
+                v[4][e] = k2.F1[jc * FLD + D + kc] * keep;
+                v[5][e] = k2.F1[jc * FLD + 2 * D + kc] * keep;
+            }
+            whh[x] = (f32x2){v[0][0], v[0][1]}; whu[x] = (f32x2){v[1][0], v[1][1]}; whr[x] = (f32x2){v[2][0], v[2][1]};
+            wfx[x] = (f32x2){v[3][0], v[3][1]}; wfu[x] = (f32x2){v[4][0], v[4][1]}; wfr[x] = (f32x2){v[5][0], v[5][1]};
+        }
+    }
+    for (int x = tid0; x < g.total; x += PD_THREADS) lds[x] = 0.f;
+    __syncthreads();
+    for (int x = tid0; x < DP * MS; x += PD_THREADS) {
+        const int kp = x / MS, mm = x % MS, m = p * MS + mm;
+        WsL[kp * (MS + 4) + mm] = (kp < D && m < M) ? k2.Ws1[(size_t)kp * M + m] : 0.f;
+    }
+    float dsj;
+    {
+        const int j = p * PD_UNITS + tid0 / PD_KSPLIT;
+        dsj = j < D ? gb.ds[(size_t)b * DSL + D + j] : 0.f;
+    }
+    u64* const gA1 = gbase + PB_SMALL;
+    u64* const gB1 = gA1 + PD_MAXV;
+    u64* const gX0 = gA1 + 3 * PD_MAXV;
+    u64* const gQ1 = gA1 + 4 * PD_MAXV;
+    u64* const gD = gbase + PB_SMALL + PB_STACK_EXTRA;
+    u64* const gE1 = gD + (size_t)3 * P * 512;
+    const bool plain = cluster_shares_xcd(gbase + 4 * PD_MAXV, 2 * P, P + p, abort_word);
+    __syncthreads();
+    for (int n = 0; n < L; ++n) {
+        const int i = L - 1 - n;
+        const unsigned epoch = (unsigned)(n + 1);
+        const int tid = lvsr_unhoisted((int)threadIdx.x), q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT;
+        const int j = p * PD_UNITS + jl;
+        const bool junit = j < D;
+        const size_t row = (size_t)i * B + b;
+        const size_t jc = (size_t)min(j, D - 1);
+        const Win wi = attdec_window(a, i);
+        const float uu = junit ? k2.U1[row * D + jc] : 0.f, rr = junit ? k2.R1[row * D + jc] : 0.f, cc = junit ? k2.C1[row * D + jc] : 0.f;
+        const float sp = junit ? a.S[row * SLD + D + jc] : 0.f;
+        const float dsr = (junit && gb.dS_r) ? gb.dS_r[row * SLD + D + jc] : 0.f;
+        const float ym = a.ymask ? a.ymask[row] : 1.f;
+        // ---- GRU backward of this layer
+        const float dsn = ym * dsj;
+        const float dpc = junit ? dsn * uu * (1.f - cc * cc) : 0.f;
+        const float dpu = junit ? dsn * (cc - sp) * uu * (1.f - uu) : 0.f;
+        float part = dsn * (1.f - uu) + (1.f - ym) * dsj + dsr;
+        if (q == 0 && junit) granule_store(gA1 + j, epoch, dpc, plain);
+        {
+            float v[PD_NV];
+            if (!pd_gather(gA1, D, epoch, abort_word, v)) return;
+            if (tid < D) { dpcs[pd_slot(tid, PD_KD)] = v[0]; dgl[tid] = v[0]; }
+        }
+        __syncthreads();
+        const float drh = pd_dot<PD_KD, PD_KSPLIT>(whh, dpcs, q);
+        const float dpr = junit ? drh * sp * rr * (1.f - rr) : 0.f;
+        part += drh * rr;
+        if (q == 0 && junit) {
+            granule_store(gB1 + j, epoch, dpu, plain);
+            granule_store(gB1 + DP + j, epoch, dpr, plain);
+            float* dx = k2.DXG1 + row * G3;
+            dx[j] = dpc; dx[D + j] = dpu; dx[2 * D + j] = dpr;
+        }
+        {
+            u64 wv[NB];
+            unsigned spins = 0;
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int e = 0; e < NB; ++e) {
+                    const int gi = tid + e * PD_THREADS;
+                    wv[e] = (u64)epoch << 32;
+                    if (gi % DP < D) wv[e] = __hip_atomic_load(gB1 + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = ok && (unsigned)(wv[e] >> 32) == epoch;
+                }
+                if (__all(ok)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                const int gi = tid + e * PD_THREADS, u = gi % DP;
+                if (u < D) {
+                    const float v = __uint_as_float((unsigned)wv[e]);
+                    if (gi < DP) { dpus[pd_slot(u, PD_KD)] = v; dgl[D + u] = v; }
+                    else { dprs[pd_slot(u, PD_KD)] = v; dgl[2 * D + u] = v; }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- X0: what the state of layer 0 this label produced receives through fork_1 (the main cluster waits for it)
+        {
+            const float x0 = pd_dot<PD_KD, PD_KSPLIT>(wfx, dpcs, q) + pd_dot<PD_KD, PD_KSPLIT>(wfu, dpus, q) + pd_dot<PD_KD, PD_KSPLIT>(wfr, dprs, q);
+            if (q == 0 && junit) granule_store(gX0 + j, epoch, x0, plain);
+        }
+        const float dsacc = part + pd_dot<PD_KD, PD_KSPLIT>(whu, dpus, q) + pd_dot<PD_KD, PD_KSPLIT>(whr, dprs, q);
+        // ---- Q1: this layer's share of q for the own positions
+        {
+            const int qtl = tid / QL, l16 = tid % QL, qt = qtl * P + p;
+            const bool qok = qtl < nown && qt < Tp && qt >= wi.begin && qt < wi.end;
+            const unsigned awoff = 4u * ((unsigned)min(qt, Tp - 1) * (unsigned)(B * AWld) + 4u * l16);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                const int col = 4 * l16 + 4 * QL * e;
+                const float4 aw = (qok && col < G3p) ? pb_ld<float4>(k2.AW1 + (size_t)b * AWld + 4 * QL * e, awoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 dg = (col < G3p) ? *(const float4*)(dgl + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                s0 += aw.x * dg.x + aw.y * dg.y;
+                s1 += aw.z * dg.z + aw.w * dg.w;
+            }
+            const float qs = group_sum<QL>(s0 + s1);
+            if (l16 == 0 && qtl < nown && qt < Tp) granule_store(gQ1 + qt, epoch, qok ? qs : 0.f, plain);
+        }
+        // ---- transform_states#1 part of this layer's state gradient, from the main cluster's dsW partials of the label
+        {
+            const int src = tid / MS, mm = tid % MS;
+            const bool mine = src < P && p * MS + mm < M;
+            u64 wv = (u64)epoch << 32;
+            unsigned spins = 0;
+            for (;;) {
+                if (mine) wv = __hip_atomic_load(gD + (size_t)src * 512 + p * MS + mm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+        }
+        __syncthreads();
+        if (tid < MS) {
+            float s = 0.f;
+#pragma unroll
+            for (int src = 0; src < PMAX; ++src) s += r8[src * MS + tid];
+            dsws[tid] = s;
+        }
+        __syncthreads();
+        {
+            constexpr int NC = MS / TPU, NC4 = NC / 4;
+            const int ku = tid / TPU, partn = tid % TPU;
+            const float4* dv = (const float4*)(dsws + partn * NC);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int x = 0; x < NC4; ++x) {
+                const float4 d4 = dv[x], w4 = *(const float4*)(WsL + ku * (MS + 4) + partn * NC + 4 * x);
+                s0 += d4.x * w4.x + d4.y * w4.y;
+                s1 += d4.z * w4.z + d4.w * w4.w;
+            }
+            float s = s0 + s1;
+            if (TPU == 2) s += lvsr_dpp_quad_xor1(s);
+            if (partn == 0 && ku < D) granule_store(gE1 + (size_t)p * 512 + ku, epoch, s, plain);
+        }
+        {
+            const int src = tid / PD_UNITS, uu_ = tid % PD_UNITS;
+            const bool mine = tid < DP && src < P && p * PD_UNITS + uu_ < D;
+            u64 wv = (u64)epoch << 32;
+            unsigned spins = 0;
+            for (;;) {
+                if (mine) wv = __hip_atomic_load(gE1 + (size_t)src * 512 + p * PD_UNITS + uu_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all(!mine || (unsigned)(wv >> 32) == epoch)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            __syncthreads();                      // (every thread is past its reads of r8 above)
+            if (tid < DP) r8[tid] = mine ? __uint_as_float((unsigned)wv) : 0.f;
+        }
+        __syncthreads();
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int src = 0; src < PMAX; ++src) s += r8[src * PD_UNITS + jl];
+            dsj = junit ? dsacc + s : 0.f;
+        }
+        __syncthreads();
+    }
+    {
+        const int q = tid0 & (PD_KSPLIT - 1), j = p * PD_UNITS + tid0 / PD_KSPLIT;
+        if (q == 0 && j < D) gb.ds[(size_t)b * DSL + D + j] = dsj;
+    }
+}
+
+template <int KC, class SH, bool STACK = false>
+__global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr_attdec_plain w, PbGeom g, u64* planes, int* abort_word, PbStack k2) {
     constexpr int KCP = (KC + 3) / 4 * 4;
     constexpr int PD_UNITS = SH::UNITS, PD_KSPLIT = SH::KSPLIT, PD_KD = SH::KD;
     constexpr int DP = SH::DMAX > 256 ? 512 : 256;        // padded decoder width: planes A / B / E, rows of the Ws slice
@@ -143,11 +376,19 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const nx = lds + g.o_nx;       // [5][64] saved gate values of the own units, fetched one label ahead
     const int P = g.P, nown = g.nown;
     int b, p;
-    if (!cluster_of_block(P, a.B, 0, b, p)) return;                  // (work-groups of the grid's padding)
+    if (!cluster_of_block(STACK ? 2 * P : P, a.B, 0, b, p)) return;  // (work-groups of the grid's padding)
+    u64* const gA = planes + (size_t)b * (STACK ? PB_SMALL + PB_STACK_EXTRA + (size_t)P * PB_PERWG_STACK : PB_SMALL + (size_t)P * PB_PERWG);
+    if (STACK && p >= P) {            // the second cluster of the utterance: layer 1 of the stack
+        pb_stack_layer1<SH>(gb, g, k2, lds, gA, abort_word, b, p - P);
+        return;
+    }
     const int tid = threadIdx.x, q = tid & (PD_KSPLIT - 1), jl = tid / PD_KSPLIT, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c16 = lane & 15, g4 = lane >> 4;
     const int D = a.D, M = a.M, Tp = a.Tp, B = a.B, K = a.K, L = a.L, G3 = 3 * a.D;
+    // row strides of the state slots / the readout's state gradient and of the running state gradient (two-layer launch: 2 D, this
+    // layer in front)
+    const int SLD = a.S_ld ? a.S_ld : D, DSL = gb.ds_ld ? gb.ds_ld : D;
     // AW rows are read 16 bytes at a time: row stride AWld (a multiple of 4, the host pads when 3D is not), columns up to G3p;
     // the gradient vector they are contracted with is zero beyond 3D
     const int AWld = w.AW_ld ? w.AW_ld : G3, G3p = (G3 + 3) & ~3;
@@ -214,14 +455,15 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     }
     if (KC > 0 && g.FTL)
         for (int x = tid; x < a.K * g.FW; x += PD_THREADS) fT[(x % g.FW) * KCP + x / g.FW] = a.filters[x];
-    float dsj = junit ? gb.ds[(size_t)b * D + j] : 0.f;            // running gradient wrt the state (caller: zeros + readout part)
-    u64* const gA = planes + (size_t)b * (PB_SMALL + (size_t)P * PB_PERWG);
+    float dsj = junit ? gb.ds[(size_t)b * DSL + j] : 0.f;          // running gradient wrt the state (caller: zeros + readout part)
     u64* const gB = gA + PD_MAXV;                     // [2][DP]
     u64* const gC = gA + 3 * PD_MAXV;
-    u64* const gD = gA + PB_SMALL;                    // [P][512]
+    u64* const gX0 = gA + PB_SMALL + 3 * PD_MAXV;     // (two-layer launch) from the layer-1 cluster: fork_1 part of this layer's state gradient
+    u64* const gQ1 = gA + PB_SMALL + 4 * PD_MAXV;     // ... and its share of q
+    u64* const gD = gA + PB_SMALL + (STACK ? PB_STACK_EXTRA : 0);     // [P][512]
     u64* const gE = gD + (size_t)P * 512;             // [P][512] (DP used)
     u64* const gF = gE + (size_t)P * 512;             // [P][512]
-    const bool plain = cluster_shares_xcd(gA + 4 * PD_MAXV, P, p, abort_word);
+    const bool plain = cluster_shares_xcd(gA + 4 * PD_MAXV, STACK ? 2 * P : P, p, abort_word);
     __syncthreads();
     PdClock clk;
     clk.start(g.prof != 0 && blockIdx.x == 0 && tid == 0, lds + g.o_clk);
@@ -239,10 +481,25 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         const Win wi = attdec_window(a, i);
         // ---- this label's saved values
         float uu, rr, cc, sp, dsr;
+        if (STACK) {
+            // the layer above hands down what this layer's state of the label receives through fork_1: every lane polls the granule
+            // of its unit (before any other load of the label is issued: a poll behind a load waits for it)
+            u64 wv;
+            unsigned spins = 0;
+            for (;;) {
+                wv = __hip_atomic_load(gX0 + min(j, D - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__all((unsigned)(wv >> 32) == epoch)) break;
+                if (((++spins) & 127u) == 0u) {
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+                    if (spins > PERSIST_SPIN_LIMIT) { __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+                }
+            }
+            if (junit) dsj += __uint_as_float((unsigned)wv);
+        }
         if (n == 0) {
             uu = junit ? pb_ld<float>(a.U + row * D, jb) : 0.f; rr = junit ? pb_ld<float>(a.R + row * D, jb) : 0.f;
-            cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f; sp = junit ? pb_ld<float>(a.S + row * D, jb) : 0.f;
-            dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * D, jb) : 0.f;
+            cc = junit ? pb_ld<float>(a.C + row * D, jb) : 0.f; sp = junit ? pb_ld<float>(a.S + row * SLD, jb) : 0.f;
+            dsr = (junit && gb.dS_r) ? pb_ld<float>(gb.dS_r + row * SLD, jb) : 0.f;
         } else {       // fetched into LDS behind the previous label's energy phase (below)
             uu = junit ? nx[jl] : 0.f; rr = junit ? nx[64 + jl] : 0.f; cc = junit ? nx[128 + jl] : 0.f; sp = junit ? nx[192 + jl] : 0.f;
             dsr = junit ? nx[256 + jl] : 0.f;
@@ -387,6 +644,11 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         {
             float v[PD_NV];
             if (!pd_gather(gC, Tp, epoch, abort_word, v)) return;
+            if (STACK) {          // + the layer-1 cluster's share of q
+                float v1[PD_NV];
+                if (!pd_gather(gQ1, Tp, epoch, abort_word, v1)) return;
+                v[0] += v1[0];
+            }
             if (tid < Tp) qv[tid] = v[0];
             // sd = sum_t alpha_t q_t over the window
             const bool inw = tid < Tp && tid >= wi.begin && tid < wi.end;
@@ -431,7 +693,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         // issued behind them would wait for them: vector-memory results return in order)
         if (i > 0 && wave < 5 && lane < PD_UNITS) {
             const float* arr = wave == 0 ? a.U : wave == 1 ? a.R : wave == 2 ? a.C : wave == 3 ? a.S : gb.dS_r;
-            if (arr) __builtin_amdgcn_global_load_lds(arr + (row - (size_t)B) * D + min(p * PD_UNITS + lane, D - 1), nx + wave * 64, 4, 0, 0);
+            if (arr) __builtin_amdgcn_global_load_lds(arr + (row - (size_t)B) * (wave >= 3 ? SLD : D) + min(p * PD_UNITS + lane, D - 1), nx + wave * 64, 4, 0, 0);
         }
         // ---- 3. energies backward on the matrix cores
         float swc[4], dsw[4] = {0.f, 0.f, 0.f, 0.f};
@@ -688,7 +950,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         for (int x = 0; x < PD_NPROF; ++x) out[x] = clk.acc[1 + x];
     }
     // ---- epilogue: what the caller folds / uses after the loop
-    if (q == 0 && junit) gb.ds[(size_t)b * D + j] = dsj;
+    if (q == 0 && junit) gb.ds[(size_t)b * DSL + j] = dsj;
     const size_t prow = (size_t)b * P + p;
 #pragma unroll
     for (int tile = 0; tile < 4; ++tile) {
@@ -750,7 +1012,7 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     const size_t bytes = (size_t)a.B * (PB_SMALL + (size_t)g.P * PB_PERWG) * 8;
     (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
     const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
-#define PB_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pbwd_kernel<KCV, SHAPE>), grid, block, 0, s, gb, w, g, planes, ab)
+#define PB_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pbwd_kernel<KCV, SHAPE, false>), grid, block, 0, s, gb, w, g, planes, ab, PbStack())
 #define PB_LAUNCH_KC(SHAPE)                       \
     switch (g.KC) {                               \
         case 0: PB_LAUNCH(0, SHAPE); break;       \
@@ -764,4 +1026,59 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
 #undef PB_LAUNCH_KC
 #undef PB_LAUNCH
     return lvsr_check_launch("lvsr_attdec_bwd_persistent");
+}
+
+extern "C" long long lvsr_attdec_stack2_bwd_persist_ws_bytes(const lvsr_attdec_args* args) {
+    if (args == nullptr) return 0;
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    PbGeom g;
+    if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pb_geom(a, g, false, true)) return 0;
+    return 256 + (long long)a.B * (PB_SMALL + PB_STACK_EXTRA + (long long)g.P * PB_PERWG_STACK) * 8;
+}
+
+extern "C" int lvsr_attdec_stack2_bwd_persist_clusters(const lvsr_attdec_args* args) {
+    if (args == nullptr) return 0;
+    AttDec a;
+    memcpy(&a, args, sizeof(a));
+    PbGeom g;
+    if (a.Tp <= 0 || a.B <= 0 || a.L <= 0 || a.E <= 0 || a.D <= 0 || a.M <= 0 || a.K < 0 || !pb_geom(a, g, false, true)) return 0;
+    return g.P;
+}
+
+extern "C" int lvsr_attdec_bwd_persistent_stack2(void* stream, const lvsr_attdec_bwd_args* args, const lvsr_attdec_plain* plain,
+                                                 const lvsr_attdec_stack2* l1, void* ws) {
+    LVSR_REQUIRE(args != nullptr && plain != nullptr && l1 != nullptr && ws != nullptr, "lvsr_attdec_bwd_persistent_stack2: null argument");
+    AttBwd gb;
+    memcpy(&gb, args, sizeof(gb));
+    const AttDec& a = gb.f;
+    if (int rc = attdec_check(a, "lvsr_attdec_bwd_persistent_stack2")) return rc;
+    LVSR_REQUIRE(a.label0 == 0 && (args->parts & 3) % 3 == 0 && a.S_ld >= 2 * a.D && args->ds_ld >= 2 * a.D,
+                 "lvsr_attdec_bwd_persistent_stack2: runs all labels; states and state gradients hold both layers side by side (S_ld, ds_ld >= 2 D)");
+    PbGeom g;
+    LVSR_REQUIRE((plain->AW_ld ? plain->AW_ld : 3 * a.D) % 4 == 0 && (l1->AW1_ld ? l1->AW1_ld : 3 * a.D) % 4 == 0,
+                 "lvsr_attdec_bwd_persistent_stack2: the rows of AW / AW1 must be a multiple of 4 floats apart");
+    LVSR_REQUIRE(pb_geom(a, g, false, true), "lvsr_attdec_bwd_persistent_stack2: configuration outside the kernel's limits "
+                 "(lvsr_attdec_stack2_bwd_persist_ws_bytes returns 0 for it)");
+    LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd_persistent_stack2: contexts must be contiguous (Tp,B,*)");
+    LVSR_REQUIRE(plain->Ws && plain->Whg && plain->Whh && plain->AW && gb.QR && gb.DXG && gb.DSW && gb.dPA && gb.ds && gb.accWe,
+                 "lvsr_attdec_bwd_persistent_stack2: missing buffers of the attention / layer-0 block");
+    LVSR_REQUIRE(a.K == 0 || (gb.DCV && gb.accH), "lvsr_attdec_bwd_persistent_stack2: DCV / accH missing");
+    LVSR_REQUIRE(l1->Whg1 && l1->Whh1 && l1->Ws1 && l1->F1 && l1->AW1 && l1->U1 && l1->R1 && l1->C1 && l1->DXG1,
+                 "lvsr_attdec_bwd_persistent_stack2: layer-1 block incomplete");
+    const lvsr_attdec_plain w = *plain;
+    const PbStack k2 = *l1;
+    hipStream_t s = (hipStream_t)stream;
+    int* ab = (int*)ws;
+    u64* planes = (u64*)((char*)ws + 256);
+    const size_t bytes = (size_t)a.B * (PB_SMALL + PB_STACK_EXTRA + (size_t)g.P * PB_PERWG_STACK) * 8;
+    (void)hipMemsetAsync(planes, 0, bytes, s);
+    const dim3 grid(cluster_grid(a.B, 2 * g.P, 0)), block(PD_THREADS);
+    switch (g.KC) {
+        case 0: hipLaunchKernelGGL((attdec_pbwd_kernel<0, PdShape8, true>), grid, block, 0, s, gb, w, g, planes, ab, k2); break;
+        case 4: hipLaunchKernelGGL((attdec_pbwd_kernel<4, PdShape8, true>), grid, block, 0, s, gb, w, g, planes, ab, k2); break;
+        case 10: hipLaunchKernelGGL((attdec_pbwd_kernel<10, PdShape8, true>), grid, block, 0, s, gb, w, g, planes, ab, k2); break;
+        default: hipLaunchKernelGGL((attdec_pbwd_kernel<16, PdShape8, true>), grid, block, 0, s, gb, w, g, planes, ab, k2); break;
+    }
+    return lvsr_check_launch("lvsr_attdec_bwd_persistent_stack2");
 }

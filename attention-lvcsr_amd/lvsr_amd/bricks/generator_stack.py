@@ -223,21 +223,23 @@ class StackedSequenceGenerator(SequenceGenerator):
         if d.conv:
             W[0, :, 0] = 1.0
         stream = lib.stream_for(S)
-        if not self._forward_persistent_stack2(blk, att_bufs, A, PA, Am, L, B, Tp, stream):
+        st2 = self._forward_persistent_stack2(blk, att_bufs, A, PA, Am, L, B, Tp, stream)
+        if st2 is None:
             for i in range(L):
                 self._run_step(blk, i, stream)
-        return dict(bufs=att_bufs, saved=dict(blk=blk, fb=fb))
+        return dict(bufs=att_bufs, saved=dict(blk=blk, fb=fb, stack2=st2))
 
     def _forward_persistent_stack2(self, blk, att_bufs, A, PA, Am, L, B, Tp, stream):
         """The label loop of a two-layer stack as ONE persistent launch (lvsr_attdec_fwd_persistent_stack2: per utterance a cluster
         for the attention + layer 0 and one for layer 1), writing everything the step-kernel reverse walk reads: state slots of
         both layers, alignments, energies, transformed states, convolution features, the gates of both layers; the glimpses and
-        layer 1's distribution input [glimpse | new state of layer 0] are filled in behind it.  -> False when it does not apply."""
+        layer 1's distribution input [glimpse | new state of layer 0] are filled in behind it.  -> None when it does not apply,
+        else what the persistent reverse walk re-uses (argument fields, AW0 / AW1, the concatenated distribution weights)."""
         d, p, lib, ws = self.d, self.store.p, self.lib, self.ws
         if d.n_dec != 2 or self.use_persistent_stack is False or (lib.is_emulator and not lib.emulates_concurrency()):
             if self.use_persistent_stack:
                 raise ValueError("persistent stacked decoder requested but not available (two layers, concurrent work-groups)")
-            return False
+            return None
         D, E = d.D, d.E
         l0, l1 = blk["layers"]
         n0, n1 = self.nl
@@ -254,7 +256,7 @@ class StackedSequenceGenerator(SequenceGenerator):
         if nbytes == 0:
             if self.use_persistent_stack:
                 raise ValueError("persistent stacked decoder requested but the configuration is outside the kernel's limits")
-            return False
+            return None
         sync = ws.get("gen.sync", ((nbytes + 3) // 4,), torch.int32)
         cats = self._cats()
         wd0, wd1 = ws.get("gen.Wd_cat0", (E, 3 * D)), ws.get("gen.Wd_cat1", (E + D, 3 * D))
@@ -270,7 +272,7 @@ class StackedSequenceGenerator(SequenceGenerator):
         lib.call("lvsr_attdec_glimpses", stream, ctypes.byref(args))
         WA1 = b1["WA"].view(L * B, E + D)
         lib.copy_many([(att_bufs["WA"].view(L * B, E), WA1[:, :E]), (att_bufs["S"][1:].reshape(L * B, d.D_tot)[:, :D], WA1[:, E:])])
-        return True
+        return dict(fields=f, AW0=AW0, AW1=AW1, wd0=wd0, wd1=wd1)
 
     def _backward_recurrent(self, sv, dWA_r, dS_r, gws):
         d, p, g, lib, ws = self.d, self.store.p, self.store.g, self.lib, self.ws
@@ -306,7 +308,37 @@ class StackedSequenceGenerator(SequenceGenerator):
             ent["args"] = a
             bws.append(ent)
         stream = lib.stream_for(ds)
-        for i in range(L - 1, -1, -1):
+        st2 = sv.get("stack2")
+        psync = None
+        if st2 is not None and self.use_persistent_stack is not False:
+            fargs = lib.make("lvsr_attdec_args", **st2["fields"])
+            nbytes = int(lib._lvsr_attdec_stack2_bwd_persist_ws_bytes(ctypes.byref(fargs)))
+            if nbytes > 0:
+                psync = ws.get("gen.sync_bwd", ((nbytes + 3) // 4,), torch.int32)
+        if psync is not None:
+            # the whole reverse walk of both layers as one persistent launch (csrc/decoder_persist_bwd.hip, two clusters per utterance)
+            n0, n1 = self.nl
+            P = int(lib._lvsr_attdec_stack2_bwd_persist_clusters(ctypes.byref(fargs)))
+            accH = ws.get("gen.accH_p", (B * P, Kc * d.M))
+            accWe = ws.get("gen.accWe_p", (B * P, d.M))
+            accEb = ws.get("gen.accEb_p", (B * P, 1))
+            QR = ws.get("gen.QR", (L, B, Tp))
+            lib.call("lvsr_sgemm_batched", stream, 0, 1, L, Tp, E, 1.0, lib_ptr(dWA_r), B * E, E,
+                     lib_ptr(sv["A"]), B * E, E, 0.0, lib_ptr(QR), B * Tp, Tp, B)
+            bw = lib.make("lvsr_attdec_bwd_args", dS_r=dS_r, DXG=bws[0]["DXG"], DSW=DSW, DCV=DCV, dPA=dPA, accH=accH, accWe=accWe,
+                          accEb=accEb, ds=ds, AW=st2["AW0"], QR=QR, AW_ld=0, ds_ld=DT)
+            bw.f = fargs
+            plain = lib.make("lvsr_attdec_plain", Ws=p[n0["Ws"]], Whg=p[n0["Whg"]], Whh=p[n0["Whh"]], AW=st2["AW0"], AW_ld=0)
+            b1 = layers[1]["bufs"]
+            s2 = lib.make("lvsr_attdec_stack2", Whg1=p[n1["Whg"]], Whh1=p[n1["Whh"]], Ws1=p[n1["Ws"]], F1=st2["wd1"][E:], AW1=st2["AW1"],
+                          xg1=b1["xg"], U1=b1["U"], R1=b1["R"], C1=b1["C"], RH1=b1["RH"], F1_ld=0, AW1_ld=0, DXG1=bws[1]["DXG"])
+            lib.call("lvsr_attdec_bwd_persistent_stack2", stream, ctypes.byref(bw), ctypes.byref(plain), ctypes.byref(s2), lib_ptr(psync))
+            # total gradient wrt the glimpses (the kernel does not form it): the readout's share + both layers' distribution inputs
+            DWA2 = DWA.view(nrows, E)
+            lib.copy_many([(dWA_r.view(nrows, E), DWA2)])
+            lib.sgemm(bws[0]["DXG"], st2["wd0"], DWA2, transB=True, beta=1.0)
+            lib.sgemm(bws[1]["DXG"], st2["wd1"][:E], DWA2, transB=True, beta=1.0)
+        for i in (range(L - 1, -1, -1) if psync is None else ()):
             # bws[l]["ds"] = gradient wrt the state layer l wrote at this label (slot i + 1), from everything later
             for l in range(d.n_dec - 1, -1, -1):
                 a = bws[l]["args"]

@@ -243,6 +243,7 @@ typedef struct lvsr_attdec_stack2 {
     const float* xg1;                     /* (L,B,3D) fork#1(feedback) incl. biases */
     float* U1; float* R1; float* C1; float* RH1;      /* (L,B,D) saved for the backward pass */
     int F1_ld, AW1_ld;                    /* 0 = 3D */
+    float* DXG1;                          /* lvsr_attdec_bwd_persistent_stack2 only: (L,B,3D) out, gradient wrt layer 1's [x_in | gate_in] pre-activations */
 } lvsr_attdec_stack2;
 long long lvsr_attdec_stack2_persist_ws_bytes(const lvsr_attdec_args* a);      /* 0 = not available (then: the step kernels) */
 int lvsr_attdec_fwd_persistent_stack2(void* stream, const lvsr_attdec_args* a, const lvsr_attdec_plain* w,
@@ -295,6 +296,15 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* a, int use_graph);
 long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* a);
 int lvsr_attdec_bwd_persist_clusters(const lvsr_attdec_args* a);      /* work-groups per utterance the launch will use (0 = not available) */
 int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_args* a, const lvsr_attdec_plain* w, void* ws);
+/* The reverse walk of the two-layer launch (csrc/decoder_persist_bwd.hip): the attention + layer-0 cluster works as
+ * lvsr_attdec_bwd_persistent does, the layer-1 cluster runs that layer's GRU backward, hands the fork_1 part of layer 0's state
+ * gradient and its share of the glimpse gradient (DXG1 . AW1) to the main cluster and takes its transform_states#1 part from the
+ * main cluster's dsW.  `a`: the block of layer 0 as for the forward launch (f.S_ld = 2D); dS_r (L,B,2D) and ds (B,2D, ds_ld = 2D)
+ * hold both layers side by side; QR as for lvsr_attdec_bwd_persistent; DXG / l1->DXG1 out. */
+long long lvsr_attdec_stack2_bwd_persist_ws_bytes(const lvsr_attdec_args* a);
+int lvsr_attdec_stack2_bwd_persist_clusters(const lvsr_attdec_args* a);       /* work-groups of the attention cluster = rows of accH / accWe / accEb per utterance */
+int lvsr_attdec_bwd_persistent_stack2(void* stream, const lvsr_attdec_bwd_args* a, const lvsr_attdec_plain* w,
+                                      const lvsr_attdec_stack2* l1, void* ws);
 /* gradient wrt conv1d.filters (K,2c+1) from DCV and the alignment slots of the forward block; ws: scratch of at least
  * ceil(L*B / R) * K * (2c+1) floats with R = min(4, 8192 / (K*Tp)) rows per work-group (L*B*K*(2c+1) floats always suffice) */
 int lvsr_attdec_filter_grad(void* stream, const lvsr_attdec_args* f, const float* DCV, float* dfilters, float* ws,

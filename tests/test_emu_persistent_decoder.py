@@ -87,9 +87,9 @@ def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K,
     check_against(rec, cm, None, out, grads)
 
 
-# dec_stack = 2: the label loop of the two-layer stack as one persistent launch (lvsr_attdec_fwd_persistent_stack2: a cluster for
-# the attention + layer 0 and one for layer 1 per utterance); the reverse walk stays on the step kernels.  Costs, alignments and
-# every gradient against the reference's goldens / the float64 oracle.
+# dec_stack = 2: the label loop of the two-layer stack and its reverse walk as one persistent launch each
+# (lvsr_attdec_fwd_persistent_stack2 / lvsr_attdec_bwd_persistent_stack2: a cluster for the attention + layer 0 and one for layer 1
+# per utterance).  Costs, alignments and every gradient against the reference's goldens / the float64 oracle.
 @pytest.mark.parametrize("case", ["tiny_conv_stack2", "small_conv_stack2"])
 def test_persistent_two_layer_stack_against_oracle_and_golden(case):
     lib = emu_lib()
@@ -103,6 +103,7 @@ def test_persistent_two_layer_stack_against_oracle_and_golden(case):
         rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=meta["cfg"], use_persistent_decoder=True)
         cm = rec.cost_and_gradients(batch)
         assert engaged(rec), "persistent stacked decoder did not engage"
+        assert any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs), "persistent stacked reverse walk did not engage"
         rec.generator.check_persistent()
         check_against(rec, cm, z, out, grads)
     finally:
