@@ -7,6 +7,8 @@ from lvsr_amd import native
 
 class FakeLib(object):
     is_emulator = False
+    step_graph = True              # (native.Lib constructor arguments)
+    sync_after_graph = True
 
     def __init__(self):
         self.capturing = False
