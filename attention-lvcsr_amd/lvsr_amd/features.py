@@ -36,6 +36,19 @@ class Fbank(object):
         ang = 2 * numpy.pi * numpy.arange(512) / 512.0
         t = lambda a: torch.tensor(numpy.asarray(a, numpy.float32), device=self.device)
         self.window, self.melw, self.twiddle = t(win), t(W), t(numpy.stack([numpy.cos(ang), numpy.sin(ang)]))
+        # the filters' non-zero spans for the batched kernel (lvsr_fbank_batch): first bin and up to 64 weights per filter
+        starts, packed, self.batchable = numpy.zeros(self.num_mel, numpy.int32), numpy.zeros((self.num_mel, 64), numpy.float32), self.num_mel <= 64
+        for b in range(self.num_mel):
+            nz = numpy.nonzero(W[b])[0]
+            if len(nz) == 0:
+                continue
+            if nz[-1] - nz[0] + 1 > 64:
+                self.batchable = False
+                break
+            starts[b] = nz[0]
+            packed[b, : nz[-1] - nz[0] + 1] = W[b, nz[0]: nz[-1] + 1]
+        self.mel_start = torch.tensor(starts, device=self.device)
+        self.mel_packed = t(packed)
 
     def num_frames(self, nsamp):
         return int(self.lib._lvsr_fbank_num_frames(int(nsamp), ctypes.byref(self.cfg)))
@@ -48,6 +61,40 @@ class Fbank(object):
         out = torch.empty(T, self.num_mel + int(self.use_energy), dtype=torch.float32, device=self.device)
         self.lib.call("lvsr_fbank", self.lib.stream_for(out), ptr(wav), wav.numel(), ctypes.byref(self.cfg), ptr(self.window),
                       ptr(self.melw), ptr(self.twiddle), ptr(out))
+        return out
+
+    def batch(self, wavs):
+        """A set of utterances in ONE launch (lvsr_fbank_batch: a 512-point FFT per frame, one wave per frame).  wavs: list of 1-D
+        int16 arrays / tensors -> (feats (total_frames, num_mel + use_energy) device tensor, frame_off (n + 1) int32 device tensor);
+        utterance u = rows frame_off[u]:frame_off[u+1]."""
+        if not self.batchable:
+            raise ValueError("the batched front end holds filters of up to 64 bins (num_mel <= 64): use __call__ per utterance")
+        host = [numpy.asarray(w.cpu() if torch.is_tensor(w) else w, dtype=numpy.int16).ravel() for w in wavs]
+        lens = numpy.array([len(w) for w in host], dtype=numpy.int64)
+        nfr = numpy.array([self.num_frames(int(n)) for n in lens], dtype=numpy.int64)
+        wav_off = numpy.concatenate([[0], numpy.cumsum(lens)]).astype(numpy.int64)
+        frame_off = numpy.concatenate([[0], numpy.cumsum(nfr)]).astype(numpy.int32)
+        wav = torch.from_numpy(numpy.concatenate(host) if host else numpy.zeros(0, numpy.int16)).to(self.device)
+        return self.batch_resident(wav, torch.from_numpy(wav_off).to(self.device), torch.from_numpy(frame_off).to(self.device), len(host),
+                                   int(frame_off[-1]))
+
+    def batch_resident(self, wav, wav_off, frame_off, n, total_frames):
+        """The same with everything already on the device (wav int16 back to back, wav_off int64 / frame_off int32 of n + 1 entries)."""
+        out = torch.empty(total_frames, self.num_mel + int(self.use_energy), dtype=torch.float32, device=self.device)
+        if total_frames:
+            self.lib.call("lvsr_fbank_batch", self.lib.stream_for(out), ptr(wav), ptr(wav_off), ptr(frame_off), int(n), int(total_frames),
+                          ctypes.byref(self.cfg), ptr(self.window), ptr(self.mel_start), ptr(self.mel_packed), ptr(self.twiddle), ptr(out))
+        return out, frame_off
+
+    def add_deltas_cmvn_batch(self, feats, frame_off, mean=None, std=None):
+        """(total_frames, dim) of a set of utterances -> (total_frames, 3*dim); the deltas' edge frames are replicated per utterance."""
+        T, dim = int(feats.shape[0]), int(feats.shape[1])
+        out = torch.empty(T, 3 * dim, dtype=torch.float32, device=self.device)
+        m = None if mean is None else torch.as_tensor(mean, dtype=torch.float32, device=self.device).contiguous()
+        i = None if std is None else (1.0 / torch.as_tensor(std, dtype=torch.float32, device=self.device)).contiguous()
+        if T:
+            self.lib.call("lvsr_add_deltas_cmvn_batch", self.lib.stream_for(out), ptr(feats.contiguous()), ptr(frame_off), int(frame_off.numel()) - 1,
+                          T, dim, ptr(m), ptr(i), ptr(out))
         return out
 
     def add_deltas_cmvn(self, feats, mean=None, std=None):

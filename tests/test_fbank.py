@@ -29,6 +29,26 @@ def run_fbank(device, lib, n):
     assert_allclose(normed, (FO.add_deltas(ref) - mean) / std, rtol=1e-3, atol=2e-3)
 
 
+def run_fbank_batch(device, lib, lengths):
+    """The batched front end (FFT per frame, one launch for the set) against the oracle and against the per-utterance kernels:
+    utterances of different lengths, one of them shorter than a frame (no frames)."""
+    wavs = [_wav(n, seed=i) for i, n in enumerate(lengths)]
+    fb = Fbank(device=device, lib=lib)
+    feats, off = fb.batch(wavs)
+    off_h = off.cpu().numpy()
+    full = fb.add_deltas_cmvn_batch(feats, off).cpu().numpy()
+    feats = feats.cpu().numpy()
+    for u, w in enumerate(wavs):
+        ref = FO.fbank(w)
+        got = feats[off_h[u]: off_h[u + 1]]
+        assert got.shape == ref.shape
+        if not len(ref):
+            continue
+        assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+        assert_allclose(got, fb(w).cpu().numpy(), rtol=2e-4, atol=2e-4)              # the direct-DFT kernel
+        assert_allclose(full[off_h[u]: off_h[u + 1]], FO.add_deltas(ref), rtol=2e-4, atol=5e-4)
+
+
 def test_oracle_self_consistency():
     w = FO.mel_weights()
     assert w.shape == (40, 256) and (w >= 0).all() and (w.sum(1) > 0).all()
@@ -99,6 +119,16 @@ def test_fbank_emulated():
     run_fbank("cpu", emu_lib(), 400 + 160 * 5)
 
 
+def test_fbank_batch_emulated():
+    from emu import emu_lib
+    run_fbank_batch("cpu", emu_lib(), [400 + 160 * 3, 100, 400, 400 + 160 * 6 + 77])
+
+
 @pytest.mark.gpu
 def test_fbank_gpu(gpu_device):
     run_fbank(gpu_device, None, 16000 * 3)
+
+
+@pytest.mark.gpu
+def test_fbank_batch_gpu(gpu_device):
+    run_fbank_batch(gpu_device, None, [16000 * 3, 100, 16000 * 2 + 123, 400, 16000 * 5 + 7] + [16000 + 37 * i for i in range(27)])

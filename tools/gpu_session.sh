@@ -9,7 +9,7 @@ for what in "$@"; do
   case $what in
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 4 $O/pytest.log;;
     newtests) timeout 900 python -m pytest tests -m gpu -x -q -k "wsj_base_median or whole_list or persistent_decoder or wsj_deep or wsj_paper or stack2" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -n 6 $O/pytest_new.log;;
-    bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step')}, d.get('sustained'), d.get('strong'), d.get('fbank',{}).get('lvsr_fbank'), d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
+    bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step')}, d.get('sustained'), d.get('strong'), {k:(v.get('achieved'),v.get('frac'),v.get('launch_us')) for k,v in d.get('fbank',{}).items() if isinstance(v,dict)}, d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
     quick) timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; python -c "import json;d=json.load(open('$O/quick.json'));print('wsj_base', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 2 $O/quick.err;;
     quick8) timeout 300 python bench.py --steps 20 --warmup 5 $B --knob dec_cluster=8 > $O/quick8.json 2> $O/quick8.err; python -c "import json;d=json.load(open('$O/quick8.json'));print('wsj_base clusters of 8', d['ms_per_step'], d['value'])"; tail -n 2 $O/quick8.err;;
     dec) for k in dec_cluster=0 dec_cluster=8; do timeout 300 python tools/probe_decoder_persist.py wsj_base $k > $O/dec_fwd_$k.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base $k > $O/dec_bwd_$k.txt 2>&1; echo "== $k"; grep -v "^    " $O/dec_fwd_$k.txt | tail -n 4; grep -v "^    " $O/dec_bwd_$k.txt | tail -n 4; done;;
@@ -35,6 +35,7 @@ for what in "$@"; do
          for st in 1 8; do timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decprof$st -o dec -- python $R/tools/bench_decode.py --utts 8 --streams $st > $R/$O/decprof$st.log 2>&1; done
          cd $R; for st in 1 8; do python tools/rocpd_stats.py $(find $O/decprof$st -name "*.db" | head -n 1) > $O/decode_kernel_stats_$st.md 2>&1; tail -n 2 $O/decprof$st.log | cut -c1-400; head -n 34 $O/decode_kernel_stats_$st.md | cut -c1-150; done;;
     profb:*) bb=${what#profb:}; cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/profb$bb -o bench -- python $R/bench.py --steps 6 --warmup 2 --batch $bb $B > $R/$O/profb$bb.log 2>&1; cd $R; python tools/rocpd_timeline.py $(find $O/profb$bb -name "*.db" | head -n 1) > $O/timeline_b$bb.txt 2>&1; head -n 12 $O/timeline_b$bb.txt; python tools/rocpd_stats.py $(find $O/profb$bb -name "*.db" | head -n 1) > $O/kernel_stats_b$bb.md 2>&1; head -n 9 $O/kernel_stats_b$bb.md | cut -c1-140;;
+    fbtests) timeout 300 python -m pytest tests/test_fbank.py -m gpu -x -q > $O/pytest_fb.log 2>&1; echo "pytest(fbank) rc=$?"; tail -n 3 $O/pytest_fb.log;;
     enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
     knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
     *) echo "unknown item $what";;
