@@ -129,6 +129,7 @@ __device__ __forceinline__ int fb_bitrev9(int n) {
     return r;
 }
 
+#define FBF_OFFS 2048          // frame offsets staged in LDS (a binary search through global memory costs ~10 dependent loads per frame)
 // utterance of global frame f: frame_off[u] <= f < frame_off[u+1]
 __device__ __forceinline__ int fb_find_utt(const int* frame_off, int n, int f) {
     int lo = 0, hi = n - 1;
@@ -142,16 +143,29 @@ __device__ __forceinline__ int fb_find_utt(const int* frame_off, int n, int f) {
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
                                                                    int total_frames, lvsr_fbank_cfg c, const float* window, const int* mel_start,
                                                                    const float* mel_w, const float* twid, float* out) {
+    // twiddles per stage, contiguous: entry [half + j] = exp(-2 pi i j / (2 half)) for the stage with butterflies `half` apart (the
+    // strided reads of one 512-entry table hit 2 banks in the middle stages)
     __shared__ float cs[FB_NFFT], sn[FB_NFFT], win[FB_NFFT];
     __shared__ float mw[64][FBF_SPAN + 1];
     __shared__ int ms[64];
+    __shared__ int offs[FBF_OFFS];
     __shared__ float re_all[FBF_WAVES][FB_NFFT], im_all[FBF_WAVES][FB_NFFT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int x = tid; x < FB_NFFT; x += 64 * FBF_WAVES) {
-        cs[x] = twid[x];
-        sn[x] = twid[FB_NFFT + x];
         win[x] = x < c.frame_length ? window[x] : 0.f;
+        if (x >= 1) {
+            int half = 1;
+            while (2 * half <= x) half *= 2;
+            const int j = x - half;                                        // x = half + j
+            const int idx = j * (FB_NFFT / (2 * half));
+            cs[x] = twid[idx];
+            sn[x] = twid[FB_NFFT + idx];
+        } else { cs[0] = 1.f; sn[0] = 0.f; }
     }
+    const bool offs_lds = n_utts + 1 <= FBF_OFFS;
+    if (offs_lds)
+        for (int x = tid; x <= n_utts; x += 64 * FBF_WAVES) offs[x] = frame_off[x];
+    const int* const foff = offs_lds ? offs : frame_off;
     for (int x = tid; x < 64 * FBF_SPAN; x += 64 * FBF_WAVES) {
         const int m = x / FBF_SPAN, i = x % FBF_SPAN;
         mw[m][i] = m < c.num_mel ? mel_w[(size_t)m * FBF_SPAN + i] : 0.f;
@@ -162,8 +176,8 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     float* const im = im_all[wave];
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
     for (int f = blockIdx.x * FBF_WAVES + wave; f < total_frames; f += gridDim.x * FBF_WAVES) {
-        const int u = fb_find_utt(frame_off, n_utts, f);
-        const long long s0 = wav_off[u] + (long long)(f - frame_off[u]) * c.frame_shift;
+        const int u = fb_find_utt(foff, n_utts, f);
+        const long long s0 = wav_off[u] + (long long)(f - foff[u]) * c.frame_shift;
         // ---- samples, mean, raw energy (after DC removal, before pre-emphasis / windowing)
         float xv[FB_NFFT / 64];
         float sum = 0.f;
@@ -203,14 +217,14 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         // ---- radix-2 decimation in time, 9 stages, 256 butterflies each (4 per lane)
 #pragma unroll
         for (int st = 1; st <= 9; ++st) {
-            const int half = 1 << (st - 1), tstep = FB_NFFT >> st;
+            const int half = 1 << (st - 1);
             float a0[4], a1[4], b0[4], b1[4];
             int i0[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bf = lane + 64 * r, j = bf & (half - 1);
                 i0[r] = ((bf >> (st - 1)) << st) + j;
-                const float wr = cs[j * tstep], wi = -sn[j * tstep];
+                const float wr = cs[half + j], wi = -sn[half + j];
                 const float xr = re[i0[r] + half], xi = im[i0[r] + half];
                 b0[r] = wr * xr - wi * xi;
                 b1[r] = wr * xi + wi * xr;
@@ -249,10 +263,16 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 // add-deltas + CMVN over a set of utterances: edge frames are replicated per UTTERANCE; 4 frames per work-group
 __global__ __launch_bounds__(256) void deltas_cmvn_batch_kernel(const float* feats, const int* frame_off, int n_utts, int total_frames, int dim,
                                                                const float* mean, const float* istd, float* out) {
+    __shared__ int offs[FBF_OFFS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool offs_lds = n_utts + 1 <= FBF_OFFS;
+    if (offs_lds)
+        for (int x = threadIdx.x; x <= n_utts; x += 256) offs[x] = frame_off[x];
+    __syncthreads();
+    const int* const foff = offs_lds ? offs : frame_off;
     for (int t = blockIdx.x * 4 + wave; t < total_frames; t += gridDim.x * 4) {
-        const int u = fb_find_utt(frame_off, n_utts, t);
-        const int t0 = frame_off[u], t1 = frame_off[u + 1] - 1;
+        const int u = fb_find_utt(foff, n_utts, t);
+        const int t0 = foff[u], t1 = foff[u + 1] - 1;
         for (int j = lane; j < dim; j += 64) {
             const float s1[5] = {-0.2f, -0.1f, 0.f, 0.1f, 0.2f};
             const float s2[9] = {0.04f, 0.04f, 0.01f, -0.04f, -0.1f, -0.04f, 0.01f, 0.04f, 0.04f};
