@@ -116,20 +116,29 @@ __global__ __launch_bounds__(256) void deltas_cmvn_kernel(const float* feats, in
 // (0.4 MB of PCM): 53 us per 8-second utterance, 0.09 % of the HBM roofline (round-4 bench).  The front end is integer-in /
 // float-out streaming work — 320 bytes of new PCM and 164 bytes of features per frame — so this version (a) takes a whole set
 // of utterances per launch (PCM back to back, per-utterance sample / frame offsets on the device), (b) gives each frame to ONE
-// wave: samples -> LDS (coalesced 2-byte loads), mean / raw energy by DPP sums, pre-emphasis + window, an in-place radix-2 FFT in
-// the wave's own LDS slice (9 stages x 4 butterflies per lane, no work-group barrier), power spectrum, and the mel filters from a
-// packed table of their non-zero spans (a triangle covers <= 31 of the 256 bins at 40 filters; the table lives in LDS).
+// wave: lane L loads samples n = L + 64 k (coalesced 2-byte loads), mean / raw energy by wave sums, pre-emphasis (neighbour through
+// a lane shift) and window in registers, then a 512-point FFT as THREE radix-8 passes in registers with two exchanges through the
+// wave's own LDS slice (the first version ran nine radix-2 stages through LDS: LDS-bandwidth bound, 130 KB of LDS traffic per frame):
+//   positions idx = 64 h + 8 m + lo of the bit-reversed order; lane L's samples sit at idx = 8 brev6(L) + brev3(k): stages 1-3 are
+//   local to the loading lane (constant twiddles); pass 2 (stages 4-6) regroups by (lo, h), pass 3 (stages 7-9) by (m, lo) and
+//   leaves bin l + 64 m in lane l; the LDS address of a position is swizzled so that all three access patterns are 2-way conflicts
+//   at most (fbf_addr);
+// then the power spectrum and the mel filters from their non-zero spans, the weights of a lane's filter in REGISTERS.
 #define FBF_WAVES 4
 #define FBF_SPAN 64            // longest mel-filter span the packed table holds
+#define FBF_OFFS 2048          // frame offsets staged in LDS (a binary search through global memory costs ~10 dependent loads per frame)
 
-__device__ __forceinline__ int fb_bitrev9(int n) {
+__device__ __forceinline__ int fb_bitrev(int n, int bits) {
     int r = 0;
-#pragma unroll
-    for (int bit = 0; bit < 9; ++bit) r |= ((n >> bit) & 1) << (8 - bit);
+    for (int bit = 0; bit < bits; ++bit) r |= ((n >> bit) & 1) << (bits - 1 - bit);
     return r;
 }
-
-#define FBF_OFFS 2048          // frame offsets staged in LDS (a binary search through global memory costs ~10 dependent loads per frame)
+// LDS word of position (h, m, lo): 32 * row + bank with bank bits chosen so that each of the three access patterns — fixed lo over
+// (h, m), fixed m over (lo, h), fixed h over (m, lo) — maps its 64 lanes onto all 32 banks (two lanes each); bijective on 0..511
+__device__ __forceinline__ int fbf_addr(int h, int m, int lo) {
+    const int bank = ((lo ^ m ^ h) & 7) | ((((m & 3) ^ (h >> 1)) & 3) << 3);
+    return 32 * (lo + 8 * (m >> 2)) + bank;
+}
 // utterance of global frame f: frame_off[u] <= f < frame_off[u+1]
 __device__ __forceinline__ int fb_find_utt(const int* frame_off, int n, int f) {
     int lo = 0, hi = n - 1;
@@ -139,120 +148,163 @@ __device__ __forceinline__ int fb_find_utt(const int* frame_off, int n, int f) {
     }
     return lo;
 }
+// three radix-2 stages on the 8 values a lane holds (local index = the three index bits the pass works on): stage a pairs (x, x+1)
+// with twiddle w1, stage b pairs (x, x+2) with w2[x & 1], stage c pairs (x, x+4) with w4[x & 3]
+__device__ __forceinline__ void fbf_radix8(float (&re)[8], float (&im)[8], float w1r, float w1i, const float (&w2r)[2], const float (&w2i)[2],
+                                           const float (&w4r)[4], const float (&w4i)[4]) {
+#pragma unroll
+    for (int x = 0; x < 8; x += 2) {
+        const float tr = w1r * re[x + 1] - w1i * im[x + 1], ti = w1r * im[x + 1] + w1i * re[x + 1];
+        re[x + 1] = re[x] - tr; im[x + 1] = im[x] - ti;
+        re[x] += tr; im[x] += ti;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 8; blk += 4)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int x = blk + j;
+            const float tr = w2r[j] * re[x + 2] - w2i[j] * im[x + 2], ti = w2r[j] * im[x + 2] + w2i[j] * re[x + 2];
+            re[x + 2] = re[x] - tr; im[x + 2] = im[x] - ti;
+            re[x] += tr; im[x] += ti;
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float tr = w4r[j] * re[j + 4] - w4i[j] * im[j + 4], ti = w4r[j] * im[j + 4] + w4i[j] * re[j + 4];
+        re[j + 4] = re[j] - tr; im[j + 4] = im[j] - ti;
+        re[j] += tr; im[j] += ti;
+    }
+}
 
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
                                                                    int total_frames, lvsr_fbank_cfg c, const float* window, const int* mel_start,
                                                                    const float* mel_w, const float* twid, float* out) {
-    // twiddles per stage, contiguous: entry [half + j] = exp(-2 pi i j / (2 half)) for the stage with butterflies `half` apart (the
-    // strided reads of one 512-entry table hit 2 banks in the middle stages)
-    __shared__ float cs[FB_NFFT], sn[FB_NFFT], win[FB_NFFT];
-    __shared__ float mw[64][FBF_SPAN + 1];
-    __shared__ int ms[64];
     __shared__ int offs[FBF_OFFS];
     __shared__ float re_all[FBF_WAVES][FB_NFFT], im_all[FBF_WAVES][FB_NFFT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int x = tid; x < FB_NFFT; x += 64 * FBF_WAVES) {
-        win[x] = x < c.frame_length ? window[x] : 0.f;
-        if (x >= 1) {
-            int half = 1;
-            while (2 * half <= x) half *= 2;
-            const int j = x - half;                                        // x = half + j
-            const int idx = j * (FB_NFFT / (2 * half));
-            cs[x] = twid[idx];
-            sn[x] = twid[FB_NFFT + idx];
-        } else { cs[0] = 1.f; sn[0] = 0.f; }
-    }
     const bool offs_lds = n_utts + 1 <= FBF_OFFS;
     if (offs_lds)
         for (int x = tid; x <= n_utts; x += 64 * FBF_WAVES) offs[x] = frame_off[x];
-    const int* const foff = offs_lds ? offs : frame_off;
-    for (int x = tid; x < 64 * FBF_SPAN; x += 64 * FBF_WAVES) {
-        const int m = x / FBF_SPAN, i = x % FBF_SPAN;
-        mw[m][i] = m < c.num_mel ? mel_w[(size_t)m * FBF_SPAN + i] : 0.f;
-    }
-    if (tid < 64) ms[tid] = tid < c.num_mel ? mel_start[tid] : 0;
     __syncthreads();
+    const int* const foff = offs_lds ? offs : frame_off;
     float* const re = re_all[wave];
     float* const im = im_all[wave];
+    // ---- per-lane constants, in registers for every frame of the wave
+    // twiddle of stage s (butterflies `half` = 2^(s-1) apart) at offset j: exp(-2 pi i j / (2 half)) = (cos, -sin)(2 pi j (256 / half) / 512)
+    auto tw = [&](int half, int j, float& wr, float& wi) {
+        const int idx = j * (FB_NFFT / 2 / half);
+        wr = twid[idx]; wi = -twid[FB_NFFT + idx];
+    };
+    const int lo2 = lane & 7, h2 = lane >> 3;          // pass 2: this lane's (lo, h); its 8 values run over m
+    const int lo3 = lane & 7, m3 = lane >> 3;          // pass 3: this lane's (m, lo) = bin l + 64 x; its 8 values run over h
+    float p2w1r, p2w1i, p2w2r[2], p2w2i[2], p2w4r[4], p2w4i[4];
+    float p3w1r, p3w1i, p3w2r[2], p3w2i[2], p3w4r[4], p3w4i[4];
+    tw(8, lo2, p2w1r, p2w1i);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tw(16, lo2 + 8 * j, p2w2r[j], p2w2i[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw(32, lo2 + 8 * j, p2w4r[j], p2w4i[j]);
+    tw(64, lane, p3w1r, p3w1i);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) tw(128, lane + 64 * j, p3w2r[j], p3w2i[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tw(256, lane + 64 * j, p3w4r[j], p3w4i[j]);
+    const float R = 0.70710678118654752f;
+    const float p1w2r[2] = {1.f, 0.f}, p1w2i[2] = {0.f, -1.f};
+    const float p1w4r[4] = {1.f, R, 0.f, -R}, p1w4i[4] = {0.f, -R, -1.f, -R};
+    float winv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) winv[k] = (lane + 64 * k) < c.frame_length ? window[lane + 64 * k] : 0.f;
+    const int g1 = fb_bitrev(lane, 6), h1 = g1 >> 3, m1 = g1 & 7;      // pass 1: this lane's samples sit at positions (h1, m1, lo = brev3(k))
+    // mel filter of this lane: first bin, weights of its span
+    const int mf = lane < c.num_mel ? lane : 0;
+    const int mst = mel_start[mf];
+    float mwv[FBF_SPAN];
+    int span = 0;
+#pragma unroll
+    for (int i = 0; i < FBF_SPAN; ++i) {
+        mwv[i] = lane < c.num_mel ? mel_w[(size_t)mf * FBF_SPAN + i] : 0.f;
+        if (mwv[i] != 0.f) span = i + 1;
+    }
+    // (the longest span of the wave bounds the loop: 31 at 40 filters)
+    span = (int)wave_max((float)span);
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
     for (int f = blockIdx.x * FBF_WAVES + wave; f < total_frames; f += gridDim.x * FBF_WAVES) {
         const int u = fb_find_utt(foff, n_utts, f);
         const long long s0 = wav_off[u] + (long long)(f - foff[u]) * c.frame_shift;
-        // ---- samples, mean, raw energy (after DC removal, before pre-emphasis / windowing)
-        float xv[FB_NFFT / 64];
+        // ---- samples n = lane + 64 k, mean, raw energy (after DC removal, before pre-emphasis / windowing)
+        float xv[8];
         float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < FB_NFFT / 64; ++r) {
-            const int n = lane + 64 * r;
-            xv[r] = n < c.frame_length ? (float)wav[s0 + n] : 0.f;
-            sum += xv[r];
+        for (int k = 0; k < 8; ++k) {
+            const int n = lane + 64 * k;
+            xv[k] = n < c.frame_length ? (float)wav[s0 + n] : 0.f;
+            sum += xv[k];
         }
         const float mean = c.remove_dc ? wave_sum(sum) / (float)c.frame_length : 0.f;
         float e = 0.f;
 #pragma unroll
-        for (int r = 0; r < FB_NFFT / 64; ++r) {
-            const int n = lane + 64 * r;
-            xv[r] = n < c.frame_length ? xv[r] - mean : 0.f;
-            e += xv[r] * xv[r];
-            re[n] = xv[r];
+        for (int k = 0; k < 8; ++k) {
+            xv[k] = (lane + 64 * k) < c.frame_length ? xv[k] - mean : 0.f;
+            e += xv[k] * xv[k];
         }
         e = wave_sum(e);
-        __builtin_amdgcn_wave_barrier();
-        // ---- pre-emphasis (needs the neighbour: through LDS), window; into bit-reversed order for the in-place transform
-        float yv[FB_NFFT / 64];
+        // ---- pre-emphasis: x[n-1] sits one lane down (lane 0: lane 63 of the previous k); window
+        float ar[8], ai[8];
+        {
+            float prev[8];
 #pragma unroll
-        for (int r = 0; r < FB_NFFT / 64; ++r) {
-            const int n = lane + 64 * r;
-            const float prev = n > 0 ? re[n - 1] : xv[r];
-            yv[r] = n < c.frame_length ? (xv[r] - c.preemph * prev) * win[n] : 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int r = 0; r < FB_NFFT / 64; ++r) {
-            const int n = lane + 64 * r, br = fb_bitrev9(n);
-            re[br] = yv[r];
-            im[br] = 0.f;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // ---- radix-2 decimation in time, 9 stages, 256 butterflies each (4 per lane)
-#pragma unroll
-        for (int st = 1; st <= 9; ++st) {
-            const int half = 1 << (st - 1);
-            float a0[4], a1[4], b0[4], b1[4];
-            int i0[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int bf = lane + 64 * r, j = bf & (half - 1);
-                i0[r] = ((bf >> (st - 1)) << st) + j;
-                const float wr = cs[half + j], wi = -sn[half + j];
-                const float xr = re[i0[r] + half], xi = im[i0[r] + half];
-                b0[r] = wr * xr - wi * xi;
-                b1[r] = wr * xi + wi * xr;
-                a0[r] = re[i0[r]];
-                a1[r] = im[i0[r]];
+            for (int k = 0; k < 8; ++k) {
+                const float dn = __shfl_up(xv[k], 1, 64);
+                const float wrap = k > 0 ? __shfl(xv[k > 0 ? k - 1 : 0], 63, 64) : xv[0];
+                prev[k] = lane > 0 ? dn : wrap;
             }
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                re[i0[r]] = a0[r] + b0[r]; im[i0[r]] = a1[r] + b1[r];
-                re[i0[r] + half] = a0[r] - b0[r]; im[i0[r] + half] = a1[r] - b1[r];
+            for (int k = 0; k < 8; ++k) {
+                const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
+                ar[lo] = (xv[k] - c.preemph * prev[k]) * winv[k];
+                ai[lo] = 0.f;
             }
-            __builtin_amdgcn_wave_barrier();
         }
-        // ---- power spectrum of bins 0..255 (in place: a lane only touches its own bins), mel filters, log
+        // ---- pass 1: stages 1-3 inside the lane's group of 8 positions (twiddles 1 | 1, -i | W8^j)
+        fbf_radix8(ar, ai, 1.f, 0.f, p1w2r, p1w2i, p1w4r, p1w4i);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int k = lane + 64 * r;
-            re[k] = re[k] * re[k] + im[k] * im[k];
+        for (int lo = 0; lo < 8; ++lo) {
+            const int at = fbf_addr(h1, m1, lo);
+            re[at] = ar[lo]; im[at] = ai[lo];
         }
+        __builtin_amdgcn_wave_barrier();
+        // ---- pass 2: stages 4-6 over m (positions 64 h + 8 m + lo of this lane's (lo, h))
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int at = fbf_addr(h2, m, lo2);
+            ar[m] = re[at]; ai[m] = im[at];
+        }
+        fbf_radix8(ar, ai, p2w1r, p2w1i, p2w2r, p2w2i, p2w4r, p2w4i);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int at = fbf_addr(h2, m, lo2);
+            re[at] = ar[m]; im[at] = ai[m];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- pass 3: stages 7-9 over h (positions 64 h + lane): bin lane + 64 h ends up in ar[h]
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int at = fbf_addr(h, m3, lo3);
+            ar[h] = re[at]; ai[h] = im[at];
+        }
+        fbf_radix8(ar, ai, p3w1r, p3w1i, p3w2r, p3w2i, p3w4r, p3w4i);
+        __builtin_amdgcn_wave_barrier();
+        // ---- power spectrum of bins 0..255 (plain order in the wave's slice), mel filters, log
+#pragma unroll
+        for (int h = 0; h < 4; ++h) re[lane + 64 * h] = ar[h] * ar[h] + ai[h] * ai[h];
         __builtin_amdgcn_wave_barrier();
         float* o = out + (size_t)f * width;
         {
-            const int m = lane < c.num_mel ? lane : 0;
-            const int st = ms[m];
             float acc = 0.f;
-#pragma unroll 8
-            for (int i = 0; i < FBF_SPAN; ++i) acc += mw[m][i] * re[min(st + i, FB_NFFT / 2 - 1)];
+#pragma unroll
+            for (int i = 0; i < FBF_SPAN; ++i)
+                if (i < span) acc += mwv[i] * re[min(mst + i, FB_NFFT / 2 - 1)];
             if (lane < c.num_mel) o[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc, 1.1920929e-07f));
         }
         if (c.use_energy && lane == 0) o[0] = logf(fmaxf(e, 1.1920929e-07f));
