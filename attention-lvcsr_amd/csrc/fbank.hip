@@ -175,6 +175,7 @@ __device__ __forceinline__ void fbf_radix8(float (&re)[8], float (&im)[8], float
     }
 }
 
+template <int SP>      // registers for the mel weights of a lane's filter: the longest span rounded up to 32 / 64
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
                                                                    int total_frames, lvsr_fbank_cfg c, const float* window, const int* mel_start,
                                                                    const float* mel_w, const float* twid, float* out) {
@@ -218,28 +219,37 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     // mel filter of this lane: first bin, weights of its span
     const int mf = lane < c.num_mel ? lane : 0;
     const int mst = mel_start[mf];
-    float mwv[FBF_SPAN];
+    float mwv[SP];
     int span = 0;
 #pragma unroll
-    for (int i = 0; i < FBF_SPAN; ++i) {
+    for (int i = 0; i < SP; ++i) {
         mwv[i] = lane < c.num_mel ? mel_w[(size_t)mf * FBF_SPAN + i] : 0.f;
         if (mwv[i] != 0.f) span = i + 1;
     }
     // (the longest span of the wave bounds the loop: 31 at 40 filters)
     span = (int)wave_max((float)span);
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
-    for (int f = blockIdx.x * FBF_WAVES + wave; f < total_frames; f += gridDim.x * FBF_WAVES) {
+    // the samples of a frame are fetched one frame ahead (a wave works on its frames one after the other: without it every frame
+    // starts with two dependent memory latencies — the utterance's sample offset, then the samples)
+    short nx[8];
+    auto fetch = [&](int f) {
         const int u = fb_find_utt(foff, n_utts, f);
         const long long s0 = wav_off[u] + (long long)(f - foff[u]) * c.frame_shift;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) nx[k] = (lane + 64 * k) < c.frame_length ? wav[s0 + lane + 64 * k] : (short)0;
+    };
+    const int f_first = blockIdx.x * FBF_WAVES + wave, f_step = gridDim.x * FBF_WAVES;
+    if (f_first < total_frames) fetch(f_first);
+    for (int f = f_first; f < total_frames; f += f_step) {
         // ---- samples n = lane + 64 k, mean, raw energy (after DC removal, before pre-emphasis / windowing)
         float xv[8];
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int n = lane + 64 * k;
-            xv[k] = n < c.frame_length ? (float)wav[s0 + n] : 0.f;
+            xv[k] = (float)nx[k];
             sum += xv[k];
         }
+        if (f + f_step < total_frames) fetch(f + f_step);
         const float mean = c.remove_dc ? wave_sum(sum) / (float)c.frame_length : 0.f;
         float e = 0.f;
 #pragma unroll
@@ -303,7 +313,7 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         {
             float acc = 0.f;
 #pragma unroll
-            for (int i = 0; i < FBF_SPAN; ++i)
+            for (int i = 0; i < SP; ++i)
                 if (i < span) acc += mwv[i] * re[min(mst + i, FB_NFFT / 2 - 1)];
             if (lane < c.num_mel) o[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc, 1.1920929e-07f));
         }
@@ -375,8 +385,8 @@ int lvsr_add_deltas_cmvn(void* stream, const float* feats, int T, int dim, const
 }
 
 int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, const int* frame_off, int n, int total_frames,
-                     const lvsr_fbank_cfg* cfg, const float* window, const int* mel_start, const float* mel_w, const float* twiddle,
-                     float* out) {
+                     const lvsr_fbank_cfg* cfg, const float* window, const int* mel_start, const float* mel_w, int mel_span,
+                     const float* twiddle, float* out) {
     LVSR_REQUIRE(cfg && wav && wav_off && frame_off && window && mel_start && mel_w && twiddle && out && n > 0, "lvsr_fbank_batch: null argument");
     lvsr_fbank_cfg c;
     memcpy(&c, cfg, sizeof(c));
@@ -385,8 +395,13 @@ int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, c
     if (total_frames <= 0) return LVSR_OK;
     int nb = (total_frames + FBF_WAVES - 1) / FBF_WAVES;
     if (nb > 2048) nb = 2048;          // grid-stride over the frames: the tables are staged once per work-group
-    hipLaunchKernelGGL(fbank_fft_kernel, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
-                       window, mel_start, mel_w, twiddle, out);
+    LVSR_REQUIRE(mel_span >= 0 && mel_span <= FBF_SPAN, "lvsr_fbank_batch: mel_span outside [0, 64]");
+    if (mel_span > 0 && mel_span <= 32)
+        hipLaunchKernelGGL(fbank_fft_kernel<32>, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
+                           window, mel_start, mel_w, twiddle, out);
+    else
+        hipLaunchKernelGGL(fbank_fft_kernel<64>, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
+                           window, mel_start, mel_w, twiddle, out);
     return lvsr_check_launch("lvsr_fbank_batch");
 }
 

@@ -38,6 +38,7 @@ class Fbank(object):
         self.window, self.melw, self.twiddle = t(win), t(W), t(numpy.stack([numpy.cos(ang), numpy.sin(ang)]))
         # the filters' non-zero spans for the batched kernel (lvsr_fbank_batch): first bin and up to 64 weights per filter
         starts, packed, self.batchable = numpy.zeros(self.num_mel, numpy.int32), numpy.zeros((self.num_mel, 64), numpy.float32), self.num_mel <= 64
+        self.mel_span = 0
         for b in range(self.num_mel):
             nz = numpy.nonzero(W[b])[0]
             if len(nz) == 0:
@@ -47,6 +48,7 @@ class Fbank(object):
                 break
             starts[b] = nz[0]
             packed[b, : nz[-1] - nz[0] + 1] = W[b, nz[0]: nz[-1] + 1]
+            self.mel_span = max(self.mel_span, int(nz[-1] - nz[0] + 1))
         self.mel_start = torch.tensor(starts, device=self.device)
         self.mel_packed = t(packed)
 
@@ -83,7 +85,7 @@ class Fbank(object):
         out = torch.empty(total_frames, self.num_mel + int(self.use_energy), dtype=torch.float32, device=self.device)
         if total_frames:
             self.lib.call("lvsr_fbank_batch", self.lib.stream_for(out), ptr(wav), ptr(wav_off), ptr(frame_off), int(n), int(total_frames),
-                          ctypes.byref(self.cfg), ptr(self.window), ptr(self.mel_start), ptr(self.mel_packed), ptr(self.twiddle), ptr(out))
+                          ctypes.byref(self.cfg), ptr(self.window), ptr(self.mel_start), ptr(self.mel_packed), int(self.mel_span), ptr(self.twiddle), ptr(out))
         return out, frame_off
 
     def add_deltas_cmvn_batch(self, feats, frame_off, mean=None, std=None):

@@ -495,11 +495,11 @@ int lvsr_add_deltas_cmvn(void* stream, const float* feats, int T, int dim, const
  * frame): `wav` holds the utterances' PCM back to back, utterance u = samples [wav_off[u], wav_off[u+1]) and output rows
  * [frame_off[u], frame_off[u+1]) (device arrays of n + 1 entries; frame_off[u+1] - frame_off[u] = lvsr_fbank_num_frames of its
  * length).  One wave per frame, a 512-point FFT in LDS instead of the direct DFT; the mel filters come as their non-zero spans:
- * mel_start (num_mel) first bin, mel_w (num_mel, 64) weights (zero padded) — num_mel <= 64, spans <= 64 bins (the 40-filter
- * front end of the recipe: <= 31).  Same arithmetic up to float32 summation order. */
+ * mel_start (num_mel) first bin, mel_w (num_mel, 64) weights (zero padded), mel_span = the longest span (0 = unknown: 64) — num_mel
+ * <= 64, spans <= 64 bins (the 40-filter front end of the recipe: <= 31).  Same arithmetic up to float32 summation order. */
 int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, const int* frame_off, int n, int total_frames,
-                     const lvsr_fbank_cfg* cfg, const float* window, const int* mel_start, const float* mel_w, const float* twiddle,
-                     float* out);
+                     const lvsr_fbank_cfg* cfg, const float* window, const int* mel_start, const float* mel_w, int mel_span,
+                     const float* twiddle, float* out);
 /* deltas + CMVN over the same set: edge frames replicated per utterance */
 int lvsr_add_deltas_cmvn_batch(void* stream, const float* feats, const int* frame_off, int n, int total_frames, int dim, const float* mean,
                                const float* istd, float* out);
