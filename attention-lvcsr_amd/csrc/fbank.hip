@@ -216,18 +216,17 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 #pragma unroll
     for (int k = 0; k < 8; ++k) winv[k] = (lane + 64 * k) < c.frame_length ? window[lane + 64 * k] : 0.f;
     const int g1 = fb_bitrev(lane, 6), h1 = g1 >> 3, m1 = g1 & 7;      // pass 1: this lane's samples sit at positions (h1, m1, lo = brev3(k))
-    // mel filter of this lane: first bin, weights of its span
-    const int mf = lane < c.num_mel ? lane : 0;
-    const int mst = mel_start[mf];
-    float mwv[SP];
-    int span = 0;
+    // the LDS words of the three access patterns are the same for every frame: 24 registers instead of ~240 integer operations per frame
+    int at1[8], at2[8], at3[8];
 #pragma unroll
-    for (int i = 0; i < SP; ++i) {
-        mwv[i] = lane < c.num_mel ? mel_w[(size_t)mf * FBF_SPAN + i] : 0.f;
-        if (mwv[i] != 0.f) span = i + 1;
-    }
-    // (the longest span of the wave bounds the loop: 31 at 40 filters)
-    span = (int)wave_max((float)span);
+    for (int x = 0; x < 8; ++x) { at1[x] = fbf_addr(h1, m1, x); at2[x] = fbf_addr(h2, x, lo2); at3[x] = fbf_addr(x, m3, lo3); }
+    // mel filter of this lane: first bin, weights of its span
+    // (a filter that starts fewer than SP bins below bin 256 is shifted down, its weights up: the loop reads SP bins unconditionally)
+    const int mf = lane < c.num_mel ? lane : 0;
+    const int mst0 = mel_start[mf], mst = min(mst0, FB_NFFT / 2 - SP), msh = mst0 - mst;
+    float mwv[SP];
+#pragma unroll
+    for (int i = 0; i < SP; ++i) mwv[i] = (lane < c.num_mel && i - msh >= 0) ? mel_w[(size_t)mf * FBF_SPAN + (i - msh)] : 0.f;
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
     // the samples of a frame are fetched one frame ahead (a wave works on its frames one after the other: without it every frame
     // starts with two dependent memory latencies — the utterance's sample offset, then the samples)
@@ -250,22 +249,23 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             sum += xv[k];
         }
         if (f + f_step < total_frames) fetch(f + f_step);
-        const float mean = c.remove_dc ? wave_sum(sum) / (float)c.frame_length : 0.f;
+        const float mean = c.remove_dc ? wave_sum_dpp(sum) / (float)c.frame_length : 0.f;
         float e = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             xv[k] = (lane + 64 * k) < c.frame_length ? xv[k] - mean : 0.f;
             e += xv[k] * xv[k];
         }
-        e = wave_sum(e);
+        e = wave_sum_dpp(e);
         // ---- pre-emphasis: x[n-1] sits one lane down (lane 0: lane 63 of the previous k); window
         float ar[8], ai[8];
         {
             float prev[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const float dn = __shfl_up(xv[k], 1, 64);
-                const float wrap = k > 0 ? __shfl(xv[k > 0 ? k - 1 : 0], 63, 64) : xv[0];
+                // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane instead of two LDS-crossbar shuffles
+                const float dn = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k]), 0x138, 0xf, 0xf, false));
+                const float wrap = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0]), 63)) : xv[0];
                 prev[k] = lane > 0 ? dn : wrap;
             }
 #pragma unroll
@@ -278,31 +278,19 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         // ---- pass 1: stages 1-3 inside the lane's group of 8 positions (twiddles 1 | 1, -i | W8^j)
         fbf_radix8(ar, ai, 1.f, 0.f, p1w2r, p1w2i, p1w4r, p1w4i);
 #pragma unroll
-        for (int lo = 0; lo < 8; ++lo) {
-            const int at = fbf_addr(h1, m1, lo);
-            re[at] = ar[lo]; im[at] = ai[lo];
-        }
+        for (int lo = 0; lo < 8; ++lo) { re[at1[lo]] = ar[lo]; im[at1[lo]] = ai[lo]; }
         __builtin_amdgcn_wave_barrier();
         // ---- pass 2: stages 4-6 over m (positions 64 h + 8 m + lo of this lane's (lo, h))
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int at = fbf_addr(h2, m, lo2);
-            ar[m] = re[at]; ai[m] = im[at];
-        }
+        for (int m = 0; m < 8; ++m) { ar[m] = re[at2[m]]; ai[m] = im[at2[m]]; }
         fbf_radix8(ar, ai, p2w1r, p2w1i, p2w2r, p2w2i, p2w4r, p2w4i);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int at = fbf_addr(h2, m, lo2);
-            re[at] = ar[m]; im[at] = ai[m];
-        }
+        for (int m = 0; m < 8; ++m) { re[at2[m]] = ar[m]; im[at2[m]] = ai[m]; }
         __builtin_amdgcn_wave_barrier();
         // ---- pass 3: stages 7-9 over h (positions 64 h + lane): bin lane + 64 h ends up in ar[h]
 #pragma unroll
-        for (int h = 0; h < 8; ++h) {
-            const int at = fbf_addr(h, m3, lo3);
-            ar[h] = re[at]; ai[h] = im[at];
-        }
+        for (int h = 0; h < 8; ++h) { ar[h] = re[at3[h]]; ai[h] = im[at3[h]]; }
         fbf_radix8(ar, ai, p3w1r, p3w1i, p3w2r, p3w2i, p3w4r, p3w4i);
         __builtin_amdgcn_wave_barrier();
         // ---- power spectrum of bins 0..255 (plain order in the wave's slice), mel filters, log
@@ -312,9 +300,9 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         float* o = out + (size_t)f * width;
         {
             float acc = 0.f;
+            const float* pwr = re + mst;
 #pragma unroll
-            for (int i = 0; i < SP; ++i)
-                if (i < span) acc += mwv[i] * re[min(mst + i, FB_NFFT / 2 - 1)];
+            for (int i = 0; i < SP; ++i) acc += mwv[i] * pwr[i];
             if (lane < c.num_mel) o[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc, 1.1920929e-07f));
         }
         if (c.use_energy && lane == 0) o[0] = logf(fmaxf(e, 1.1920929e-07f));

@@ -263,6 +263,7 @@ inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
     int l = hipemu::lane_id();
     if (ctrl == 0x140) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | (15 - (l & 15)));      // row_mirror
     if (ctrl == 0x141) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~7) | (7 - (l & 7)));        // row_half_mirror
+    if (ctrl == 0x138) return (int)hipemu::shfl_generic<long long, long long>(v, l > 0 ? l - 1 : l);                 // wave_shr:1 (lane 0 keeps its value)
     if (ctrl >= 0x121 && ctrl <= 0x12F) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | ((l - (ctrl - 0x120)) & 15));
     if (ctrl >= 0x100) { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
     return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
