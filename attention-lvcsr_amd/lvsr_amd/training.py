@@ -155,6 +155,13 @@ class Trainer(object):
                 t[:16].zero_()
         rec.encoder.use_persistent, rec.encoder.persist_auto = False, False
         rec.generator.use_persistent = False
+        if hasattr(rec.generator, "use_persistent_stack"):
+            rec.generator.use_persistent_stack = False
+        # the captured whole-step graphs replay the cluster launches: forget them (the next step of every shape is enqueued eagerly,
+        # the one after captured again — on the step kernels)
+        getattr(rec, "_regions", {}).clear()
+        getattr(self, "_regions", {}).clear()
+        rec.lib._lvsr_graph_clear()
 
     def _all_reduce_gradients(self):
         """ONE collective per step over the flat gradient bucket (sum); RCCL over xGMI when the tensors are on GPUs.

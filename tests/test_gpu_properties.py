@@ -220,3 +220,48 @@ def test_concurrent_searches_equal_sequential_ones(gpu_device):
                     slots[k] = None
     for i in range(len(utts)):
         assert got[i] == want[i], i
+
+
+def test_step_of_an_aborted_cluster_is_skipped_inside_the_graph_and_recovered(gpu_device):
+    """The guard at full size, inside the replayed whole-step graph: a raised (sticky) abort word of the decoder's cluster workspace
+    makes the captured lvsr_opt_step skip the step on the device — parameters and rule state bit-identical — and Trainer.recover()
+    drops the captured graphs, moves the run onto the step kernels and the batch run again gives the step an undisturbed run on
+    the step kernels takes."""
+    from lvsr_amd.training import Trainer
+    cfg = spec.wsj_base()
+    params = synthetic.make_params(cfg, seed=13, scales=WSJ_COND_TRAIN)
+    batch = synthetic.make_batch(cfg, B, T, L, seed=78, ragged=True)
+    rules = dict(gradient_threshold=100.0, rules=("momentum", "adadelta"), scale=0.1, momentum=0.0, decay_rate=0.95, epsilon=1e-8,
+                 max_norm=1.0)
+    ref = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg, use_persistent=False, use_persistent_decoder=False)
+    tr_ref = Trainer(ref, distributed=False, **rules)
+    for _ in range(4):
+        tr_ref.train_step(batch)
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    tr = Trainer(rec, distributed=False, **rules)
+    for _ in range(3):                       # eager, capture, replay
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    assert not tr.step_was_skipped()
+    assert any(s["seen"] >= 3 for s in rec._regions.values())
+    before = rec.store.get_values()
+    state = {k: numpy.asarray(v).copy() for k, v in tr.state_dict().items() if k != "layout"}
+    words = [t for k, t in rec.ws._bufs.items() if k[0] in ("gen.sync", "gen.sync_bwd")]
+    assert len(words) == 2, "the decoder did not run on its cluster kernels"
+    words[1][0] = 1        # "a work-group of the cluster was never scheduled"
+    tr.train_step(batch)                     # a replay of the captured step
+    torch.cuda.synchronize()
+    assert tr.step_was_skipped()
+    for k, v in rec.store.get_values().items():
+        assert (v == before[k]).all(), "a skipped step changed %s" % k
+    for k, v in tr.state_dict().items():
+        if k != "layout":
+            assert (numpy.asarray(v) == state[k]).all(), "a skipped step changed the optimiser's %s" % k
+    tr.recover()
+    tr.train_step(batch)
+    torch.cuda.synchronize()
+    assert not tr.step_was_skipped() and rec.generator.use_persistent is False and not rec.encoder.use_persistent
+    got, want = rec.store.get_values(), ref.store.get_values()
+    for k in want:
+        scale = max(1e-3, numpy.abs(want[k]).max())
+        assert numpy.abs(got[k] - want[k]).max() / scale < 5e-3, k
