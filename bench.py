@@ -164,13 +164,12 @@ PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_bench.json")
 
 
 def csrc_sha():
-    """Hash of the sources the dominant kernel is compiled from (csrc/encoder_persist.hip and every header of csrc/)."""
+    """Hash of the sources the dominant kernel is compiled from: csrc/encoder_persist.hip and the csrc headers it includes."""
     import hashlib
     csrc = os.path.join(REPO, "attention-lvcsr_amd", "csrc")
     h = hashlib.sha256()
-    for f in sorted(os.listdir(csrc)):
-        if f.endswith(".h") or f in ("encoder_persist.hip", "encoder.hip"):
-            h.update(open(os.path.join(csrc, f), "rb").read())
+    for f in ("common.h", "encoder_persist.hip", "graph_cache.h", "persist.h"):
+        h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 
 
