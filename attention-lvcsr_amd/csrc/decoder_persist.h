@@ -53,6 +53,21 @@ static inline bool pd_pick(int B, int D, int M, PdPick& k, bool allow16 = true) 
     return set(0, PdShape8::UNITS, PdShape8::KD, PdShape8::MC, PdShape8::AWS);
 }
 
+// Utterances per launch.  All of them when their clusters fit the chip at once; otherwise — when nothing couples the utterances of a
+// batch (no window prior: the windows' centres are the one thing clusters of different utterances exchange) — the fewest equal
+// passes that fit, launched back to back on the stream (per-GPU batches of 64 / 128: 2 / 4 passes of 32 utterances in clusters of 8
+// instead of the step kernels).
+static inline bool pd_pick_passes(int B, int D, int M, bool independent, PdPick& k, int& nb, bool allow16 = true) {
+    nb = B;
+    if (pd_pick(B, D, M, k, allow16)) return true;
+    if (!independent) return false;
+    for (int passes = 2; passes <= 8; ++passes) {
+        nb = (B + passes - 1) / passes;
+        if (pd_pick(nb, D, M, k, allow16)) return true;
+    }
+    return false;
+}
+
 __host__ __device__ __forceinline__ int pd_slot(int k, int KX) { return (k / KX) * (KX + 4) + (k % KX); }
 
 // Window of label i (attdec_window) with the window centres taken from LDS: the centres of ALL utterances bound the window

@@ -38,6 +38,7 @@
 struct PdGeom {
     int P, nown, nownp, KC, KCP, FW, prof, RL, shape;
     int o_pa, o_a, o_cv, o_al, o_sv, o_rs, o_xw, o_red, o_pos, o_clk, o_cp, o_sw, o_s0, Bp, total;
+    int nb, b0;          // utterances of this launch: [b0, b0 + nb) (pd_pick_passes)
 };
 
 
@@ -61,7 +62,9 @@ static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true, bool stack 
         k.shape = 0; k.UNITS = PdShape8::UNITS; k.KSPLIT = PdShape8::KSPLIT; k.KD = PdShape8::KD; k.MC = PdShape8::MC; k.AWS = PdShape8::AWS;
         k.P = (a.D + k.UNITS - 1) / k.UNITS;
         if (a.M > k.P * k.MC * k.UNITS || a.B * 2 * k.P > lvsr_max_cluster_wgs()) return false;
-    } else if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
+    } else if (!pd_pick_passes(a.B, a.D, a.M, a.K == 0 || a.prior_type == 0, k, g.nb, allow16)) return false;
+    if (stack) g.nb = a.B;
+    g.b0 = 0;
     g.P = k.P; g.shape = k.shape;
     g.nown = (a.Tp + g.P - 1) / g.P;
     g.nownp = (g.nown + PD_CH - 1) / PD_CH * PD_CH;
@@ -345,7 +348,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pfwd_kernel(AttDec a, lvsr_
     float* const cp = lds + g.o_cp;       // [PD_NW][16][17] convolution partial tiles
     const int P = g.P, nown = g.nown;
     int b, p;
-    if (!cluster_of_block(STACK ? 2 * P : P, a.B, 0, b, p)) return;  // (work-groups of the grid's padding)
+    if (!cluster_of_block(STACK ? 2 * P : P, g.nb, 0, b, p)) return;  // (work-groups of the grid's padding)
+    b += g.b0;
     if (STACK && p >= P) {            // the second cluster of the utterance: layer 1 of the stack
         pd_stack_layer1<SH>(a, g, k2, lds, planes, abort_word, b, p - P);
         return;
@@ -907,8 +911,12 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
     const size_t bytes = ((size_t)a.B * PD_NPLANE * PD_MAXV + 2 * g.Bp + (size_t)a.B * PD_MAXP) * 8;
     auto enqueue = [&]() {
         (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
-        const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
-#define PD_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pfwd_kernel<KCV, SHAPE, false>), grid, block, 0, s, a, w, g, planes, ab, PdStack())
+        const dim3 block(PD_THREADS);
+        PdGeom gp = g;
+        for (gp.b0 = 0; gp.b0 < a.B; gp.b0 += g.nb) {
+        gp.nb = min(g.nb, a.B - gp.b0);
+        const dim3 grid(cluster_grid(gp.nb, g.P, 0));
+#define PD_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pfwd_kernel<KCV, SHAPE, false>), grid, block, 0, s, a, w, gp, planes, ab, PdStack())
 #define PD_LAUNCH_KC(SHAPE)                       \
         switch (g.KC) {                           \
             case 0: PD_LAUNCH(0, SHAPE); break;   \
@@ -919,6 +927,7 @@ extern "C" int lvsr_attdec_fwd_persistent(void* stream, const lvsr_attdec_args* 
         if (g.shape == 0) { PD_LAUNCH_KC(PdShape8) }
         else if (g.shape == 1) { PD_LAUNCH_KC(PdShape16) }
         else { PD_LAUNCH_KC(PdShape32) }
+        }
 #undef PD_LAUNCH_KC
 #undef PD_LAUNCH
     };

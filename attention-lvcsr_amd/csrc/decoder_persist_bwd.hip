@@ -40,6 +40,7 @@ typedef lvsr_attdec_bwd_args AttBwd;
 struct PbGeom {
     int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL;
     int o_ft, o_nx, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
+    int nb, b0;          // utterances of this launch: [b0, b0 + nb) (pd_pick_passes)
 };
 
 static int pb_kc(int K) {
@@ -61,7 +62,9 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack 
         k.shape = 0; k.UNITS = PdShape8::UNITS; k.KSPLIT = PdShape8::KSPLIT; k.KD = PdShape8::KD; k.MC = PdShape8::MC; k.AWS = PdShape8::AWS;
         k.P = (a.D + k.UNITS - 1) / k.UNITS;
         if (a.M > k.P * k.MC * k.UNITS || a.B * 2 * k.P > lvsr_max_cluster_wgs()) return false;
-    } else if (!pd_pick(a.B, a.D, a.M, k, allow16)) return false;
+    } else if (!pd_pick_passes(a.B, a.D, a.M, a.K == 0 || a.prior_type == 0, k, g.nb, allow16)) return false;
+    if (stack) g.nb = a.B;
+    g.b0 = 0;
     g.P = k.P; g.shape = k.shape;
     const int DP = k.KSPLIT * k.KD > 256 ? 512 : 256, MS = k.MC * k.UNITS;      // padded decoder width of the exchanges, match columns per work-group
     g.nown = (a.Tp + g.P - 1) / g.P;
@@ -376,7 +379,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const nx = lds + g.o_nx;       // [5][64] saved gate values of the own units, fetched one label ahead
     const int P = g.P, nown = g.nown;
     int b, p;
-    if (!cluster_of_block(STACK ? 2 * P : P, a.B, 0, b, p)) return;  // (work-groups of the grid's padding)
+    if (!cluster_of_block(STACK ? 2 * P : P, g.nb, 0, b, p)) return;  // (work-groups of the grid's padding)
+    b += g.b0;
     u64* const gA = planes + (size_t)b * (STACK ? PB_SMALL + PB_STACK_EXTRA + (size_t)P * PB_PERWG_STACK : PB_SMALL + (size_t)P * PB_PERWG);
     if (STACK && p >= P) {            // the second cluster of the utterance: layer 1 of the stack
         pb_stack_layer1<SH>(gb, g, k2, lds, gA, abort_word, b, p - P);
@@ -1011,8 +1015,12 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     u64* planes = (u64*)((char*)ws + 256);
     const size_t bytes = (size_t)a.B * (PB_SMALL + (size_t)g.P * PB_PERWG) * 8;
     (void)hipMemsetAsync(planes, 0, bytes, s);          // the abort word in front of the planes is sticky: cleared by the host only
-    const dim3 grid(cluster_grid(a.B, g.P, 0)), block(PD_THREADS);
-#define PB_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pbwd_kernel<KCV, SHAPE, false>), grid, block, 0, s, gb, w, g, planes, ab, PbStack())
+    const dim3 block(PD_THREADS);
+    PbGeom gp = g;
+    for (gp.b0 = 0; gp.b0 < a.B; gp.b0 += g.nb) {
+    gp.nb = min(g.nb, a.B - gp.b0);
+    const dim3 grid(cluster_grid(gp.nb, g.P, 0));
+#define PB_LAUNCH(KCV, SHAPE) hipLaunchKernelGGL((attdec_pbwd_kernel<KCV, SHAPE, false>), grid, block, 0, s, gb, w, gp, planes, ab, PbStack())
 #define PB_LAUNCH_KC(SHAPE)                       \
     switch (g.KC) {                               \
         case 0: PB_LAUNCH(0, SHAPE); break;       \
@@ -1023,6 +1031,7 @@ extern "C" int lvsr_attdec_bwd_persistent(void* stream, const lvsr_attdec_bwd_ar
     if (g.shape == 0) { PB_LAUNCH_KC(PdShape8) }
     else if (g.shape == 1) { PB_LAUNCH_KC(PdShape16) }
     else { PB_LAUNCH_KC(PdShape32) }
+    }
 #undef PB_LAUNCH_KC
 #undef PB_LAUNCH
     return lvsr_check_launch("lvsr_attdec_bwd_persistent");

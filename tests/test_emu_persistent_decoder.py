@@ -64,6 +64,36 @@ def test_persistent_decoder_against_oracle_and_golden(concurrent_lib, case):
 
 
 
+@pytest.mark.parametrize("case,passes", [("tiny_conv_expanding", True), ("tiny_conv_median", False)])
+def test_batches_larger_than_the_chip_run_in_passes(case, passes):
+    """A batch whose clusters do not fit the chip at once (knob max_cluster_wgs plays a small chip here) runs the persistent kernels
+    in equal passes over the utterances when nothing couples them (expanding prior: decoder_persist.h pd_pick_passes) — same costs,
+    alignments and gradients —, and falls back to the step kernels under a window prior (the centres of ALL utterances bound the
+    window: the clusters of a batch exchange them label by label)."""
+    lib = emu_lib()
+    lib._dll.hipemu_set_concurrent(1)
+    z, meta = load_golden(case)
+    B = meta["B"]
+    assert B >= 3
+    lib.set_knob("max_cluster_wgs", B - 1)          # clusters of one work-group (D <= 16): two passes of ceil(B / 2) utterances
+    try:
+        params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+        batch = synthetic.make_batch(meta["cfg"], B, meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+        out, grads = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float64).cost_and_grads(batch)
+        rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=meta["cfg"], use_persistent=False,
+                               use_persistent_decoder=True if passes else None)
+        cm = rec.cost_and_gradients(batch)
+        assert engaged(rec) == passes
+        if passes:
+            assert any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs)
+            rec.generator.check_persistent()
+        check_against(rec, cm, z, out, grads, tol=1.0)
+    finally:
+        lib.set_knob("max_cluster_wgs", 0)
+        lib._dll.hipemu_set_concurrent(0)
+
+
+
 
 # the backward kernel's filter-count instantiations (K <= 4 / 10 / 16) and matcher widths that are / are not a multiple of 4
 # (16-byte vs element loads of the transform_states rows), clusters of one and two work-groups

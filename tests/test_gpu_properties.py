@@ -122,6 +122,31 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
         assert numpy.abs(g_p[k] - g_s[k]).max() / scale < gtol, k
 
 
+def test_persistent_decoder_in_passes_at_batch_64(gpu_device, setup):
+    """Per-GPU batch 64: 64 clusters of 8 work-groups do not fit the 256 CUs at once; under the expanding prior the utterances are
+    independent and the persistent kernels run two passes of 32 utterances (decoder_persist.h pd_pick_passes).  Against the step
+    kernels: costs, alignment argmax of every label, every gradient."""
+    s = setup
+    batch = synthetic.make_batch(s["cfg"], 64, 480, 60, seed=79, ragged=True)
+    out = {}
+    for persistent in (True, False):
+        rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_persistent_decoder=persistent)
+        cm = rec.cost_and_gradients(batch).cpu().numpy()
+        torch.cuda.synchronize()
+        rec.generator.check_persistent()
+        assert any(k[0] == "gen.sync" for k in rec.ws._bufs) == persistent, "persistent decoder engaged / did not engage"
+        assert any(k[0] == "gen.sync_bwd" for k in rec.ws._bufs) == persistent, "persistent decoder backward engaged / did not engage"
+        out[persistent] = (cm, rec.generator.last["weights"].cpu().numpy(), rec.store.get_grads())
+    (cm_p, w_p, g_p), (cm_s, w_s, g_s) = out[True], out[False]
+    assert abs(cm_p.sum() - cm_s.sum()) / abs(cm_s.sum()) < 1e-5
+    assert_allclose(cm_p, cm_s, rtol=1e-3, atol=1e-3)
+    assert (w_p.argmax(axis=2) == w_s.argmax(axis=2)).all()
+    assert_allclose(w_p, w_s, rtol=2e-3, atol=2e-6)
+    for k in g_s:
+        scale = max(1e-3, numpy.abs(g_s[k]).max())
+        assert numpy.abs(g_p[k] - g_s[k]).max() / scale < 2e-3, k
+
+
 def test_persistent_decoder_at_the_paper_width(gpu_device):
     """The README-recommended model (wsj_paper7: 250-unit BiGRUs, decoder and matcher, one location filter) has a decoder width that
     is not a multiple of 4: the persistent reverse walk reads its AW rows 16 bytes at a time and runs there with padded rows
