@@ -151,7 +151,30 @@ __device__ __forceinline__ double fin_score_of(const lvsr_beam_args& a, float co
     return (double)cost - a.char_discount * (double)(pos + 2);
 }
 
-__global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_args a) {
+// Argument block of search g of a grouped launch (lvsr_beam_args.groups): every buffer is G consecutive blocks
+__device__ __forceinline__ lvsr_beam_args beam_group(lvsr_beam_args a, int g) {
+    if (g == 0) return a;
+    const size_t K = (size_t)a.K, r = (size_t)g * K, V = (size_t)a.V, D = (size_t)a.D, Tp = (size_t)a.Tp;
+#define BG_OFF(field, n) if (a.field) a.field += (n)
+    BG_OFF(ctl, (size_t)g * 16); BG_OFF(fctl, (size_t)g * 4);
+    BG_OFF(neglogp, r * V); BG_OFF(running, r); BG_OFF(live_col, r);
+    BG_OFF(hist_parent, (size_t)g * a.max_length * K); BG_OFF(hist_char, (size_t)g * a.max_length * K); BG_OFF(hist_cost, (size_t)g * a.max_length * K);
+    BG_OFF(fin_pos, (size_t)g * a.fin_cap); BG_OFF(fin_col, (size_t)g * a.fin_cap); BG_OFF(fin_cost, (size_t)g * a.fin_cap); BG_OFF(fin_score, (size_t)g * a.fin_cap);
+    BG_OFF(keep, r); BG_OFF(chars, r); BG_OFF(parents, r);
+    BG_OFF(S_live, r * D); BG_OFF(W_live, r * Tp); BG_OFF(S_sel, r * D); BG_OFF(W_sel, r * Tp);
+    BG_OFF(lm_states_live, r * 7); BG_OFF(lm_weights_live, r * 7); BG_OFF(lm_states_sel, r * 7); BG_OFF(lm_weights_sel, r * 7);
+    BG_OFF(pos_live, r); BG_OFF(pos_sel, r);
+    BG_OFF(fork_xg, r * 3 * D);
+    BG_OFF(pos_new, r); BG_OFF(pos_live_out, r);
+    BG_OFF(S_new, r * D); BG_OFF(W_new, r * Tp); BG_OFF(S_live_out, r * D); BG_OFF(W_live_out, r * Tp);
+    BG_OFF(lm_states_new, r * 7); BG_OFF(lm_weights_new, r * 7); BG_OFF(lm_add_new, r * V);
+    BG_OFF(lm_states_live_out, r * 7); BG_OFF(lm_weights_live_out, r * 7); BG_OFF(lm_add_live_out, r * V);
+#undef BG_OFF
+    return a;
+}
+
+__global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_args a0) {
+    const lvsr_beam_args a = beam_group(a0, blockIdx.x);
     __shared__ unsigned keys[BEAM_MAX_CAND];
     __shared__ unsigned hist[256];
     __shared__ int scal[8];
@@ -171,6 +194,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
     if (tid == 8) s_best = ctl[CTL_POS] == 0 ? (double)a.fctl[0] : *(const double*)(a.fctl + 2);
     __syncthreads();
     if (s_ctl[CTL_DONE] != 0) return;
+    const int max_length = a.groups > 1 ? ctl[8] : a.max_length;          // (grouped: every search has its own limit)
     const int n = s_ctl[CTL_NLIVE], p = s_ctl[CTL_POS];
     int nf = s_ctl[CTL_NFIN];
     for (int i = tid; i < n; i += nt) { s_run[i] = a.running[i]; s_col[i] = a.live_col[i]; }
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         } else if (nf >= K) {
             float mn = s_run[0];
             for (int i = 1; i < n; ++i) mn = fminf(mn, s_run[i]);
-            const double bound = (double)mn - a.char_discount * (double)a.max_length;
+            const double bound = (double)mn - a.char_discount * (double)max_length;
             if (fin_score_of(a, a.fin_cost[K - 1], a.fin_pos[K - 1]) < bound) stop = 1;
         }
         s_stop = stop; s_bad = 0;
@@ -289,7 +313,7 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         ctl[CTL_NSEL] = nsel;
         ctl[CTL_ERR] = s_ctl[CTL_ERR];
         ctl[CTL_STEPS] = s_ctl[CTL_STEPS] + 1;
-        if (p + 1 >= a.max_length) ctl[CTL_DONE] = 3;
+        if (p + 1 >= max_length) ctl[CTL_DONE] = 3;
         a.fctl[0] = (float)s_best; *(double*)(a.fctl + 2) = s_best;
     }
 }
@@ -297,7 +321,8 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
 // rows of the next-state pass: sel[k] = live[parent of candidate k] (state, alignment, window centre, language-model state
 // set) and, for one-hot feedback, the fork inputs of the chosen character (OneOfNFeedback + Fork = row gathers + biases,
 // lvsr/bricks/__init__.py:97-104); one work-group per row
-__global__ __launch_bounds__(256) void beam_rows_kernel(lvsr_beam_args a) {
+__global__ __launch_bounds__(256) void beam_rows_kernel(lvsr_beam_args a0) {
+    const lvsr_beam_args a = beam_group(a0, blockIdx.y);
     const int k = blockIdx.x, par = a.parents[k], tid = threadIdx.x;
     const float* __restrict__ s_src = a.S_live + (size_t)par * a.D;
     const float* __restrict__ w_src = a.W_live + (size_t)par * a.Tp;
@@ -324,7 +349,8 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(lvsr_beam_args a) {
 }
 
 // new live rows <- rows keep[i] of the next-state pass (all K rows: the tail replicates row keep[0])
-__global__ __launch_bounds__(256) void beam_compact_kernel(lvsr_beam_args a) {
+__global__ __launch_bounds__(256) void beam_compact_kernel(lvsr_beam_args a0) {
+    const lvsr_beam_args a = beam_group(a0, blockIdx.y);
     const int i = blockIdx.x, k = a.keep[i];
     const float* __restrict__ s_src = a.S_new + (size_t)k * a.D;
     const float* __restrict__ w_src = a.W_new + (size_t)k * a.Tp;
@@ -350,6 +376,7 @@ static int beam_check(const lvsr_beam_args& a, const char* what) {
                  a.fin_pos && a.fin_col && a.fin_cost && a.fin_score && a.keep && a.chars && a.parents, "%s: null state buffer", what);
     LVSR_REQUIRE(a.stop_on == 0 || a.stop_on == 1, "%s: unknown stopping criterion %d", what, a.stop_on);
     LVSR_REQUIRE(a.fin_cap >= 2 * a.K, "%s: finished list shorter than 2 * beam", what);
+    LVSR_REQUIRE(a.groups >= 0 && a.groups <= 65535, "%s: bad number of searches", what);
     return LVSR_OK;
 }
 
@@ -362,15 +389,16 @@ int lvsr_beam_select(void* stream, const lvsr_beam_args* args) {
                  "lvsr_beam_select: null row buffers");
     LVSR_REQUIRE(!args->fork_xg || (args->fork_Wi && args->fork_Wg && args->fork_bi && args->fork_bg && args->fork_rows > 0),
                  "lvsr_beam_select: incomplete fork description");
-    hipLaunchKernelGGL(beam_select_kernel, dim3(1), dim3(BEAM_THREADS), 0, (hipStream_t)stream, *args);
-    hipLaunchKernelGGL(beam_rows_kernel, dim3(args->K), dim3(256), 0, (hipStream_t)stream, *args);
+    const int G = args->groups > 1 ? args->groups : 1;
+    hipLaunchKernelGGL(beam_select_kernel, dim3(G), dim3(BEAM_THREADS), 0, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(beam_rows_kernel, dim3(args->K, G), dim3(256), 0, (hipStream_t)stream, *args);
     return lvsr_check_launch("lvsr_beam_select");
 }
 
 int lvsr_beam_compact(void* stream, const lvsr_beam_args* args) {
     LVSR_REQUIRE(args != nullptr, "lvsr_beam_compact: null args");
     LVSR_REQUIRE(args->keep && args->S_new && args->W_new && args->S_live_out && args->W_live_out, "lvsr_beam_compact: null row buffers");
-    hipLaunchKernelGGL(beam_compact_kernel, dim3(args->K), dim3(256), 0, (hipStream_t)stream, *args);
+    hipLaunchKernelGGL(beam_compact_kernel, dim3(args->K, args->groups > 1 ? args->groups : 1), dim3(256), 0, (hipStream_t)stream, *args);
     return lvsr_check_launch("lvsr_beam_compact");
 }
 

@@ -28,36 +28,50 @@ inline int att_kc(int K) {
 struct Win { int begin, end; };
 int attdec_check(const AttDec& a, const char* what);
 
-// Window of take_glimpses (lvsr/bricks/attention.py:123-161).  Content-only attention: whole sequence.
-__device__ __forceinline__ Win attdec_window(const AttDec& a, int i) {
+// Row groups (lvsr_attdec_args.group_rows: batched beam search): group of row b, the context column a row reads, its attended length
+__device__ __forceinline__ int attdec_group(const AttDec& a, int b) { return a.group_rows > 0 ? b / a.group_rows : 0; }
+__device__ __forceinline__ int attdec_ctx(const AttDec& a, int b) { return a.group_rows > 0 ? b / a.group_rows : b; }
+
+// Window of take_glimpses (lvsr/bricks/attention.py:123-161) for the rows [b0, b0 + nb) that form one batch of the reference (all
+// rows; with row groups the rows of a group), Tp = the attended length of that batch, stepw = its position counter.
+// Content-only attention: whole sequence.
+__device__ __forceinline__ Win attdec_window_of(const AttDec& a, int i, int b0, int nb, int Tp, const int* stepw) {
     Win w;
-    w.begin = 0; w.end = a.Tp;
+    w.begin = 0; w.end = Tp;
     if (a.K == 0) return w;
     if (a.prior_type == 0) {
         // int64 step * floatX constant -> float64 arithmetic on the f32-rounded speeds (:127-132,160-161)
-        const double step = (double)(a.step0 + i + (a.step_dev ? *a.step_dev : 0));
+        const double step = (double)(a.step0 + i + (stepw ? *stepw : 0));
         double bg = a.p0 + step * a.p2, en = a.p1 + step * a.p3;
-        bg = fmax(0.0, fmin((double)(a.Tp - 1), bg));
-        en = fmax(0.0, fmin((double)a.Tp, en));
+        bg = fmax(0.0, fmin((double)(Tp - 1), bg));
+        en = fmax(0.0, fmin((double)Tp, en));
         w.begin = (int)floor(bg); w.end = (int)ceil(en);
         return w;
     }
     const float before = (float)a.p0, after = (float)a.p1;
     float mn = 3.0e38f, mx = -3.0e38f;
-    for (int b = 0; b < a.B; ++b) {
+    for (int b = b0; b < b0 + nb; ++b) {
         const float p = a.pos[(size_t)i * a.B + b];
         mn = fminf(mn, floorf(p - before));
         mx = fmaxf(mx, ceilf(p + after));
     }
     w.begin = (int)fmaxf(0.f, mn);
-    w.end = (int)fminf((float)a.Tp, mx);
+    w.end = (int)fminf((float)Tp, mx);
     if (w.end < w.begin) w.end = w.begin;
     return w;
+}
+__device__ __forceinline__ Win attdec_window(const AttDec& a, int i) { return attdec_window_of(a, i, 0, a.B, a.Tp, a.step_dev); }
+// ... as row b sees it
+__device__ __forceinline__ Win attdec_window_row(const AttDec& a, int i, int b) {
+    if (a.group_rows <= 0) return attdec_window(a, i);
+    const int g = b / a.group_rows;
+    return attdec_window_of(a, i, g * a.group_rows, a.group_rows, a.group_Tp ? a.group_Tp[g] : a.Tp,
+                            a.step_dev ? a.step_dev + (size_t)g * a.step_stride : nullptr);
 }
 
 // attended_mask_cut * additional_mask for position t of utterance b (:148-168)
 __device__ __forceinline__ float attdec_mask(const AttDec& a, int i, int b, int t) {
-    float m = a.Am[(size_t)t * a.Am_ts + (size_t)b * a.Am_bs];
+    float m = a.Am[(size_t)t * a.Am_ts + (size_t)attdec_ctx(a, b) * a.Am_bs];
     if (a.K > 0 && a.prior_type != 0) {
         const float p = a.pos[(size_t)i * a.B + b];
         const float lo = floorf(p - (float)a.p0), hi = ceilf(p + (float)a.p1);

@@ -745,6 +745,7 @@ int lvsr_attdec_bwd(void* stream, const lvsr_attdec_bwd_args* args, int use_grap
     LVSR_REQUIRE(parts == 1 || g.ds_ld == 0 || g.ds_ld == a.D, "lvsr_attdec_bwd: ds_ld is for the GRU part alone (parts = 1)");
     LVSR_REQUIRE(a.S_ld == 0 || a.S_ld >= a.D, "lvsr_attdec_bwd: S_ld < D");
     LVSR_REQUIRE(a.PA_bs == a.M && a.PA_ts == (long long)a.B * a.M, "lvsr_attdec_bwd: contexts must be contiguous (Tp,B,*)");
+    LVSR_REQUIRE(a.group_rows == 0, "lvsr_attdec_bwd: row groups are a generation-time layout");
     hipStream_t s = (hipStream_t)stream;
     const int rt = (a.B + 15) / 16, ntD = (a.D + 15) / 16, ntE = (a.E + 15) / 16;
     const int nchunk = (a.Tp + ATT_TB - 1) / ATT_TB, ntile = (a.Tp + ATT_TT - 1) / ATT_TT, nslice = (a.M + ATT_MS - 1) / ATT_MS;

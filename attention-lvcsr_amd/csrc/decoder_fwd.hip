@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
     }
     blk -= g.nmm;
     const int ch = blk % g.nch, k = (blk / g.nch) % a.K, b = blk / (g.nch * a.K);
-    const Win w = attdec_window(a, i);
+    const Win w = attdec_window_row(a, i, b);
     const float* wprev = a.W + ((size_t)i * B + b) * Tp;
     for (int t = threadIdx.x; t < Tp; t += 256) al[t] = (t >= w.begin && t < w.end) ? wprev[t] : 0.f;
     const int FW = 2 * a.c + 1;
@@ -99,13 +99,13 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
     __shared__ float cs[ATT_TT][ATT_MS + 1];
     const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
     const int t0 = blockIdx.z * ATT_TT;
-    const Win w = attdec_window(a, i);
+    const Win w = attdec_window_row(a, i, b);
     if (t0 >= w.end || t0 + ATT_TT <= w.begin) return;             // tile outside the window: nothing to add
     float* ep = a.ep + ((size_t)b * nslice + slice) * Tp;
     const int ml = threadIdx.x & 31, tg = threadIdx.x >> 5, m = slice * ATT_MS + ml;
     const bool mok = m < M;
     float pav[8];
-    const float* pab = a.PA + (size_t)b * a.PA_bs + m;
+    const float* pab = a.PA + (size_t)attdec_ctx(a, b) * a.PA_bs + m;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int t = t0 + tg + 8 * r;
@@ -153,13 +153,13 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float red[4];
     __shared__ float part[32][33];
     const int b = blockIdx.y, chunk = blockIdx.x, B = a.B, Tp = a.Tp, E = a.E;
-    const Win w = attdec_window(a, i);
+    const Win w = attdec_window_row(a, i, b);
     __shared__ float en[ATT_MAX_T];
     // The attended rows do not depend on the alignment: fetch this thread's share (8 float4 = the first 256 positions of
     // the window) before the softmax, so the stream's latency hides behind it.  Block = 32 columns x 32 position groups.
     const int cg = threadIdx.x & 7, tg = threadIdx.x >> 3;
     const int col = chunk * 32 + cg * 4;
-    const float* Ab = a.A + (size_t)b * a.A_bs + col;
+    const float* Ab = a.A + (size_t)attdec_ctx(a, b) * a.A_bs + col;
     const bool vec = ((a.A_ts & 3) == 0) && ((a.A_bs & 3) == 0) && ((((size_t)a.A) & 15) == 0);
     const int nvalid = E - col;
     float4 pv[8];
@@ -307,6 +307,8 @@ int attdec_check(const AttDec& a, const char* what) {
     LVSR_REQUIRE(a.K == 0 || 2 * a.c + 1 <= ATT_MAX_FW, "%s: conv filter too wide", what);
     LVSR_REQUIRE(a.prior_type >= 0 && a.prior_type <= 2, "%s: unknown prior type", what);
     LVSR_REQUIRE(a.K == 0 || a.prior_type == 0 || a.pos != nullptr, "%s: window_around_* priors need pos", what);
+    LVSR_REQUIRE(a.group_rows >= 0 && (a.group_rows == 0 || (a.B % a.group_rows == 0 && (a.step_dev == nullptr || a.step_stride > 0))),
+                 "%s: the rows must be whole groups (B = %d, group_rows = %d) with a position counter each (step_stride)", what, a.B, a.group_rows);
     return LVSR_OK;
 }
 

@@ -51,7 +51,7 @@ static int pd_kc(int K) {
 
 // stack: the two-layer launch (lvsr_attdec_fwd_persistent_stack2): clusters of 8 (PdShape8), two of them per utterance
 static bool pd_geom(const AttDec& a, PdGeom& g, bool allow16 = true, bool stack = false) {
-    if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
+    if ((a.phases & 3) != 3 || a.step_dev != nullptr || a.group_rows != 0) return false;
     if (a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
     g.KC = pd_kc(a.K);
     if (g.KC < 0) return false;

@@ -51,7 +51,7 @@ static int pb_kc(int K) {
 }
 
 static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack = false) {
-    if ((a.phases & 3) != 3 || a.step_dev != nullptr) return false;
+    if ((a.phases & 3) != 3 || a.step_dev != nullptr || a.group_rows != 0) return false;
     if (a.M > PD_MAXV || a.Tp > PD_MAXV) return false;
     g.KC = pb_kc(a.K);
     if (g.KC < 0) return false;

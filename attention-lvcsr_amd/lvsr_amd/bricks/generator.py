@@ -130,11 +130,14 @@ class SequenceGenerator(object):
         return kind, (float(pr["before"]), float(pr["after"]), 0.0, 0.0)
 
     # ---- argument block shared by training and generation ------------------------------------------
-    def _attdec_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast):
+    def _attdec_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast, groups=0, group_Tp=None):
         d, p, n = self.d, self.store.p, self.n
         Tp = int(A.shape[0])
         kind, pp = self._prior()
-        if broadcast:      # one utterance shared by every hypothesis (beam search)
+        if groups:         # batched beam search: rows [g B/groups, (g+1) B/groups) read utterance g (lvsr_attdec_args.group_rows)
+            strides = dict(A_ts=groups * d.E, A_bs=d.E, PA_ts=groups * d.M, PA_bs=d.M, Am_ts=groups, Am_bs=1,
+                           group_rows=B // groups, step_stride=16, group_Tp=group_Tp)
+        elif broadcast:    # one utterance shared by every hypothesis (beam search)
             strides = dict(A_ts=d.E, A_bs=0, PA_ts=d.M, PA_bs=0, Am_ts=1, Am_bs=0)
         else:
             strides = dict(A_ts=B * d.E, A_bs=d.E, PA_ts=B * d.M, PA_bs=d.M, Am_ts=B, Am_bs=1)
@@ -516,11 +519,17 @@ def _generation_methods():
         """context_computer (search.py:97-104): keep the single utterance's contexts; every hypothesis of the
         beam reads them with a zero batch stride (no tiling as in search.py:336-338)."""
         d = self.d
-        Tp = int(attended.shape[0])
-        assert int(attended.shape[1]) == 1, "generation mode decodes one utterance at a time"
+        Tp, N = int(attended.shape[0]), int(attended.shape[1])
         A = attended.contiguous()
         PA = self.preprocess(A)
-        self._gen = dict(Tp=Tp, A=A.view(Tp, d.E), Am=attended_mask.contiguous().view(Tp), PA=PA.view(Tp, d.M))
+        if N == 1:
+            self._gen = dict(Tp=Tp, A=A.view(Tp, d.E), Am=attended_mask.contiguous().view(Tp), PA=PA.view(Tp, d.M))
+        else:
+            # several utterances at once (BeamSearch.search_batch): the beams of all of them advance in the same launches, every
+            # row reading the contexts of its own utterance (`beam_begin` with groups); `lengths` = attended length of each
+            Am = attended_mask.contiguous()
+            self._gen = dict(Tp=Tp, A=A, Am=Am, PA=PA, N=N, lengths=self.ws.get("gen.glen", (N,), torch.int32))
+            self._gen["lengths"].copy_(Am.sum(dim=0).to(torch.int32))
 
     def generation_initial_states(self, n=1):
         """initial_state_computer (search.py:106-110): states = tiled initial_state (recurrent.py:622-624),
@@ -736,14 +745,32 @@ CTL = dict(nlive=0, pos=1, done=2, nfin=3, patience=4, nsel=5, err=6, steps=7)
 def _beam_methods():
     def beam_begin(self, K, eol, max_length, ignore_first_eol=False, char_discount=0.0, round_to_inf=1e9, stop_on="patience"):
         """Allocate (once per (K, T', max_length)) and reset the device state of a beam search over the contexts set by
-        `init_generation`: hypothesis 0 = initial state / initial glimpses (search.py:287-299), every other row a copy."""
+        `init_generation`: hypothesis 0 = initial state / initial glimpses (search.py:287-299), every other row a copy.
+        After `init_generation` on a batch of N utterances: N searches side by side (`max_length` = one limit per utterance),
+        search g in rows [g K, g K + K) of every state buffer and block g of the bookkeeping buffers (lvsr_beam_args.groups)."""
         d, p, n_, lib, ws, g = self.d, self.store.p, self.n, self.lib, self.ws, self._gen
         Tp, dev = g["Tp"], g["A"].device
         lm = self.language_model
         on_dev_lm = lm is not None and getattr(lm, "on_device", False)
-        tag = ".K%d" % K
+        G = int(g.get("N", 1))
+        if G > 1:
+            limits = [int(m) for m in max_length]
+            assert len(limits) == G
+            assert d.n_dec == 1 and (lm is None or on_dev_lm), "batched search: one decoder layer, language model on the device"
+            max_length = max(limits)
+            return self._beam_begin(K * G, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
+        return self._beam_begin(K, K, 1, None, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
+
+    def _beam_begin(self, R, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on):
+        """R = G * K rows: G searches of beam K."""
+        d, p, n_, lib, ws, g = self.d, self.store.p, self.n, self.lib, self.ws, self._gen
+        Tp, dev = g["Tp"], g["A"].device
+        lm = self.language_model
+        on_dev_lm = lm is not None and getattr(lm, "on_device", False)
+        tag = ".K%d" % K if G == 1 else ".K%dx%d" % (K, G)
+        K_one, K = K, R            # below, K counts ROWS of the state buffers; K_one is the beam size
         i32, i64, f64 = torch.int32, torch.int64, torch.float64
-        fin_cap = 2 * K if stop_on == "patience" else K * (max_length + 1)
+        fin_cap = 2 * K_one if stop_on == "patience" else K_one * (max_length + 1)
         Kc = max(d.K, 1)
         pos_needed = d.conv and self._prior()[0] != 0
         SW = self._state_width()
@@ -761,15 +788,16 @@ def _beam_methods():
                         sg=ws.get("bs.sg" + t, (K, 2 * d.D)), xin=ws.get("bs.xin" + t, (K, d.D)),
                         ep=ws.get("bs.ep" + t, (K, (d.M + ATT_MS - 1) // ATT_MS, Tp)))
         A_, B_ = attbufs("a", 1), attbufs("b", 3)
-        st = dict(K=K, Tp=Tp, max_length=int(max_length), fin_cap=fin_cap, A=A_, B=B_,
-                  ctl=ws.get("bs.ctl" + tag, (16,), i32), fctl=ws.get("bs.fctl" + tag, (4,)),
+        gshape = (lambda *dims: dims) if G == 1 else (lambda *dims: (G,) + dims)
+        st = dict(K=K_one, rows=K, groups=G, Tp=Tp, max_length=int(max_length), limits=limits, fin_cap=fin_cap, A=A_, B=B_,
+                  ctl=ws.get("bs.ctl" + tag, gshape(16), i32), fctl=ws.get("bs.fctl" + tag, gshape(4)),
                   neglogp=ws.get("bs.neglogp" + tag, (K, d.V)), running=ws.get("bs.running" + tag, (K,)),
                   live_col=ws.get("bs.live_col" + tag, (K,), i32),
-                  hist_parent=ws.get("bs.hist_parent" + tag, (max_length, K), i32),
-                  hist_char=ws.get("bs.hist_char" + tag, (max_length, K), i32),
-                  hist_cost=ws.get("bs.hist_cost" + tag, (max_length, K)),
-                  fin_pos=ws.get("bs.fin_pos" + tag, (fin_cap,), i32), fin_col=ws.get("bs.fin_col" + tag, (fin_cap,), i32),
-                  fin_cost=ws.get("bs.fin_cost" + tag, (fin_cap,)), fin_score=ws.get("bs.fin_score" + tag, (fin_cap,)),
+                  hist_parent=ws.get("bs.hist_parent" + tag, gshape(max_length, K_one), i32),
+                  hist_char=ws.get("bs.hist_char" + tag, gshape(max_length, K_one), i32),
+                  hist_cost=ws.get("bs.hist_cost" + tag, gshape(max_length, K_one)),
+                  fin_pos=ws.get("bs.fin_pos" + tag, gshape(fin_cap), i32), fin_col=ws.get("bs.fin_col" + tag, gshape(fin_cap), i32),
+                  fin_cost=ws.get("bs.fin_cost" + tag, gshape(fin_cap)), fin_score=ws.get("bs.fin_score" + tag, gshape(fin_cap)),
                   keep=ws.get("bs.keep" + tag, (K,), i32), chars=ws.get("bs.chars" + tag, (K,), i64),
                   parents=ws.get("bs.parents" + tag, (K,), i32),
                   fb=ws.get("bs.fb" + tag, (K, d.FB)) if d.embed else None, lm=None)
@@ -783,18 +811,19 @@ def _beam_methods():
         pk = self._packed()
         # window centres travel with the rows (select / compact move them), so neither pass recomputes slot 0: phases bit 2
         skip_pos = 4 if pos_needed else 0
-        fa = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, A_, phases=1 | skip_pos, step0=0, broadcast=True)
-        pos_word = st["ctl"][CTL["pos"]:]
+        grp = dict(groups=G, group_Tp=g["lengths"]) if G > 1 else {}
+        fa = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, A_, phases=1 | skip_pos, step0=0, broadcast=True, **grp)
+        pos_word = st["ctl"].view(-1)[CTL["pos"]:]
         st["argsA"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fa)
         if stacked:
             st["stepB"] = self._beam_step_blocks(pk, g, K, B_, skip_pos, pos_word, tag)
         else:
-            fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True)
+            fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True, **grp)
             st["argsB"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fb_)     # runs after the select kernel moved on: step0 = -1
         L = st["lm"] or {}
         host_fork = d.embed or stacked      # the fork of the chosen characters as separate launches of pass B
         st["args"] = lib.make(
-            "lvsr_beam_args", K=K, V=d.V, eol=int(eol), ignore_first_eol=int(bool(ignore_first_eol)),
+            "lvsr_beam_args", K=K_one, groups=G, V=d.V, eol=int(eol), ignore_first_eol=int(bool(ignore_first_eol)),
             stop_on={"patience": 0, "optimistic_future_cost": 1}[stop_on], max_length=int(max_length), fin_cap=fin_cap, D=SW, Tp=Tp,
             round_to_inf=float(numpy.float32(min(float(round_to_inf), 3.0e38))), char_discount=float(char_discount),
             ctl=st["ctl"], fctl=st["fctl"], neglogp=st["neglogp"], running=st["running"], live_col=st["live_col"],
@@ -815,10 +844,12 @@ def _beam_methods():
         st["readout"] = self._readout_step_args(A_["S"][0], A_["WA"][0], K, neglogp=st["neglogp"],
                                                 lm_add=L.get("add_live") if lm is not None else None)
         # ---- reset: one live hypothesis, replicated over the K rows
-        ctl0 = numpy.zeros(16, numpy.int32)
-        ctl0[CTL["nlive"]], ctl0[CTL["patience"]] = 1, -1
-        st["ctl"].copy_(torch.from_numpy(ctl0))
-        st["fctl"].copy_(torch.tensor([1000.0, 0.0, 0.0, 0.0]))
+        ctl0 = numpy.zeros((G, 16), numpy.int32)
+        ctl0[:, CTL["nlive"]], ctl0[:, CTL["patience"]] = 1, -1
+        if G > 1:
+            ctl0[:, 8] = limits            # every search's own position limit
+        st["ctl"].copy_(torch.from_numpy(ctl0.reshape(st["ctl"].shape)))
+        st["fctl"].copy_(torch.tensor([1000.0, 0.0, 0.0, 0.0]).repeat(G).view(st["fctl"].shape))
         st["running"].zero_()
         st["live_col"].zero_()
         A_["S"][0].copy_(self._initial_state().unsqueeze(0).expand(K, SW))
@@ -838,7 +869,7 @@ def _beam_methods():
         # kernel arguments of the readout, its tables and error word are pointers inside the FST walk's argument block
         lm_key = None if lm is None else (float(lm.lm_weight), float(lm.am_beta), tuple(bool(v) for v in lm.norm), float(getattr(lm, "no_transition_cost", 0.0)))
         lm_ptrs = () if not on_dev_lm else tuple(sorted((k, t.data_ptr()) for k, t in lm._dev.items())) + (lm._err.data_ptr(),)
-        st["key"] = ("beam_step", K, Tp, int(max_length), stop_on, int(bool(ignore_first_eol)), int(eol), float(char_discount),
+        st["key"] = ("beam_step", K_one, G, Tp, int(max_length), stop_on, int(bool(ignore_first_eol)), int(eol), float(char_discount),
                      float(round_to_inf), lm is not None, on_dev_lm, lm_key)
         st["volatile"] = (g["A"].data_ptr(), g["PA"].data_ptr(), g["Am"].data_ptr(), ws.generation, id(pk), self.store.version, lm_ptrs)
         self._beam = st
@@ -878,7 +909,7 @@ def _beam_methods():
         computed for) + compute_states with the chosen characters (next_state_computer, search.py:112-124), language-model
         transition, then the surviving rows become the new beam."""
         d, lib, st = self.d, self.lib, self._beam
-        K, B_ = st["K"], st["B"]
+        K, B_ = st["rows"], st["B"]
         if "stepB" in st:
             self._beam_step_run(st)
         else:
@@ -916,7 +947,7 @@ def _beam_methods():
                 self.beam_advance()
         self.lib.region(self, (st["key"], "x%d" % n), st["ctl"], enabled=self.use_graph, volatile=st["volatile"], drain=False).run(enqueue)
 
-    return dict(beam_begin=beam_begin, beam_costs=beam_costs, beam_select=beam_select, beam_advance=beam_advance,
+    return dict(beam_begin=beam_begin, _beam_begin=_beam_begin, beam_costs=beam_costs, beam_select=beam_select, beam_advance=beam_advance,
                 beam_step=beam_step, beam_steps=beam_steps, _readout_step_args=_readout_step_args)
 
 

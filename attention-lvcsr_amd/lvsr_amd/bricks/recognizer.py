@@ -283,6 +283,32 @@ class SpeechRecognizer(object):
         encoded, encoded_mask = self.encoder.apply(self.bottom.apply(xb, False), None, save_for_backward=False)
         self.generator.init_generation(encoded, encoded_mask)
 
+    def compute_contexts_batch(self, recordings, pad_to=64):
+        """Encoder pass of several utterances at once (`recordings`: list of (T_i, F) arrays) for `BeamSearch.search_batch`: padded
+        to a common length (a multiple of `pad_to` frames, so that few distinct shapes — and captured graphs — occur) under an input
+        mask.  A masked recurrent step keeps its state (recurrent.py:297-300), so every utterance's contexts are those of its own
+        unmasked batch-1 pass (`compute_contexts`) up to its own attended length."""
+        recs = [numpy.asarray(r, dtype=numpy.float32).reshape(len(r), -1) for r in recordings]
+        T = max(len(r) for r in recs)
+        T = (T + pad_to - 1) // pad_to * pad_to
+        x = numpy.zeros((T, len(recs), recs[0].shape[1]), numpy.float32)
+        m = numpy.zeros((T, len(recs)), numpy.float32)
+        for i, r in enumerate(recs):
+            x[: len(r), i] = r
+            m[: len(r), i] = 1.0
+        xb, mb = self._t(x, torch.float32, "recordings"), self._t(m, torch.float32, "recordings_mask")
+        encoded, encoded_mask = self.encoder.apply(self.bottom.apply(xb, False), mb, save_for_backward=False)
+        self.generator.init_generation(encoded, encoded_mask)
+
+    def beam_search_batch(self, recordings, **kwargs):
+        """`beam_search` for a list of utterances in one set of launches -> list of (outputs, costs) or of the exception the
+        single search would have raised (CandidateNotFoundError, ...)."""
+        self.init_beam_search(self.beam_size)
+        recs = [numpy.asarray(r, dtype=numpy.float32) for r in recordings]
+        limits = [int(r.shape[0] / self.max_decoded_length_scale) for r in recs]
+        results = self._beam_search.search_batch(recs, self.eos_label, limits, ignore_first_eol=self.data_prepend_eos, **kwargs)
+        return [r if isinstance(r, Exception) else ([[int(t) for t in o] for o in r[0]], [float(c) for c in r[1]]) for r in results]
+
     def init_beam_search(self, beam_size):
         from ..search import BeamSearch
         if getattr(self, "_beam_search", None) is not None and self.beam_size == beam_size:

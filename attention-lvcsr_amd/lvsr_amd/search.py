@@ -91,6 +91,72 @@ class BeamSearch(object):
         return dict(st=st, positions=0, max_length=int(max_length), done=False, ctl=None, host=host, event=None,
                     first_token=0 if lm is not None else gen.d.V, char_discount=char_discount)
 
+    # ---- several utterances in one set of launches ---------------------------------------------------------------------
+    def search_batch(self, recordings, eol_symbol, max_lengths, ignore_first_eol=False, char_discount=0, round_to_inf=1e9,
+                     stop_on="patience", as_arrays=False):
+        """The searches of N utterances side by side: one encoder pass over the padded batch, then every launch of a position
+        serves the N beams at once (rows [g K, g K + K) of the state buffers belong to utterance g; windows, position counters,
+        stopping rules and finished lists stay per utterance: lvsr_attdec_args.group_rows, lvsr_beam_args.groups).  A beam step
+        is dispatch bound for one utterance (13 launches of 5-14 us per position); here the launches are shared.
+        -> list of N results, each what `search` returns for that utterance alone — or the exception it would raise."""
+        run = self.begin_batch(recordings, eol_symbol, max_lengths, ignore_first_eol=ignore_first_eol, char_discount=char_discount,
+                               round_to_inf=round_to_inf, stop_on=stop_on)
+        while not run["done"]:
+            self.advance(run, POLL_EVERY, wait=True)
+        return self.finish_batch(run, as_arrays=as_arrays)
+
+    def begin_batch(self, recordings, eol_symbol, max_lengths, ignore_first_eol=False, char_discount=0, round_to_inf=1e9,
+                    stop_on="patience"):
+        rec, gen = self.rec, self.rec.generator
+        if stop_on not in ("patience", "optimistic_future_cost"):
+            raise ValueError("Unknown stopping criterion {}".format(stop_on))
+        if len(recordings) == 1:
+            run = self.begin({"recordings": numpy.asarray(recordings[0], numpy.float32)}, eol_symbol, max_lengths[0],
+                             ignore_first_eol=ignore_first_eol, char_discount=char_discount, round_to_inf=round_to_inf, stop_on=stop_on)
+            run["single"] = True
+            return run
+        lm = gen.language_model
+        assert lm is None or getattr(lm, "on_device", False), "the batched search needs the device language model"
+        limits = [int(m) for m in max_lengths]
+        with rec._on_stream():
+            rec.compute_contexts_batch(recordings)
+            st = gen.beam_begin(self.beam_size, eol_symbol, [max(m, 1) for m in limits], ignore_first_eol, char_discount, round_to_inf, stop_on)
+        host = None
+        if rec.device.type == "cuda":
+            host = torch.empty(tuple(st["ctl"].shape), dtype=torch.int32).pin_memory()
+        return dict(st=st, positions=0, max_length=max(max(limits), 1), limits=limits, done=False, ctl=None, host=host, event=None,
+                    first_token=0 if lm is not None else gen.d.V, char_discount=char_discount)
+
+    def finish_batch(self, run, as_arrays=False):
+        """-> one entry per utterance: the result, or the exception the single search raises in its place."""
+        if run.get("single"):
+            try:
+                return [self.finish(run, as_arrays=as_arrays)]
+            except (CandidateNotFoundError, AssertionError, RuntimeError, UnboundLocalError) as e:
+                return [e]
+        rec, gen, st = self.rec, self.rec.generator, run["st"]
+        assert run["done"]
+        lm = gen.language_model
+        out, stats = [], []
+        with rec._on_stream():
+            if lm is not None and getattr(lm, "on_device", False):
+                lm.check_error()
+            rec.encoder.check_persistent()
+            ctl = st["ctl"].cpu().numpy()
+            host = {k: st[k].cpu().numpy() for k in ("fin_pos", "fin_col", "hist_parent", "hist_char", "hist_cost")}
+            for g in range(st["groups"]):
+                view = {k: torch.from_numpy(v[g]) for k, v in host.items()}
+                try:
+                    if run["limits"][g] <= 0:
+                        raise CandidateNotFoundError()
+                    self._raise_device_errors(ctl[g])
+                    out.append(self._collect(view, ctl[g], run["first_token"], run["char_discount"], as_arrays))
+                except (CandidateNotFoundError, AssertionError, RuntimeError, UnboundLocalError) as e:
+                    out.append(e)
+                stats.append(dict(positions=int(ctl[g][CTL["steps"]]), finished=int(ctl[g][CTL["nfin"]]), done=int(ctl[g][CTL["done"]])))
+        self.last_stats = dict(positions=max(s["positions"] for s in stats), per_utterance=stats)
+        return out
+
     def advance(self, run, positions=POLL_EVERY, wait=False):
         """Enqueue up to `positions` more positions and a look at the control block.  wait=False returns at once; the look is
         picked up by the next call (or by `ready`)."""
@@ -103,7 +169,7 @@ class BeamSearch(object):
             run["event"].synchronize()
             run["event"] = None
             run["ctl"] = run["host"].numpy().copy()
-            if run["ctl"][CTL["done"]] or run["positions"] >= run["max_length"]:
+            if self._all_done(run["ctl"]) or run["positions"] >= run["max_length"]:
                 run["done"] = True
                 return True
         if positions <= 0:
@@ -118,7 +184,7 @@ class BeamSearch(object):
             run["positions"] += n
             if run["host"] is None:                        # CPU emulator: plain synchronous look
                 run["ctl"] = st["ctl"].cpu().numpy()
-                run["done"] = bool(run["ctl"][CTL["done"]]) or run["positions"] >= run["max_length"]
+                run["done"] = self._all_done(run["ctl"]) or run["positions"] >= run["max_length"]
                 return run["done"]
             run["host"].copy_(st["ctl"], non_blocking=True)
             run["event"] = torch.cuda.Event()
@@ -126,6 +192,11 @@ class BeamSearch(object):
         if wait:
             return self.advance(run, 0, wait=True) if run["event"] is not None else run["done"]
         return False
+
+    @staticmethod
+    def _all_done(ctl):
+        """ctl: the control block of one search (16 words) or of a batch of searches (N, 16)."""
+        return bool(numpy.all(numpy.asarray(ctl).reshape(-1, 16)[:, CTL["done"]] != 0))
 
     def finish(self, run, as_arrays=False):
         """Collect the result of a search whose `advance` reported done."""

@@ -191,19 +191,19 @@ def pmc_record(kernel):
     return (rec, None) if rec else (None, "kernel %s not in the PMC record" % kernel)
 
 
-def decode_leg(dev, utterances, streams=8):
+def decode_leg(dev, utterances, batch=32, streams=2):
     """configs[4] in the default line: a bounded sample of the decode workload (`--workload wsj_decode` runs all 1000 utterances) —
     beam 16 + char-trigram FST LM on the device, window_around_median(10, 100), exp/wsj/decode.sh settings, 800-frame synthetic
-    utterances, `streams` searches in flight on one GPU (tools/bench_decode.py)."""
-    from tools.bench_decode import build, run_concurrent
+    utterances, `batch` utterances per set of launches and `streams` such batches in flight on one GPU (tools/bench_decode.py)."""
+    from tools.bench_decode import build, run_batched
     recs = [build(dev, 16)[0] for _ in range(streams)]
-    sec, done, nframes, chars, steps = run_concurrent(recs, utterances, 800)
+    sec, done, nframes, chars, steps = run_batched(recs, utterances, 800, batch=batch)
     return dict(workload="wsj_decode sample: %d of the 1000 synthetic 800-frame utterances, WSJ-base weights, beam 16, device FST LM "
                          "(weight 0.5, no_transition_cost 20), char_discount 1.0, max length T/3" % done,
                 utterances=done, ms_per_utterance=sec / done * 1e3, utterances_per_s=done / sec, frames_per_s=nframes / sec,
-                searches_in_flight=streams, positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1),
+                utterances_per_launch_set=batch, searches_in_flight=streams * batch, positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1),
                 mean_best_hypothesis_length=chars / max(done, 1),
-                parity="tests/test_decode_golden.py::test_full_size_wsj_decode_matches_the_reference_gpu (reference-generated golden)")
+                parity="tests/test_decode_golden.py::test_full_size_wsj_decode_batched_whole_list_matches_the_reference_gpu (reference-generated golden)")
 
 
 PEAK_HBM = 8.0e12               # bytes/s (MI355X_MICROARCH.md)
@@ -308,7 +308,8 @@ def main(backend=None):
     ap.add_argument("--labels", type=int, default=None, help="labels per utterance override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (configs[4] sample) of the default line")
-    ap.add_argument("--decode-utterances", type=int, default=32)
+    ap.add_argument("--decode-utterances", type=int, default=128)
+    ap.add_argument("--decode-batch", type=int, default=32, help="decode: utterances per set of launches (1: one search per recognizer, --streams in flight)")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
                     help="tuning knob of the library (include/lvsr_hip.h LVSR_KNOB_*), for A/B measurements; recorded in config.knobs")
     ap.add_argument("--no-graph", action="store_true")
@@ -323,7 +324,7 @@ def main(backend=None):
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="data parallel: reduce the decoder's gradients while the encoder's BPTT runs (two buckets, Trainer(overlap_allreduce=True))")
     ap.add_argument("--utterances", type=int, default=None, help="wsj_decode: number of utterances (default 1000 = configs[4])")
-    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: beam searches in flight per GPU (default 8)")
+    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: recognizers (streams) in flight per GPU (default 2 batches; 8 searches with --decode-batch 1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -607,7 +608,7 @@ def main(backend=None):
             if world == 1 and not args.no_fbank and args.workload == "wsj_base":
                 out["fbank"] = fbank_leg(dev)
             if world == 1 and not args.no_decode and args.workload == "wsj_base":
-                out["decode"] = decode_leg(dev, args.decode_utterances)
+                out["decode"] = decode_leg(dev, args.decode_utterances, batch=args.decode_batch)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg, params, B0, T, L, args.workload)
         print(json.dumps(out), file=json_out, flush=True)

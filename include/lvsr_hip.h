@@ -204,6 +204,13 @@ typedef struct lvsr_attdec_args {
     int label0;                           /* lvsr_attdec_fwd / lvsr_attdec_bwd run the steps [label0, L) only (0: all).  A stacked decoder
                                              (RecurrentStack, lvsr/bricks/recognizer.py:250-262) is driven label by label with one
                                              block for the attention over the concatenated states and one per GRU layer */
+    /* Row groups (batched beam search, step kernels only: several utterances' beams in one set of launches).  group_rows = n > 0:
+       rows [g n, g n + n) are the hypotheses of utterance g — they read context column g (element (t,g,x) at base[t*ts + g*bs + x]),
+       the batch-wide window of the window_around_* priors is the window of the GROUP's rows, the position counter of group g is
+       step_dev[g * step_stride], and the attended length of group g is group_Tp[g] (<= Tp, NULL: Tp) — the windows are clamped
+       to it as they would be for the utterance decoded alone.  0: one group of all rows, the fields above as described. */
+    int group_rows, step_stride;
+    const int* group_Tp;
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
@@ -429,6 +436,11 @@ typedef struct lvsr_beam_args {
     const float* S_new; const float* W_new; float* S_live_out; float* W_live_out;
     const long long* lm_states_new; const double* lm_weights_new; const float* lm_add_new;      /* or NULL */
     long long* lm_states_live_out; double* lm_weights_live_out; float* lm_add_live_out;
+    /* groups = G > 1: G independent searches (utterances) advanced by the same launches.  Every buffer above is then G consecutive
+     * blocks of the shape given (ctl: 16 words per search, fctl: 4; rows of the state buffers: search g owns rows [g K, g K + K));
+     * row indices (parents, keep, live_col, ...) stay local to their search.  The position limit of search g is ctl[16 g + 8]
+     * (max_length above is the capacity of the history buffers). 0 / 1: one search. */
+    int groups;
 } lvsr_beam_args;
 /* two launches: the selection kernel (one work-group) and the row gather / feedback fork of the K chosen candidates */
 int lvsr_beam_select(void* stream, const lvsr_beam_args* a);

@@ -97,6 +97,56 @@ def test_full_size_wsj_decode_whole_list_matches_the_reference_gpu(gpu_device, d
         assert rec._beam_search.last_stats["positions"] > 0
 
 
+def run_batched_decode_case(device, lib, fixture, stable, min_checked, repeat=1):
+    """The fixture's utterances decoded side by side (BeamSearch.search_batch, device language model) against the reference's
+    hypotheses — `repeat` copies of the list, so that the batch is larger than the fixture and equal utterances must give equal results."""
+    z, meta = load_golden(fixture)
+    cfg = meta["cfg"]
+    V = cfg["num_phonemes"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=cfg)
+    fst, cmap = _fst_from_arcs(z["arcs"], V)
+    rec.set_language_model(LM.DeviceFSTLanguageModel(fst, device, lib=rec.lib, nn_char_map=cmap, **meta["lm"]))
+    rows = [r for r in meta["beam"]]
+    settings = [dict(r["settings"]) for r in rows]
+    assert all(s == settings[0] for s in settings), "the fixture's utterances share one set of decode settings"
+    s = settings[0]
+    rec.init_beam_search(s.pop("beam_size"))
+    xs = [z["x%d" % r["utt"]] for r in rows] * repeat
+    checked = 0
+    for _ in range(2):                      # eager / captured, then the replayed step graph
+        results = rec.beam_search_batch(xs, **s)
+        assert len(results) == len(xs)
+        for i, got in enumerate(results):
+            r = rows[i % len(rows)]
+            if r.get("error"):
+                assert isinstance(got, CandidateNotFoundError)
+                continue
+            outs, costs = got
+            if stable is None:
+                n = len(r["outputs"])
+                assert len(outs) == n, "utterance %d: %d hypotheses, the reference has %d" % (r["utt"], len(outs), n)
+            else:
+                n = sum(1 for h in r["outputs"] if len(h) <= stable)
+            assert outs[:n] == r["outputs"][:n], "utterance %d" % r["utt"]
+            assert_allclose(costs[:n], r["costs"][:n], rtol=1e-4, atol=1e-4)
+            checked += n
+    assert checked >= min_checked
+    return rec
+
+
+@pytest.mark.gpu
+def test_full_size_wsj_decode_batched_whole_list_matches_the_reference_gpu(gpu_device):
+    """configs[4] at full size, the well-conditioned fixture, 3 x 4 utterances side by side: the WHOLE ranked list of every one."""
+    rec = run_batched_decode_case(gpu_device, None, "wsj_decode_full2", None, 2 * 4 * 193, repeat=4)
+    assert rec._beam_search.last_stats["positions"] > 0
+
+
+@pytest.mark.gpu
+def test_mid_size_decode_batched_matches_the_reference_gpu(gpu_device):
+    run_batched_decode_case(gpu_device, None, "mid_conv_lm_decode", STABLE_LENGTH, 12, repeat=2)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_oracles_reproduce_the_whole_list_of_the_well_conditioned_decode(dtype):

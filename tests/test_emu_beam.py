@@ -163,3 +163,50 @@ def test_validator_sees_every_finished_hypothesis_once_the_patience_list_was_cut
     assert seen_dev == seen                                       # the same hypotheses were shown to the validator, in the same order
     assert outs == ref_outs and all(len(o) % 2 == 0 for o in outs)          # (+1 initial pseudo-token = odd length as the validator counts)
     assert_allclose(costs, ref_costs, rtol=2e-5, atol=2e-5)
+
+
+# ---- several utterances in one set of launches (BeamSearch.search_batch) ---------------------------------------------------------
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_nowindow", "tiny_content_embed", "tiny_conv_logistic"])
+def test_batched_search_equals_the_single_searches_emulated(case):
+    """All utterances of the fixture's (ragged) batch decoded side by side — rows [g K, g K + K) of the state buffers belong to
+    utterance g, windows / position counters / stopping rules / finished lists per utterance — give, utterance by utterance, the
+    hypotheses of the single search (and, for the fixture's utterance, of the reference), under every setting of the fixture."""
+    run_batched_case(case, "cpu", emu_lib())
+
+
+def run_batched_case(case, device, lib, cost_tol=2e-5):
+    z, meta = load_golden(case)
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=meta["cfg"])
+    lens = [int(batch["recordings_mask"][:, u].sum()) for u in range(meta["B"])]
+    xs = [batch["recordings"][:tl, u] for u, tl in enumerate(lens)]
+    assert len(set(lens)) > 1 or not meta["ragged"]
+    seen = set()
+    for b in meta["beam"]:
+        s = dict(b["settings"])
+        utt, bs = s.pop("utt", 0), s.pop("beam_size")
+        key = repr(sorted(s.items())) + str(bs)
+        rec.init_beam_search(bs)
+        if key not in seen:
+            seen.add(key)
+            singles = []
+            for x in xs:
+                try:
+                    singles.append(rec.beam_search({"recordings": x}, **s))
+                except CandidateNotFoundError as e:
+                    singles.append(e)
+            batched = rec.beam_search_batch(xs, **s)
+            assert len(batched) == len(xs)
+            for u, (one, many) in enumerate(zip(singles, batched)):
+                if isinstance(one, Exception):
+                    assert type(many) is type(one), (case, u)
+                    continue
+                assert not isinstance(many, Exception), (case, u, many)
+                assert many[0] == one[0], (case, u)
+                assert_allclose(many[1], one[1], rtol=cost_tol, atol=cost_tol)
+        if b.get("error"):
+            assert isinstance(batched[utt], CandidateNotFoundError)
+        else:
+            assert batched[utt][0] == b["outputs"], (case, utt)
+            assert_allclose(batched[utt][1], b["costs"], rtol=2e-5, atol=2e-5)

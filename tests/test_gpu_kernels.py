@@ -170,6 +170,16 @@ def test_beam_search_vs_reference_golden(gpu_device, case):
     run_beam_case(case, gpu_device, None)
 
 
+@pytest.mark.parametrize("case", ["tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_logistic", "tiny_conv_relu", "tiny_conv_bottom",
+                                  "tiny_conv_postmerge2", "tiny_content_embed", "tiny_content_relu", "small_conv_median"])
+def test_batched_beam_search_vs_single_searches_and_golden(gpu_device, case):
+    """BeamSearch.search_batch: the fixture's whole ragged batch decoded side by side == every utterance decoded alone == the
+    reference's hypotheses for the fixture's utterance.  Twice (eager / captured, then replayed step graphs)."""
+    from test_emu_beam import run_batched_case
+    run_batched_case(case, gpu_device, None)
+    run_batched_case(case, gpu_device, None)
+
+
 def test_topk_smallest_on_the_gpu(gpu_device):
     from test_emu_beam import check_smallest
     from lvsr_amd.search import BeamSearch

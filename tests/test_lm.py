@@ -220,6 +220,42 @@ def test_beam_search_with_device_fst_emulated():
     run_fused_beam("cpu", emu_lib(), device_lm=True)
 
 
+def run_fused_beam_batched(device, lib):
+    """Four utterances of different lengths decoded side by side with the device language model (BeamSearch.search_batch: one
+    FST walk / readout / selection launch per position for all of them) against the oracle's single searches."""
+    from oracle import lvsr_oracle as O
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    params = synthetic.make_params(CFG, seed=41)
+    fst, cmap = LM.char_ngram_fst(6, seed=5)
+    arcs = [(s, d, l, w) for s, lst in fst.arcs.items() for (l, d, w) in lst]
+    dense = LO.DenseFST(arcs, fst.start, 6)
+    model = LM.DeviceFSTLanguageModel(fst, device, lib=lib, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5)
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=CFG)
+    rec.set_language_model(model)
+    orc = O.OracleRecognizer(CFG, params, dtype=torch.float32)
+    lm = dict(dense=dense, remap=model.remap_table, no_transition_cost=20.0, weight=0.5)
+    xs = [numpy.random.RandomState(seed).normal(size=(T, 5)).astype(numpy.float32) for seed, T in ((1, 14), (2, 9), (3, 17), (4, 12))]
+    for beam, kw in ((4, dict(char_discount=0.2, stop_on="optimistic_future_cost")), (3, dict(char_discount=1.0, round_to_inf=15.0))):
+        rec.init_beam_search(beam)
+        for _ in range(2):                 # (the second time through the captured step graph on a GPU)
+            results = rec.beam_search_batch(xs, **kw)
+            for x, (outs, costs) in zip(xs, results):
+                ref_outs, ref_costs = orc.beam_search(x, beam, lm=lm, **kw)
+                assert outs == ref_outs
+                assert_allclose(costs, ref_costs, rtol=1e-4, atol=1e-4)
+
+
+def test_batched_beam_search_with_device_fst_emulated():
+    from emu import emu_lib
+    run_fused_beam_batched("cpu", emu_lib())
+
+
+@pytest.mark.gpu
+def test_batched_beam_search_with_device_fst_gpu(gpu_device):
+    run_fused_beam_batched(gpu_device, None)
+
+
 @pytest.mark.gpu
 def test_device_fst_walk_gpu(gpu_device):
     run_device_walk(gpu_device, None)

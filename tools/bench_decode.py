@@ -110,6 +110,54 @@ def run_concurrent(recs, utterances, frames, rank=0, world=1, warm=None):
     return time.perf_counter() - t0, done, done * frames, chars, steps
 
 
+def run_batched(recs, utterances, frames, rank=0, world=1, batch=32):
+    """The same set decoded `batch` utterances at a time in ONE set of launches per position (BeamSearch.search_batch: the beams
+    of all of them are rows of the same kernels), with len(recs) such batches in flight (one recognizer + stream each: a batch
+    runs as long as its longest search, the other batch fills the chip meanwhile).  Returns what `run` returns."""
+    from lvsr_amd.search import CandidateNotFoundError
+    kw = dict(char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")
+    ids = list(range(rank, utterances, world))
+
+    def wav(i):
+        return numpy.random.RandomState(1234 + i).normal(size=(frames, 40)).astype(numpy.float32)
+
+    def start(rec, chunk):
+        xs = [wav(i) for i in chunk]
+        limits = [int(x.shape[0] / rec.max_decoded_length_scale) for x in xs]
+        return rec._beam_search.begin_batch(xs, rec.eos_label, limits, ignore_first_eol=rec.data_prepend_eos, **kw)
+
+    for rec in recs:                                    # warm-up: workspaces, graph capture of the step
+        with torch.cuda.stream(rec.stream):
+            for _ in range(2):
+                run_ = start(rec, (ids * batch)[:batch])
+                while not rec._beam_search.advance(run_, 8, wait=True):
+                    pass
+                rec._beam_search.finish_batch(run_)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    chunks = [ids[i: i + batch] for i in range(0, len(ids), batch)]
+    slots = [None] * len(recs)
+    done = chars = steps = 0
+    while chunks or any(s is not None for s in slots):
+        for k, rec in enumerate(recs):
+            bs = rec._beam_search
+            with torch.cuda.stream(rec.stream):
+                if slots[k] is None:
+                    if not chunks:
+                        continue
+                    slots[k] = start(rec, chunks.pop(0))
+                if bs.advance(slots[k], 8, wait=len(recs) == 1):
+                    for r in bs.finish_batch(slots[k]):
+                        if not isinstance(r, Exception):
+                            chars += len(r[0][0])
+                        done += 1
+                    st = bs.last_stats
+                    steps += sum(u["positions"] for u in st["per_utterance"]) if "per_utterance" in st else st.get("positions", 0)
+                    slots[k] = None
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, done, done * frames, chars, steps
+
+
 def decode_bench(args, rank, world, local_rank, json_out=None):
     """The bench.py line of configs[4]."""
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -122,12 +170,15 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
     json_out = json_out or sys.stdout
     utterances = args.utterances or 1000
     frames, beam = 800, 16
-    streams = max(1, int(getattr(args, "streams", None) or 8))
+    batch = int(getattr(args, "decode_batch", None) or 32)
+    streams = max(1, int(getattr(args, "streams", None) or (2 if batch > 1 else 8)))
     recs = [build(dev, beam)[0] for _ in range(streams)]
     rec = recs[0]
     if dist:
         torch.distributed.barrier()
-    if streams == 1:
+    if batch > 1:
+        sec, done, nframes, chars, steps = run_batched(recs, utterances, frames, rank, world, batch)
+    elif streams == 1:
         sec, done, nframes, chars, steps = run(rec, utterances, frames, rank, world)
     else:
         sec, done, nframes, chars, steps = run_concurrent(recs, utterances, frames, rank, world)
@@ -148,13 +199,14 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
                                         "no_transition_cost 20), char_discount 1.0, max length T/3, stop_on optimistic_future_cost"
                                         % (int(done), frames, beam),
                                utterances_per_sec=done / sec, sec_per_utterance=sec / max(done / world, 1), parallelism="replicas%d" % world,
-                               searches_in_flight_per_gpu=streams,
+                               utterances_per_launch_set=batch, searches_in_flight_per_gpu=streams * batch,
                                mean_best_hypothesis_length=chars / max(done, 1), positions_per_utterance=steps / max(done, 1),
                                us_per_position=(sec * 1e6 * world / steps if steps else None),
                                launches_per_position="one hipGraph replay per 8 positions (21 kernel nodes each: 2 x attention pass, "
-                                                     "readout, fusion, select, feedback fork, GRU, FST walk, compaction); no "
-                                                     "device->host synchronisation except one look at the `done` word per replay",
-                               encoder="persistent clusters, batch 1 (8 work-groups)"))
+                                                     "readout, fusion, select, feedback fork, GRU, FST walk, compaction) shared by the "
+                                                     "%d utterances of a batch; no device->host synchronisation except one look at the "
+                                                     "`done` words per replay" % batch,
+                               encoder="persistent clusters, one pass over the padded batch"))
         print(json.dumps(out), file=json_out, flush=True)
     if dist:
         torch.distributed.barrier()
@@ -168,15 +220,19 @@ if __name__ == "__main__":
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
-    ap.add_argument("--streams", type=int, default=1, help="searches in flight (one recognizer + stream each)")
+    ap.add_argument("--streams", type=int, default=1, help="searches (or batches) in flight (one recognizer + stream each)")
+    ap.add_argument("--batch", type=int, default=1, help="utterances per set of launches (BeamSearch.search_batch)")
     a = ap.parse_args()
     kind = "none" if a.no_lm else ("host" if a.host_lm else "device")
-    if a.streams > 1:
+    if a.batch > 1:
+        recs = [build("cuda:0", a.beam, kind)[0] for _ in range(a.streams)]
+        sec, done, nframes, chars, steps = run_batched(recs, a.utts, a.frames, batch=a.batch)
+    elif a.streams > 1:
         recs = [build("cuda:0", a.beam, kind)[0] for _ in range(a.streams)]
         sec, done, nframes, chars, steps = run_concurrent(recs, a.utts, a.frames)
     else:
         rec, _ = build("cuda:0", a.beam, kind)
         sec, done, nframes, chars, steps = run(rec, a.utts, a.frames)
     print(json.dumps(dict(metric="beam-search decode", utterances=done, beam=a.beam, lm=not a.no_lm, frames_per_utt=a.frames,
-                          streams=a.streams, sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,
+                          streams=a.streams, batch=a.batch, sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,
                           positions_per_utt=steps / done, us_per_position=sec * 1e6 / max(steps, 1))))

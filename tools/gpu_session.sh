@@ -30,6 +30,8 @@ for what in "$@"; do
          done
          cd $R; python tools/pmc_summary.py --json $O/pmc_bench.json --tag wsj_base $(find $O/pmc_* -name "*.db") > $O/pmc_bench_wsj_base.md 2>> $O/pmc_FETCH_SIZE.log; head -n 12 $O/pmc_bench_wsj_base.md | cut -c1-260; python -c "import json;d=json.load(open('$O/pmc_bench.json'));print({k:v for k,v in d.items() if 'enc_p' in k or k=='__stamp__'})";;
     timeline) python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>&1; head -n 24 $O/timeline.txt;;
+    dectests) timeout 900 python -m pytest tests -m gpu -x -q -k "batched or decode or beam" > $O/pytest_dec.log 2>&1; echo "pytest(decode) rc=$?"; grep "^E " $O/pytest_dec.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_dec.log;;
+    decb:*) bb=${what#decb:}; timeout 600 python tools/bench_decode.py --utts 128 --batch ${bb%x*} --streams ${bb#*x} > $O/decb_$bb.json 2> $O/decb_$bb.err; cat $O/decb_$bb.json; tail -n 2 $O/decb_$bb.err;;
     decode) timeout 900 python bench.py --workload wsj_decode > $O/decode.json 2> $O/decode.err; echo "decode rc=$?"; cut -c1-600 $O/decode.json; tail -n 2 $O/decode.err;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log;;
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
