@@ -148,6 +148,10 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
 
 // masked softmax over the window + glimpse; grid (ceil(E/32), B).  Chunk 0 also writes the new alignment
 // row (pasted into zeros) and the next window centre.
+// FUSED = false (row groups: grid (1, B)): the softmax part alone — the weighted averages of a group's rows share the group's
+// attended sequence and are formed as one small product per group afterwards (alignments (rows, T') x attended (T', E),
+// lvsr_sgemm_batched): the attended rows are then read once per utterance instead of once per hypothesis and chunk.
+template <bool FUSED>
 __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float al[ATT_MAX_T];
     __shared__ float red[4];
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int t = w.begin + tg + 32 * r;
-        pv[r] = t < w.end ? ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        pv[r] = (FUSED && t < w.end) ? ld4g(Ab + (size_t)t * a.A_ts, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int nslice = (a.M + ATT_MS - 1) / ATT_MS;
     const float* ep = a.ep + (size_t)b * nslice * Tp;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
             if (threadIdx.x == 0) a.pos[(size_t)(i + 1) * B + b] = r;
         }
     }
+    if (!FUSED) return;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -322,6 +327,7 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
     LVSR_REQUIRE(a.S_ld == 0 || a.S_ld >= a.D, "lvsr_attdec_fwd: S_ld < D");
     hipStream_t s = (hipStream_t)stream;
     const PreGrid g = attdec_pre_grid(a);
+    int inner_rc = LVSR_OK;          // of the library calls inside the enqueue code
     auto enqueue = [&]() {
         if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0 && a.label0 == 0)
             hipLaunchKernelGGL(attdec_pos_kernel, dim3(a.B), dim3(64), 0, s, a, 0);
@@ -339,7 +345,15 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
                     case 10: hipLaunchKernelGGL(attdec_energy_kernel<10>, eg, dim3(256), 0, s, a, i); break;
                     default: hipLaunchKernelGGL(attdec_energy_kernel<16>, eg, dim3(256), 0, s, a, i); break;
                 }
-                hipLaunchKernelGGL(attdec_glimpse_kernel, dim3((a.E + 31) / 32, a.B), dim3(256), 0, s, a, i);
+                if (a.group_rows > 0) {
+                    hipLaunchKernelGGL(attdec_glimpse_kernel<false>, dim3(1, a.B), dim3(256), 0, s, a, i);
+                    const int rc = lvsr_sgemm_batched(s, 0, 0, a.group_rows, a.E, a.Tp, 1.f, a.W + (size_t)(i + 1) * a.B * a.Tp, a.Tp,
+                                             (long long)a.group_rows * a.Tp, a.A, (int)a.A_ts, a.A_bs, 0.f, a.WA + (size_t)i * a.B * a.E, a.E,
+                                             (long long)a.group_rows * a.E, a.B / a.group_rows);
+                    if (rc != LVSR_OK && inner_rc == LVSR_OK) inner_rc = rc;
+                } else {
+                    hipLaunchKernelGGL(attdec_glimpse_kernel<true>, dim3((a.E + 31) / 32, a.B), dim3(256), 0, s, a, i);
+                }
             }
             if (a.phases & 2) {
                 hipLaunchKernelGGL(attdec_gru1_kernel, dim3((a.D + 15) / 16 + (2 * a.D + 15) / 16, g.rt), dim3(256), 0, s, a, i);
@@ -349,5 +363,6 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
     };
     GraphKey key("attdec_fwd");
     key.add(&a, sizeof(a));
-    return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd");
+    const int rc = lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd");
+    return rc != LVSR_OK ? rc : inner_rc;
 }

@@ -32,6 +32,9 @@ for what in "$@"; do
     timeline) python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>&1; head -n 24 $O/timeline.txt;;
     dectests) timeout 900 python -m pytest tests -m gpu -x -q -k "batched or decode or beam" > $O/pytest_dec.log 2>&1; echo "pytest(decode) rc=$?"; grep "^E " $O/pytest_dec.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_dec.log;;
     decb:*) bb=${what#decb:}; timeout 600 python tools/bench_decode.py --utts 128 --batch ${bb%x*} --streams ${bb#*x} > $O/decb_$bb.json 2> $O/decb_$bb.err; cat $O/decb_$bb.json; tail -n 2 $O/decb_$bb.err;;
+    decbprof:*) bb=${what#decbprof:}; cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+         timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decbprof -o dec -- python $R/tools/bench_decode.py --utts 64 --batch ${bb%x*} --streams ${bb#*x} > $R/$O/decbprof.log 2>&1
+         cd $R; python tools/rocpd_stats.py $(find $O/decbprof -name "*.db" | head -n 1) > $O/decode_batched_kernel_stats.md 2>&1; tail -n 2 $O/decbprof.log | cut -c1-400; head -n 40 $O/decode_batched_kernel_stats.md | cut -c1-160;;
     decode) timeout 900 python bench.py --workload wsj_decode > $O/decode.json 2> $O/decode.err; echo "decode rc=$?"; cut -c1-600 $O/decode.json; tail -n 2 $O/decode.err;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log;;
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
