@@ -93,55 +93,65 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
 // issues all of its loads (handler column, 8 PA values, conv features) before the first use, and ~4 work-groups
 // share a CU so their latencies overlap.  The slice's partial energies go to `ep`; the glimpse kernel folds the
 // slices in a fixed order.
+// Row groups (batched beam search: grid.y = groups): the rows of a group share the utterance's preprocessed attended and the
+// window, so ONE work-group serves all of them for its (slice, tile) — PA tile, handler column and w_e are fetched once for
+// the 16 hypotheses instead of once each (the kernel was bound by exactly that L2 traffic at 512 rows).
+// A thread holds 8 CONSECUTIVE positions: its conv features come as two 16-byte LDS reads per filter.
 template <int KC>      // compile-time bound of the filter loop, see att_kc()
 __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
-    __shared__ float cvs[ATT_KMAX][ATT_TT];
+    __shared__ __attribute__((aligned(16))) float cvs[ATT_KMAX][ATT_TT];
     __shared__ float cs[ATT_TT][ATT_MS + 1];
-    const int b = blockIdx.y, slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    const int slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
+    const int rows = a.group_rows > 0 ? a.group_rows : 1, bfirst = blockIdx.y * rows;
     const int t0 = blockIdx.z * ATT_TT;
-    const Win w = attdec_window_row(a, i, b);
+    const Win w = attdec_window_row(a, i, bfirst);
     if (t0 >= w.end || t0 + ATT_TT <= w.begin) return;             // tile outside the window: nothing to add
-    float* ep = a.ep + ((size_t)b * nslice + slice) * Tp;
     const int ml = threadIdx.x & 31, tg = threadIdx.x >> 5, m = slice * ATT_MS + ml;
     const bool mok = m < M;
     float pav[8];
-    const float* pab = a.PA + (size_t)attdec_ctx(a, b) * a.PA_bs + m;
+    const float* pab = a.PA + (size_t)attdec_ctx(a, bfirst) * a.PA_bs + m;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const int t = t0 + tg + 8 * r;
+        const int t = t0 + 8 * tg + r;
         pav[r] = (t >= w.begin && t < w.end && mok) ? pab[(size_t)t * a.PA_ts] : 0.f;
     }
     float Hk[KC > 0 ? KC : 1];
 #pragma unroll
     for (int k = 0; k < KC; ++k) Hk[k] = (k < K && mok) ? a.handler[(size_t)k * M + m] : 0.f;
     const float we_m = mok ? a.w_e[m] : 0.f;
-    const float sw_m = mok ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
-    for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
-        const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
-        cvs[k][tl] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int tl = tg + 8 * r, t = t0 + tl;
-        float c = 0.f;
-        if (t >= w.begin && t < w.end && mok) {
-            float x = pav[r] + sw_m;
-#pragma unroll
-            for (int k = 0; k < KC; ++k)
-                if (KC == K || k < K) x += cvs[k][tl] * Hk[k];
-            c = we_m * tanh_fast(x);
+    for (int row = 0; row < rows; ++row) {
+        const int b = bfirst + row;
+        const float sw_m = mok ? a.sW[((size_t)i * B + b) * M + m] : 0.f;
+        if (row > 0) __syncthreads();                              // the previous row's partials have been folded
+        for (int x = threadIdx.x; x < K * ATT_TT; x += 256) {
+            const int k = x / ATT_TT, tl = x % ATT_TT, t = t0 + tl;
+            cvs[k][tl] = (t < Tp) ? a.CV[(((size_t)i * B + b) * K + k) * Tp + t] : 0.f;
         }
-        cs[tl][ml] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x < ATT_TT) {
-        const int t = t0 + threadIdx.x;
-        if (t >= w.begin && t < w.end) {
-            float e = 0.f;
+        __syncthreads();
+        float x8[8];
 #pragma unroll
-            for (int j = 0; j < ATT_MS; ++j) e += cs[threadIdx.x][j];
-            ep[t] = e;
+        for (int r = 0; r < 8; ++r) x8[r] = pav[r] + sw_m;
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (KC == K || k < K) {
+                const float4 c0 = *(const float4*)&cvs[k][8 * tg], c1 = *(const float4*)&cvs[k][8 * tg + 4];
+                x8[0] += c0.x * Hk[k]; x8[1] += c0.y * Hk[k]; x8[2] += c0.z * Hk[k]; x8[3] += c0.w * Hk[k];
+                x8[4] += c1.x * Hk[k]; x8[5] += c1.y * Hk[k]; x8[6] += c1.z * Hk[k]; x8[7] += c1.w * Hk[k];
+            }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int tl = 8 * tg + r, t = t0 + tl;
+            cs[tl][ml] = (t >= w.begin && t < w.end && mok) ? we_m * tanh_fast(x8[r]) : 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < ATT_TT) {
+            const int t = t0 + threadIdx.x;
+            if (t >= w.begin && t < w.end) {
+                float e = 0.f;
+#pragma unroll
+                for (int j = 0; j < ATT_MS; ++j) e += cs[threadIdx.x][j];
+                a.ep[((size_t)b * nslice + slice) * Tp + t] = e;
+            }
         }
     }
 }
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
 // masked softmax over the window + glimpse; grid (ceil(E/32), B).  Chunk 0 also writes the new alignment
 // row (pasted into zeros) and the next window centre.
 // FUSED = false (row groups: grid (1, B)): the softmax part alone — the weighted averages of a group's rows share the group's
-// attended sequence and are formed as one small product per group afterwards (alignments (rows, T') x attended (T', E),
-// lvsr_sgemm_batched): the attended rows are then read once per utterance instead of once per hypothesis and chunk.
+// attended sequence and are formed per group afterwards (attdec_group_wa_kernel): the attended rows are then read once per
+// utterance instead of once per hypothesis and chunk.
 template <bool FUSED>
 __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float al[ATT_MAX_T];
@@ -247,6 +257,59 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     }
 }
 
+// Weighted averages of a row group (batched beam search): WA[r, :] = sum_t alpha[r, t] * attended_g[t, :] for the rows r of group g,
+// which share the group's attended sequence.  Grid (ceil(E/64), groups): a work-group keeps the group's alignments in LDS
+// (rows x T' <= 16 x 4096 floats at most; rows <= GW_ROWS per pass) and streams 64 columns of the attended rows once for all of
+// them (the fused glimpse kernel reads them once per row: 16 times here); thread = (column, row quad).
+#define GW_ROWS 16
+#define GW_FLOATS 12288
+__global__ __launch_bounds__(256) void attdec_group_wa_kernel(AttDec a, int i) {
+    __shared__ float gw_al[GW_FLOATS];             // [rows of a pass][span] alignments of the group over their common window
+    const int g = blockIdx.y, rows = a.group_rows, B = a.B, Tp = a.Tp, E = a.E;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    const Win w = attdec_window_row(a, i, g * rows);
+    const int span = w.end - w.begin;
+    const int per = max(1, min(GW_ROWS, GW_FLOATS / max(span, 1)));       // rows per pass (16 up to T' = 768)
+    for (int r0 = 0; r0 < rows; r0 += per) {
+        const int nr = min(per, rows - r0);
+        __syncthreads();
+        for (int x = threadIdx.x; x < nr * span; x += 256) {
+            const int r = x / span, t = w.begin + x % span;
+            gw_al[r * span + (t - w.begin)] = a.W[((size_t)(i + 1) * B + g * rows + r0 + r) * Tp + t];
+        }
+        __syncthreads();
+        const float* Ab = a.A + (size_t)g * a.A_bs + min(col, E - 1);
+        float acc[GW_ROWS / 4] = {};
+        int t = 0;
+        for (; t + 8 <= span; t += 8) {              // eight attended rows in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = Ab[(size_t)(w.begin + t + u) * a.A_ts];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < GW_ROWS / 4; ++q) {
+                    const int r = rq * (GW_ROWS / 4) + q;
+                    acc[q] += (r < nr ? gw_al[r * span + t + u] : 0.f) * v[u];
+                }
+        }
+        for (; t < span; ++t) {
+            const float v = Ab[(size_t)(w.begin + t) * a.A_ts];
+#pragma unroll
+            for (int q = 0; q < GW_ROWS / 4; ++q) {
+                const int r = rq * (GW_ROWS / 4) + q;
+                acc[q] += (r < nr ? gw_al[r * span + t] : 0.f) * v;
+            }
+        }
+        if (col < E)
+#pragma unroll
+            for (int q = 0; q < GW_ROWS / 4; ++q) {
+                const int r = rq * (GW_ROWS / 4) + q;
+                if (r < nr) a.WA[((size_t)i * B + g * rows + r0 + r) * E + col] = acc[q];
+            }
+    }
+}
+
 // GRU part 1: x_in = fork_x + wa @ W_di;  g = sigmoid(sg + fork_g + wa @ W_dg) -> u, r, rh = r*s
 __global__ __launch_bounds__(256) void attdec_gru1_kernel(AttDec a, int i) {
     const int D = a.D, B = a.B, E = a.E;
@@ -327,7 +390,6 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
     LVSR_REQUIRE(a.S_ld == 0 || a.S_ld >= a.D, "lvsr_attdec_fwd: S_ld < D");
     hipStream_t s = (hipStream_t)stream;
     const PreGrid g = attdec_pre_grid(a);
-    int inner_rc = LVSR_OK;          // of the library calls inside the enqueue code
     auto enqueue = [&]() {
         if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0 && a.label0 == 0)
             hipLaunchKernelGGL(attdec_pos_kernel, dim3(a.B), dim3(64), 0, s, a, 0);
@@ -335,7 +397,7 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
             if (g.nmm + g.nconv > 0)
                 hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm + g.nconv), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
-                const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
+                const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.group_rows > 0 ? a.B / a.group_rows : a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
                 switch (att_kc(a.K)) {
                     case 0: hipLaunchKernelGGL(attdec_energy_kernel<0>, eg, dim3(256), 0, s, a, i); break;
                     case 1: hipLaunchKernelGGL(attdec_energy_kernel<1>, eg, dim3(256), 0, s, a, i); break;
@@ -347,10 +409,7 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
                 }
                 if (a.group_rows > 0) {
                     hipLaunchKernelGGL(attdec_glimpse_kernel<false>, dim3(1, a.B), dim3(256), 0, s, a, i);
-                    const int rc = lvsr_sgemm_batched(s, 0, 0, a.group_rows, a.E, a.Tp, 1.f, a.W + (size_t)(i + 1) * a.B * a.Tp, a.Tp,
-                                             (long long)a.group_rows * a.Tp, a.A, (int)a.A_ts, a.A_bs, 0.f, a.WA + (size_t)i * a.B * a.E, a.E,
-                                             (long long)a.group_rows * a.E, a.B / a.group_rows);
-                    if (rc != LVSR_OK && inner_rc == LVSR_OK) inner_rc = rc;
+                    hipLaunchKernelGGL(attdec_group_wa_kernel, dim3((a.E + 63) / 64, a.B / a.group_rows), dim3(256), 0, s, a, i);
                 } else {
                     hipLaunchKernelGGL(attdec_glimpse_kernel<true>, dim3((a.E + 31) / 32, a.B), dim3(256), 0, s, a, i);
                 }
@@ -363,6 +422,5 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
     };
     GraphKey key("attdec_fwd");
     key.add(&a, sizeof(a));
-    const int rc = lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd");
-    return rc != LVSR_OK ? rc : inner_rc;
+    return lvsr_run_graph(s, use_graph, key, enqueue, "lvsr_attdec_fwd");
 }
