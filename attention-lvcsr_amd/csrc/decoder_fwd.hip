@@ -19,22 +19,31 @@ __global__ __launch_bounds__(64) void attdec_pos_kernel(AttDec a, int slot) {
     if (threadIdx.x == 0) a.pos[(size_t)slot * a.B + b] = r;
 }
 
-struct PreGrid { int rt, ntS, ntG, nmm, nch, nconv; };
+// Location convolution inside the pre kernel: a work-group serves one row and `kf` of its filters; a thread owns FOUR consecutive
+// output positions of one filter and walks the taps four at a time — 16 FMAs on two 16-byte reads of the (zero-padded, cut)
+// alignment and one of the filter from LDS.  (One output and one tap per step, as before round 4, is two LDS reads per FMA: the
+// kernel was LDS-issue bound, 20 us at 512 rows.)
+#define PRE_FL 4096          // filter floats in LDS (kf filters, taps padded to a multiple of 4)
+#define PRE_AL (ATT_MAX_T + ATT_MAX_FW + 16)
+struct PreGrid { int rt, ntS, ntG, nmm, nq, kf, nkg, nconv; };
 __host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
     PreGrid g;
     g.rt = (a.B + 15) / 16;
     g.ntS = (a.phases & 1) ? (a.M + 15) / 16 : 0;
     g.ntG = (a.phases & 2) ? (2 * a.D + 15) / 16 : 0;
     g.nmm = (g.ntS + g.ntG) * g.rt;
-    g.nch = (a.Tp + 255) / 256;
-    g.nconv = ((a.phases & 1) && a.K > 0) ? a.B * a.K * g.nch : 0;
+    g.nq = (a.Tp + 3) / 4;                                           // output quads of a row
+    const int fw4 = (2 * a.c + 1 + 3) / 4 * 4;
+    g.kf = max(1, min(min(a.K, 256 / g.nq), PRE_FL / fw4));          // filters per work-group
+    g.nkg = a.K > 0 ? (a.K + g.kf - 1) / g.kf : 0;
+    g.nconv = ((a.phases & 1) && a.K > 0) ? a.B * g.nkg : 0;
     return g;
 }
 
 // pre: sW = s @ W_s (attention), sg = s @ W_hg (gate pre-activation, state part), cv = conv(alpha_prev)
 __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
-    __shared__ float al[ATT_MAX_T];
-    __shared__ float fl[ATT_MAX_FW];
+    __shared__ __attribute__((aligned(16))) float al[PRE_AL];
+    __shared__ __attribute__((aligned(16))) float fl[PRE_FL];
     const PreGrid g = attdec_pre_grid(a);
     const int D = a.D, B = a.B, Tp = a.Tp;
     int blk = blockIdx.x;
@@ -59,32 +68,42 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
         return;
     }
     blk -= g.nmm;
-    const int ch = blk % g.nch, k = (blk / g.nch) % a.K, b = blk / (g.nch * a.K);
+    const int kg = blk % g.nkg, b = blk / g.nkg, c = a.c, FW = 2 * c + 1, FW4 = (FW + 3) / 4 * 4;
+    const int k0 = kg * g.kf, nk = min(g.kf, a.K - k0);
     const Win w = attdec_window_row(a, i, b);
     const float* wprev = a.W + ((size_t)i * B + b) * Tp;
-    for (int t = threadIdx.x; t < Tp; t += 256) al[t] = (t >= w.begin && t < w.end) ? wprev[t] : 0.f;
-    const int FW = 2 * a.c + 1;
-    for (int j = threadIdx.x; j < FW; j += 256) fl[j] = a.filters[(size_t)k * FW + j];
+    // al[OFF + t] = cut alignment at t, zeros from OFF - (c + 3) to OFF + Tp + c + 3; OFF such that the reads below are 16-byte aligned
+    const int OFF = (c + 3 + 3) / 4 * 4 + ((3 - c) % 4 + 4) % 4;
+    for (int x = threadIdx.x; x < OFF + Tp + c + 8; x += 256) {
+        const int t = x - OFF;
+        al[x] = (t >= w.begin && t < w.end) ? wprev[t] : 0.f;
+    }
+    for (int x = threadIdx.x; x < nk * FW4; x += 256) {
+        const int k = x / FW4, e = x % FW4;
+        fl[x] = e < FW ? a.filters[(size_t)(k0 + k) * FW + e] : 0.f;
+    }
     __syncthreads();
-    const int t = ch * 256 + threadIdx.x;
-    if (t < Tp) {
-        float s = 0.f;
-        if (t >= w.begin && t < w.end) {
-            // true convolution of the CUT alignment: out[t] = sum_d f[c+d] * al[t-d], t-d inside the window
-            const int dlo = max(-a.c, t - (w.end - 1)), dhi = min(a.c, t - w.begin);
-            // 4 independent accumulators: the loop is LDS-latency bound when every FMA waits for the previous one
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-            int d = dlo;
-            for (; d + 3 <= dhi; d += 4) {
-                s0 += fl[a.c + d] * al[t - d];
-                s1 += fl[a.c + d + 1] * al[t - d - 1];
-                s2 += fl[a.c + d + 2] * al[t - d - 2];
-                s3 += fl[a.c + d + 3] * al[t - d - 3];
+    // true convolution of the CUT alignment: out[t] = sum_e f[e] * al[t + c - e] (e = c + d), the alignment zero outside the window
+    for (int x = threadIdx.x; x < nk * g.nq; x += 256) {
+        const int k = x / g.nq, t = (x % g.nq) * 4;
+        const float* f = fl + k * FW4;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        if (t + 3 >= w.begin && t < w.end)
+            for (int e = 0; e < FW4; e += 4) {
+                const float4 fe = *(const float4*)(f + e);
+                const float* src = al + (OFF + t + c - e - 3);          // v[n] = al_cut[t + c - e - 3 + n]
+                const float4 lo = *(const float4*)src, hi = *(const float4*)(src + 4);
+                // out[t + j] += f[e + q] * v[j - q + 3]
+                o0 += fe.x * lo.w; o0 += fe.y * lo.z; o0 += fe.z * lo.y; o0 += fe.w * lo.x;
+                o1 += fe.x * hi.x; o1 += fe.y * lo.w; o1 += fe.z * lo.z; o1 += fe.w * lo.y;
+                o2 += fe.x * hi.y; o2 += fe.y * hi.x; o2 += fe.z * lo.w; o2 += fe.w * lo.z;
+                o3 += fe.x * hi.z; o3 += fe.y * hi.y; o3 += fe.z * hi.x; o3 += fe.w * lo.w;
             }
-            for (; d <= dhi; ++d) s0 += fl[a.c + d] * al[t - d];
-            s = (s0 + s1) + (s2 + s3);
-        }
-        a.CV[(((size_t)i * B + b) * a.K + k) * Tp + t] = s;
+        float* out = a.CV + (((size_t)i * B + b) * a.K + k0 + k) * Tp;
+        const float o[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (t + j < Tp) out[t + j] = (t + j >= w.begin && t + j < w.end) ? o[j] : 0.f;
     }
 }
 
