@@ -40,14 +40,12 @@ __host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
     return g;
 }
 
-// pre: sW = s @ W_s (attention), sg = s @ W_hg (gate pre-activation, state part), cv = conv(alpha_prev)
+// pre: sW = s @ W_s (attention), sg = s @ W_hg (gate pre-activation, state part)
 __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
-    __shared__ __attribute__((aligned(16))) float al[PRE_AL];
-    __shared__ __attribute__((aligned(16))) float fl[PRE_FL];
     const PreGrid g = attdec_pre_grid(a);
-    const int D = a.D, B = a.B, Tp = a.Tp;
+    const int D = a.D, B = a.B;
     int blk = blockIdx.x;
-    if (blk < g.nmm) {
+    {
         const int tileAll = blk % (g.ntS + g.ntG), b0 = (blk / (g.ntS + g.ntG)) * 16;
         const int ldS = a.S_ld ? a.S_ld : D;
         const float* Srow = a.S + ((size_t)i * B + b0) * ldS;
@@ -65,9 +63,15 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
             const int j = tile * 16 + (threadIdx.x & 15);
             if (b < B && j < 2 * D) a.sg[(size_t)b * 2 * D + j] = v;
         }
-        return;
     }
-    blk -= g.nmm;
+}
+
+// pre, second part: cv = conv(alpha_prev) (a kernel of its own: its 36 KB of LDS would halve the occupancy of the products above)
+__global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
+    __shared__ __attribute__((aligned(16))) float al[PRE_AL];
+    __shared__ __attribute__((aligned(16))) float fl[PRE_FL];
+    const PreGrid g = attdec_pre_grid(a);
+    const int B = a.B, Tp = a.Tp, blk = blockIdx.x;
     const int kg = blk % g.nkg, b = blk / g.nkg, c = a.c, FW = 2 * c + 1, FW4 = (FW + 3) / 4 * 4;
     const int k0 = kg * g.kf, nk = min(g.kf, a.K - k0);
     const Win w = attdec_window_row(a, i, b);
@@ -413,8 +417,8 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
         if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0 && a.label0 == 0)
             hipLaunchKernelGGL(attdec_pos_kernel, dim3(a.B), dim3(64), 0, s, a, 0);
         for (int i = a.label0; i < a.L; ++i) {
-            if (g.nmm + g.nconv > 0)
-                hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm + g.nconv), dim3(256), 0, s, a, i);
+            if (g.nconv > 0) hipLaunchKernelGGL(attdec_conv_kernel, dim3(g.nconv), dim3(256), 0, s, a, i);
+            if (g.nmm > 0) hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
                 const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.group_rows > 0 ? a.B / a.group_rows : a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
                 switch (att_kc(a.K)) {
