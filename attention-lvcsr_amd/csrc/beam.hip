@@ -169,6 +169,8 @@ __device__ __forceinline__ lvsr_beam_args beam_group(lvsr_beam_args a, int g) {
     BG_OFF(S_new, r * D); BG_OFF(W_new, r * Tp); BG_OFF(S_live_out, r * D); BG_OFF(W_live_out, r * Tp);
     BG_OFF(lm_states_new, r * 7); BG_OFF(lm_weights_new, r * 7); BG_OFF(lm_add_new, r * V);
     BG_OFF(lm_states_live_out, r * 7); BG_OFF(lm_weights_live_out, r * 7); BG_OFF(lm_add_live_out, r * V);
+    BG_OFF(WA_live, r * a.E); BG_OFF(WA_sel, r * a.E); BG_OFF(W1_live, r * Tp); BG_OFF(W1_sel, r * Tp);
+    BG_OFF(pos1_live, r); BG_OFF(pos1_sel, r);
 #undef BG_OFF
     return a;
 }
@@ -305,6 +307,21 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         a.keep[i] = k;
         if (i < nl) { a.live_col[i] = k; a.running[i] = s_cost[k]; }
     }
+    if (tid == 0 && a.WA_live) {
+        // do the selected rows span the window centres of the live rows (all K rows of either pass: the tails replicate row 0 /
+        // candidate 0)?  Then the second attention pass would repeat the first one row by row: see lvsr_beam_args.WA_live
+        int same = 1;
+        if (a.pos_live) {
+            float mnA = 3.0e38f, mxA = -3.0e38f, mnB = 3.0e38f, mxB = -3.0e38f;
+            for (int k = 0; k < K; ++k) {
+                const float pa = a.pos_live[k], pb = a.pos_live[s_par[k]];
+                mnA = fminf(mnA, pa); mxA = fmaxf(mxA, pa); mnB = fminf(mnB, pb); mxB = fmaxf(mxB, pb);
+            }
+            same = (mnA == mnB && mxA == mxB) ? 1 : 0;
+        }
+        ctl[9] = same;
+        ctl[10] += same;
+    }
     if (tid == 0) {
         ctl[CTL_NLIVE] = nl;
         ctl[CTL_POS] = p + 1;
@@ -331,6 +348,15 @@ __global__ __launch_bounds__(256) void beam_rows_kernel(lvsr_beam_args a0) {
     for (int j = tid; j < a.D; j += 256) s_dst[j] = s_src[j];
     for (int j = tid; j < a.Tp; j += 256) w_dst[j] = w_src[j];
     if (a.pos_live && tid == 0) a.pos_sel[k] = a.pos_live[par];
+    if (a.WA_live && a.ctl[9] != 0) {          // the second attention pass is skipped for this search: its results are the parent's
+        const float* __restrict__ wa_src = a.WA_live + (size_t)par * a.E;
+        const float* __restrict__ w1_src = a.W1_live + (size_t)par * a.Tp;
+        float* __restrict__ wa_dst = a.WA_sel + (size_t)k * a.E;
+        float* __restrict__ w1_dst = a.W1_sel + (size_t)k * a.Tp;
+        for (int j = tid; j < a.E; j += 256) wa_dst[j] = wa_src[j];
+        for (int j = tid; j < a.Tp; j += 256) w1_dst[j] = w1_src[j];
+        if (a.pos1_live && tid == 0) a.pos1_sel[k] = a.pos1_live[par];
+    }
     if (a.lm_states_live && tid < 7) {
         a.lm_states_sel[(size_t)k * 7 + tid] = a.lm_states_live[(size_t)par * 7 + tid];
         a.lm_weights_sel[(size_t)k * 7 + tid] = a.lm_weights_live[(size_t)par * 7 + tid];
@@ -377,6 +403,8 @@ static int beam_check(const lvsr_beam_args& a, const char* what) {
     LVSR_REQUIRE(a.stop_on == 0 || a.stop_on == 1, "%s: unknown stopping criterion %d", what, a.stop_on);
     LVSR_REQUIRE(a.fin_cap >= 2 * a.K, "%s: finished list shorter than 2 * beam", what);
     LVSR_REQUIRE(a.groups >= 0 && a.groups <= 65535, "%s: bad number of searches", what);
+    LVSR_REQUIRE(!a.WA_live || (a.WA_sel && a.W1_live && a.W1_sel && a.E > 0 && (!a.pos_live || (a.pos1_live && a.pos1_sel))),
+                 "%s: incomplete description of the attention results to reuse", what);
     return LVSR_OK;
 }
 

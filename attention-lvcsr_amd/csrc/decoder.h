@@ -32,6 +32,11 @@ int attdec_check(const AttDec& a, const char* what);
 __device__ __forceinline__ int attdec_group(const AttDec& a, int b) { return a.group_rows > 0 ? b / a.group_rows : 0; }
 __device__ __forceinline__ int attdec_ctx(const AttDec& a, int b) { return a.group_rows > 0 ? b / a.group_rows : b; }
 
+// lvsr_attdec_args.skip: the attention part of row b's group has been filled in by the caller
+__device__ __forceinline__ bool attdec_skip(const AttDec& a, int b) {
+    return a.skip != nullptr && a.skip[(size_t)attdec_group(a, b) * a.skip_stride] != 0;
+}
+
 // Window of take_glimpses (lvsr/bricks/attention.py:123-161) for the rows [b0, b0 + nb) that form one batch of the reference (all
 // rows; with row groups the rows of a group), Tp = the attended length of that batch, stepw = its position counter.
 // Content-only attention: whole sequence.

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
         const int b = b0 + (threadIdx.x >> 4);
         f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
         if (tileAll < g.ntS) {
+            if (attdec_skip(a, b0) && attdec_skip(a, min(b0 + 15, B - 1)) && (a.group_rows == 0 || a.group_rows >= 16)) return;   // (a tile of 16 rows touches at most two groups then)
             rb_mm(acc0, acc1, row_src(Srow, ldS, B - b0, D), a.Ws_p, D, tileAll);
             const float v = rb_reduce(acc0, acc1);
             const int j = tileAll * 16 + (threadIdx.x & 15);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
     const PreGrid g = attdec_pre_grid(a);
     const int B = a.B, Tp = a.Tp, blk = blockIdx.x;
     const int kg = blk % g.nkg, b = blk / g.nkg, c = a.c, FW = 2 * c + 1, FW4 = (FW + 3) / 4 * 4;
+    if (attdec_skip(a, b)) return;
     const int k0 = kg * g.kf, nk = min(g.kf, a.K - k0);
     const Win w = attdec_window_row(a, i, b);
     const float* wprev = a.W + ((size_t)i * B + b) * Tp;
@@ -127,6 +129,7 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
     const int slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
     const int rows = a.group_rows > 0 ? a.group_rows : 1, bfirst = blockIdx.y * rows;
     const int t0 = blockIdx.z * ATT_TT;
+    if (attdec_skip(a, bfirst)) return;
     const Win w = attdec_window_row(a, i, bfirst);
     if (t0 >= w.end || t0 + ATT_TT <= w.begin) return;             // tile outside the window: nothing to add
     const int ml = threadIdx.x & 31, tg = threadIdx.x >> 5, m = slice * ATT_MS + ml;
@@ -190,6 +193,7 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
     __shared__ float red[4];
     __shared__ float part[32][33];
     const int b = blockIdx.y, chunk = blockIdx.x, B = a.B, Tp = a.Tp, E = a.E;
+    if (attdec_skip(a, b)) return;
     const Win w = attdec_window_row(a, i, b);
     __shared__ float en[ATT_MAX_T];
     // The attended rows do not depend on the alignment: fetch this thread's share (8 float4 = the first 256 positions of
@@ -290,6 +294,7 @@ __global__ __launch_bounds__(256) void attdec_group_wa_kernel(AttDec a, int i) {
     __shared__ float gw_al[GW_FLOATS];             // [rows of a pass][span] alignments of the group over their common window
     const int g = blockIdx.y, rows = a.group_rows, B = a.B, Tp = a.Tp, E = a.E;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
+    if (attdec_skip(a, g * rows)) return;
     const Win w = attdec_window_row(a, i, g * rows);
     const int span = w.end - w.begin;
     const int per = max(1, min(GW_ROWS, GW_FLOATS / max(span, 1)));       // rows per pass (16 up to T' = 768)
@@ -398,6 +403,7 @@ int attdec_check(const AttDec& a, const char* what) {
     LVSR_REQUIRE(a.K == 0 || 2 * a.c + 1 <= ATT_MAX_FW, "%s: conv filter too wide", what);
     LVSR_REQUIRE(a.prior_type >= 0 && a.prior_type <= 2, "%s: unknown prior type", what);
     LVSR_REQUIRE(a.K == 0 || a.prior_type == 0 || a.pos != nullptr, "%s: window_around_* priors need pos", what);
+    LVSR_REQUIRE(a.skip == nullptr || (a.L == 1 && a.skip_stride >= 0), "%s: skip is for single-step (generation) calls", what);
     LVSR_REQUIRE(a.group_rows >= 0 && (a.group_rows == 0 || (a.B % a.group_rows == 0 && (a.step_dev == nullptr || a.step_stride > 0))),
                  "%s: the rows must be whole groups (B = %d, group_rows = %d) with a position counter each (step_stride)", what, a.B, a.group_rows);
     return LVSR_OK;

@@ -819,7 +819,9 @@ def _beam_methods():
             st["stepB"] = self._beam_step_blocks(pk, g, K, B_, skip_pos, pos_word, tag)
         else:
             fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True, **grp)
-            st["argsB"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fb_)     # runs after the select kernel moved on: step0 = -1
+            # the select launch raises word 9 of a search's control block when pass B's glimpses would repeat pass A's row by row
+            # (and copies them): lvsr_beam_args.WA_live
+            st["argsB"] = lib.make("lvsr_attdec_args", step_dev=pos_word, skip=st["ctl"].view(-1)[9:], skip_stride=16, **fb_)     # runs after the select kernel moved on: step0 = -1
         L = st["lm"] or {}
         host_fork = d.embed or stacked      # the fork of the chosen characters as separate launches of pass B
         st["args"] = lib.make(
@@ -840,7 +842,9 @@ def _beam_methods():
             # one-hot feedback: the fork of the chosen characters is a row gather the select launch does itself
             fork_xg=None if host_fork else B_["xg"], fork_Wi=None if host_fork else p[n_["Wfi"]],
             fork_Wg=None if host_fork else p[n_["Wfg"]], fork_bi=None if host_fork else p[n_["bfi"]],
-            fork_bg=None if host_fork else p[n_["bfg"]], fork_rows=0 if host_fork else d.FB)
+            fork_bg=None if host_fork else p[n_["bfg"]], fork_rows=0 if host_fork else d.FB,
+            **({} if stacked else dict(WA_live=A_["WA"][0], WA_sel=B_["WA"][0], W1_live=A_["W"][1], W1_sel=B_["W"][1], E=d.E,
+                                       pos1_live=A_["pos"][1] if pos_needed else None, pos1_sel=B_["pos"][1] if pos_needed else None)))
         st["readout"] = self._readout_step_args(A_["S"][0], A_["WA"][0], K, neglogp=st["neglogp"],
                                                 lm_add=L.get("add_live") if lm is not None else None)
         # ---- reset: one live hypothesis, replicated over the K rows

@@ -153,8 +153,9 @@ class BeamSearch(object):
                     out.append(self._collect(view, ctl[g], run["first_token"], run["char_discount"], as_arrays))
                 except (CandidateNotFoundError, AssertionError, RuntimeError, UnboundLocalError) as e:
                     out.append(e)
-                stats.append(dict(positions=int(ctl[g][CTL["steps"]]), finished=int(ctl[g][CTL["nfin"]]), done=int(ctl[g][CTL["done"]])))
-        self.last_stats = dict(positions=max(s["positions"] for s in stats), per_utterance=stats)
+                stats.append(dict(positions=int(ctl[g][CTL["steps"]]), finished=int(ctl[g][CTL["nfin"]]), done=int(ctl[g][CTL["done"]]),
+                                  reused=int(ctl[g][10])))
+        self.last_stats = dict(positions=max(s["positions"] for s in stats), reused=sum(s["reused"] for s in stats), per_utterance=stats)
         return out
 
     def advance(self, run, positions=POLL_EVERY, wait=False):
@@ -213,7 +214,8 @@ class BeamSearch(object):
         with self.rec._on_stream():
             self.rec.encoder.check_persistent()
             self._raise_device_errors(ctl)
-            self.last_stats = dict(positions=int(ctl[CTL["steps"]]), finished=int(ctl[CTL["nfin"]]), done=int(ctl[CTL["done"]]))
+            self.last_stats = dict(positions=int(ctl[CTL["steps"]]), finished=int(ctl[CTL["nfin"]]), done=int(ctl[CTL["done"]]),
+                                   reused=int(ctl[10]))        # positions whose second attention pass was the first one's results
             return self._collect(st, ctl, first_token, char_discount, as_arrays)
 
     @staticmethod

@@ -211,6 +211,11 @@ typedef struct lvsr_attdec_args {
        to it as they would be for the utterance decoded alone.  0: one group of all rows, the fields above as described. */
     int group_rows, step_stride;
     const int* group_Tp;
+    /* skip[g * skip_stride] != 0 (device word per row group; one group when group_rows = 0): the attention part of this call is
+       not computed for group g — the caller has put the results (WA, slot 1 of W and pos) there already.  The second attention
+       pass of a beam-search position repeats the first one on re-arranged rows; lvsr_beam_select raises the word when the
+       re-arranged rows see the same window as the live ones (always, with the expanding prior), and copies the results. NULL: compute. */
+    const int* skip; int skip_stride;
 } lvsr_attdec_args;
 int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* a, int use_graph);
 
@@ -441,6 +446,13 @@ typedef struct lvsr_beam_args {
      * row indices (parents, keep, live_col, ...) stay local to their search.  The position limit of search g is ctl[16 g + 8]
      * (max_length above is the capacity of the history buffers). 0 / 1: one search. */
     int groups;
+    /* Reuse of the first attention pass (optional, all NULL: off).  The next-state pass recomputes the glimpses of the selected
+     * rows because the window of the location prior depends on the batch it is computed for (lvsr/bricks/attention.py:133-157); when
+     * the selected rows span the same window centres as the live rows (min and max of pos equal; no pos: expanding prior, always)
+     * every one of those glimpses equals the one its parent got in the first pass: lvsr_beam_select then sets ctl[9] = 1 (else 0)
+     * and copies, row k <- row parents[k]: WA_sel <- WA_live (K,E), W1_sel <- W1_live (K,Tp: the NEW alignments), pos1_sel <-
+     * pos1_live.  The caller's second lvsr_attdec_fwd takes skip = ctl + 9 (lvsr_attdec_args.skip). */
+    const float* WA_live; float* WA_sel; const float* W1_live; float* W1_sel; const float* pos1_live; float* pos1_sel; int E;
 } lvsr_beam_args;
 /* two launches: the selection kernel (one work-group) and the row gather / feedback fork of the K chosen candidates */
 int lvsr_beam_select(void* stream, const lvsr_beam_args* a);

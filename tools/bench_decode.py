@@ -110,6 +110,9 @@ def run_concurrent(recs, utterances, frames, rank=0, world=1, warm=None):
     return time.perf_counter() - t0, done, done * frames, chars, steps
 
 
+REUSED = [0]          # positions (summed over utterances) whose second attention pass reused the first one's results
+
+
 def run_batched(recs, utterances, frames, rank=0, world=1, batch=32):
     """The same set decoded `batch` utterances at a time in ONE set of launches per position (BeamSearch.search_batch: the beams
     of all of them are rows of the same kernels), with len(recs) such batches in flight (one recognizer + stream each: a batch
@@ -153,6 +156,7 @@ def run_batched(recs, utterances, frames, rank=0, world=1, batch=32):
                         done += 1
                     st = bs.last_stats
                     steps += sum(u["positions"] for u in st["per_utterance"]) if "per_utterance" in st else st.get("positions", 0)
+                    REUSED[0] += st.get("reused", 0)
                     slots[k] = None
     torch.cuda.synchronize()
     return time.perf_counter() - t0, done, done * frames, chars, steps
@@ -235,4 +239,5 @@ if __name__ == "__main__":
         sec, done, nframes, chars, steps = run(rec, a.utts, a.frames)
     print(json.dumps(dict(metric="beam-search decode", utterances=done, beam=a.beam, lm=not a.no_lm, frames_per_utt=a.frames,
                           streams=a.streams, batch=a.batch, sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,
-                          positions_per_utt=steps / done, us_per_position=sec * 1e6 / max(steps, 1))))
+                          positions_per_utt=steps / done, us_per_position=sec * 1e6 / max(steps, 1),
+                          second_pass_reused=REUSED[0] / max(steps, 1))))
