@@ -191,7 +191,7 @@ def pmc_record(kernel):
     return (rec, None) if rec else (None, "kernel %s not in the PMC record" % kernel)
 
 
-def decode_leg(dev, utterances, batch=32, streams=2):
+def decode_leg(dev, utterances, batch=64, streams=2):
     """configs[4] in the default line: a bounded sample of the decode workload (`--workload wsj_decode` runs all 1000 utterances) —
     beam 16 + char-trigram FST LM on the device, window_around_median(10, 100), exp/wsj/decode.sh settings, 800-frame synthetic
     utterances, `batch` utterances per set of launches and `streams` such batches in flight on one GPU (tools/bench_decode.py)."""
@@ -309,7 +309,7 @@ def main(backend=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (configs[4] sample) of the default line")
     ap.add_argument("--decode-utterances", type=int, default=128)
-    ap.add_argument("--decode-batch", type=int, default=32, help="decode: utterances per set of launches (1: one search per recognizer, --streams in flight)")
+    ap.add_argument("--decode-batch", type=int, default=64, help="decode: utterances per set of launches (1: one search per recognizer, --streams in flight)")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
                     help="tuning knob of the library (include/lvsr_hip.h LVSR_KNOB_*), for A/B measurements; recorded in config.knobs")
     ap.add_argument("--no-graph", action="store_true")

@@ -37,6 +37,11 @@ def _decode_driver(device, lib):
     for row in rep["per_utterance"]:
         assert numpy.isfinite(row["groundtruth_cost"])
         assert row["char_errors"] == ER.edit_distance(row["groundtruth"], row["recognized"])
+    # the same report with the utterances decoded side by side (decode.search(batch=))
+    rep2 = decode.search(rec, utts, beam_size=3, char_discount=0.3, to_words=lambda ls: ["w%d" % l for l in ls if l != 5], batch=2)
+    assert [r["recognized"] for r in rep2["per_utterance"]] == [r["recognized"] for r in rep["per_utterance"]]
+    assert_allclose([r["search_cost"] for r in rep2["per_utterance"]], [r["search_cost"] for r in rep["per_utterance"]], rtol=1e-5)
+    assert rep2["cer"] == rep["cer"] and rep2["wer"] == rep["wer"]
     return rep
 
 

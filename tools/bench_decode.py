@@ -174,7 +174,7 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
     json_out = json_out or sys.stdout
     utterances = args.utterances or 1000
     frames, beam = 800, 16
-    batch = int(getattr(args, "decode_batch", None) or 32)
+    batch = int(getattr(args, "decode_batch", None) or 64)
     streams = max(1, int(getattr(args, "streams", None) or (2 if batch > 1 else 8)))
     recs = [build(dev, beam)[0] for _ in range(streams)]
     rec = recs[0]
