@@ -180,7 +180,11 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
     // WSJ-base step 17.5 -> 16.7 ms (profiles/r03_persist_probe_wide.txt).  At B = 16 that is 256 work-groups: the limit is what the
     // device can hold at once — the occupancy the runtime reports for these kernels (two work-groups per CU) times the CUs
     // (lvsr_max_cluster_wgs) — not one work-group per CU.  PF_NARROW keeps clusters of 4.
-    if (!(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NARROW) && g.NTH == 512 && g.HP == 256 && 2 * g.rt * 8 <= wide_cluster_capacity()) {
+    // Round 4: ... and only while the wide clusters still sit ONE per CU.  Two per CU share the CU's LDS ports and issue slots: at a
+    // per-GPU batch of 32 (512 work-groups) the step took 2.17 us against 1.93 us for 256 work-groups in clusters of 4 (WSJ-base step
+    // 19.2 -> 17.1 ms; batch 64, two utterances per cluster: 31.0 -> 28.7 ms; gpurun session b1).
+    if (!(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NARROW) && g.NTH == 512 && g.HP == 256 &&
+        2 * g.rt * 8 <= min(wide_cluster_capacity(), lvsr_max_cluster_wgs())) {
         g.KS = 16; g.KSPLIT = 16; g.UNITS = 32; g.P = 8;
     }
     g.grid = cluster_grid(2 * g.rt, g.P, lvsr_knob(LVSR_KNOB_PERSIST_FLAGS));     // (resident: 2 rt P; the padding exits at once)

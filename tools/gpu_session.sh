@@ -43,6 +43,7 @@ for what in "$@"; do
     profb:*) bb=${what#profb:}; cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/profb$bb -o bench -- python $R/bench.py --steps 6 --warmup 2 --batch $bb $B > $R/$O/profb$bb.log 2>&1; cd $R; python tools/rocpd_timeline.py $(find $O/profb$bb -name "*.db" | head -n 1) > $O/timeline_b$bb.txt 2>&1; head -n 12 $O/timeline_b$bb.txt; python tools/rocpd_stats.py $(find $O/profb$bb -name "*.db" | head -n 1) > $O/kernel_stats_b$bb.md 2>&1; head -n 9 $O/kernel_stats_b$bb.md | cut -c1-140;;
     fbtests) timeout 300 python -m pytest tests/test_fbank.py -m gpu -x -q > $O/pytest_fb.log 2>&1; echo "pytest(fbank) rc=$?"; tail -n 3 $O/pytest_fb.log;;
     enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
+    bk:*) x=${what#bk:}; bb=${x%%:*}; k=${x#*:}; timeout 300 python bench.py --steps 8 --warmup 2 --batch $bb $B --knob $k > $O/batch_${bb}_$k.json 2> $O/batch_${bb}_$k.err; python -c "import json;d=json.load(open('$O/batch_${bb}_$k.json'));print('batch $bb $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/batch_${bb}_$k.err;;
     knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
     *) echo "unknown item $what";;
   esac
