@@ -143,6 +143,33 @@ def test_full_size_wsj_decode_batched_whole_list_matches_the_reference_gpu(gpu_d
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("beam", [5, 32])
+def test_full_size_batched_decode_equals_single_searches_at_other_beam_widths_gpu(gpu_device, beam):
+    """Row groups that are not the 16 rows of an MFMA tile (beam 5: a tile of 16 rows spans four searches; beam 32: two tiles per
+    search, two passes of the weighted-average kernel) and utterances of different lengths (T' = 200 / 160 / 250: windows clamped to
+    the utterance's own attended length, per-search position limits): every utterance of the batch == the same utterance decoded
+    alone, whole ranked list, on the well-conditioned full-size fixture's network and language model."""
+    z, meta = load_golden("wsj_decode_full2")
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
+    rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
+    fst, cmap = _fst_from_arcs(z["arcs"], cfg["num_phonemes"])
+    rec.set_language_model(LM.DeviceFSTLanguageModel(fst, gpu_device, lib=rec.lib, nn_char_map=cmap, **meta["lm"]))
+    s = dict(meta["beam"][0]["settings"])
+    s.pop("beam_size")
+    rec.init_beam_search(beam)
+    x0, x1, x3 = z["x0"], z["x1"], z["x3"]
+    xs = [x0, x1[:640], numpy.concatenate([x3, x0[:200]], axis=0), x1]
+    singles = [rec.beam_search({"recordings": x}, **s) for x in xs]
+    for _ in range(2):
+        batched = rec.beam_search_batch(xs, **s)
+        for u, (one, many) in enumerate(zip(singles, batched)):
+            assert not isinstance(many, Exception), (u, many)
+            assert many[0] == one[0], "utterance %d: the ranked lists differ" % u
+            assert_allclose(many[1], one[1], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
 def test_mid_size_decode_batched_matches_the_reference_gpu(gpu_device):
     run_batched_decode_case(gpu_device, None, "mid_conv_lm_decode", STABLE_LENGTH, 12, repeat=2)
 
