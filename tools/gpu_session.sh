@@ -35,6 +35,12 @@ for what in "$@"; do
            timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/$O/fbpmc_$n -o pmc -- python $R/tools/probes/fbank_batch_probe.py > $R/$O/fbpmc_$n.log 2>&1; echo "fbpmc $n rc=$?"
          done
          cd $R; python tools/pmc_summary.py --json $O/fbpmc.json --tag fbank $(find $O/fbpmc_* -name "*.db") > $O/pmc_fbank.md 2>> $O/fbpmc_FETCH_SIZE.log; grep -i "fbank\|deltas\|kernel |" $O/pmc_fbank.md | cut -c1-300;;
+    decpmc) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+         for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY"; do
+           n=$(echo $c | cut -d" " -f1)
+           timeout 600 rocprofv3 --kernel-trace --pmc $c -d $R/$O/decpmc_$n -o pmc -- python $R/tools/bench_decode.py --utts 32 --batch 32 --streams 1 > $R/$O/decpmc_$n.log 2>&1; echo "decpmc $n rc=$?"
+         done
+         cd $R; python tools/pmc_summary.py --json $O/decpmc.json --tag decode $(find $O/decpmc_* -name "*.db") > $O/pmc_decode.md 2>> $O/decpmc_FETCH_SIZE.log; grep "attdec\|beam\|readout\|fst\|kernel |" $O/pmc_decode.md | cut -c1-260;;
     timeline) python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>&1; head -n 24 $O/timeline.txt;;
     dectests) timeout 900 python -m pytest tests -m gpu -x -q -k "batched or decode or beam" > $O/pytest_dec.log 2>&1; echo "pytest(decode) rc=$?"; grep "^E " $O/pytest_dec.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_dec.log;;
     decb:*) bb=${what#decb:}; timeout 600 python tools/bench_decode.py --utts 128 --batch ${bb%x*} --streams ${bb#*x} > $O/decb_$bb.json 2> $O/decb_$bb.err; cat $O/decb_$bb.json; tail -n 2 $O/decb_$bb.err;;
