@@ -756,7 +756,7 @@ def _beam_methods():
         if G > 1:
             limits = [int(m) for m in max_length]
             assert len(limits) == G
-            assert d.n_dec == 1 and (lm is None or on_dev_lm), "batched search: one decoder layer, language model on the device"
+            assert lm is None or on_dev_lm, "batched search: language model on the device"
             max_length = max(limits)
             return self._beam_begin(K * G, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
         return self._beam_begin(K, K, 1, None, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
@@ -816,7 +816,7 @@ def _beam_methods():
         pos_word = st["ctl"].view(-1)[CTL["pos"]:]
         st["argsA"] = lib.make("lvsr_attdec_args", step_dev=pos_word, **fa)
         if stacked:
-            st["stepB"] = self._beam_step_blocks(pk, g, K, B_, skip_pos, pos_word, tag)
+            st["stepB"] = self._beam_step_blocks(pk, g, K, B_, skip_pos, pos_word, tag, **grp)
         else:
             fb_ = self._attdec_fields(pk, g["A"], g["PA"], g["Am"], 1, K, B_, phases=3 | skip_pos, step0=-1, broadcast=True, **grp)
             # the select launch raises word 9 of a search's control block when pass B's glimpses would repeat pass A's row by row

@@ -118,22 +118,27 @@ class StackedSequenceGenerator(SequenceGenerator):
             return dict(A_ts=d.E, A_bs=0, PA_ts=d.M, PA_bs=0, Am_ts=1, Am_bs=0)
         return dict(A_ts=B * d.E, A_bs=d.E, PA_ts=B * d.M, PA_bs=d.M, Am_ts=B, Am_bs=1)
 
-    def _att_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast):
-        """The attention over the concatenated states: the one-layer block with D = n*D and no GRU part."""
+    def _att_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast, groups=0, group_Tp=None):
+        """The attention over the concatenated states: the one-layer block with D = n*D and no GRU part.  groups: batched beam
+        search (rows [g B/groups, ...) read utterance g: lvsr_attdec_args.group_rows)."""
         d, p, n = self.d, self.store.p, self.n
         kind, pp = self._prior()
         f = dict(Tp=int(A.shape[0]), B=B, L=L, E=d.E, D=d.D_tot, M=d.M, K=d.K, c=d.c, prior_type=kind, step0=step0,
                  phases=phases, p0=pp[0], p1=pp[1], p2=pp[2], p3=pp[3], A=A, PA=PA, Am=Am, Ws_p=pk["Ws"], w_e=p[n["we"]],
                  normalizer=NORMALIZER_KIND[d.normalizer], e_bias=p[n["eb"]] if d.energy_bias else None,
                  filters=p[n["filters"]] if d.conv else None, handler=p[n["handler"]] if d.conv else None)
-        f.update(self._strides(B, broadcast))
+        if groups:
+            f.update(A_ts=groups * d.E, A_bs=d.E, PA_ts=groups * d.M, PA_bs=d.M, Am_ts=groups, Am_bs=1,
+                     group_rows=B // groups, step_stride=16, group_Tp=group_Tp)
+        else:
+            f.update(self._strides(B, broadcast))
         f.update(bufs)
         return f
 
-    def _attdec_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast):
+    def _attdec_fields(self, pk, A, PA, Am, L, B, bufs, phases, step0, broadcast, groups=0, group_Tp=None):
         assert not phases & 2, "a stacked decoder has no one-block GRU step"
         return self._att_fields(pk, A, PA, Am, L, B, {k: v for k, v in bufs.items() if k not in ("U", "R", "C", "RH", "sg", "xin", "xg")},
-                                phases, step0, broadcast)
+                                phases, step0, broadcast, groups=groups, group_Tp=group_Tp)
 
     def _layer_fields(self, l, pk, A, PA, Am, L, B, bufs, broadcast):
         """GRU layer l: the one-layer block with the GRU part only, E = width of [glimpse | state below], no location prior."""
@@ -162,7 +167,7 @@ class StackedSequenceGenerator(SequenceGenerator):
                 lib.call("lvsr_gather_rows", st, lib_ptr(p[n["Wfg"]]), 2 * d.D, lib_ptr(labels_flat), nrows, d.FB, 2 * d.D,
                          lib_ptr(p[n["bfg"]]), lib_ptr(xg[:, d.D:]), 3 * d.D)
 
-    def _step_blocks(self, pk, A, PA, Am, L, B, tag, att_bufs, ym, att_phases, step0, broadcast, step_dev=None):
+    def _step_blocks(self, pk, A, PA, Am, L, B, tag, att_bufs, ym, att_phases, step0, broadcast, step_dev=None, groups=0, group_Tp=None):
         """Buffers and argument blocks of `L` label steps: att_bufs = the attention block's slots (S (L+1,B,n*D), W, pos, WA,
         EN, ...); per layer its own state slots, gate tensors and distribution input."""
         d, lib, ws = self.d, self.lib, self.ws
@@ -178,7 +183,7 @@ class StackedSequenceGenerator(SequenceGenerator):
             fields = self._layer_fields(l, pk, A, PA, Am, L, B, bufs, broadcast)
             fields["S_ld"] = d.D_tot
             layers.append(dict(bufs=bufs, fields=fields, args=lib.make("lvsr_attdec_args", **fields)))
-        fields = self._att_fields(pk, A, PA, Am, L, B, att_bufs, att_phases, step0, broadcast)
+        fields = self._att_fields(pk, A, PA, Am, L, B, att_bufs, att_phases, step0, broadcast, groups=groups, group_Tp=group_Tp)
         extra = {} if step_dev is None else dict(step_dev=step_dev)
         return dict(L=L, att=dict(bufs=att_bufs, fields=fields, args=lib.make("lvsr_attdec_args", **dict(fields, **extra))),
                     layers=layers)
@@ -389,17 +394,17 @@ class StackedSequenceGenerator(SequenceGenerator):
                     fwd_args=lib.make("lvsr_attdec_args", **att["fields"]))
 
     # ---- device beam search: pass B (csrc/beam.hip, generator.beam_begin / beam_advance) ---------------------------------
-    def _beam_step_blocks(self, pk, g, K, B_, skip_pos, pos_word, tag):
+    def _beam_step_blocks(self, pk, g, K, B_, skip_pos, pos_word, tag, groups=0, group_Tp=None):
         att_bufs = {k: B_[k] for k in ("S", "W", "pos", "WA", "EN", "ZB", "sW", "CV", "ep")}
         # the select kernel has moved the position counter on: step0 = -1
         return self._step_blocks(pk, g["A"], g["PA"], g["Am"], 1, K, "bs" + tag, att_bufs, None, att_phases=1 | skip_pos, step0=-1,
-                                 broadcast=True, step_dev=pos_word)
+                                 broadcast=True, step_dev=pos_word, groups=groups, group_Tp=group_Tp)
 
     def _beam_step_run(self, st):
         lib, blk = self.lib, st["stepB"]
         S = blk["att"]["bufs"]["S"]
         layers = blk["layers"]
-        self._feedback_forks(st["chars"], st["K"], [lay["bufs"]["xg"] for lay in layers], st["fb"])
+        self._feedback_forks(st["chars"], st["rows"], [lay["bufs"]["xg"] for lay in layers], st["fb"])
         self._run_step(blk, 0, lib.stream_for(S))
 
     # ---- free-running generation -----------------------------------------------------------------------------------------

@@ -166,7 +166,8 @@ def test_validator_sees_every_finished_hypothesis_once_the_patience_list_was_cut
 
 
 # ---- several utterances in one set of launches (BeamSearch.search_batch) ---------------------------------------------------------
-@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_nowindow", "tiny_content_embed", "tiny_conv_logistic"])
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_nowindow", "tiny_content_embed", "tiny_conv_logistic",
+                                  "tiny_conv_stack2", "tiny_content_stack3"])
 def test_batched_search_equals_the_single_searches_emulated(case):
     """All utterances of the fixture's (ragged) batch decoded side by side — rows [g K, g K + K) of the state buffers belong to
     utterance g, windows / position counters / stopping rules / finished lists per utterance — give, utterance by utterance, the

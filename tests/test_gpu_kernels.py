@@ -171,7 +171,8 @@ def test_beam_search_vs_reference_golden(gpu_device, case):
 
 
 @pytest.mark.parametrize("case", ["tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_logistic", "tiny_conv_relu", "tiny_conv_bottom",
-                                  "tiny_conv_postmerge2", "tiny_content_embed", "tiny_content_relu", "small_conv_median"])
+                                  "tiny_conv_postmerge2", "tiny_content_embed", "tiny_content_relu", "small_conv_median",
+                                  "tiny_conv_stack2", "tiny_content_stack3", "small_conv_stack2"])
 def test_batched_beam_search_vs_single_searches_and_golden(gpu_device, case):
     """BeamSearch.search_batch: the fixture's whole ragged batch decoded side by side == every utterance decoded alone == the
     reference's hypotheses for the fixture's utterance.  Twice (eager / captured, then replayed step graphs)."""
