@@ -211,3 +211,32 @@ def run_batched_case(case, device, lib, cost_tol=2e-5):
         else:
             assert batched[utt][0] == b["outputs"], (case, utt)
             assert_allclose(batched[utt][1], b["costs"], rtol=2e-5, atol=2e-5)
+
+
+def test_batched_search_edge_cases_emulated():
+    """A batch of one (the single search), utterances of one and two frames next to long ones (attended length 1: every window
+    clamps to it; a position limit of 1), and a beam wider than the number of candidates of the first position."""
+    z, meta = load_golden("tiny_conv_median")
+    params = synthetic.make_params(meta["cfg"], seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(meta["cfg"], meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=meta["cfg"])
+    x = batch["recordings"]
+    xs = [x[:, 0], x[:1, 1], x[:2, 0], x[:7, 2]]
+    for beam, kw in ((3, dict()), (12, dict(char_discount=0.3, stop_on="optimistic_future_cost"))):
+        rec.init_beam_search(beam)
+        singles = []
+        for u in xs:
+            try:
+                singles.append(rec.beam_search({"recordings": u}, **kw))
+            except CandidateNotFoundError as e:
+                singles.append(e)
+        one = rec.beam_search_batch(xs[:1], **kw)
+        assert len(one) == 1 and one[0][0] == singles[0][0]
+        many = rec.beam_search_batch(xs, **kw)
+        for u, (a, b) in enumerate(zip(singles, many)):
+            if isinstance(a, Exception):
+                assert type(b) is type(a), u
+            else:
+                assert not isinstance(b, Exception), (u, b)
+                assert b[0] == a[0], u
+                assert_allclose(b[1], a[1], rtol=2e-5, atol=2e-5)
