@@ -258,6 +258,18 @@ __device__ void wg_matvec(const float* x, int K, const float* W, int N, const fl
     __syncthreads();
 }
 
+// lvsr_readout_merge: tile (16 rows x 16 columns) per work-group, the contraction split over the four waves (rb_mm)
+__global__ __launch_bounds__(256) void readout_merge_kernel(const float* S, int lds, const float* WA, int ldwa, int n, int D, int E, int P,
+                                                            const float* Wms_p, const float* Wmw_p, const float* bias1, float* R1, int ldr1) {
+    const int tile = blockIdx.x, b0 = blockIdx.y * 16;
+    const int b = b0 + (threadIdx.x >> 4), j = tile * 16 + (threadIdx.x & 15);
+    f32x4 acc0 = F32X4_ZERO, acc1 = F32X4_ZERO;
+    rb_mm(acc0, acc1, row_src(WA + (size_t)b0 * ldwa, ldwa, n - b0, E), Wmw_p, E, tile);
+    if (Wms_p) rb_mm(acc0, acc1, row_src(S + (size_t)b0 * lds, lds, n - b0, D), Wms_p, D, tile);
+    const float v = rb_reduce_once(acc0, acc1);
+    if (b < n && j < P) R1[(size_t)b * ldr1 + j] = v + (bias1 ? bias1[j] : 0.f);
+}
+
 __global__ __launch_bounds__(256) void readout_step_kernel(lvsr_readout_step_args a) {
     __shared__ float xin[RS_MAX_IN];
     __shared__ float r1[RS_MAX_P];
@@ -266,6 +278,10 @@ __global__ __launch_bounds__(256) void readout_step_kernel(lvsr_readout_step_arg
     const int r = blockIdx.x, tid = threadIdx.x;
     const int nin = (a.Wms ? a.D : 0) + a.E;
     // inputs: [s | wa] against the stacked weight [W_ms ; W_mw] — two passes over the same output instead of a stacked copy
+    if (a.R1) {                               // merged by lvsr_readout_merge
+        for (int j = tid; j < a.P; j += 256) r1[j] = a.R1[(size_t)r * a.ldr1 + j];
+        __syncthreads();
+    } else {
     for (int k = tid; k < a.E; k += 256) xin[k] = a.WA[(size_t)r * a.ldwa + k];
     for (int k = tid; k < (a.Wms ? a.D : 0); k += 256) xin[a.E + k] = a.S[(size_t)r * a.lds + k];
     __syncthreads();
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(256) void readout_step_kernel(lvsr_readout_step_arg
         wg_matvec(xin + a.E, a.D, a.Wms, a.P, nullptr, tmp, part);
         for (int j = tid; j < a.P; j += 256) r1[j] += tmp[j];
         __syncthreads();
+    }
     }
     (void)nin;
     const float* logits = r1;
@@ -409,6 +426,15 @@ int lvsr_readout_step(void* stream, const lvsr_readout_step_args* args) {
                      "lvsr_readout_step: bad post-merge layer %d", h);
     hipLaunchKernelGGL(readout_step_kernel, dim3(a.n), dim3(256), 0, (hipStream_t)stream, a);
     return lvsr_check_launch("lvsr_readout_step");
+}
+
+int lvsr_readout_merge(void* stream, const float* S, int lds, const float* WA, int ldwa, int n, int D, int E, int P,
+                       const float* Wms_p, const float* Wmw_p, const float* bias1, float* R1, int ldr1) {
+    LVSR_REQUIRE(WA && Wmw_p && R1 && n > 0 && E > 0 && P > 0 && ldwa >= E && ldr1 >= P && (!Wms_p || (S && D > 0 && lds >= D)),
+                 "lvsr_readout_merge: bad arguments");
+    hipLaunchKernelGGL(readout_merge_kernel, dim3((P + 15) / 16, (n + 15) / 16), dim3(256), 0, (hipStream_t)stream, S, lds, WA, ldwa, n,
+                       D, E, P, Wms_p, Wmw_p, bias1, R1, ldr1);
+    return lvsr_check_launch("lvsr_readout_merge");
 }
 
 int lvsr_gather_rows(void* stream, const float* table, int ldt, const long long* idx, int n, int nrows, int width,

@@ -113,6 +113,26 @@ class SequenceGenerator(object):
         self._packs = ent
         return ent
 
+    MERGE_ROWS = 64          # rows of a beam step from which the readout's merge products run as 16-row tiles (lvsr_readout_merge)
+
+    def _readout_packs(self):
+        """Packed copies of the merge weights for lvsr_readout_merge (many-row readout of the batched beam search), per parameter version."""
+        hit = getattr(self, "_ro_packs", None)
+        if hit is not None and hit["version"] == self.store.version:
+            return hit
+        d, p, n, lib, ws = self.d, self.store.p, self.n, self.lib, self.ws
+        ent = dict(version=self.store.version, Wms=None)
+        Wmw = p[n["Wmw"]]
+        ent["Wmw"] = ws.get("gen.Wmw_p", (lib.pack_size(int(Wmw.shape[0]), int(Wmw.shape[1])),))
+        jobs = [(Wmw, ent["Wmw"], False)]
+        if d.use_states_for_readout:
+            Wms = self._merge_states_weight()
+            ent["Wms"] = ws.get("gen.Wms_p", (lib.pack_size(int(Wms.shape[0]), int(Wms.shape[1])),))
+            jobs.append((Wms.contiguous(), ent["Wms"], False))
+        lib.pack_many(jobs)
+        self._ro_packs = ent
+        return ent
+
     def _ensure_packs(self, ent):
         if not ent.get("packed", True):
             self.lib.pack_many(ent["_jobs"], use_graph=self.use_graph, cache=self._pack_cache)
@@ -845,8 +865,14 @@ def _beam_methods():
             fork_bg=None if host_fork else p[n_["bfg"]], fork_rows=0 if host_fork else d.FB,
             **({} if stacked else dict(WA_live=A_["WA"][0], WA_sel=B_["WA"][0], W1_live=A_["W"][1], W1_sel=B_["W"][1], E=d.E,
                                        pos1_live=A_["pos"][1] if pos_needed else None, pos1_sel=B_["pos"][1] if pos_needed else None)))
+        # many rows (batched search): the merge products as 16-row tiles in a launch of their own (lvsr_readout_merge)
+        R1 = ws.get("bs.R1" + tag, (K, d.P)) if K >= self.MERGE_ROWS else None
+        if R1 is not None:
+            ro = self._readout_packs()
+            st["merge"] = (lib_ptr(A_["S"][0]), int(A_["S"][0].stride(0)), lib_ptr(A_["WA"][0]), int(A_["WA"][0].stride(0)), K, SW, d.E, d.P,
+                           lib_ptr(ro["Wms"]), lib_ptr(ro["Wmw"]), lib_ptr(p[n_["bpm"]] if d.post_merge else p[n_["bro"]]), lib_ptr(R1), int(R1.stride(0)))
         st["readout"] = self._readout_step_args(A_["S"][0], A_["WA"][0], K, neglogp=st["neglogp"],
-                                                lm_add=L.get("add_live") if lm is not None else None)
+                                                lm_add=L.get("add_live") if lm is not None else None, R1=R1)
         # ---- reset: one live hypothesis, replicated over the K rows
         ctl0 = numpy.zeros((G, 16), numpy.int32)
         ctl0[:, CTL["nlive"]], ctl0[:, CTL["patience"]] = 1, -1
@@ -879,7 +905,7 @@ def _beam_methods():
         self._beam = st
         return st
 
-    def _readout_step_args(self, S2, WA2, n, neglogp=None, lm_add=None, uniforms=None, outputs=None, costs=None, logits=None):
+    def _readout_step_args(self, S2, WA2, n, neglogp=None, lm_add=None, uniforms=None, outputs=None, costs=None, logits=None, R1=None):
         """Argument block of the fused generation-time readout + emitter (lvsr_readout_step)."""
         d, p, n_ = self.d, self.store.p, self.n
         lm = self.language_model
@@ -892,6 +918,7 @@ def _beam_methods():
             am_beta=lm.am_beta if lm_add is not None else 1.0, lm_weight=lm.lm_weight if lm_add is not None else 0.0,
             norm_am=int(lm.norm[0]) if lm_add is not None else 1, norm_lm=int(lm.norm[1]) if lm_add is not None else 0,
             norm_tot=int(lm.norm[2]) if lm_add is not None else 0, neglogp=neglogp, logits=logits, uniforms=uniforms,
+            R1=R1, ldr1=0 if R1 is None else int(R1.stride(0)),
             outputs=outputs, costs=costs, n_hidden=len(self.pm_hidden), Wh=[p[w] for w, _, _ in self.pm_hidden],
             bh=[p[b] for _, b, _ in self.pm_hidden], dimh=[w for _, _, w in self.pm_hidden])
 
@@ -901,6 +928,8 @@ def _beam_methods():
         d, lib, st = self.d, self.lib, self._beam
         K, A_ = st["K"], st["A"]
         lib.call("lvsr_attdec_fwd", lib.stream_for(A_["S"]), ctypes.byref(st["argsA"]), 0)
+        if "merge" in st:
+            lib.call("lvsr_readout_merge", lib.stream_for(st["neglogp"]), *st["merge"])
         lib.call("lvsr_readout_step", lib.stream_for(st["neglogp"]), ctypes.byref(st["readout"]))
 
     def beam_select(self):

@@ -399,8 +399,16 @@ typedef struct lvsr_readout_step_args {
      * previous width to dimh[h] (Wh[h] (prev, dimh[h]), bh[h]) and is followed by `act` (2 or 3 only); Wout then has dimh[last] rows */
     int n_hidden; int dimh[3];
     const float* Wh[3]; const float* bh[3];
+    /* R1 != NULL: the merged pre-activations (n,P) = S @ Wms + WA @ Wmw + bias1 have been computed by lvsr_readout_merge (row
+     * stride ldr1); the per-row products above are skipped (S, WA, Wms, Wmw are not read) */
+    const float* R1; int ldr1;
 } lvsr_readout_step_args;
 int lvsr_readout_step(void* stream, const lvsr_readout_step_args* a);
+/* The merge of lvsr_readout_step for MANY rows (batched beam search: n = searches x beam): R1 (n,P) = S @ Wms + WA @ Wmw + bias1
+ * as 16-row MFMA tiles over PACKED weights (lvsr_pack_b of the (D,P) / (E,P) matrices; Wms_p NULL: no state part) — the
+ * per-row kernel reads the 0.75 MB of merge weights once per ROW out of L2 (24 us at 512 rows, L2-bandwidth bound). */
+int lvsr_readout_merge(void* stream, const float* S, int lds, const float* WA, int ldwa, int n, int D, int E, int P,
+                       const float* Wms_p, const float* Wmw_p, const float* bias1, float* R1, int ldr1);
 /* SoftmaxEmitter.emit + cost on given readouts (n,V): outputs[r] = class drawn at uniforms[r], costs[r] = -log p (or NULL) */
 int lvsr_softmax_emit(void* stream, const float* logits, int ld, const float* uniforms, int n, int V, long long* outputs,
                       float* costs);

@@ -213,6 +213,15 @@ def run_batched_case(case, device, lib, cost_tol=2e-5):
             assert_allclose(batched[utt][1], b["costs"], rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_content_embed", "tiny_conv_postmerge2", "tiny_conv_stack2"])
+def test_batched_search_with_the_tiled_readout_merge_emulated(case, monkeypatch):
+    """lvsr_readout_merge (the readout's merge products as 16-row MFMA tiles, used from 64 rows on) forced on for the small
+    fixtures: same hypotheses as the single searches and the reference."""
+    from lvsr_amd.bricks.generator import SequenceGenerator
+    monkeypatch.setattr(SequenceGenerator, "MERGE_ROWS", 1)
+    run_batched_case(case, "cpu", emu_lib(), cost_tol=1e-4)
+
+
 def test_batched_search_edge_cases_emulated():
     """A batch of one (the single search), utterances of one and two frames next to long ones (attended length 1: every window
     clamps to it; a position limit of 1), and a beam wider than the number of candidates of the first position."""
