@@ -193,9 +193,13 @@ __global__ __launch_bounds__(256) void attdec_energy_kernel(AttDec a, int i) {
 // stay in registers for all rows of the group.  (The VALU kernel above spends 10 FMAs + 10 LDS reads per element on the
 // contraction: 39.5 us per pass at 512 rows.)
 template <int KCP>     // filters padded to a multiple of 4
-__global__ __launch_bounds__(256) void attdec_energy_mfma_kernel(AttDec a, int i) {
+__global__ __launch_bounds__(256) void attdec_energy_mfma_kernel(AttDec a, int i, int rpw) {
+    // rpw = rows of the group this work-group serves (grid.y = groups x ceil(rows / rpw)): all of them keeps the PA tile's traffic
+    // lowest, fewer gives more, shorter work-groups — a work-group's loop over 16 rows is the kernel's whole duration when the grid
+    // is a single round of work-groups (32 utterances: 2 048)
     const int slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
-    const int rows = a.group_rows > 0 ? a.group_rows : 1, bfirst = blockIdx.y * rows;
+    const int rows = a.group_rows > 0 ? a.group_rows : 1, nsub = (rows + rpw - 1) / rpw;
+    const int bfirst = (blockIdx.y / nsub) * rows, rbeg = (blockIdx.y % nsub) * rpw, rend = min(rows, rbeg + rpw);
     const int t0 = blockIdx.z * ATT_TT;
     if (attdec_skip(a, bfirst)) return;
     const Win w = attdec_window_row(a, i, bfirst);
@@ -235,10 +239,10 @@ __global__ __launch_bounds__(256) void attdec_energy_mfma_kernel(AttDec a, int i
             dst[sq] = k < K ? a.CV[(((size_t)i * B + b) * K + k) * Tp + tA] : 0.f;
         }
     };
-    fetch(bfirst, av);
-    for (int row = 0; row < rows; ++row) {
+    fetch(bfirst + rbeg, av);
+    for (int row = rbeg; row < rend; ++row) {
         const int b = bfirst + row;
-        if (row + 1 < rows) fetch(b + 1, an);
+        if (row + 1 < rend) fetch(b + 1, an);
         f32x4 acc[2];
 #pragma unroll
         for (int tile = 0; tile < 2; ++tile) {
@@ -524,12 +528,17 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
             if (g.nmm > 0) hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
                 const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.group_rows > 0 ? a.B / a.group_rows : a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
+                // rows of a group per work-group of the MFMA kernel: 4 while the grid would otherwise be a single round of work-groups
+                const int rows_g = a.group_rows > 0 ? a.group_rows : 1;
+                const int knob_rpw = lvsr_knob(LVSR_KNOB_ENERGY_ROWS);
+                const int rpw = knob_rpw > 0 ? min(knob_rpw, rows_g) : ((long long)eg.x * eg.y * eg.z <= 4096 ? min(4, rows_g) : rows_g);
+                const dim3 egm(eg.x, eg.y * ((rows_g + rpw - 1) / rpw), eg.z);
                 switch (a.K > 0 ? (a.K + 3) / 4 * 4 : 0) {          // location-aware attention: the contraction on the matrix cores
                     case 0: hipLaunchKernelGGL(attdec_energy_kernel<0>, eg, dim3(256), 0, s, a, i); break;
-                    case 4: hipLaunchKernelGGL(attdec_energy_mfma_kernel<4>, eg, dim3(256), 0, s, a, i); break;
-                    case 8: hipLaunchKernelGGL(attdec_energy_mfma_kernel<8>, eg, dim3(256), 0, s, a, i); break;
-                    case 12: hipLaunchKernelGGL(attdec_energy_mfma_kernel<12>, eg, dim3(256), 0, s, a, i); break;
-                    default: hipLaunchKernelGGL(attdec_energy_mfma_kernel<16>, eg, dim3(256), 0, s, a, i); break;
+                    case 4: hipLaunchKernelGGL(attdec_energy_mfma_kernel<4>, egm, dim3(256), 0, s, a, i, rpw); break;
+                    case 8: hipLaunchKernelGGL(attdec_energy_mfma_kernel<8>, egm, dim3(256), 0, s, a, i, rpw); break;
+                    case 12: hipLaunchKernelGGL(attdec_energy_mfma_kernel<12>, egm, dim3(256), 0, s, a, i, rpw); break;
+                    default: hipLaunchKernelGGL(attdec_energy_mfma_kernel<16>, egm, dim3(256), 0, s, a, i, rpw); break;
                 }
                 if (a.group_rows > 0) {
                     hipLaunchKernelGGL(attdec_glimpse_kernel<false>, dim3(1, a.B), dim3(256), 0, s, a, i);

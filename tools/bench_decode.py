@@ -229,7 +229,11 @@ if __name__ == "__main__":
     ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
     ap.add_argument("--streams", type=int, default=1, help="searches (or batches) in flight (one recognizer + stream each)")
     ap.add_argument("--batch", type=int, default=1, help="utterances per set of launches (BeamSearch.search_batch)")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT", help="library knob (include/lvsr_hip.h LVSR_KNOB_*)")
     a = ap.parse_args()
+    if a.knob:
+        from lvsr_amd import native
+        native.get().set_knobs(a.knob)
     kind = "none" if a.no_lm else ("host" if a.host_lm else "device")
     if a.batch > 1:
         recs = [build("cuda:0", a.beam, kind)[0] for _ in range(a.streams)]

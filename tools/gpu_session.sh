@@ -43,6 +43,7 @@ for what in "$@"; do
          cd $R; python tools/pmc_summary.py --json $O/decpmc.json --tag decode $(find $O/decpmc_* -name "*.db") > $O/pmc_decode.md 2>> $O/decpmc_FETCH_SIZE.log; grep "attdec\|beam\|readout\|fst\|kernel |" $O/pmc_decode.md | cut -c1-260;;
     timeline) python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>&1; head -n 24 $O/timeline.txt;;
     dectests) timeout 900 python -m pytest tests -m gpu -x -q -k "batched or decode or beam" > $O/pytest_dec.log 2>&1; echo "pytest(decode) rc=$?"; grep "^E " $O/pytest_dec.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_dec.log;;
+    deck:*) x=${what#deck:}; bb=${x%%:*}; k=${x#*:}; timeout 600 python tools/bench_decode.py --utts 128 --batch ${bb%x*} --streams ${bb#*x} --knob $k > $O/deck_${bb}_$k.json 2> $O/deck_${bb}_$k.err; echo "$k: $(cut -c1-330 $O/deck_${bb}_$k.json)"; tail -n 1 $O/deck_${bb}_$k.err;;
     decb:*) bb=${what#decb:}; timeout 600 python tools/bench_decode.py --utts 128 --batch ${bb%x*} --streams ${bb#*x} > $O/decb_$bb.json 2> $O/decb_$bb.err; cat $O/decb_$bb.json; tail -n 2 $O/decb_$bb.err;;
     decbprof:*) bb=${what#decbprof:}; cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decbprof -o dec -- python $R/tools/bench_decode.py --utts 64 --batch ${bb%x*} --streams ${bb#*x} > $R/$O/decbprof.log 2>&1
