@@ -528,10 +528,13 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
             if (g.nmm > 0) hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
                 const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.group_rows > 0 ? a.B / a.group_rows : a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
-                // rows of a group per work-group of the MFMA kernel: 4 while the grid would otherwise be a single round of work-groups
+                // rows of a group per work-group of the MFMA kernel: all of them, or 8 while the grid is at most one round of
+                // work-groups (measured with two batches in flight, tools/bench_decode.py: 32 utterances 1.52 / 1.47 / 1.52 ms per
+                // utterance at 16 / 8 / 4 rows; 64 utterances 1.18 / 1.20 / 1.28 / 1.46 at 16 / 8 / 4 / 2: the chip is busy with
+                // the other batch, shorter work-groups only add PA traffic)
                 const int rows_g = a.group_rows > 0 ? a.group_rows : 1;
                 const int knob_rpw = lvsr_knob(LVSR_KNOB_ENERGY_ROWS);
-                const int rpw = knob_rpw > 0 ? min(knob_rpw, rows_g) : ((long long)eg.x * eg.y * eg.z <= 4096 ? min(4, rows_g) : rows_g);
+                const int rpw = knob_rpw > 0 ? min(knob_rpw, rows_g) : ((long long)eg.x * eg.y * eg.z <= 2048 ? min(8, rows_g) : rows_g);
                 const dim3 egm(eg.x, eg.y * ((rows_g + rpw - 1) / rpw), eg.z);
                 switch (a.K > 0 ? (a.K + 3) / 4 * 4 : 0) {          // location-aware attention: the contraction on the matrix cores
                     case 0: hipLaunchKernelGGL(attdec_energy_kernel<0>, eg, dim3(256), 0, s, a, i); break;

@@ -50,7 +50,7 @@ int lvsr_region_end(void* stream, int keep);
 #define LVSR_KNOB_CLUSTER_RESERVE 5   /* CUs left free by cluster launches for other work on the device (default 0) */
 #define LVSR_KNOB_GEMM_MID_TILES 6    /* lvsr_sgemm with K <= 2048 uses 64 x 64 tiles when the output has fewer 128 x 128 tiles than this (0 = 2048; 1 = never) */
 #define LVSR_KNOB_DEC_CLUSTER 7       /* persistent decoder at D <= 256: 0 = clusters of 16 work-groups per utterance when they fit the chip, else 8; 8 / 16 = only that */
-#define LVSR_KNOB_ENERGY_ROWS 8       /* step-kernel energies (row groups): rows of a group per work-group; 0 = 4 while the grid is a single round of work-groups, else all */
+#define LVSR_KNOB_ENERGY_ROWS 8       /* step-kernel energies (row groups): rows of a group per work-group; 0 = 8 while the grid is at most one round of work-groups, else all */
 #define LVSR_KNOB_COUNT 9
 int lvsr_set_knob(int knob, int value);
 int lvsr_get_knob(int knob);
