@@ -19,12 +19,12 @@ __global__ __launch_bounds__(64) void attdec_pos_kernel(AttDec a, int slot) {
     if (threadIdx.x == 0) a.pos[(size_t)slot * a.B + b] = r;
 }
 
-// Location convolution: a work-group serves one row and `kf` of its filters; a thread owns EIGHT consecutive output positions of
-// one filter and walks the taps four at a time — 32 FMAs on one new 16-byte read of the (zero-padded, cut) alignment and one of
-// the filter from LDS.  (One output and one tap per step, as before round 4, is two LDS reads per FMA: the
+// Location convolution inside the pre kernel: a work-group serves one row and `kf` of its filters; a thread owns FOUR consecutive
+// output positions of one filter and walks the taps four at a time — 16 FMAs on two 16-byte reads of the (zero-padded, cut)
+// alignment and one of the filter from LDS.  (One output and one tap per step, as before round 4, is two LDS reads per FMA: the
 // kernel was LDS-issue bound, 20 us at 512 rows.)
 #define PRE_FL 4096          // filter floats in LDS (kf filters, taps padded to a multiple of 4)
-#define PRE_AL (ATT_MAX_T + ATT_MAX_FW + 32)
+#define PRE_AL (ATT_MAX_T + ATT_MAX_FW + 16)
 struct PreGrid { int rt, ntS, ntG, nmm, nq, kf, nkg, nconv; };
 __host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
     PreGrid g;
@@ -32,7 +32,7 @@ __host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
     g.ntS = (a.phases & 1) ? (a.M + 15) / 16 : 0;
     g.ntG = (a.phases & 2) ? (2 * a.D + 15) / 16 : 0;
     g.nmm = (g.ntS + g.ntG) * g.rt;
-    g.nq = (a.Tp + 7) / 8;                                           // output octets of a row
+    g.nq = (a.Tp + 3) / 4;                                           // output quads of a row
     const int fw4 = (2 * a.c + 1 + 3) / 4 * 4;
     g.kf = max(1, min(min(a.K, 256 / g.nq), PRE_FL / fw4));          // filters per work-group
     g.nkg = a.K > 0 ? (a.K + g.kf - 1) / g.kf : 0;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
     const float* wprev = a.W + ((size_t)i * B + b) * Tp;
     // al[OFF + t] = cut alignment at t, zeros from OFF - (c + 3) to OFF + Tp + c + 3; OFF such that the reads below are 16-byte aligned
     const int OFF = (c + 3 + 3) / 4 * 4 + ((3 - c) % 4 + 4) % 4;
-    for (int x = threadIdx.x; x < OFF + Tp + c + 20; x += 256) {
+    for (int x = threadIdx.x; x < OFF + Tp + c + 8; x += 256) {
         const int t = x - OFF;
         al[x] = (t >= w.begin && t < w.end) ? wprev[t] : 0.f;
     }
@@ -89,32 +89,27 @@ __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
         fl[x] = e < FW ? a.filters[(size_t)(k0 + k) * FW + e] : 0.f;
     }
     __syncthreads();
-    // true convolution of the CUT alignment: out[t] = sum_e f[e] * al[t + c - e] (e = c + d), the alignment zero outside the window.
-    // A thread owns EIGHT consecutive outputs; per block of four taps it needs al_cut[t + c - e - 3 .. + 10]: the upper eight of
-    // those are the lower eight of the previous block, so ONE new 16-byte read of the alignment and one of the taps feed 32 FMAs.
+    // true convolution of the CUT alignment: out[t] = sum_e f[e] * al[t + c - e] (e = c + d), the alignment zero outside the window
     for (int x = threadIdx.x; x < nk * g.nq; x += 256) {
-        const int k = x / g.nq, t = (x % g.nq) * 8;
+        const int k = x / g.nq, t = (x % g.nq) * 4;
         const float* f = fl + k * FW4;
-        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (t + 7 >= w.begin && t < w.end) {
-            const float* base = al + (OFF + t + c - 3);                 // v[n] = base[n - e] at tap block e
-            float4 w1 = *(const float4*)(base + 4), w2 = *(const float4*)(base + 8);
-#pragma unroll 2
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        if (t + 3 >= w.begin && t < w.end)
+#pragma unroll 4
             for (int e = 0; e < FW4; e += 4) {
-                const float4 w0 = *(const float4*)(base - e);
                 const float4 fe = *(const float4*)(f + e);
-                const float v[11] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z};
-                const float fq[4] = {fe.x, fe.y, fe.z, fe.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) o[j] += fq[q] * v[j - q + 3];
-                w2 = w1; w1 = w0;
+                const float* src = al + (OFF + t + c - e - 3);          // v[n] = al_cut[t + c - e - 3 + n]
+                const float4 lo = *(const float4*)src, hi = *(const float4*)(src + 4);
+                // out[t + j] += f[e + q] * v[j - q + 3]
+                o0 += fe.x * lo.w; o0 += fe.y * lo.z; o0 += fe.z * lo.y; o0 += fe.w * lo.x;
+                o1 += fe.x * hi.x; o1 += fe.y * lo.w; o1 += fe.z * lo.z; o1 += fe.w * lo.y;
+                o2 += fe.x * hi.y; o2 += fe.y * hi.x; o2 += fe.z * lo.w; o2 += fe.w * lo.z;
+                o3 += fe.x * hi.z; o3 += fe.y * hi.y; o3 += fe.z * hi.x; o3 += fe.w * lo.w;
             }
-        }
         float* out = a.CV + (((size_t)i * B + b) * a.K + k0 + k) * Tp;
+        const float o[4] = {o0, o1, o2, o3};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < 4; ++j)
             if (t + j < Tp) out[t + j] = (t + j >= w.begin && t + j < w.end) ? o[j] : 0.f;
     }
 }
