@@ -25,7 +25,11 @@ __global__ __launch_bounds__(64) void attdec_pos_kernel(AttDec a, int slot) {
 // kernel was LDS-issue bound, 20 us at 512 rows.)
 #define PRE_FL 4096          // filter floats in LDS (kf filters, taps padded to a multiple of 4)
 #define PRE_AL (ATT_MAX_T + ATT_MAX_FW + 16)
-struct PreGrid { int rt, ntS, ntG, nmm, nq, kf, nkg, nconv; };
+// ... and the sizes of the SMALL instantiation (T' + taps <= 1520: WSJ's 200..450 positions x 201 taps): 10 KB instead of 36 KB of
+// LDS per work-group — the kernel is bound by the waves it has in flight (see the rejected eight-output variant)
+#define PRE_FL_S 1024
+#define PRE_AL_S 1536
+struct PreGrid { int rt, ntS, ntG, nmm, nq, kf, nkg, nconv, small; };
 __host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
     PreGrid g;
     g.rt = (a.B + 15) / 16;
@@ -34,7 +38,8 @@ __host__ __device__ __forceinline__ PreGrid attdec_pre_grid(const AttDec& a) {
     g.nmm = (g.ntS + g.ntG) * g.rt;
     g.nq = (a.Tp + 3) / 4;                                           // output quads of a row
     const int fw4 = (2 * a.c + 1 + 3) / 4 * 4;
-    g.kf = max(1, min(min(a.K, 256 / g.nq), PRE_FL / fw4));          // filters per work-group
+    g.small = a.Tp + fw4 + 16 <= PRE_AL_S && fw4 <= PRE_FL_S;
+    g.kf = max(1, min(min(a.K, 256 / g.nq), (g.small ? PRE_FL_S : PRE_FL) / fw4));          // filters per work-group
     g.nkg = a.K > 0 ? (a.K + g.kf - 1) / g.kf : 0;
     g.nconv = ((a.phases & 1) && a.K > 0) ? a.B * g.nkg : 0;
     return g;
@@ -68,9 +73,10 @@ __global__ __launch_bounds__(256) void attdec_pre_kernel(AttDec a, int i) {
 }
 
 // pre, second part: cv = conv(alpha_prev) (a kernel of its own: its 36 KB of LDS would halve the occupancy of the products above)
+template <int AL, int FL>
 __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
-    __shared__ __attribute__((aligned(16))) float al[PRE_AL];
-    __shared__ __attribute__((aligned(16))) float fl[PRE_FL];
+    __shared__ __attribute__((aligned(16))) float al[AL];
+    __shared__ __attribute__((aligned(16))) float fl[FL];
     const PreGrid g = attdec_pre_grid(a);
     const int B = a.B, Tp = a.Tp, blk = blockIdx.x;
     const int kg = blk % g.nkg, b = blk / g.nkg, c = a.c, FW = 2 * c + 1, FW4 = (FW + 3) / 4 * 4;
@@ -524,7 +530,8 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
         if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0 && a.label0 == 0)
             hipLaunchKernelGGL(attdec_pos_kernel, dim3(a.B), dim3(64), 0, s, a, 0);
         for (int i = a.label0; i < a.L; ++i) {
-            if (g.nconv > 0) hipLaunchKernelGGL(attdec_conv_kernel, dim3(g.nconv), dim3(256), 0, s, a, i);
+            if (g.nconv > 0 && g.small) hipLaunchKernelGGL((attdec_conv_kernel<PRE_AL_S, PRE_FL_S>), dim3(g.nconv), dim3(256), 0, s, a, i);
+            else if (g.nconv > 0) hipLaunchKernelGGL((attdec_conv_kernel<PRE_AL, PRE_FL>), dim3(g.nconv), dim3(256), 0, s, a, i);
             if (g.nmm > 0) hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm), dim3(256), 0, s, a, i);
             if (a.phases & 1) {
                 const dim3 eg((a.M + ATT_MS - 1) / ATT_MS, a.group_rows > 0 ? a.B / a.group_rows : a.B, (a.Tp + ATT_TT - 1) / ATT_TT);
