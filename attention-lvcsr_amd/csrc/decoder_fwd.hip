@@ -1,6 +1,8 @@
-// Attention decoder, forward (K5-K9 of SURVEY.md §2.3): one decoder step = up to five small kernels
-// (pre: state projections + location convolution | energies | masked softmax + glimpse | GRU gates |
-// GRU candidate), the whole label loop captured into one hipGraph.  Same structure as encoder.hip:
+// Attention decoder, forward (K5-K9 of SURVEY.md §2.3), step kernels: one decoder step = up to six small kernels
+// (location convolution | state projections | energies | masked softmax + glimpse | GRU gates | GRU candidate), the
+// whole label loop captured into one hipGraph.  The teacher-forced pass normally runs the persistent kernels instead
+// (decoder_persist.hip); these serve generation / beam search (with row groups: several utterances' beams in one set of
+// launches, lvsr_attdec_args.group_rows) and the shapes the clusters do not fit.  Same structure as encoder.hip:
 // every cross-unit dependency inside a step is a kernel boundary, every contraction with the batch as
 // the 16-row MFMA tile (rb_mm), everything else wave-parallel VALU work with shuffle reductions.
 //
@@ -19,10 +21,9 @@ __global__ __launch_bounds__(64) void attdec_pos_kernel(AttDec a, int slot) {
     if (threadIdx.x == 0) a.pos[(size_t)slot * a.B + b] = r;
 }
 
-// Location convolution inside the pre kernel: a work-group serves one row and `kf` of its filters; a thread owns FOUR consecutive
+// Location convolution (attdec_conv_kernel): a work-group serves one row and `kf` of its filters; a thread owns FOUR consecutive
 // output positions of one filter and walks the taps four at a time — 16 FMAs on two 16-byte reads of the (zero-padded, cut)
-// alignment and one of the filter from LDS.  (One output and one tap per step, as before round 4, is two LDS reads per FMA: the
-// kernel was LDS-issue bound, 20 us at 512 rows.)
+// alignment and one of the filter from LDS.  (One output and one tap per step, as before round 4, is two LDS reads per FMA.)
 #define PRE_FL 4096          // filter floats in LDS (kf filters, taps padded to a multiple of 4)
 #define PRE_AL (ATT_MAX_T + ATT_MAX_FW + 16)
 // ... and the sizes of the SMALL instantiation (T' + taps <= 1520: WSJ's 200..450 positions x 201 taps): 10 KB instead of 36 KB of
