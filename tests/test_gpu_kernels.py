@@ -123,8 +123,10 @@ def test_recognizer_vs_reference_golden(gpu_device, case, use_graph):
 # Fingerprint = (norm, sum, dot with a fixed random direction) of a gradient tensor; sum and dot are cancellation residues far below
 # the norm, so their absolute tolerance is a fraction of the NORM.  wsj_base_median: the backward chain through 100 labels under a
 # window prior has a conditioning of its own — the float32 and float64 oracles differ by 5e-4 of a tensor's maximum there, the
-# reference and the float32 oracle by up to 9e-4 on the norms (gen_golden.py WSJ_COND_TRAIN) — hence 2e-3 of the norm for it.
-FP_ATOL = {"wsj_base_median": 2e-3}
+# reference and the float32 oracle by up to 9e-4 on the norms (gen_golden.py WSJ_COND_TRAIN); the HIP path is within 1.4e-3 with its
+# default kernels and 2.2e-3 under the kernel-variant knobs (`pytest --knob persist_flags=64`: another summation order in the
+# encoder) — hence 3e-3 of the norm for it.
+FP_ATOL = {"wsj_base_median": 3e-3}
 
 
 @pytest.mark.parametrize("case,persistent_decoder", [("timit_tiny", None), ("wsj_base", None), ("wsj_deep", None), ("wsj_stack2", None),

@@ -9,6 +9,7 @@ for what in "$@"; do
   case $what in
     tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 4 $O/pytest.log;;
     k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > "$O/pytest_k_$(echo ${what#k:} | cut -c1-12 | tr " " _).log" 2>&1; echo "pytest -k rc=$?"; grep "^E " $O/pytest_k_*.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_k_*.log;;
+    testsk:*) k=${what#testsk:}; timeout 900 python -m pytest tests -m gpu -x -q --knob $k > $O/pytest_$k.log 2>&1; echo "pytest --knob $k rc=$?"; tail -n 3 $O/pytest_$k.log;;
     newtests) timeout 900 python -m pytest tests -m gpu -x -q -k "wsj_base_median or whole_list or persistent_decoder or wsj_deep or wsj_paper or stack2" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -n 6 $O/pytest_new.log;;
     bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step')}, d.get('sustained'), d.get('strong'), {k:(v.get('achieved'),v.get('frac'),v.get('launch_us')) for k,v in d.get('fbank',{}).items() if isinstance(v,dict)}, d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
     quick) timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; python -c "import json;d=json.load(open('$O/quick.json'));print('wsj_base', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 2 $O/quick.err;;
