@@ -495,9 +495,7 @@ static int sgemm_launch(void* stream, int transA, int transB, int M, int N, int 
     // per CU) and K is long
     const int slots = mid ? 1024 : 512;
     if (ws && 2 * tiles <= slots && K >= 1024) {
-        // k-chunks per tile: as many as keep tiles x chunks within ONE round of the resident slots (round 4: rounding up put
-        // 192 tiles x 6 = 1 152 work-groups on 1 024 slots — an eighth of them alone on the chip in a second round)
-        int want = slots / tiles;
+        int want = (slots + tiles - 1) / tiles;
         int maxk = K / 256;
         if (want > maxk) want = maxk;
         long long need = (long long)want * M * N * 4;
