@@ -301,6 +301,9 @@ WORKLOADS = {
     # the WSJ-base network with the two-layer RecurrentStack decoder of exp/wsj/configs/wsj_jan_wsj13v2.yaml (dec_stack: 2)
     "wsj_stack2": (lambda: dict(wsj_base(), dec_stack=2), 16, 800, 100),
     "wsj_paper": (wsj_paper, 10, 800, 100),
+    # WSJ-base under the window prior of the full-size training fixture (tests/golden/wsj_base_median.npz): the clusters of the
+    # persistent decoder exchange their windows' centres label by label
+    "wsj_base_median": (lambda: wsj_base(prior=dict(type="window_around_median", before=10, after=100)), 16, 800, 100),
 }
 
 

@@ -20,6 +20,7 @@ for what in "$@"; do
           timeout 300 python tools/probe_decoder_persist.py wsj_deep > $O/deep_dec_fwd.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_deep > $O/deep_dec_bwd.txt 2>&1; grep -v "^    " $O/deep_dec_fwd.txt | tail -n 4; grep -v "^    " $O/deep_dec_bwd.txt | tail -n 4;;
     long) for T in 864 1000 1200 1600; do timeout 300 python bench.py --steps 10 --warmup 3 --frames $T $B > $O/frames_$T.json 2> $O/frames_$T.err; python -c "import json;d=json.load(open('$O/frames_$T.json'));print('frames $T', d['ms_per_step'], d['value'])"; tail -n 1 $O/frames_$T.err; done;;
     stack) timeout 300 python bench.py --workload wsj_stack2 --steps 10 --warmup 3 $B > $O/stack2.json 2> $O/stack2.err; python -c "import json;d=json.load(open('$O/stack2.json'));print('wsj_stack2', d['ms_per_step'], d['value'])"; tail -n 1 $O/stack2.err;;
+    median) timeout 300 python bench.py --workload wsj_base_median --steps 10 --warmup 3 $B > $O/median.json 2> $O/median.err; python -c "import json;d=json.load(open('$O/median.json'));print('wsj_base_median', d['ms_per_step'], d['value'])"; tail -n 1 $O/median.err;;
     paper) timeout 300 python bench.py --workload wsj_paper --steps 10 --warmup 3 $B > $O/paper.json 2> $O/paper.err; python -c "import json;d=json.load(open('$O/paper.json'));print('wsj_paper', d['ms_per_step'], d['value'])"; tail -n 1 $O/paper.err;;
     batches) for b in 10 32 64 128; do timeout 300 python bench.py --steps 8 --warmup 2 --batch $b $B > $O/batch_$b.json 2> $O/batch_$b.err; python -c "import json;d=json.load(open('$O/batch_$b.json'));print('batch $b', d['ms_per_step'], d['value'])"; tail -n 1 $O/batch_$b.err; done;;
     gemm) timeout 400 python tools/probes/gemm_k_sweep.py sustained > $O/gemm_k_sweep.txt 2>&1; tail -n 22 $O/gemm_k_sweep.txt;;
