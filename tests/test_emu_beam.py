@@ -166,8 +166,9 @@ def test_validator_sees_every_finished_hypothesis_once_the_patience_list_was_cut
 
 
 # ---- several utterances in one set of launches (BeamSearch.search_batch) ---------------------------------------------------------
-@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_nowindow", "tiny_content_embed", "tiny_conv_logistic",
-                                  "tiny_conv_stack2", "tiny_content_stack3"])
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_nowindow", "tiny_content_embed", "tiny_conv_stack2",
+                                  pytest.param("tiny_conv_logistic", marks=pytest.mark.slow),
+                                  pytest.param("tiny_content_stack3", marks=pytest.mark.slow)])
 def test_batched_search_equals_the_single_searches_emulated(case):
     """All utterances of the fixture's (ragged) batch decoded side by side — rows [g K, g K + K) of the state buffers belong to
     utterance g, windows / position counters / stopping rules / finished lists per utterance — give, utterance by utterance, the
@@ -213,7 +214,9 @@ def run_batched_case(case, device, lib, cost_tol=2e-5):
             assert_allclose(batched[utt][1], b["costs"], rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_content_embed", "tiny_conv_postmerge2", "tiny_conv_stack2"])
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_postmerge2",
+                                  pytest.param("tiny_content_embed", marks=pytest.mark.slow),
+                                  pytest.param("tiny_conv_stack2", marks=pytest.mark.slow)])
 def test_batched_search_with_the_tiled_readout_merge_emulated(case, monkeypatch):
     """lvsr_readout_merge (the readout's merge products as 16-row MFMA tiles, used from 64 rows on) forced on for the small
     fixtures: same hypotheses as the single searches and the reference."""
