@@ -128,7 +128,8 @@ __device__ __forceinline__ float attdec_pos_of_row_wave(const AttDec& a, const f
         const bool prev = lane == 0 ? carry : below != 0;
         const bool cross = ge && !prev && (t0 + lane) > 0;
         const unsigned long long m = __ballot(cross);
-        if (!found && m != 0ull) { res = (float)(t0 + (__ffsll((long long)m) - 1) - 1); found = true; }
+        if (m != 0ull) { res = (float)(t0 + (__ffsll((long long)m) - 1) - 1); found = true; }
+        if (found) break;                  // (wave-uniform: the rest of the chain cannot move the first crossing)
         carry = (c - 0.5f) >= 0.f;
     }
     return res;
