@@ -50,6 +50,7 @@ for what in "$@"; do
     decbprof:*) bb=${what#decbprof:}; cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decbprof -o dec -- python $R/tools/bench_decode.py --utts 64 --batch ${bb%x*} --streams ${bb#*x} > $R/$O/decbprof.log 2>&1
          cd $R; python tools/rocpd_stats.py $(find $O/decbprof -name "*.db" | head -n 1) > $O/decode_batched_kernel_stats.md 2>&1; tail -n 2 $O/decbprof.log | cut -c1-400; head -n 40 $O/decode_batched_kernel_stats.md | cut -c1-160;;
+    decodeb:*) bb=${what#decodeb:}; timeout 900 python bench.py --workload wsj_decode --decode-batch ${bb%x*} --streams ${bb#*x} > $O/decode_$bb.json 2> $O/decode_$bb.err; python -c "import json;d=json.load(open('$O/decode_$bb.json'));print('wsj_decode $bb', d['ms_per_step'], d['value'])"; tail -n 1 $O/decode_$bb.err;;
     decode) timeout 900 python bench.py --workload wsj_decode > $O/decode.json 2> $O/decode.err; echo "decode rc=$?"; cut -c1-600 $O/decode.json; tail -n 2 $O/decode.err;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log;;
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
