@@ -324,7 +324,7 @@ def main(backend=None):
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="data parallel: reduce the decoder's gradients while the encoder's BPTT runs (two buckets, Trainer(overlap_allreduce=True))")
     ap.add_argument("--utterances", type=int, default=None, help="wsj_decode: number of utterances (default 1000 = configs[4])")
-    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: recognizers (streams) in flight per GPU (default 3 batches; 8 searches with --decode-batch 1)")
+    ap.add_argument("--streams", type=int, default=None, help="wsj_decode: recognizers (streams) in flight per GPU (default 4 batches; 8 searches with --decode-batch 1)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
