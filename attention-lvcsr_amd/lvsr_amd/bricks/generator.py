@@ -777,7 +777,9 @@ def _beam_methods():
             limits = [int(m) for m in max_length]
             assert len(limits) == G
             assert lm is None or on_dev_lm, "batched search: language model on the device"
-            max_length = max(limits)
+            # capacity of the history buffers (and part of the step graph's key): the largest limit, rounded up so that batches of
+            # slightly different lengths share buffers and graph; every search stops at its own limit (ctl word 8)
+            max_length = (max(limits) + 31) // 32 * 32
             return self._beam_begin(K * G, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
         return self._beam_begin(K, K, 1, None, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
 
