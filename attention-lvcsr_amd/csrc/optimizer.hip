@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void opt_apply_kernel(Opt o) {
     }
 }
 
-struct GuardPack { const int* w[16]; int n; };
+struct GuardPack { const int* w[64]; int n; };
 __global__ void guard_collect_kernel(GuardPack pk, float* out) {
     if (threadIdx.x == 0) {
         int bad = 0;
@@ -171,10 +171,10 @@ __global__ void guard_collect_kernel(GuardPack pk, float* out) {
 }
 
 extern "C" int lvsr_guard_collect(void* stream, const int* const* words, int n, float* out) {
-    LVSR_REQUIRE(n >= 0 && n <= 16 && out && (n == 0 || words), "lvsr_guard_collect: at most 16 words");
+    LVSR_REQUIRE(n >= 0 && n <= 64 && out && (n == 0 || words), "lvsr_guard_collect: at most 64 words");
     GuardPack pk;
     pk.n = n;
-    for (int i = 0; i < 16; ++i) pk.w[i] = i < n ? words[i] : nullptr;
+    for (int i = 0; i < 64; ++i) pk.w[i] = i < n ? words[i] : nullptr;
     hipLaunchKernelGGL(guard_collect_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, pk, out);
     return lvsr_check_launch("lvsr_guard_collect");
 }

@@ -115,12 +115,15 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                 continue
             gbs = batch.pop("global_batch_size", None)
             cm = trainer.train_step(batch, global_batch_size=gbs)
-            if trainer.step_was_skipped():
+            for attempt in range(3):
+                if not trainer.step_was_skipped():
+                    break
                 # a persistent cluster kernel gave up waiting for its partners (its work-groups were not all resident: the device is
-                # shared): the optimiser skipped the step on the device — on every rank, the flag travels with the gradients.  Go on
-                # with the step kernels and run the batch again.
-                trainer.recover()
-                log.append(dict(iterations_done=iterations, persistent_kernels_aborted=True))
+                # shared): the optimiser skipped the step on the device — on every rank, the flag travels with the gradients.
+                # Trainer.recover() first leaves CUs free for the other tenant, then falls back to the step kernels for a while
+                # (and arms the cluster kernels again after Trainer.REARM_STEPS clean steps); run the batch again.
+                action = trainer.recover()
+                log.append(dict(iterations_done=iterations, persistent_kernels_aborted=True, **action))
                 cm = trainer.train_step(batch, global_batch_size=gbs)
             iterations += 1
             row = dict(iterations_done=iterations, epochs_done=epoch, train_cost=float(cm.sum()) / int(batch["labels"].shape[1]),

@@ -92,3 +92,12 @@ def fingerprint(name, g):
     """(l2 norm, sum, dot with the fixed probe) of a tensor, in float64."""
     g = numpy.asarray(g, numpy.float64)
     return numpy.array([numpy.sqrt((g * g).sum()), g.sum(), (g * grad_probe(name, g.shape)).sum()])
+
+
+def grad_sample_index(name, shape, n=2048):
+    """Fixed flat indices (sorted, without repetition) at which the full-size golden fixtures keep the reference's gradient
+    ELEMENTS themselves (`gsub:<name>`), next to the three-number fingerprint: small tensors whole, large ones n elements."""
+    size = int(numpy.prod(shape))
+    if size <= n:
+        return numpy.arange(size)
+    return numpy.sort(_rng_for(name + "#sample", 0).choice(size, size=n, replace=False))

@@ -8,6 +8,7 @@ RCCL collective over the flat gradient buffer, then divided by the GLOBAL batch 
 kernel; all ranks apply identical updates.
 """
 import ctypes
+import logging
 import os
 
 import numpy
@@ -20,7 +21,25 @@ def _is_weight(name):
     return name.endswith(".W") or name.endswith("state_to_state") or name.endswith("state_to_gates")
 
 
+logger = logging.getLogger(__name__)
+
+
+def _is_sync_word(key):
+    """Workspace names of the cluster kernels' scratch (abort word first): decoder, encoder layers (and their passes)."""
+    return key[0] in ("gen.sync", "gen.sync_bwd") or (key[0].startswith("enc") and key[0].endswith(".sync"))
+
+
 class Trainer(object):
+    # What recover() does about an aborted cluster launch (a work-group of a cluster was not resident: something else holds CUs).
+    # First abort: the cluster kernels stay, `cluster_reserve` CUs are left free from now on (the knob of csrc/runtime.hip; cluster
+    # shapes that no longer fit fall to the next smaller shape).  Another abort within REARM_STEPS steps: encoder and decoder move to
+    # the step kernels — for REARM_STEPS clean steps, after which the cluster kernels are armed again (with the reserve).
+    RECOVER_RESERVE = 32
+    REARM_STEPS = 200
+    # CUs the cluster launches leave free when an RCCL kernel can be co-resident with them: only with overlap_allreduce (without it
+    # the collective is stream-ordered BETWEEN the backward pass and the optimiser: it never shares the device with a cluster launch)
+    OVERLAP_RESERVE = 32
+
     def __init__(self, recognizer, gradient_threshold=None, rules=("momentum",), scale=0.1, momentum=0.0,
                  decay_rate=0.95, epsilon=1e-8, max_norm=0.0, max_norm_exclude_lookup=False, nonfinite_scaler=0.0,
                  burn_in_steps=0, adaptive_clipping=None, process_group=None, distributed=None, dp_region=True,
@@ -82,6 +101,15 @@ class Trainer(object):
         # all be resident (what concurrent GEMMs did to them is in bricks/__init__.py: slower, not faster).
         self.overlap_allreduce = bool(overlap_allreduce)
         self._comm = None
+        if self.overlap_allreduce and self.world > 1 and recognizer.lib.get_knob("cluster_reserve") == 0:
+            recognizer.lib.set_knob("cluster_reserve", self.OVERLAP_RESERVE)
+        # host mirror of scratch[3] ("the optimiser skipped the last step"), copied behind every optimiser step: train_step looks at
+        # it (no synchronisation) before it enqueues the next step and refuses to go on over a skipped step nobody recovered from
+        self._skip_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
+        self.aborts = 0               # cluster launches that gave up so far (recover() calls)
+        self._fallback = None         # while on the step kernels: dict(clean=steps since, saved=kernel choices to restore)
+        self._last_abort_step = None
+        self.steps_done = 0
 
     @classmethod
     def from_config(cls, recognizer, training, regularization=None, adaptive_clipping=True, **kw):
@@ -129,9 +157,10 @@ class Trainer(object):
         abort words in front of their workspaces).  The optimiser skips the step on the device when it is non-zero; under data
         parallelism the word is the first element of the gradient bucket, so every rank sees the sum and skips together."""
         rec, st, lib = self.rec, self.rec.store, self.rec.lib
-        words = [t for k, t in rec.ws._bufs.items() if k[0] in ("gen.sync", "gen.sync_bwd") or (k[0].startswith("enc") and k[0].endswith(".sync"))]
-        arr = (ctypes.c_void_p * 16)(*[t.data_ptr() for t in words[:16]])
-        lib.call("lvsr_guard_collect", lib.stream_for(st.flat), arr, min(len(words), 16), ptr(st.guard))
+        words = [t for k, t in rec.ws._bufs.items() if _is_sync_word(k)]
+        assert len(words) <= 64, "more cluster workspaces than lvsr_guard_collect takes"
+        arr = (ctypes.c_void_p * 64)(*[t.data_ptr() for t in words])
+        lib.call("lvsr_guard_collect", lib.stream_for(st.flat), arr, len(words), ptr(st.guard))
 
     def _enqueue_optimizer(self, global_batch_size):
         st, lib = self.rec.store, self.rec.lib
@@ -140,28 +169,80 @@ class Trainer(object):
                      scratch=self.scratch, n=st.flat.numel(), nseg=int(self.segments.shape[0]), max_cols=self.max_cols,
                      grad_scale=1.0 / float(global_batch_size), clip_state=self.clip_state, guard=st.guard, **self.conf)
         lib.call("lvsr_opt_step", lib.stream_for(st.flat), ctypes.byref(a))
+        if self._skip_host is not None:
+            self._skip_host.copy_(self.scratch[3:4], non_blocking=True)
 
     def step_was_skipped(self):
         """After a step (synchronises): did the optimiser skip it because a persistent cluster kernel gave up (lvsr_opt_args.guard)?"""
         return float(self.scratch[3]) != 0.0
 
     def recover(self):
-        """Call when step_was_skipped(): clear the abort words, put encoder and decoder on their step kernels for the rest of the run
-        (a cluster launch needs all its work-groups resident at once — something else is using the device's CUs) and tell the
-        caller to run the batch again.  Parameters and rule state are untouched by the skipped step."""
-        rec = self.rec
+        """Call when step_was_skipped(): clear the abort words, change what caused the abort (class comment: first leave
+        `RECOVER_RESERVE` CUs free and keep the cluster kernels; on a second abort within REARM_STEPS steps run on the step kernels
+        for REARM_STEPS clean steps, then arm the cluster kernels again), drop the captured graphs and tell the caller to run the
+        batch again.  Parameters and rule state are untouched by the skipped step.  -> dict describing what was done (also logged)."""
+        rec, lib = self.rec, self.rec.lib
         for k, t in rec.ws._bufs.items():
-            if k[0] in ("gen.sync", "gen.sync_bwd") or (k[0].startswith("enc") and k[0].endswith(".sync")):
+            if _is_sync_word(k):
                 t[:16].zero_()
-        rec.encoder.use_persistent, rec.encoder.persist_auto = False, False
-        rec.generator.use_persistent = False
-        if hasattr(rec.generator, "use_persistent_stack"):
-            rec.generator.use_persistent_stack = False
-        # the captured whole-step graphs replay the cluster launches: forget them (the next step of every shape is enqueued eagerly,
-        # the one after captured again — on the step kernels)
-        getattr(rec, "_regions", {}).clear()
-        getattr(self, "_regions", {}).clear()
+        self.aborts += 1
+        repeated = self._last_abort_step is not None and self.steps_done - self._last_abort_step < self.REARM_STEPS
+        self._last_abort_step = self.steps_done
+        action = dict(aborts=self.aborts, step=self.steps_done)
+        if not repeated and self._fallback is None and lib.get_knob("cluster_reserve") < self.RECOVER_RESERVE:
+            lib.set_knob("cluster_reserve", self.RECOVER_RESERVE)
+            action.update(action="cluster_reserve", cluster_reserve=self.RECOVER_RESERVE)
+            logger.warning("a persistent cluster kernel gave up waiting for its partners (step %d): the step was skipped on the device; "
+                           "cluster launches now leave %d CUs free; run the batch again", self.steps_done, self.RECOVER_RESERVE)
+        else:
+            if self._fallback is None:
+                self._fallback = dict(saved=(rec.encoder.use_persistent, rec.encoder.persist_auto, rec.generator.use_persistent,
+                                             getattr(rec.generator, "use_persistent_stack", None)))
+            self._fallback["clean"] = 0
+            rec.encoder.use_persistent, rec.encoder.persist_auto = False, False
+            rec.generator.use_persistent = False
+            if hasattr(rec.generator, "use_persistent_stack"):
+                rec.generator.use_persistent_stack = False
+            action.update(action="step_kernels", rearm_after=self.REARM_STEPS)
+            logger.warning("a persistent cluster kernel gave up again (step %d, abort %d): encoder and decoder run on the STEP KERNELS "
+                           "(several times slower) for the next %d steps, then the cluster kernels are armed again",
+                           self.steps_done, self.aborts, self.REARM_STEPS)
+        self._forget_graphs()
+        if self._skip_host is not None:
+            torch.cuda.synchronize(rec.store.device)
+            self._skip_host.zero_()
+        return action
+
+    def _forget_graphs(self):
+        """The captured whole-step graphs replay the launches of the old kernel choice: forget them and every region's counters (the
+        next step of every shape is enqueued eagerly — workspaces of the new choice come into being — the one after captured)."""
+        rec = self.rec
+        for owner in (rec, self, rec.encoder, rec.generator, rec.bottom):
+            getattr(owner, "_regions", {}).clear()
         rec.lib._lvsr_graph_clear()
+
+    def _rearm(self):
+        """REARM_STEPS clean steps on the step kernels: back to the cluster kernels (the reserve stays)."""
+        rec = self.rec
+        enc_p, enc_auto, gen_p, gen_stack = self._fallback["saved"]
+        rec.encoder.use_persistent, rec.encoder.persist_auto = enc_p, enc_auto
+        rec.generator.use_persistent = gen_p
+        if gen_stack is not None:
+            rec.generator.use_persistent_stack = gen_stack
+        self._fallback = None
+        self._forget_graphs()
+        logger.warning("step %d: %d clean steps on the step kernels; the persistent cluster kernels are armed again", self.steps_done,
+                       self.REARM_STEPS)
+
+    def _before_step(self):
+        if self._skip_host is not None and float(self._skip_host[0]) != 0.0:
+            raise RuntimeError("the previous training step was skipped on the device (a persistent cluster kernel gave up waiting); "
+                               "call Trainer.recover() and run that batch again (lvsr_amd.main.train does)")
+        if self._fallback is not None:
+            self._fallback["clean"] += 1
+            if self._fallback["clean"] > self.REARM_STEPS:
+                self._rearm()
+        self.steps_done += 1
 
     def _all_reduce_gradients(self):
         """ONE collective per step over the flat gradient bucket (sum); RCCL over xGMI when the tensors are on GPUs.
@@ -207,6 +288,7 @@ class Trainer(object):
         utterances of the whole (all ranks) minibatch, the divisor of the summed cost (lvsr/main.py:340-345); when omitted
         under data parallelism it is obtained by reducing the shard sizes."""
         B_local = int(batch["labels"].shape[1])
+        self._before_step()
         if self.distributed:
             if global_batch_size is None:
                 # shards may differ in size (a global batch that does not divide over the ranks): the divisor of the summed

@@ -121,6 +121,11 @@ def run_case(name, cfg, B, T, L, ragged, param_seed, batch_seed, scale=1.0, stor
         out["weights_sub"] = w[:, : min(B, 4)].astype(numpy.float32)
         out["encoded_fp"] = synthetic.fingerprint("encoded", enc)
         out["encoded_sub"] = enc[:: max(1, enc.shape[0] // 8), :2, :16].astype(numpy.float32)
+        # round 5: the reference's gradient ELEMENTS at fixed sample positions (small tensors whole), so that the full-size
+        # gradients are pinned element-wise to the reference itself and not only through three-number fingerprints
+        for n in names:
+            out["gsub:" + n] = g[n].ravel()[synthetic.grad_sample_index(n, g[n].shape)].astype(numpy.float32)
+            out["gmax:" + n] = numpy.float32(numpy.abs(g[n]).max())
     out["grad_fp"] = numpy.stack([synthetic.fingerprint(n, g[n]) for n in names])
     out["grad_names"] = numpy.array(names)
 
@@ -471,6 +476,16 @@ CASES = {
     "wsj_base_median": lambda: run_case(
         "wsj_base_median", spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100)), B=16, T=800, L=100,
         ragged=False, param_seed=13, batch_seed=1234, scales=WSJ_COND_TRAIN, store_full=False),
+    # round 5: configs[1] RAGGED (T_i in [400, 800], L_i in [50, 100]; utterance 0 full length): the reference's mask semantics at
+    # full size — the backward direction starting in padding (recurrent.py:617-619), masked label steps (attention.py:650-662),
+    # fuel Padding (transformers/__init__.py:691-720) — through the 8/16-work-group cluster kernels
+    "wsj_base_ragged": lambda: run_case(
+        "wsj_base_ragged", spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100)), B=16, T=800, L=100,
+        ragged=True, param_seed=13, batch_seed=1234, scales=WSJ_COND_TRAIN, store_full=False),
+    # round 5: configs[1] under window_around_mean (lvsr/bricks/attention.py:135-137,148-157), window 30 before / 40 after
+    "wsj_base_mean": lambda: run_case(
+        "wsj_base_mean", spec.wsj_base(prior=dict(type="window_around_mean", before=30, after=40)), B=16, T=800, L=100,
+        ragged=False, param_seed=13, batch_seed=1234, scales=WSJ_COND_TRAIN, store_full=False),
     # the WSJ-base network with the two-layer RecurrentStack decoder of wsj_jan_wsj13v2.yaml, full size (fingerprints).  Scale 0.7:
     # at 1.0 this seed's two-layer recurrence amplifies float32 rounding along the 100 labels (float32 and float64 oracles 4.7e-3
     # apart in the costs, 4e-2 in the alignments); at 0.7 they agree to 7e-7 / 2e-7 with alignments that are still peaked (max 0.14)
@@ -489,6 +504,6 @@ CASES = {
 
 if __name__ == "__main__":
     which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "wsj_stack2", "wsj_paper", "mid_conv_lm_decode", "wsj_decode_full",
-                                                          "wsj_base_median", "wsj_decode_full2")]
+                                                          "wsj_base_median", "wsj_decode_full2", "wsj_base_ragged", "wsj_base_mean")]
     for k in which:
         CASES[k]()

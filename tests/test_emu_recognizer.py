@@ -57,6 +57,30 @@ def test_one_recognizer_many_shapes_emulated():
         check_against(rec, cm, None, out, grads)
 
 
+@pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_conv_bottom"])
+def test_encoder_in_passes_emulated(case):
+    """Per-GPU batches the cluster kernels cannot hold run the ENCODER in passes over utterance columns (bricks.Encoder
+    _apply_in_passes / _backward_in_passes; the decoder sees the whole batch — its window priors couple the utterances,
+    lvsr/bricks/attention.py:148-157): same costs, alignments and gradients (incl. the bottom MLP's, through the assembled input
+    gradient) as the oracle on the whole batch, with passes of 2, 2 and 1 utterances; then again in one piece on the same recognizer."""
+    z, meta = load_golden(case)
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
+    orc = O.OracleRecognizer(cfg, params, dtype=torch.float64)
+    batch = synthetic.make_batch(cfg, 5, 17, 6, seed=81, ragged=True)
+    out, grads = orc.cost_and_grads(batch)
+    rec.encoder.force_passes, rec.encoder.PASS_ROWS = True, 2
+    for rep in range(2):
+        cm = rec.cost_and_gradients(batch)
+        assert [c.pfx for c in rec.encoder._passes] == ["enc.p0_", "enc.p1_", "enc.p2_"] and rec.encoder._pass_cols == [(0, 2), (2, 4), (4, 5)]
+        check_against(rec, cm, None, out, grads)
+    rec.encoder.force_passes = False
+    cm = rec.cost_and_gradients(batch)
+    assert rec.encoder._pass_cols is None
+    check_against(rec, cm, None, out, grads)
+
+
 @pytest.mark.parametrize("case", ["tiny_conv_median", "tiny_content_embed"])
 def test_degenerate_sizes_emulated(case):
     """Smallest inputs the path accepts: one utterance, one label, an attended sequence of one position (T equal to the

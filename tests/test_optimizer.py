@@ -193,3 +193,40 @@ def test_adaptive_clipping_kernel_matches_the_reference_class_emulated():
 @pytest.mark.gpu
 def test_adaptive_clipping_kernel_matches_the_reference_class_gpu(gpu_device):
     run_adaptive_kernel_vs_reference(gpu_device, None)
+
+
+def test_recover_state_machine_emulated():
+    """Trainer.recover(): the first abort keeps the cluster kernels and leaves CUs free (`cluster_reserve`); another abort within
+    REARM_STEPS steps moves encoder and decoder to the step kernels; after REARM_STEPS clean steps the cluster kernels are armed
+    again; every change forgets the captured graph regions of recognizer, trainer, encoder and generator."""
+    from emu import emu_lib
+    lib = emu_lib()
+    params = synthetic.make_params(CFG, seed=21)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=CFG)
+    tr = Trainer(rec, distributed=False, **RULES)
+    tr.REARM_STEPS = 2
+    batch = synthetic.make_batch(CFG, 3, 12, 4, seed=5, ragged=True)
+    rec.encoder.use_persistent, rec.encoder.persist_auto, rec.generator.use_persistent = True, True, True      # as on the GPU
+    old = lib.get_knob("cluster_reserve")
+    try:
+        lib.set_knob("cluster_reserve", 0)
+        for owner in (rec, rec.encoder, rec.generator):
+            owner._regions = {"k": dict(seen=5)}
+        a = tr.recover()
+        assert a["action"] == "cluster_reserve" and lib.get_knob("cluster_reserve") == Trainer.RECOVER_RESERVE
+        assert rec.encoder.use_persistent and rec.generator.use_persistent and tr._fallback is None
+        assert not rec._regions and not rec.encoder._regions and not rec.generator._regions
+        a = tr.recover()                                                            # second abort right away
+        assert a["action"] == "step_kernels" and tr.aborts == 2
+        assert rec.encoder.use_persistent is False and rec.encoder.persist_auto is False and rec.generator.use_persistent is False
+        saved = tr._fallback["saved"]
+        assert saved[0] is True and saved[1] is True and saved[2] is True
+        rec.encoder.use_persistent = rec.generator.use_persistent = False
+        tr._fallback["saved"] = (False, True, False, saved[3])                       # what the emulator can run when re-armed
+        for k in range(2):
+            tr.train_step(batch)
+            assert tr._fallback is not None
+        tr.train_step(batch)                                                        # the third step arms the cluster kernels again
+        assert tr._fallback is None and rec.encoder.persist_auto is True
+    finally:
+        lib.set_knob("cluster_reserve", old)
