@@ -48,9 +48,11 @@ __device__ __forceinline__ Win attdec_window_of(const AttDec& a, int i, int b0, 
         // int64 step * floatX constant -> float64 arithmetic on the f32-rounded speeds (:127-132,160-161)
         const double step = (double)(a.step0 + i + (stepw ? *stepw : 0));
         double bg = a.p0 + step * a.p2, en = a.p1 + step * a.p3;
-        bg = fmax(0.0, fmin((double)(Tp - 1), bg));
-        en = fmax(0.0, fmin((double)Tp, en));
-        w.begin = (int)floor(bg); w.end = (int)ceil(en);
+        // clamp(., 0, Tp - 1) / clamp(., 0, Tp) commute with floor / ceil (integer bounds): the upper clamps are done on the integers,
+        // so no (double)Tp lives in a register pair across the label loop of the persistent kernels (it was spilled there)
+        bg = fmax(0.0, fmin(2.0e9, bg));
+        en = fmax(0.0, fmin(2.0e9, en));
+        w.begin = min((int)floor(bg), Tp - 1); w.end = min((int)ceil(en), Tp);
         return w;
     }
     const float before = (float)a.p0, after = (float)a.p1;

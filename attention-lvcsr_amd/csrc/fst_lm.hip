@@ -93,7 +93,9 @@ __device__ __forceinline__ double fst_total(const int n, const double* w) {     
 
 __global__ __launch_bounds__(64) void fst_lm_step_kernel(lvsr_fst f, const long long* states, const double* weights,
                                                         const long long* outputs, int n, long long* new_states,
-                                                        double* new_weights, float* add, int* err) {
+                                                        double* new_weights, float* add, int* err, const int* ctl, int group_rows) {
+    // batched beam search: the rows of a search that is over carry stale characters — no walk for them (and no error raised by one)
+    if (ctl && ctl[(size_t)(blockIdx.x / group_rows) * 16 + 2] != 0) return;
     __shared__ int l_st[64][FST_CAP + 1];
     __shared__ double l_w[64][FST_CAP];
     __shared__ long long cur_st[FST_MAX_STATES];
@@ -159,8 +161,21 @@ int lvsr_fst_lm_step(void* stream, const lvsr_fst* f, const long long* states, c
     LVSR_REQUIRE(states && weights && err && (!outputs || (new_states && new_weights)), "lvsr_fst_lm_step: null buffers");
     if (n <= 0) return LVSR_OK;
     hipLaunchKernelGGL(fst_lm_step_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *f, states, weights, outputs, n,
-                       new_states, new_weights, add, err);
+                       new_states, new_weights, add, err, (const int*)nullptr, 1);
     return lvsr_check_launch("lvsr_fst_lm_step");
+}
+
+int lvsr_fst_lm_step_groups(void* stream, const lvsr_fst* f, const long long* states, const double* weights,
+                            const long long* outputs, int n, long long* new_states, double* new_weights, float* add, int* err,
+                            const int* ctl, int group_rows) {
+    LVSR_REQUIRE(f && f->arc_off && f->eps_off && f->topo && f->remap && f->num_states > 0 && f->V > 0,
+                 "lvsr_fst_lm_step_groups: incomplete automaton table");
+    LVSR_REQUIRE(states && weights && err && (!outputs || (new_states && new_weights)) && ctl && group_rows > 0 && n % group_rows == 0,
+                 "lvsr_fst_lm_step_groups: null buffers / rows are not whole groups");
+    if (n <= 0) return LVSR_OK;
+    hipLaunchKernelGGL(fst_lm_step_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, *f, states, weights, outputs, n,
+                       new_states, new_weights, add, err, ctl, group_rows);
+    return lvsr_check_launch("lvsr_fst_lm_step_groups");
 }
 
 }  // extern "C"

@@ -763,7 +763,8 @@ CTL = dict(nlive=0, pos=1, done=2, nfin=3, patience=4, nsel=5, err=6, steps=7)
 
 
 def _beam_methods():
-    def beam_begin(self, K, eol, max_length, ignore_first_eol=False, char_discount=0.0, round_to_inf=1e9, stop_on="patience"):
+    def beam_begin(self, K, eol, max_length, ignore_first_eol=False, char_discount=0.0, round_to_inf=1e9, stop_on="patience",
+                   force_merge=False):
         """Allocate (once per (K, T', max_length)) and reset the device state of a beam search over the contexts set by
         `init_generation`: hypothesis 0 = initial state / initial glimpses (search.py:287-299), every other row a copy.
         After `init_generation` on a batch of N utterances: N searches side by side (`max_length` = one limit per utterance),
@@ -780,11 +781,13 @@ def _beam_methods():
             # capacity of the history buffers (and part of the step graph's key): the largest limit, rounded up so that batches of
             # slightly different lengths share buffers and graph; every search stops at its own limit (ctl word 8)
             max_length = (max(limits) + 31) // 32 * 32
-            return self._beam_begin(K * G, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
-        return self._beam_begin(K, K, 1, None, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on)
+            return self._beam_begin(K * G, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on, True)
+        return self._beam_begin(K, K, 1, None, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on, force_merge)
 
-    def _beam_begin(self, R, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on):
-        """R = G * K rows: G searches of beam K."""
+    def _beam_begin(self, R, K, G, limits, eol, max_length, ignore_first_eol, char_discount, round_to_inf, stop_on, force_merge=False):
+        """R = G * K rows: G searches of beam K.  `force_merge`: the readout's merge products through lvsr_readout_merge whatever
+        the number of rows (every batched decode, so that an utterance's hypotheses do not depend on how many others share its
+        launches: a row of that kernel is summed in the same order in any batch)."""
         d, p, n_, lib, ws, g = self.d, self.store.p, self.n, self.lib, self.ws, self._gen
         Tp, dev = g["Tp"], g["A"].device
         lm = self.language_model
@@ -868,7 +871,7 @@ def _beam_methods():
             **({} if stacked else dict(WA_live=A_["WA"][0], WA_sel=B_["WA"][0], W1_live=A_["W"][1], W1_sel=B_["W"][1], E=d.E,
                                        pos1_live=A_["pos"][1] if pos_needed else None, pos1_sel=B_["pos"][1] if pos_needed else None)))
         # many rows (batched search): the merge products as 16-row tiles in a launch of their own (lvsr_readout_merge)
-        R1 = ws.get("bs.R1" + tag, (K, d.P)) if K >= self.MERGE_ROWS else None
+        R1 = ws.get("bs.R1" + tag, (K, d.P)) if (K >= self.MERGE_ROWS or force_merge) else None
         if R1 is not None:
             ro = self._readout_packs()
             st["merge"] = (lib_ptr(A_["S"][0]), int(A_["S"][0].stride(0)), lib_ptr(A_["WA"][0]), int(A_["WA"][0].stride(0)), K, SW, d.E, d.P,
@@ -902,7 +905,7 @@ def _beam_methods():
         lm_key = None if lm is None else (float(lm.lm_weight), float(lm.am_beta), tuple(bool(v) for v in lm.norm), float(getattr(lm, "no_transition_cost", 0.0)))
         lm_ptrs = () if not on_dev_lm else tuple(sorted((k, t.data_ptr()) for k, t in lm._dev.items())) + (lm._err.data_ptr(),)
         st["key"] = ("beam_step", K_one, G, Tp, int(max_length), stop_on, int(bool(ignore_first_eol)), int(eol), float(char_discount),
-                     float(round_to_inf), lm is not None, on_dev_lm, lm_key)
+                     float(round_to_inf), lm is not None, on_dev_lm, lm_key, R1 is not None)
         st["volatile"] = (g["A"].data_ptr(), g["PA"].data_ptr(), g["Am"].data_ptr(), ws.generation, id(pk), self.store.version, lm_ptrs)
         self._beam = st
         return st
@@ -953,9 +956,14 @@ def _beam_methods():
             lib.call("lvsr_attdec_fwd", lib.stream_for(B_["S"]), ctypes.byref(st["argsB"]), 0)
         if st["on_dev_lm"]:
             L, lm = st["lm"], self.language_model
-            lib.call("lvsr_fst_lm_step", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
-                     lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
-                     lib_ptr(L["add_new"]), lib_ptr(lm._err))
+            if st["groups"] > 1:       # the rows of finished searches are skipped (their characters are stale)
+                lib.call("lvsr_fst_lm_step_groups", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
+                         lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
+                         lib_ptr(L["add_new"]), lib_ptr(lm._err), lib_ptr(st["ctl"]), st["K"])
+            else:
+                lib.call("lvsr_fst_lm_step", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
+                         lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
+                         lib_ptr(L["add_new"]), lib_ptr(lm._err))
         lib.call("lvsr_beam_compact", lib.stream_for(st["ctl"]), ctypes.byref(st["args"]))
 
     def beam_step(self):

@@ -33,7 +33,11 @@ def search(recognizer, utterances, beam_size=10, char_discount=0.0, round_to_inf
            report=None, batch=1):
     """-> dict(per_utterance=[...], cer=, wer=, nll_groundtruth=, nll_recognized=).  `to_words(labels) -> list[str]` turns a
     label sequence into words for WER (the reference decodes characters with its character map, lvsr/main.py:788-800).
-    `batch` (an addition): utterances decoded side by side; same hypotheses, several times the throughput on a GPU."""
+    `batch` (an addition): utterances decoded side by side, several times the throughput on a GPU.  An utterance's hypotheses do not
+    depend on the batch it is decoded in for any batch > 1 (trailing chunks and one-utterance chunks included: the readout's merge
+    products always run through lvsr_readout_merge there); against batch = 1 (per-row VALU products below 64 rows: another float32
+    summation order) costs agree to ~1e-5 relative and candidates closer than that may swap ranks.  A host-side language model
+    or a validator decode one utterance at a time whatever `batch` says (BeamSearch.search_batch)."""
     recognizer.init_beam_search(beam_size)
     rows, tot_err, tot_len, tot_werr, tot_wlen = [], 0, 0, 0, 0
     kw = dict(char_discount=char_discount, round_to_inf=round_to_inf, stop_on=stop_on)

@@ -75,7 +75,7 @@ class BeamSearch(object):
     # ---- the same search in pieces that never block the host: several searches (one recognizer + stream each) can be kept in
     #      flight from one thread (tools/bench_decode.py: decoding is "replicas only", also within a GPU) -----------------------
     def begin(self, input_values, eol_symbol, max_length, ignore_first_eol=False, char_discount=0, round_to_inf=1e9,
-              stop_on="patience"):
+              stop_on="patience", force_merge=False):
         """Enqueue the encoder pass and the reset of the beam state; returns the handle of the running search."""
         rec, gen = self.rec, self.rec.generator
         if stop_on not in ("patience", "optimistic_future_cost"):
@@ -84,7 +84,8 @@ class BeamSearch(object):
         assert lm is None or getattr(lm, "on_device", False), "the free-running search needs the device language model"
         with rec._on_stream():
             rec.compute_contexts(input_values["recordings"])
-            st = gen.beam_begin(self.beam_size, eol_symbol, int(max_length), ignore_first_eol, char_discount, round_to_inf, stop_on)
+            st = gen.beam_begin(self.beam_size, eol_symbol, int(max_length), ignore_first_eol, char_discount, round_to_inf, stop_on,
+                                force_merge=force_merge)
         host = None
         if rec.device.type == "cuda":
             host = torch.empty(16, dtype=torch.int32).pin_memory()
@@ -93,12 +94,25 @@ class BeamSearch(object):
 
     # ---- several utterances in one set of launches ---------------------------------------------------------------------
     def search_batch(self, recordings, eol_symbol, max_lengths, ignore_first_eol=False, char_discount=0, round_to_inf=1e9,
-                     stop_on="patience", as_arrays=False):
+                     stop_on="patience", as_arrays=False, validate_solution_function=None):
         """The searches of N utterances side by side: one encoder pass over the padded batch, then every launch of a position
         serves the N beams at once (rows [g K, g K + K) of the state buffers belong to utterance g; windows, position counters,
         stopping rules and finished lists stay per utterance: lvsr_attdec_args.group_rows, lvsr_beam_args.groups).  A beam step
         is dispatch bound for one utterance (13 launches of 5-14 us per position); here the launches are shared.
-        -> list of N results, each what `search` returns for that utterance alone — or the exception it would raise."""
+        -> list of N results, each what `search` returns for that utterance alone — or the exception it would raise.
+        A language model walked on the host or a `validate_solution_function` put the host inside every position (module
+        docstring): there is nothing to share then, and the utterances are searched one after the other."""
+        lm = self.rec.generator.language_model
+        if validate_solution_function is not None or (lm is not None and not getattr(lm, "on_device", False)):
+            out = []
+            for x, limit in zip(recordings, max_lengths):
+                try:
+                    out.append(self.search({"recordings": numpy.asarray(x, numpy.float32)[:, None, :]}, eol_symbol, limit,
+                                           ignore_first_eol=ignore_first_eol, as_arrays=as_arrays, char_discount=char_discount,
+                                           round_to_inf=round_to_inf, stop_on=stop_on, validate_solution_function=validate_solution_function))
+                except (CandidateNotFoundError, AssertionError, RuntimeError, UnboundLocalError) as e:
+                    out.append(e)
+            return out
         run = self.begin_batch(recordings, eol_symbol, max_lengths, ignore_first_eol=ignore_first_eol, char_discount=char_discount,
                                round_to_inf=round_to_inf, stop_on=stop_on)
         while not run["done"]:
@@ -112,7 +126,8 @@ class BeamSearch(object):
             raise ValueError("Unknown stopping criterion {}".format(stop_on))
         if len(recordings) == 1:
             run = self.begin({"recordings": numpy.asarray(recordings[0], numpy.float32)}, eol_symbol, max_lengths[0],
-                             ignore_first_eol=ignore_first_eol, char_discount=char_discount, round_to_inf=round_to_inf, stop_on=stop_on)
+                             ignore_first_eol=ignore_first_eol, char_discount=char_discount, round_to_inf=round_to_inf, stop_on=stop_on,
+                             force_merge=True)       # the kernels of the batched search: the same hypotheses in any batch
             run["single"] = True
             return run
         lm = gen.language_model

@@ -160,7 +160,7 @@ def gemm_probe(rec, dims, T, B):
                 frac=big["frac"], layer_shapes=out)
 
 
-PMC_FILE = os.path.join(REPO, "profiles", "r04_pmc_bench.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r05_pmc_bench.json")
 
 
 def csrc_sha():
@@ -204,6 +204,17 @@ def decode_leg(dev, utterances, batch=64, streams=2):
                 utterances_per_launch_set=batch, searches_in_flight=streams * batch, positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1),
                 mean_best_hypothesis_length=chars / max(done, 1),
                 parity="tests/test_decode_golden.py::test_full_size_wsj_decode_batched_whole_list_matches_the_reference_gpu (reference-generated golden)")
+
+
+def beam200_leg(dev, utterances=8, batch=4):
+    """The beam width the reference's README recommends for its best numbers (exp/wsj/README.md:58-60, exp/wsj/decode.sh:12): 200
+    hypotheses x 33 characters = 6 600 candidates per position in lvsr_beam_select, row groups of 200 across the 16-row tiles.
+    A bounded sample; parity: tests/test_decode_golden.py::test_beam_200_*."""
+    from tools.bench_decode import build, run_batched
+    recs = [build(dev, 200)[0]]
+    sec, done, nframes, chars, steps = run_batched(recs, utterances, 800, batch=batch)
+    return dict(beam_size=200, utterances=done, utterances_per_launch_set=batch, ms_per_utterance=sec / done * 1e3,
+                positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1), mean_best_hypothesis_length=chars / max(done, 1))
 
 
 PEAK_HBM = 8.0e12               # bytes/s (MI355X_MICROARCH.md)
@@ -321,6 +332,8 @@ def main(backend=None):
     ap.add_argument("--no-strong", action="store_true",
                     help="skip the `strong` sub-object (global batch of configs[2] split over the ranks, speed-up over ONE GPU at that batch)")
     ap.add_argument("--no-fbank", action="store_true", help="skip the front-end leg (lvsr_fbank GB/s)")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the `ragged` sub-object (the same job on ragged minibatches, real frames/s)")
+    ap.add_argument("--no-beam200", action="store_true", help="skip decode.beam200 (the README's beam width, exp/wsj/README.md:58-60)")
     ap.add_argument("--overlap-allreduce", action="store_true",
                     help="data parallel: reduce the decoder's gradients while the encoder's BPTT runs (two buckets, Trainer(overlap_allreduce=True))")
     ap.add_argument("--utterances", type=int, default=None, help="wsj_decode: number of utterances (default 1000 = configs[4])")
@@ -488,6 +501,22 @@ def main(backend=None):
                          how="same replayed whole-step graph as the timed region, %d steps back to back; per-step figures are host intervals "
                              "(the host blocks until a step's graph has drained), rank 0's" % n_sus)
 
+    # ---- secondary run of SURVEY.md 8(d): the same job on RAGGED minibatches (T_i ~ U{T/2..T}, L_i ~ U{L/2..L}, zero padded to (T, L);
+    # utterance 0 of every global batch full length) — real (unpadded) frames per second
+    ragged = None
+    if backend.measured and not args.ragged and not args.no_ragged and args.scaling == "weak":
+        rb, rframes = [], 0.0
+        for k in range(2):
+            gbatch = synthetic.make_batch(cfg, global_batch, T, L, seed=2345 + k, ragged=True)
+            sh = synthetic.shard_batch(gbatch, rank, world)
+            rframes += float(gbatch["recordings_mask"].sum()) / 2
+            rb.append({kk: torch.from_numpy(v).to(dev) for kk, v in sh.items()})
+        n_rg = max(5, min(args.steps, 10))
+        el, _ = timed(trainer, rb, n_rg, global_batch, 3)
+        ragged = dict(steps=n_rg, ms_per_step=el / n_rg * 1e3, real_frames_per_step=rframes, padded_frames_per_step=float(global_batch * T),
+                      value=rframes * n_rg / el, unit="real frames/s", fraction_of_all_ones_value=(rframes * n_rg / el) / (frames_per_step * args.steps / elapsed),
+                      how="T_i ~ U{T/2..T}, L_i ~ U{L/2..L} (synthetic.make_batch(ragged=True)), zero padded; frames counted = sum of the input mask")
+
     # ---- strong scaling (north_star: global batch 128 = BASELINE configs[2] sharded over the ranks, rank r takes r::N; target >= 6x
     # at 8 GPUs): the same job in the SAME launch as the weak line, and the one-GPU step at that global batch it is measured against
     strong = None
@@ -504,10 +533,13 @@ def main(backend=None):
             strong = dict(global_batch=GB, per_gpu_batch=GB // world, steps=n_st, ms_per_step=el / n_st * 1e3,
                           value=GB * T * n_st / el, unit="frames/s", scaling="strong",
                           encoder_kernels=("persistent clusters" if rec.encoder._sync_ws(0, GB // world, dims.Hs[0]) is not None else "step kernels"))
-            if world > 1:
-                # the one-GPU step at the global batch, live: rank 0 alone (no collective), the other ranks wait at the barrier
-                one = None
-                if rank == 0:
+            def one_gpu_step_ms(passes):
+                """The one-GPU step at the global batch, live: rank 0 alone (no collective).  passes=True: the encoder in passes of
+                <= 64 utterances on the cluster kernels (the default, bricks.Encoder.PASS_ROWS); False: one pass on the step kernels
+                (what round 4 measured as the one-GPU baseline)."""
+                keep = rec.encoder.PASS_ROWS
+                rec.encoder.PASS_ROWS = keep if passes else 1 << 30
+                try:
                     solo = Trainer(rec, distributed=False, **TRAIN_CONF)
                     full = [{kk: torch.from_numpy(v).to(dev) for kk, v in synthetic.make_batch(cfg, GB, T, L, seed=4321 + k).items()} for k in range(2)]
                     for k in range(3):
@@ -517,16 +549,35 @@ def main(backend=None):
                     for k in range(n_st):
                         solo.train_step(full[k % 2], global_batch_size=GB)
                     sync()
-                    one = (time.perf_counter() - t_a) / n_st * 1e3
-                    del full
-                barrier()
-                if rank == 0:
-                    strong.update(one_gpu_ms_per_step=one, speedup_vs_one_gpu=one / strong["ms_per_step"],
-                                  one_gpu_how="rank 0 alone on the whole global batch (no collective) in this same launch")
-            else:
-                strong.update(one_gpu_ms_per_step=strong["ms_per_step"], speedup_vs_one_gpu=1.0)
+                    return (time.perf_counter() - t_a) / n_st * 1e3
+                finally:
+                    rec.encoder.PASS_ROWS = keep
+            one = one_steps = None
+            if rank == 0 and (world > 1 or GB // world > rec.encoder.PASS_ROWS):
+                one, one_steps = one_gpu_step_ms(True), one_gpu_step_ms(False)
+            barrier()
+            if rank == 0:
+                if one is None:
+                    one = one_steps = strong["ms_per_step"]
+                strong.update(one_gpu_ms_per_step=min(one, one_steps), speedup_vs_one_gpu=min(one, one_steps) / strong["ms_per_step"],
+                              one_gpu_ms_per_step_encoder_in_passes=one, one_gpu_ms_per_step_encoder_step_kernels=one_steps,
+                              speedup_vs_one_gpu_encoder_step_kernels=one_steps / strong["ms_per_step"],
+                              one_gpu_how="rank 0 alone on the whole global batch (no collective) in this same launch; the speed-up is "
+                                          "quoted against the FASTER of the two one-GPU forms (encoder in passes of 64 utterances on the "
+                                          "cluster kernels / one pass on the step kernels)")
     last_cost = float(cm.sum())
     assert numpy.isfinite(last_cost), "training diverged in the benchmark"
+    # ---- self-check inputs (all ranks): was any step skipped, did the step replay as a captured graph region
+    skipped_local = 1.0 if trainer.step_was_skipped() else 0.0
+    regions = list(getattr(rec, "_regions", {}).values())
+    graph_local = 1.0 if (args.no_graph or not backend.measured or (regions and any(r.get("seen", 0) >= 3 for r in regions) and not any(r.get("bad") for r in regions))) else 0.0
+    if dist:
+        t = torch.tensor([skipped_local, 1.0 - graph_local], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t)
+        skipped_total, graph_region_ok = float(t[0]), float(t[1]) == 0.0
+    else:
+        skipped_total, graph_region_ok = skipped_local, graph_local == 1.0
+    check_ok = skipped_total == 0 and graph_region_ok and ((not dist) or torch.distributed.get_world_size() == args.gpus)
     rec.generator.check_persistent()
     rec.encoder.check_persistent()          # raises if a persistent cluster kernel gave up waiting (results would be invalid)
     ms = elapsed / args.steps * 1e3
@@ -565,6 +616,8 @@ def main(backend=None):
                        final_cost_per_utterance=last_cost / B, knobs=knobs))
         if sustained:
             out["sustained"] = sustained
+        if ragged:
+            out["ragged"] = ragged
         if strong:
             out["strong"] = strong
         if dist:
@@ -572,6 +625,11 @@ def main(backend=None):
             out["config"].update(collective_backend=torch.distributed.get_backend(), collective_world_size=torch.distributed.get_world_size(),
                                  allreduce_ms=allreduce_ms, allreduce_bytes=int(rec.store.grad.numel()) * 4,
                                  whole_step_graph_region=bool(trainer.dp_region))
+        # self-check of the run (every rank's verdict, reduced): the collective spans exactly --gpus ranks, the step replays as a
+        # whole-step graph region, no step of any rank was skipped by the guard and no cluster launch gave up
+        out["self_check"] = dict(ok=bool(check_ok), collective_world_size_is_n_gpus=(not dist) or torch.distributed.get_world_size() == args.gpus,
+                                 whole_step_graph_region=bool(graph_region_ok), steps_skipped=int(skipped_total), cluster_aborts=int(trainer.aborts),
+                                 cluster_reserve=int(rec.lib.get_knob("cluster_reserve")))
         if backend.measured:
             pr = dominant_kernel_probe(rec, dims, T, B)
             ach = pr["flops"] / pr["launch_s"] / 1e12
@@ -588,7 +646,7 @@ def main(backend=None):
                         us_per_recurrent_step=pr["launch_s"] * 1e6 / pr["steps_per_launch"], flops_per_launch=pr["flops"],
                         algorithmic_bytes_per_launch=pr["algorithmic_bytes"],
                         frac_source="HIP events around the kernel on the recognizer's stream inside this run (layer 0, T steps; rocprofv3 "
-                                    "of the same command: profiles/r04_bench_wsj_base_kernel_stats.md)",
+                                    "of the same command: profiles/r05_bench_wsj_base_kernel_stats.md)",
                         note="latency bound by construction: a chain of T dependent GRU steps, two cluster-wide exchanges each; the "
                              "contraction runs on the VALU (GEMV per utterance), formally priced against the fp32 MFMA peak")
             if pmc:
@@ -609,6 +667,8 @@ def main(backend=None):
                 out["fbank"] = fbank_leg(dev)
             if world == 1 and not args.no_decode and args.workload == "wsj_base":
                 out["decode"] = decode_leg(dev, args.decode_utterances, batch=args.decode_batch)
+                if not args.no_beam200:
+                    out["decode"]["beam200"] = beam200_leg(dev)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(cfg, params, B0, T, L, args.workload)
         print(json.dumps(out), file=json_out, flush=True)

@@ -507,6 +507,12 @@ typedef struct lvsr_fst {
  * 3 when a chosen character has no FST label. */
 int lvsr_fst_lm_step(void* stream, const lvsr_fst* f, const long long* states, const double* weights,
                      const long long* outputs, int n, long long* new_states, double* new_weights, float* add, int* err);
+/* The same for the rows of several beam searches side by side (BeamSearch.search_batch): row b belongs to search b / group_rows,
+ * whose control block is ctl[16 * g ...]; the rows of a search whose `done` word (ctl word 2) is set are left alone — they carry the
+ * stale characters of its last position, and a walk over them must not raise *err for the searches still running. */
+int lvsr_fst_lm_step_groups(void* stream, const lvsr_fst* f, const long long* states, const double* weights,
+                            const long long* outputs, int n, long long* new_states, double* new_weights, float* add, int* err,
+                            const int* ctl, int group_rows);
 
 /* ---- mel-filterbank front end ------------------------------------------------------------------------
  * The reference runs Kaldi offline (exp/wsj/write_hdf_dataset.sh:94-104: compute-fbank-feats --use-energy=true

@@ -444,6 +444,14 @@ CASES = {
         param_seed=10, fst_seed=9, scale=2.0, scales=WSJ_COND_DECODE, utt_ids=[0, 1, 3],
         lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
         beams=[dict(beam_size=16, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")]),
+    # round 5: beam 200 — the width exp/wsj/README.md:58-60 recommends — on the same network and language model, 400-frame utterances
+    # (the first 400 frames of the wsj_decode_full2 utterances: RandomState(100 + u) is drawn row by row), T' = 100, up to 133 positions
+    "wsj_decode_beam200": lambda: run_lm_case(
+        "wsj_decode_beam200", dict(spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100)),
+                                   max_decoded_length_scale=3.0), T=400,
+        param_seed=10, fst_seed=9, scale=2.0, scales=WSJ_COND_DECODE, utt_ids=[1, 0],
+        lm_kwargs=dict(weight=0.5, no_transition_cost=20.0),
+        beams=[dict(beam_size=200, char_discount=1.0, round_to_inf=1e9, stop_on="optimistic_future_cost")]),
     # cost / analyze WITH the language model (both weightings of the fusion that the shipped decode scripts use)
     "tiny_conv_lm_analyze": lambda: run_lm_case(
         "tiny_conv_lm_analyze", tiny_cfg(dict(type="window_around_median", before=2, after=3), embed_outputs=True), T=14,
@@ -504,6 +512,6 @@ CASES = {
 
 if __name__ == "__main__":
     which = sys.argv[1:] or [k for k in CASES if k not in ("wsj_base", "wsj_deep", "wsj_stack2", "wsj_paper", "mid_conv_lm_decode", "wsj_decode_full",
-                                                          "wsj_base_median", "wsj_decode_full2", "wsj_base_ragged", "wsj_base_mean")]
+                                                          "wsj_base_median", "wsj_decode_full2", "wsj_base_ragged", "wsj_base_mean", "wsj_decode_beam200")]
     for k in which:
         CASES[k]()

@@ -169,6 +169,93 @@ def test_full_size_batched_decode_equals_single_searches_at_other_beam_widths_gp
             assert_allclose(many[1], one[1], rtol=1e-4, atol=1e-4)
 
 
+# Round 5: beam 200 — the width the reference's README recommends for its best numbers (exp/wsj/README.md:58-60, exp/wsj/decode.sh:12):
+# 200 hypotheses x 33 characters = 6 600 candidates per position in lvsr_beam_select (capacity 8 192), row groups of 200 = 12.5 of the
+# 16-row MFMA tiles of the merge / energy kernels, finished lists of up to 200 x (max_length + 1) entries.  A Theano beam-200 search of
+# one full-size utterance is ~12x the hours the beam-16 fixture took: the yardstick here is the float32 oracle (which reproduces the
+# reference's whole beam-16 list on this very network and language model: test_oracles_reproduce_the_whole_list...).
+def _full2_recognizer(device, lib=None):
+    z, meta = load_golden("wsj_decode_full2")
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
+    rec = SpeechRecognizer(device=device, params=params, lib=lib, net_config=cfg)
+    fst, cmap = _fst_from_arcs(z["arcs"], cfg["num_phonemes"])
+    rec.set_language_model(LM.DeviceFSTLanguageModel(fst, device, lib=rec.lib, nn_char_map=cmap, **meta["lm"]))
+    s = dict(meta["beam"][0]["settings"])
+    s.pop("beam_size")
+    return z, meta, params, rec, s
+
+
+@pytest.mark.gpu
+def test_beam_200_single_search_equals_the_float32_oracle_gpu(gpu_device):
+    """One full-size utterance (400 of the fixture's 800 frames: T' = 100, up to 133 positions) at beam 200 against the float32
+    oracle's beam search with the same language model: the same hypotheses in the same order over the head of the list the two
+    float32 implementations can agree on (costs further apart than 1e-4 relative), every cost to 1e-4; the list lengths within 2 %."""
+    import torch
+    from oracle import lvsr_oracle as O, lm_oracle as LO
+    z, meta, params, rec, s = _full2_recognizer(gpu_device)
+    V = meta["cfg"]["num_phonemes"]
+    x = z["x1"][:400]
+    rec.init_beam_search(200)
+    outs, costs = rec.beam_search({"recordings": x}, **s)
+    outs2, costs2 = rec.beam_search({"recordings": x}, **s)                    # replayed step graph
+    assert outs2 == outs and costs2 == costs
+    torch.set_num_threads(8)
+    orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float32)
+    arcs = [(int(a), int(b), int(il), float(w)) for a, b, il, w in z["arcs"]]
+    lm = dict(dense=LO.DenseFST(arcs, arcs[0][0], V), remap={c: c + 1 for c in range(V)}, **meta["lm"])
+    ref_outs, ref_costs = orc.beam_search(x, 200, lm=lm, **s)
+    assert len(outs) >= 200 and abs(len(outs) - len(ref_outs)) <= max(2, len(ref_outs) // 50), (len(outs), len(ref_outs))
+    # ranked head: identical while neighbouring costs are further apart than float32 implementations can differ
+    n = 0
+    while n < min(len(outs), len(ref_outs)) and outs[n] == ref_outs[n]:
+        n += 1
+    assert n >= 50, "only the first %d hypotheses agree" % n
+    assert_allclose(costs[:n], ref_costs[:n], rtol=1e-4, atol=1e-4)
+    # beyond the head: the same SET of hypotheses up to near-ties (every GPU hypothesis among the oracle's, with its cost)
+    ref_by = {tuple(o): c for o, c in zip(ref_outs, ref_costs)}
+    common = [(c, ref_by[tuple(o)]) for o, c in zip(outs, costs) if tuple(o) in ref_by]
+    assert len(common) >= 0.95 * len(outs), "%d of %d hypotheses are not in the oracle's list" % (len(outs) - len(common), len(outs))
+    assert_allclose([a for a, _ in common], [b for _, b in common], rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
+def test_beam_200_batched_equals_single_searches_gpu(gpu_device):
+    """Three utterances of different lengths side by side at beam 200 (600 rows: groups of 200 across the 16-row tiles, 6 600
+    candidates per search in lvsr_beam_select) == each decoded alone: whole ranked lists, eager / captured and replayed."""
+    z, meta, params, rec, s = _full2_recognizer(gpu_device)
+    rec.init_beam_search(200)
+    xs = [z["x1"][:400], z["x0"][:320], z["x3"][:480]]
+    singles = [rec.beam_search({"recordings": x}, **s) for x in xs]
+    assert all(len(o[0]) >= 100 for o in singles)
+    for _ in range(2):
+        batched = rec.beam_search_batch(xs, **s)
+        for u, (one, many) in enumerate(zip(singles, batched)):
+            assert not isinstance(many, Exception), (u, many)
+            assert many[0] == one[0], "utterance %d: the ranked lists differ" % u
+            assert_allclose(many[1], one[1], rtol=1e-4, atol=1e-4)
+
+
+def test_beam_200_emulated_equals_the_float32_oracle():
+    """Beam 200 through the emulated kernels on a small network (20 characters: 4 000 candidates per position; 679 finished
+    hypotheses): the whole ranked list of the float32 oracle, token for token."""
+    import torch
+    from emu import emu_lib
+    from oracle import lvsr_oracle as O
+    z, meta = load_golden("small_conv_median")
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
+    batch = synthetic.make_batch(cfg, meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    x = batch["recordings"][: int(batch["recordings_mask"][:, 1].sum()), 1][:28]
+    kw = dict(char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost")
+    ref = O.OracleRecognizer(cfg, params, dtype=torch.float32).beam_search(x, 200, **kw)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
+    rec.init_beam_search(200)
+    got = rec.beam_search({"recordings": x}, **kw)
+    assert len(got[0]) >= 200 and got[0] == ref[0]
+    assert_allclose(got[1], ref[1], rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.gpu
 def test_mid_size_decode_batched_matches_the_reference_gpu(gpu_device):
     run_batched_decode_case(gpu_device, None, "mid_conv_lm_decode", STABLE_LENGTH, 12, repeat=2)
