@@ -75,6 +75,13 @@ def respawn_under_torchrun(n):
     return subprocess.call(cmd, env=env)
 
 
+def encoder_kernels_of(rec, B, dims):
+    cols = rec.encoder._pass_columns(B)
+    if cols is not None:
+        return "persistent clusters, %d passes of <= %d utterances" % (len(cols), max(hi - lo for lo, hi in cols))
+    return "persistent clusters" if rec.encoder._sync_ws(0, B, dims.Hs[0]) is not None else "step kernels"
+
+
 def dominant_kernel_probe(rec, dims, T, B):
     """Average launch duration of the dominant kernel measured with HIP events on the recognizer's own stream.
     Persistent encoder (default at WSJ-base): enc_pbwd_kernel, ONE launch = the whole BPTT time loop of a layer (both
@@ -532,7 +539,7 @@ def main(backend=None):
             el, _ = timed(trainer, sb, n_st, GB, 3)
             strong = dict(global_batch=GB, per_gpu_batch=GB // world, steps=n_st, ms_per_step=el / n_st * 1e3,
                           value=GB * T * n_st / el, unit="frames/s", scaling="strong",
-                          encoder_kernels=("persistent clusters" if rec.encoder._sync_ws(0, GB // world, dims.Hs[0]) is not None else "step kernels"))
+                          encoder_kernels=encoder_kernels_of(rec, GB // world, dims))
             def one_gpu_step_ms(passes):
                 """The one-GPU step at the global batch, live: rank 0 alone (no collective).  passes=True: the encoder in passes of
                 <= 64 utterances on the cluster kernels (the default, bricks.Encoder.PASS_ROWS); False: one pass on the step kernels
@@ -609,7 +616,7 @@ def main(backend=None):
                        global_batch=global_batch, per_gpu_batch=B, frames_per_step=frames_per_step,
                        ragged=bool(args.ragged), parallelism="dp%d" % world, optimizer="clip100+adadelta+maxnorm1",
                        hip_graph=not args.no_graph, priming_steps=PRIME,
-                       encoder_kernels=("persistent clusters" if rec.encoder._sync_ws(0, B, dims.Hs[0]) is not None else "step kernels"),
+                       encoder_kernels=encoder_kernels_of(rec, B, dims),
                        h2d="value: minibatches resident in HBM when the timed region starts (bench contract); with_h2d: the same steps fed from pinned host memory",
                        with_h2d=(dict(with_h2d, value=frames_per_step / (with_h2d["ms_per_step"] * 1e-3)) if with_h2d else None),
                        value_is="steps * frames_per_step / wall time of the K steps (mean); ms_per_step_median = median of the per-step host intervals",

@@ -266,9 +266,10 @@ def test_concurrent_searches_equal_sequential_ones(gpu_device):
 
 def test_step_of_an_aborted_cluster_is_skipped_inside_the_graph_and_recovered(gpu_device):
     """The guard at full size, inside the replayed whole-step graph: a raised (sticky) abort word of the decoder's cluster workspace
-    makes the captured lvsr_opt_step skip the step on the device — parameters and rule state bit-identical — and Trainer.recover()
-    drops the captured graphs, moves the run onto the step kernels and the batch run again gives the step an undisturbed run on
-    the step kernels takes."""
+    makes the captured lvsr_opt_step skip the step on the device — parameters and rule state bit-identical — and train_step refuses
+    to go on over it.  Trainer.recover() (round 5) first KEEPS the cluster kernels and leaves CUs free (`cluster_reserve`), the batch
+    run again gives the step an undisturbed run takes; a second abort right away moves the run onto the step kernels, and after
+    REARM_STEPS clean steps the cluster kernels are armed again."""
     from lvsr_amd.training import Trainer
     cfg = spec.wsj_base()
     params = synthetic.make_params(cfg, seed=13, scales=WSJ_COND_TRAIN)
@@ -281,31 +282,61 @@ def test_step_of_an_aborted_cluster_is_skipped_inside_the_graph_and_recovered(gp
         tr_ref.train_step(batch)
     rec = SpeechRecognizer(device=gpu_device, params=params, net_config=cfg)
     tr = Trainer(rec, distributed=False, **rules)
-    for _ in range(3):                       # eager, capture, replay
+    lib = rec.lib
+    assert lib.get_knob("cluster_reserve") == 0
+    try:
+        for _ in range(3):                       # eager, capture, replay
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        assert not tr.step_was_skipped()
+        assert any(s["seen"] >= 3 for s in rec._regions.values())
+        before = rec.store.get_values()
+        state = {k: numpy.asarray(v).copy() for k, v in tr.state_dict().items() if k != "layout"}
+        words = [t for k, t in rec.ws._bufs.items() if k[0] in ("gen.sync", "gen.sync_bwd")]
+        assert len(words) == 2, "the decoder did not run on its cluster kernels"
+        words[1][0] = 1        # "a work-group of the cluster was never scheduled"
+        tr.train_step(batch)                     # a replay of the captured step
+        torch.cuda.synchronize()
+        assert tr.step_was_skipped()
+        for k, v in rec.store.get_values().items():
+            assert (v == before[k]).all(), "a skipped step changed %s" % k
+        for k, v in tr.state_dict().items():
+            if k != "layout":
+                assert (numpy.asarray(v) == state[k]).all(), "a skipped step changed the optimiser's %s" % k
+        with pytest.raises(RuntimeError):        # nobody recovered: the next step refuses
+            tr.train_step(batch)
+        action = tr.recover()
+        assert action["action"] == "cluster_reserve" and lib.get_knob("cluster_reserve") == Trainer.RECOVER_RESERVE
         tr.train_step(batch)
-    torch.cuda.synchronize()
-    assert not tr.step_was_skipped()
-    assert any(s["seen"] >= 3 for s in rec._regions.values())
-    before = rec.store.get_values()
-    state = {k: numpy.asarray(v).copy() for k, v in tr.state_dict().items() if k != "layout"}
-    words = [t for k, t in rec.ws._bufs.items() if k[0] in ("gen.sync", "gen.sync_bwd")]
-    assert len(words) == 2, "the decoder did not run on its cluster kernels"
-    words[1][0] = 1        # "a work-group of the cluster was never scheduled"
-    tr.train_step(batch)                     # a replay of the captured step
-    torch.cuda.synchronize()
-    assert tr.step_was_skipped()
-    for k, v in rec.store.get_values().items():
-        assert (v == before[k]).all(), "a skipped step changed %s" % k
-    for k, v in tr.state_dict().items():
-        if k != "layout":
-            assert (numpy.asarray(v) == state[k]).all(), "a skipped step changed the optimiser's %s" % k
-    tr.recover()
-    tr.train_step(batch)
-    torch.cuda.synchronize()
-    assert not tr.step_was_skipped() and rec.generator.use_persistent is False and not rec.encoder.use_persistent
-    got, want = rec.store.get_values(), ref.store.get_values()
-    for k in want:
-        scale = max(1e-3, numpy.abs(want[k]).max())
-        # (four AdaDelta steps from zero statistics: the first steps are sign-like and amplify the float32 differences between the
-        # cluster kernels of steps 1-3 and the step kernels of the reference run)
-        assert numpy.abs(got[k] - want[k]).max() / scale < 2e-2, k
+        torch.cuda.synchronize()
+        assert not tr.step_was_skipped() and rec.generator.use_persistent is not False and rec.encoder.use_persistent
+        got, want = rec.store.get_values(), ref.store.get_values()
+        for k in want:
+            scale = max(1e-3, numpy.abs(want[k]).max())
+            # (four AdaDelta steps from zero statistics: the first steps are sign-like and amplify the float32 differences between the
+            # cluster kernels and the step kernels of the reference run)
+            assert numpy.abs(got[k] - want[k]).max() / scale < 2e-2, k
+        # a second abort within REARM_STEPS: step kernels for a while, then the cluster kernels again
+        tr.REARM_STEPS = 2
+        words = [t for k, t in rec.ws._bufs.items() if k[0] in ("gen.sync", "gen.sync_bwd")]
+        words[0][0] = 1
+        tr.train_step(batch)
+        torch.cuda.synchronize()
+        assert tr.step_was_skipped()
+        action = tr.recover()
+        assert action["action"] == "step_kernels" and rec.generator.use_persistent is False and not rec.encoder.use_persistent
+        for _ in range(2):
+            tr.train_step(batch)
+            torch.cuda.synchronize()
+            assert not tr.step_was_skipped() and tr._fallback is not None
+        tr.train_step(batch)                     # armed again
+        torch.cuda.synchronize()
+        assert tr._fallback is None and rec.encoder.use_persistent and rec.generator.use_persistent is not False
+        assert not tr.step_was_skipped()
+        tr.train_step(batch)
+        torch.cuda.synchronize()
+        rec.generator.check_persistent()
+        rec.encoder.check_persistent()
+        assert not tr.step_was_skipped()
+    finally:
+        lib.set_knob("cluster_reserve", 0)

@@ -11,7 +11,10 @@ for what in "$@"; do
     k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > "$O/pytest_k_$(echo ${what#k:} | cut -c1-12 | tr " " _).log" 2>&1; echo "pytest -k rc=$?"; grep "^E " $O/pytest_k_*.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_k_*.log;;
     testsk:*) k=${what#testsk:}; timeout 900 python -m pytest tests -m gpu -x -q --knob $k > $O/pytest_$k.log 2>&1; echo "pytest --knob $k rc=$?"; tail -n 3 $O/pytest_$k.log;;
     newtests) timeout 900 python -m pytest tests -m gpu -x -q -k "wsj_base_median or whole_list or persistent_decoder or wsj_deep or wsj_paper or stack2" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -n 6 $O/pytest_new.log;;
-    bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step')}, d.get('sustained'), d.get('strong'), {k:(v.get('achieved'),v.get('frac'),v.get('launch_us')) for k,v in d.get('fbank',{}).items() if isinstance(v,dict)}, d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
+    parity) timeout 1500 python tools/full_size_parity.py > $O/full_size_parity.md 2> $O/full_size_parity.err; echo "parity rc=$?"; cat $O/full_size_parity.md | cut -c1-330; tail -n 3 $O/full_size_parity.err;;
+    nk:*) timeout 1500 python -m pytest tests -m gpu -q -k "${what#nk:}" > "$O/pytest_nk.log" 2>&1; echo "pytest -k rc=$?"; grep "^E \|^FAILED\|^ERROR" $O/pytest_nk.log | cut -c1-400 | head -n 40; tail -n 3 $O/pytest_nk.log;;
+    ragged) timeout 300 python bench.py --steps 10 --warmup 3 --ragged $B > $O/ragged.json 2> $O/ragged.err; python -c "import json;d=json.load(open('$O/ragged.json'));print('ragged', d['ms_per_step'], d['value'])"; tail -n 1 $O/ragged.err;;
+    bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step','self_check','ragged')}, d.get('decode'), d.get('sustained'), d.get('strong'), {k:(v.get('achieved'),v.get('frac'),v.get('launch_us')) for k,v in d.get('fbank',{}).items() if isinstance(v,dict)}, d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
     quick) timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; python -c "import json;d=json.load(open('$O/quick.json'));print('wsj_base', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 2 $O/quick.err;;
     quick8) timeout 300 python bench.py --steps 20 --warmup 5 $B --knob dec_cluster=8 > $O/quick8.json 2> $O/quick8.err; python -c "import json;d=json.load(open('$O/quick8.json'));print('wsj_base clusters of 8', d['ms_per_step'], d['value'])"; tail -n 2 $O/quick8.err;;
     dec) for k in dec_cluster=0 dec_cluster=8; do timeout 300 python tools/probe_decoder_persist.py wsj_base $k > $O/dec_fwd_$k.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base $k > $O/dec_bwd_$k.txt 2>&1; echo "== $k"; grep -v "^    " $O/dec_fwd_$k.txt | tail -n 4; grep -v "^    " $O/dec_bwd_$k.txt | tail -n 4; done;;
