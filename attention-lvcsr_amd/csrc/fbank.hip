@@ -175,6 +175,51 @@ __device__ __forceinline__ void fbf_radix8(float (&re)[8], float (&im)[8], float
     }
 }
 
+// pass 1 of the FFT: the three stages inside a lane's group of 8 positions have the constant twiddles 1 | 1, -i | 1, W8, -i, W8^3 —
+// written out (a generic complex multiply by 1.0 / 0.0 is not folded away without fast-math: 60 of the 120 operations of a pass)
+__device__ __forceinline__ void fbf_radix8_first(float (&re)[8], float (&im)[8]) {
+    const float R = 0.70710678118654752f;
+#pragma unroll
+    for (int x = 0; x < 8; x += 2) {
+        const float tr = re[x + 1], ti = im[x + 1];
+        re[x + 1] = re[x] - tr; im[x + 1] = im[x] - ti;
+        re[x] += tr; im[x] += ti;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 8; blk += 4) {
+        {
+            const float tr = re[blk + 2], ti = im[blk + 2];
+            re[blk + 2] = re[blk] - tr; im[blk + 2] = im[blk] - ti;
+            re[blk] += tr; im[blk] += ti;
+        }
+        {   // twiddle -i: (tr, ti) = (im, -re)
+            const float tr = im[blk + 3], ti = -re[blk + 3];
+            re[blk + 3] = re[blk + 1] - tr; im[blk + 3] = im[blk + 1] - ti;
+            re[blk + 1] += tr; im[blk + 1] += ti;
+        }
+    }
+    {
+        const float tr = re[4], ti = im[4];
+        re[4] = re[0] - tr; im[4] = im[0] - ti; re[0] += tr; im[0] += ti;
+    }
+    {   // W8 = (R, -R)
+        const float tr = R * (re[5] + im[5]), ti = R * (im[5] - re[5]);
+        re[5] = re[1] - tr; im[5] = im[1] - ti; re[1] += tr; im[1] += ti;
+    }
+    {   // -i
+        const float tr = im[6], ti = -re[6];
+        re[6] = re[2] - tr; im[6] = im[2] - ti; re[2] += tr; im[2] += ti;
+    }
+    {   // W8^3 = (-R, -R)
+        const float tr = R * (im[7] - re[7]), ti = -R * (re[7] + im[7]);
+        re[7] = re[3] - tr; im[7] = im[3] - ti; re[3] += tr; im[3] += ti;
+    }
+}
+
+// Round 5: TWO frames per transform.  The samples are real, so one 512-point complex FFT serves a pair of frames: z = x_a + i x_b,
+//   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / 2i
+// — half the butterflies and half the LDS exchanges per frame; the split needs bin N-k, which sits in another lane: Z goes through
+// the wave's LDS slice in plain order once (where the power spectrum went before) and comes back reversed.
 template <int SP>      // registers for the mel weights of a lane's filter: the longest span rounded up to 32 / 64
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
                                                                    int total_frames, lvsr_fbank_cfg c, const float* window, const int* mel_start,
@@ -209,9 +254,6 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     for (int j = 0; j < 2; ++j) tw(128, lane + 64 * j, p3w2r[j], p3w2i[j]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) tw(256, lane + 64 * j, p3w4r[j], p3w4i[j]);
-    const float R = 0.70710678118654752f;
-    const float p1w2r[2] = {1.f, 0.f}, p1w2i[2] = {0.f, -1.f};
-    const float p1w4r[4] = {1.f, R, 0.f, -R}, p1w4i[4] = {0.f, -R, -1.f, -R};
     float winv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) winv[k] = (lane + 64 * k) < c.frame_length ? window[lane + 64 * k] : 0.f;
@@ -228,19 +270,19 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 #pragma unroll
     for (int i = 0; i < SP; ++i) mwv[i] = (lane < c.num_mel && i - msh >= 0) ? mel_w[(size_t)mf * FBF_SPAN + (i - msh)] : 0.f;
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
-    // the samples of a frame are fetched one frame ahead (a wave works on its frames one after the other: without it every frame
+    // the samples of a pair are fetched one pair ahead (a wave works on its pairs one after the other: without it every pair
     // starts with two dependent memory latencies — the utterance's sample offset, then the samples)
-    short nx[8];
-    auto fetch = [&](int f) {
-        const int u = fb_find_utt(foff, n_utts, f);
-        const long long s0 = wav_off[u] + (long long)(f - foff[u]) * c.frame_shift;
+    short nxa[8], nxb[8];
+    auto fetch = [&](int f, short (&nx)[8]) {
+        const bool live = f < total_frames;
+        const int u = fb_find_utt(foff, n_utts, live ? f : 0);
+        const long long s0 = wav_off[u] + (long long)((live ? f : 0) - foff[u]) * c.frame_shift;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) nx[k] = (lane + 64 * k) < c.frame_length ? wav[s0 + lane + 64 * k] : (short)0;
+        for (int k = 0; k < 8; ++k) nx[k] = (live && (lane + 64 * k) < c.frame_length) ? wav[s0 + lane + 64 * k] : (short)0;
     };
-    const int f_first = blockIdx.x * FBF_WAVES + wave, f_step = gridDim.x * FBF_WAVES;
-    if (f_first < total_frames) fetch(f_first);
-    for (int f = f_first; f < total_frames; f += f_step) {
-        // ---- samples n = lane + 64 k, mean, raw energy (after DC removal, before pre-emphasis / windowing)
+    // samples n = lane + 64 k of one frame -> DC removal, raw energy (after DC removal, before pre-emphasis / windowing), pre-emphasis
+    // (x[n-1] sits one lane down; lane 0: lane 63 of the previous k), window; the result lands at the lane's pass-1 positions brev3(k)
+    auto prepare = [&](const short (&nx)[8], float (&dst)[8]) -> float {
         float xv[8];
         float sum = 0.f;
 #pragma unroll
@@ -248,7 +290,6 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             xv[k] = (float)nx[k];
             sum += xv[k];
         }
-        if (f + f_step < total_frames) fetch(f + f_step);
         const float mean = c.remove_dc ? wave_sum_dpp(sum) / (float)c.frame_length : 0.f;
         float e = 0.f;
 #pragma unroll
@@ -257,26 +298,28 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             e += xv[k] * xv[k];
         }
         e = wave_sum_dpp(e);
-        // ---- pre-emphasis: x[n-1] sits one lane down (lane 0: lane 63 of the previous k); window
-        float ar[8], ai[8];
-        {
-            float prev[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane instead of two LDS-crossbar shuffles
-                const float dn = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k]), 0x138, 0xf, 0xf, false));
-                const float wrap = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0]), 63)) : xv[0];
-                prev[k] = lane > 0 ? dn : wrap;
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
-                ar[lo] = (xv[k] - c.preemph * prev[k]) * winv[k];
-                ai[lo] = 0.f;
-            }
+        for (int k = 0; k < 8; ++k) {
+            // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane instead of two LDS-crossbar shuffles
+            const float dn = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k]), 0x138, 0xf, 0xf, false));
+            const float wrap = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0]), 63)) : xv[0];
+            const float prev = lane > 0 ? dn : wrap;
+            const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
+            dst[lo] = (xv[k] - c.preemph * prev) * winv[k];
         }
+        return e;
+    };
+    const int n_pairs = (total_frames + 1) / 2;
+    const int p_first = blockIdx.x * FBF_WAVES + wave, p_step = gridDim.x * FBF_WAVES;
+    if (p_first < n_pairs) { fetch(2 * p_first, nxa); fetch(2 * p_first + 1, nxb); }
+    for (int pr = p_first; pr < n_pairs; pr += p_step) {
+        const int fa = 2 * pr, fb = fa + 1;
+        float ar[8], ai[8];
+        const float ea = prepare(nxa, ar);
+        const float eb = prepare(nxb, ai);
+        if (pr + p_step < n_pairs) { fetch(2 * (pr + p_step), nxa); fetch(2 * (pr + p_step) + 1, nxb); }
         // ---- pass 1: stages 1-3 inside the lane's group of 8 positions (twiddles 1 | 1, -i | W8^j)
-        fbf_radix8(ar, ai, 1.f, 0.f, p1w2r, p1w2i, p1w4r, p1w4i);
+        fbf_radix8_first(ar, ai);
 #pragma unroll
         for (int lo = 0; lo < 8; ++lo) { re[at1[lo]] = ar[lo]; im[at1[lo]] = ai[lo]; }
         __builtin_amdgcn_wave_barrier();
@@ -293,19 +336,39 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         for (int h = 0; h < 8; ++h) { ar[h] = re[at3[h]]; ai[h] = im[at3[h]]; }
         fbf_radix8(ar, ai, p3w1r, p3w1i, p3w2r, p3w2i, p3w4r, p3w4i);
         __builtin_amdgcn_wave_barrier();
-        // ---- power spectrum of bins 0..255 (plain order in the wave's slice), mel filters, log
+        // ---- split the pair: Z in plain order through the slice, bin N - k read back
 #pragma unroll
-        for (int h = 0; h < 4; ++h) re[lane + 64 * h] = ar[h] * ar[h] + ai[h] * ai[h];
+        for (int h = 0; h < 8; ++h) { re[lane + 64 * h] = ar[h]; im[lane + 64 * h] = ai[h]; }
         __builtin_amdgcn_wave_barrier();
-        float* o = out + (size_t)f * width;
-        {
-            float acc = 0.f;
-            const float* pwr = re + mst;
+        float pa[4], pb[4];
 #pragma unroll
-            for (int i = 0; i < SP; ++i) acc += mwv[i] * pwr[i];
-            if (lane < c.num_mel) o[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc, 1.1920929e-07f));
+        for (int h = 0; h < 4; ++h) {
+            const int k2 = (FB_NFFT - (lane + 64 * h)) & (FB_NFFT - 1);
+            const float yr = re[k2], yi = im[k2];
+            const float sr = ar[h] + yr, di = ai[h] - yi, si = ai[h] + yi, dr = ar[h] - yr;
+            pa[h] = 0.25f * (sr * sr + di * di);          // |X_a[k]|^2
+            pb[h] = 0.25f * (si * si + dr * dr);          // |X_b[k]|^2
         }
-        if (c.use_energy && lane == 0) o[0] = logf(fmaxf(e, 1.1920929e-07f));
+        __builtin_amdgcn_wave_barrier();
+        // ---- power spectra of bins 0..255 (plain order: frame a in `re`, frame b in `im`), mel filters, log
+#pragma unroll
+        for (int h = 0; h < 4; ++h) { re[lane + 64 * h] = pa[h]; im[lane + 64 * h] = pb[h]; }
+        __builtin_amdgcn_wave_barrier();
+        {
+            float acca = 0.f, accb = 0.f;
+            const float* pwa = re + mst;
+            const float* pwb = im + mst;
+#pragma unroll
+            for (int i = 0; i < SP; ++i) { acca += mwv[i] * pwa[i]; accb += mwv[i] * pwb[i]; }
+            float* oa = out + (size_t)fa * width;
+            if (lane < c.num_mel) oa[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acca, 1.1920929e-07f));
+            if (c.use_energy && lane == 0) oa[0] = logf(fmaxf(ea, 1.1920929e-07f));
+            if (fb < total_frames) {
+                float* ob = out + (size_t)fb * width;
+                if (lane < c.num_mel) ob[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(accb, 1.1920929e-07f));
+                if (c.use_energy && lane == 0) ob[0] = logf(fmaxf(eb, 1.1920929e-07f));
+            }
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -382,8 +445,8 @@ int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, c
     LVSR_REQUIRE(c.frame_length > 1 && c.frame_length <= FB_MAX_FRAME && c.frame_shift > 0 && c.num_mel > 0 && c.num_mel <= 64,
                  "lvsr_fbank_batch: unsupported framing (frame_length <= 512, num_mel <= 64; filter spans <= 64 bins: use lvsr_fbank otherwise)");
     if (total_frames <= 0) return LVSR_OK;
-    int nb = (total_frames + FBF_WAVES - 1) / FBF_WAVES;
-    if (nb > 2048) nb = 2048;          // grid-stride over the frames: the tables are staged once per work-group
+    int nb = ((total_frames + 1) / 2 + FBF_WAVES - 1) / FBF_WAVES;        // a wave takes a PAIR of frames per transform
+    if (nb > 2048) nb = 2048;          // grid-stride over the pairs: the tables are staged once per work-group
     LVSR_REQUIRE(mel_span >= 0 && mel_span <= FBF_SPAN, "lvsr_fbank_batch: mel_span outside [0, 64]");
     if (mel_span > 0 && mel_span <= 32)
         hipLaunchKernelGGL(fbank_fft_kernel<32>, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,

@@ -522,7 +522,30 @@ def main(backend=None):
         el, _ = timed(trainer, rb, n_rg, global_batch, 3)
         ragged = dict(steps=n_rg, ms_per_step=el / n_rg * 1e3, real_frames_per_step=rframes, padded_frames_per_step=float(global_batch * T),
                       value=rframes * n_rg / el, unit="real frames/s", fraction_of_all_ones_value=(rframes * n_rg / el) / (frames_per_step * args.steps / elapsed),
-                      how="T_i ~ U{T/2..T}, L_i ~ U{L/2..L} (synthetic.make_batch(ragged=True)), zero padded; frames counted = sum of the input mask")
+                      how="T_i ~ U{T/2..T}, L_i ~ U{L/2..L} (synthetic.make_batch(ragged=True)), zero padded; frames counted = sum of the input mask",
+                      note="one utterance per cluster and as many clusters as the chip holds: the step lasts as long as its longest "
+                           "utterance's chain, so iid lengths cost mean/max of the throughput whatever the kernels do (DESIGN.md 6); what "
+                           "removes the padding is the reference's own length bucketing, below")
+        # the same length distribution through the reference's data pipeline option `sort_k_batches` (lvsr/datasets/__init__.py:281-293,
+        # lvsr_amd.data.Data._sort_k): 8 minibatches' worth of utterances sorted by length, cut into minibatches, every minibatch
+        # padded to ITS longest utterance (rounded up to 32 frames: few distinct shapes = few captured step graphs)
+        if world == 1:
+            from lvsr_amd.data import Data
+            K = 8
+            big = synthetic.make_batch(cfg, global_batch * K, T, L, seed=3456, ragged=True)
+            tl, ll = big["recordings_mask"].sum(0).astype(int), big["labels_mask"].sum(0).astype(int)
+            exs = [(big["recordings"][: tl[i], i], big["labels"][: ll[i], i]) for i in range(global_batch * K)]
+            exs = list(Data._sort_k(iter(exs), global_batch * K))
+            sb, sframes, shapes = [], 0.0, []
+            for k in range(K):
+                pb = Data.pad_batch(exs[k * global_batch: (k + 1) * global_batch], pad_frames_to=32, pad_labels_to=4)
+                sframes += float(pb["recordings_mask"].sum())
+                shapes.append([int(pb["recordings"].shape[0]), int(pb["labels"].shape[0])])
+                sb.append({kk: torch.from_numpy(numpy.ascontiguousarray(v)).to(dev) for kk, v in pb.items()})
+            el, _ = timed(trainer, sb, 2 * K, global_batch, 3 * K)          # every shape: eager, captured, replayed once before the clock
+            ragged["sort_k_batches"] = dict(k=K, minibatch_shapes_TL=shapes, steps=2 * K, ms_per_step=el / (2 * K) * 1e3,
+                                            real_frames_per_step=sframes / K, value=2 * sframes / el, unit="real frames/s",
+                                            fraction_of_all_ones_value=(2 * sframes / el) / (frames_per_step * args.steps / elapsed))
 
     # ---- strong scaling (north_star: global batch 128 = BASELINE configs[2] sharded over the ranks, rank r takes r::N; target >= 6x
     # at 8 GPUs): the same job in the SAME launch as the weak line, and the one-GPU step at that global batch it is measured against

@@ -122,6 +122,7 @@ def test_fbank_emulated():
 def test_fbank_batch_emulated():
     from emu import emu_lib
     run_fbank_batch("cpu", emu_lib(), [400 + 160 * 3, 100, 400, 400 + 160 * 6 + 77])
+    run_fbank_batch("cpu", emu_lib(), [400 + 160 * 3, 100, 400, 400 + 160 * 6 + 77, 400 + 160 * 2])     # an odd number of frames: the last pair is half empty
 
 
 @pytest.mark.gpu
