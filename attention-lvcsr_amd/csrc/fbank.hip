@@ -125,7 +125,6 @@ __global__ __launch_bounds__(256) void deltas_cmvn_kernel(const float* feats, in
 //   at most (fbf_addr);
 // then the power spectrum and the mel filters from their non-zero spans, the weights of a lane's filter in REGISTERS.
 #define FBF_WAVES 4
-#define FBF_SPAN 64            // longest mel-filter span the packed table holds
 #define FBF_OFFS 2048          // frame offsets staged in LDS (a binary search through global memory costs ~10 dependent loads per frame)
 
 __device__ __forceinline__ int fb_bitrev(int n, int bits) {
@@ -220,18 +219,26 @@ __device__ __forceinline__ void fbf_radix8_first(float (&re)[8], float (&im)[8])
 //   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / 2i
 // — half the butterflies and half the LDS exchanges per frame; the split needs bin N-k, which sits in another lane: Z goes through
 // the wave's LDS slice in plain order once (where the power spectrum went before) and comes back reversed.
-template <int SP>      // registers for the mel weights of a lane's filter: the longest span rounded up to 32 / 64
+// Mel filters as at most 64 work items (filter, 16-bin chunk starting at a multiple of 4 bins), one per lane: 4 x 16-byte LDS reads and
+// 16 multiply-adds per frame and lane (the recipe's 40 filters, spans 3..31 bins, are 53 items; a lane per FILTER had to carry the
+// longest span: 32 reads / multiply-adds and 32 weight registers), the chunks of a filter summed by its lane through 64 LDS words.
+#define FBF_CHUNK 16
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
-                                                                   int total_frames, lvsr_fbank_cfg c, const float* window, const int* mel_start,
-                                                                   const float* mel_w, const float* twid, float* out) {
+                                                                   int total_frames, lvsr_fbank_cfg c, const float* window, const int* item_bin,
+                                                                   const int* item_first, const float* item_w, int n_items, const float* twid,
+                                                                   float* out) {
     __shared__ int offs[FBF_OFFS];
+    // (the utterances' sample offsets too: from global memory a frame's fetch was a chain of TWO dependent memory latencies — offset,
+    // then samples — which set the time per pair once the transform itself got cheaper: 487 us with it, round 5)
+    __shared__ long long woffs[FBF_OFFS];
     __shared__ float re_all[FBF_WAVES][FB_NFFT], im_all[FBF_WAVES][FB_NFFT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool offs_lds = n_utts + 1 <= FBF_OFFS;
     if (offs_lds)
-        for (int x = tid; x <= n_utts; x += 64 * FBF_WAVES) offs[x] = frame_off[x];
+        for (int x = tid; x <= n_utts; x += 64 * FBF_WAVES) { offs[x] = frame_off[x]; woffs[x] = wav_off[x]; }
     __syncthreads();
     const int* const foff = offs_lds ? offs : frame_off;
+    const long long* const woff = offs_lds ? woffs : wav_off;
     float* const re = re_all[wave];
     float* const im = im_all[wave];
     // ---- per-lane constants, in registers for every frame of the wave
@@ -262,13 +269,12 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     int at1[8], at2[8], at3[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) { at1[x] = fbf_addr(h1, m1, x); at2[x] = fbf_addr(h2, x, lo2); at3[x] = fbf_addr(x, m3, lo3); }
-    // mel filter of this lane: first bin, weights of its span
-    // (a filter that starts fewer than SP bins below bin 256 is shifted down, its weights up: the loop reads SP bins unconditionally)
-    const int mf = lane < c.num_mel ? lane : 0;
-    const int mst0 = mel_start[mf], mst = min(mst0, FB_NFFT / 2 - SP), msh = mst0 - mst;
-    float mwv[SP];
+    // this lane's mel work item: first bin (a multiple of 4), its 16 weights; as a FILTER lane: the range of items to add up
+    const int ibin = lane < n_items ? item_bin[lane] : 0;
+    float mwv[FBF_CHUNK];
 #pragma unroll
-    for (int i = 0; i < SP; ++i) mwv[i] = (lane < c.num_mel && i - msh >= 0) ? mel_w[(size_t)mf * FBF_SPAN + (i - msh)] : 0.f;
+    for (int i = 0; i < FBF_CHUNK; ++i) mwv[i] = lane < n_items ? item_w[(size_t)lane * FBF_CHUNK + i] : 0.f;
+    const int it0 = lane < c.num_mel ? item_first[lane] : 0, it1 = lane < c.num_mel ? item_first[lane + 1] : 0;
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
     // the samples of a pair are fetched one pair ahead (a wave works on its pairs one after the other: without it every pair
     // starts with two dependent memory latencies — the utterance's sample offset, then the samples)
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     auto fetch = [&](int f, short (&nx)[8]) {
         const bool live = f < total_frames;
         const int u = fb_find_utt(foff, n_utts, live ? f : 0);
-        const long long s0 = wav_off[u] + (long long)((live ? f : 0) - foff[u]) * c.frame_shift;
+        const long long s0 = woff[u] + (long long)((live ? f : 0) - foff[u]) * c.frame_shift;
 #pragma unroll
         for (int k = 0; k < 8; ++k) nx[k] = (live && (lane + 64 * k) < c.frame_length) ? wav[s0 + lane + 64 * k] : (short)0;
     };
@@ -356,10 +362,19 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         __builtin_amdgcn_wave_barrier();
         {
             float acca = 0.f, accb = 0.f;
-            const float* pwa = re + mst;
-            const float* pwb = im + mst;
+            const float4* pwa = (const float4*)(re + ibin);
+            const float4* pwb = (const float4*)(im + ibin);
 #pragma unroll
-            for (int i = 0; i < SP; ++i) { acca += mwv[i] * pwa[i]; accb += mwv[i] * pwb[i]; }
+            for (int i = 0; i < FBF_CHUNK / 4; ++i) {
+                const float4 va = pwa[i], vb = pwb[i];
+                acca += mwv[4 * i] * va.x + mwv[4 * i + 1] * va.y + mwv[4 * i + 2] * va.z + mwv[4 * i + 3] * va.w;
+                accb += mwv[4 * i] * vb.x + mwv[4 * i + 1] * vb.y + mwv[4 * i + 2] * vb.z + mwv[4 * i + 3] * vb.w;
+            }
+            // (words 384..447 of the slices: beyond every chunk — bins < 256 + 16 — and free once the split has read Z)
+            re[384 + lane] = acca; im[384 + lane] = accb;
+            __builtin_amdgcn_wave_barrier();
+            acca = accb = 0.f;
+            for (int it = it0; it < it1; ++it) { acca += re[384 + it]; accb += im[384 + it]; }
             float* oa = out + (size_t)fa * width;
             if (lane < c.num_mel) oa[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acca, 1.1920929e-07f));
             if (c.use_energy && lane == 0) oa[0] = logf(fmaxf(ea, 1.1920929e-07f));
@@ -437,23 +452,19 @@ int lvsr_add_deltas_cmvn(void* stream, const float* feats, int T, int dim, const
 }
 
 int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, const int* frame_off, int n, int total_frames,
-                     const lvsr_fbank_cfg* cfg, const float* window, const int* mel_start, const float* mel_w, int mel_span,
-                     const float* twiddle, float* out) {
-    LVSR_REQUIRE(cfg && wav && wav_off && frame_off && window && mel_start && mel_w && twiddle && out && n > 0, "lvsr_fbank_batch: null argument");
+                     const lvsr_fbank_cfg* cfg, const float* window, const int* item_bin, const int* item_first, const float* item_w,
+                     int n_items, const float* twiddle, float* out) {
+    LVSR_REQUIRE(cfg && wav && wav_off && frame_off && window && item_bin && item_first && item_w && twiddle && out && n > 0, "lvsr_fbank_batch: null argument");
+    LVSR_REQUIRE(n_items > 0 && n_items <= 64, "lvsr_fbank_batch: the mel filters must be at most 64 (filter, 16-bin chunk) items (use lvsr_fbank otherwise)");
     lvsr_fbank_cfg c;
     memcpy(&c, cfg, sizeof(c));
     LVSR_REQUIRE(c.frame_length > 1 && c.frame_length <= FB_MAX_FRAME && c.frame_shift > 0 && c.num_mel > 0 && c.num_mel <= 64,
-                 "lvsr_fbank_batch: unsupported framing (frame_length <= 512, num_mel <= 64; filter spans <= 64 bins: use lvsr_fbank otherwise)");
+                 "lvsr_fbank_batch: unsupported framing (frame_length <= 512, num_mel <= 64: use lvsr_fbank otherwise)");
     if (total_frames <= 0) return LVSR_OK;
     int nb = ((total_frames + 1) / 2 + FBF_WAVES - 1) / FBF_WAVES;        // a wave takes a PAIR of frames per transform
     if (nb > 2048) nb = 2048;          // grid-stride over the pairs: the tables are staged once per work-group
-    LVSR_REQUIRE(mel_span >= 0 && mel_span <= FBF_SPAN, "lvsr_fbank_batch: mel_span outside [0, 64]");
-    if (mel_span > 0 && mel_span <= 32)
-        hipLaunchKernelGGL(fbank_fft_kernel<32>, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
-                           window, mel_start, mel_w, twiddle, out);
-    else
-        hipLaunchKernelGGL(fbank_fft_kernel<64>, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
-                           window, mel_start, mel_w, twiddle, out);
+    hipLaunchKernelGGL(fbank_fft_kernel, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
+                       window, item_bin, item_first, item_w, n_items, twiddle, out);
     return lvsr_check_launch("lvsr_fbank_batch");
 }
 

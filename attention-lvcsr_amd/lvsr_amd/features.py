@@ -36,21 +36,25 @@ class Fbank(object):
         ang = 2 * numpy.pi * numpy.arange(512) / 512.0
         t = lambda a: torch.tensor(numpy.asarray(a, numpy.float32), device=self.device)
         self.window, self.melw, self.twiddle = t(win), t(W), t(numpy.stack([numpy.cos(ang), numpy.sin(ang)]))
-        # the filters' non-zero spans for the batched kernel (lvsr_fbank_batch): first bin and up to 64 weights per filter
-        starts, packed, self.batchable = numpy.zeros(self.num_mel, numpy.int32), numpy.zeros((self.num_mel, 64), numpy.float32), self.num_mel <= 64
-        self.mel_span = 0
+        # the filters as work items of the batched kernel (lvsr_fbank_batch): (filter, chunk of 16 bins starting at a multiple of 4)
+        CH = 16
+        bins, first, weights = [], [0], []
         for b in range(self.num_mel):
             nz = numpy.nonzero(W[b])[0]
-            if len(nz) == 0:
-                continue
-            if nz[-1] - nz[0] + 1 > 64:
-                self.batchable = False
-                break
-            starts[b] = nz[0]
-            packed[b, : nz[-1] - nz[0] + 1] = W[b, nz[0]: nz[-1] + 1]
-            self.mel_span = max(self.mel_span, int(nz[-1] - nz[0] + 1))
-        self.mel_start = torch.tensor(starts, device=self.device)
-        self.mel_packed = t(packed)
+            if len(nz):
+                s4 = int(nz[0]) // 4 * 4
+                for b0 in range(s4, int(nz[-1]) + 1, CH):
+                    w = numpy.zeros(CH, numpy.float32)
+                    hi = min(256, b0 + CH)
+                    w[: hi - b0] = W[b, b0: hi]
+                    bins.append(b0)
+                    weights.append(w)
+            first.append(len(bins))
+        self.batchable = self.num_mel <= 64 and 0 < len(bins) <= 64
+        self.mel_items = len(bins)
+        self.mel_item_bin = torch.tensor(numpy.asarray(bins or [0], numpy.int32), device=self.device)
+        self.mel_item_first = torch.tensor(numpy.asarray(first, numpy.int32), device=self.device)
+        self.mel_item_w = t(numpy.stack(weights) if weights else numpy.zeros((1, CH), numpy.float32))
 
     def num_frames(self, nsamp):
         return int(self.lib._lvsr_fbank_num_frames(int(nsamp), ctypes.byref(self.cfg)))
@@ -85,7 +89,8 @@ class Fbank(object):
         out = torch.empty(total_frames, self.num_mel + int(self.use_energy), dtype=torch.float32, device=self.device)
         if total_frames:
             self.lib.call("lvsr_fbank_batch", self.lib.stream_for(out), ptr(wav), ptr(wav_off), ptr(frame_off), int(n), int(total_frames),
-                          ctypes.byref(self.cfg), ptr(self.window), ptr(self.mel_start), ptr(self.mel_packed), int(self.mel_span), ptr(self.twiddle), ptr(out))
+                          ctypes.byref(self.cfg), ptr(self.window), ptr(self.mel_item_bin), ptr(self.mel_item_first), ptr(self.mel_item_w), int(self.mel_items),
+                          ptr(self.twiddle), ptr(out))
         return out, frame_off
 
     def add_deltas_cmvn_batch(self, feats, frame_off, mean=None, std=None):

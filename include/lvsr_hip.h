@@ -533,12 +533,14 @@ int lvsr_add_deltas_cmvn(void* stream, const float* feats, int T, int dim, const
 /* The same front end for a SET of utterances in one launch (the streaming form: 320 bytes of new PCM in, 164 bytes of features out per
  * frame): `wav` holds the utterances' PCM back to back, utterance u = samples [wav_off[u], wav_off[u+1]) and output rows
  * [frame_off[u], frame_off[u+1]) (device arrays of n + 1 entries; frame_off[u+1] - frame_off[u] = lvsr_fbank_num_frames of its
- * length).  One wave per frame, a 512-point FFT in LDS instead of the direct DFT; the mel filters come as their non-zero spans:
- * mel_start (num_mel) first bin, mel_w (num_mel, 64) weights (zero padded), mel_span = the longest span (0 = unknown: 64) — num_mel
- * <= 64, spans <= 64 bins (the 40-filter front end of the recipe: <= 31).  Same arithmetic up to float32 summation order. */
+ * length).  One wave per PAIR of frames (the samples are real: one 512-point complex FFT in registers / LDS transforms two frames)
+ * instead of the direct DFT; the mel filters come as n_items <= 64 work items (filter, chunk of 16 bins starting at a multiple of 4):
+ * item_bin (n_items) first bin of an item, item_w (n_items, 16) its weights (zero outside the filter), item_first (num_mel + 1): the
+ * items of filter j are [item_first[j], item_first[j + 1]) — the 40-filter front end of the recipe is 53 items.  num_mel <= 64.
+ * Same arithmetic up to float32 summation order. */
 int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, const int* frame_off, int n, int total_frames,
-                     const lvsr_fbank_cfg* cfg, const float* window, const int* mel_start, const float* mel_w, int mel_span,
-                     const float* twiddle, float* out);
+                     const lvsr_fbank_cfg* cfg, const float* window, const int* item_bin, const int* item_first, const float* item_w,
+                     int n_items, const float* twiddle, float* out);
 /* deltas + CMVN over the same set: edge frames replicated per utterance */
 int lvsr_add_deltas_cmvn_batch(void* stream, const float* feats, const int* frame_off, int n, int total_frames, int dim, const float* mean,
                                const float* istd, float* out);

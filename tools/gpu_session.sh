@@ -7,7 +7,8 @@ export PYTHONUNBUFFERED=1
 B="--no-cpu-baseline --no-decode --no-fbank --no-strong --sustained-seconds 0"
 for what in "$@"; do
   case $what in
-    tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -n 4 $O/pytest.log;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep "^FAILED\|^ERROR" $O/pytest.log | cut -c1-200 | head -n 30; tail -n 4 $O/pytest.log;;
+    fbank) timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-decode --no-strong --no-ragged --sustained-seconds 0 > $O/fbank.json 2> $O/fbank.err; python -c "import json;d=json.load(open('$O/fbank.json'));print({k:(v.get('achieved'),v.get('frac'),v.get('launch_us')) for k,v in d.get('fbank',{}).items() if isinstance(v,dict)})"; tail -n 2 $O/fbank.err;;
     k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > "$O/pytest_k_$(echo ${what#k:} | cut -c1-12 | tr " " _).log" 2>&1; echo "pytest -k rc=$?"; grep "^E " $O/pytest_k_*.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_k_*.log;;
     testsk:*) k=${what#testsk:}; timeout 900 python -m pytest tests -m gpu -x -q --knob $k > $O/pytest_$k.log 2>&1; echo "pytest --knob $k rc=$?"; tail -n 3 $O/pytest_$k.log;;
     newtests) timeout 900 python -m pytest tests -m gpu -x -q -k "wsj_base_median or whole_list or persistent_decoder or wsj_deep or wsj_paper or stack2" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -n 6 $O/pytest_new.log;;
