@@ -147,81 +147,65 @@ __device__ __forceinline__ int fb_find_utt(const int* frame_off, int n, int f) {
     }
     return lo;
 }
+// Complex values as (re, im) pairs on the packed-float32 pipe (v_pk_mul / v_pk_fma / v_pk_add_f32: two float32 operations per
+// instruction).  A radix-2 butterfly with twiddle w = (wr, wi):  t = w v = wr (vr, vi) + (-wi, wi) (vi, vr);  v' = u - t;  u' = u + t
+// — four instructions: the broadcast of wr / wi, the swap of v's halves and the negation are operand modifiers (op_sel, neg_lo).
+typedef float fb_c32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fbf_bfly(fb_c32& u, fb_c32& v, float wr, float wi) {
+    const fb_c32 sv = __builtin_shufflevector(v, v, 1, 0);
+    const fb_c32 wi2 = {-wi, wi};
+    const fb_c32 t = wr * v + wi2 * sv;
+    v = u - t;
+    u = u + t;
+}
+__device__ __forceinline__ void fbf_bfly_one(fb_c32& u, fb_c32& v) {          // twiddle 1
+    const fb_c32 t = v;
+    v = u - t;
+    u = u + t;
+}
+__device__ __forceinline__ void fbf_bfly_mi(fb_c32& u, fb_c32& v) {           // twiddle -i: t = (vi, -vr)
+    const fb_c32 t = {v.y, -v.x};
+    v = u - t;
+    u = u + t;
+}
 // three radix-2 stages on the 8 values a lane holds (local index = the three index bits the pass works on): stage a pairs (x, x+1)
 // with twiddle w1, stage b pairs (x, x+2) with w2[x & 1], stage c pairs (x, x+4) with w4[x & 3]
-__device__ __forceinline__ void fbf_radix8(float (&re)[8], float (&im)[8], float w1r, float w1i, const float (&w2r)[2], const float (&w2i)[2],
+__device__ __forceinline__ void fbf_radix8(fb_c32 (&z)[8], float w1r, float w1i, const float (&w2r)[2], const float (&w2i)[2],
                                            const float (&w4r)[4], const float (&w4i)[4]) {
 #pragma unroll
-    for (int x = 0; x < 8; x += 2) {
-        const float tr = w1r * re[x + 1] - w1i * im[x + 1], ti = w1r * im[x + 1] + w1i * re[x + 1];
-        re[x + 1] = re[x] - tr; im[x + 1] = im[x] - ti;
-        re[x] += tr; im[x] += ti;
-    }
+    for (int x = 0; x < 8; x += 2) fbf_bfly(z[x], z[x + 1], w1r, w1i);
 #pragma unroll
     for (int blk = 0; blk < 8; blk += 4)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int x = blk + j;
-            const float tr = w2r[j] * re[x + 2] - w2i[j] * im[x + 2], ti = w2r[j] * im[x + 2] + w2i[j] * re[x + 2];
-            re[x + 2] = re[x] - tr; im[x + 2] = im[x] - ti;
-            re[x] += tr; im[x] += ti;
-        }
+        for (int j = 0; j < 2; ++j) fbf_bfly(z[blk + j], z[blk + j + 2], w2r[j], w2i[j]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float tr = w4r[j] * re[j + 4] - w4i[j] * im[j + 4], ti = w4r[j] * im[j + 4] + w4i[j] * re[j + 4];
-        re[j + 4] = re[j] - tr; im[j + 4] = im[j] - ti;
-        re[j] += tr; im[j] += ti;
-    }
+    for (int j = 0; j < 4; ++j) fbf_bfly(z[j], z[j + 4], w4r[j], w4i[j]);
 }
-
-// pass 1 of the FFT: the three stages inside a lane's group of 8 positions have the constant twiddles 1 | 1, -i | 1, W8, -i, W8^3 —
-// written out (a generic complex multiply by 1.0 / 0.0 is not folded away without fast-math: 60 of the 120 operations of a pass)
-__device__ __forceinline__ void fbf_radix8_first(float (&re)[8], float (&im)[8]) {
+// pass 1 of the FFT: the three stages inside a lane's group of 8 positions have the constant twiddles 1 | 1, -i | 1, W8, -i, W8^3
+__device__ __forceinline__ void fbf_radix8_first(fb_c32 (&z)[8]) {
     const float R = 0.70710678118654752f;
 #pragma unroll
-    for (int x = 0; x < 8; x += 2) {
-        const float tr = re[x + 1], ti = im[x + 1];
-        re[x + 1] = re[x] - tr; im[x + 1] = im[x] - ti;
-        re[x] += tr; im[x] += ti;
-    }
+    for (int x = 0; x < 8; x += 2) fbf_bfly_one(z[x], z[x + 1]);
 #pragma unroll
     for (int blk = 0; blk < 8; blk += 4) {
-        {
-            const float tr = re[blk + 2], ti = im[blk + 2];
-            re[blk + 2] = re[blk] - tr; im[blk + 2] = im[blk] - ti;
-            re[blk] += tr; im[blk] += ti;
-        }
-        {   // twiddle -i: (tr, ti) = (im, -re)
-            const float tr = im[blk + 3], ti = -re[blk + 3];
-            re[blk + 3] = re[blk + 1] - tr; im[blk + 3] = im[blk + 1] - ti;
-            re[blk + 1] += tr; im[blk + 1] += ti;
-        }
+        fbf_bfly_one(z[blk], z[blk + 2]);
+        fbf_bfly_mi(z[blk + 1], z[blk + 3]);
     }
-    {
-        const float tr = re[4], ti = im[4];
-        re[4] = re[0] - tr; im[4] = im[0] - ti; re[0] += tr; im[0] += ti;
-    }
-    {   // W8 = (R, -R)
-        const float tr = R * (re[5] + im[5]), ti = R * (im[5] - re[5]);
-        re[5] = re[1] - tr; im[5] = im[1] - ti; re[1] += tr; im[1] += ti;
-    }
-    {   // -i
-        const float tr = im[6], ti = -re[6];
-        re[6] = re[2] - tr; im[6] = im[2] - ti; re[2] += tr; im[2] += ti;
-    }
-    {   // W8^3 = (-R, -R)
-        const float tr = R * (im[7] - re[7]), ti = -R * (re[7] + im[7]);
-        re[7] = re[3] - tr; im[7] = im[3] - ti; re[3] += tr; im[3] += ti;
-    }
+    fbf_bfly_one(z[0], z[4]);
+    fbf_bfly(z[1], z[5], R, -R);
+    fbf_bfly_mi(z[2], z[6]);
+    fbf_bfly(z[3], z[7], -R, -R);
 }
 
-// Round 5: TWO frames per transform.  The samples are real, so one 512-point complex FFT serves a pair of frames: z = x_a + i x_b,
+// Round 5: TWO frames per transform, on the packed-float32 pipe.  The samples are real, so one 512-point complex FFT serves a pair of
+// frames: z = x_a + i x_b,
 //   X_a[k] = (Z[k] + conj Z[N-k]) / 2,   X_b[k] = (Z[k] - conj Z[N-k]) / 2i
-// — half the butterflies and half the LDS exchanges per frame; the split needs bin N-k, which sits in another lane: Z goes through
-// the wave's LDS slice in plain order once (where the power spectrum went before) and comes back reversed.
-// Mel filters as at most 64 work items (filter, 16-bin chunk starting at a multiple of 4 bins), one per lane: 4 x 16-byte LDS reads and
-// 16 multiply-adds per frame and lane (the recipe's 40 filters, spans 3..31 bins, are 53 items; a lane per FILTER had to carry the
-// longest span: 32 reads / multiply-adds and 32 weight registers), the chunks of a filter summed by its lane through 64 LDS words.
+// — half the butterflies and half the LDS exchanges per frame; a (re, im) pair IS (frame a, frame b), so windowing, butterflies, power
+// spectra and mel sums all run two-wide.  The split needs bin N-k, which sits in another lane: Z goes through the wave's LDS slice in
+// plain order once (where the power spectrum went before) and comes back reversed.
+// Mel filters as at most 64 work items (filter, 16-bin chunk starting at a multiple of 4 bins), one per lane: 8 x 16-byte LDS reads and
+// 16 packed multiply-adds per PAIR and lane (the recipe's 40 filters, spans 3..31 bins, are 53 items; a lane per FILTER had to carry the
+// longest span: 32 reads / multiply-adds and 32 weight registers per frame), the chunks of a filter summed by its lane through LDS.
 #define FBF_CHUNK 16
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
                                                                    int total_frames, lvsr_fbank_cfg c, const float* window, const int* item_bin,
@@ -229,18 +213,21 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
                                                                    float* out) {
     __shared__ int offs[FBF_OFFS];
     // (the utterances' sample offsets too: from global memory a frame's fetch was a chain of TWO dependent memory latencies — offset,
-    // then samples — which set the time per pair once the transform itself got cheaper: 487 us with it, round 5)
+    // then samples)
     __shared__ long long woffs[FBF_OFFS];
-    __shared__ float re_all[FBF_WAVES][FB_NFFT], im_all[FBF_WAVES][FB_NFFT];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) fb_c32 z_all[FBF_WAVES][FB_NFFT];
+    // per-lane tables every wave of the work-group shares (the same for all frames; in registers they cost the third wave per SIMD):
+    // the swizzled LDS words of the three exchange patterns (6 x int4 per lane) and the lane's 16 mel weights (4 x float4)
+    __shared__ int4 tab_at[6 * 64];
+    __shared__ float4 tab_w[4 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool offs_lds = n_utts + 1 <= FBF_OFFS;
     if (offs_lds)
         for (int x = tid; x <= n_utts; x += 64 * FBF_WAVES) { offs[x] = frame_off[x]; woffs[x] = wav_off[x]; }
     __syncthreads();
     const int* const foff = offs_lds ? offs : frame_off;
     const long long* const woff = offs_lds ? woffs : wav_off;
-    float* const re = re_all[wave];
-    float* const im = im_all[wave];
+    fb_c32* const zb = z_all[wave];
     // ---- per-lane constants, in registers for every frame of the wave
     // twiddle of stage s (butterflies `half` = 2^(s-1) apart) at offset j: exp(-2 pi i j / (2 half)) = (cos, -sin)(2 pi j (256 / half) / 512)
     auto tw = [&](int half, int j, float& wr, float& wi) {
@@ -265,122 +252,149 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 #pragma unroll
     for (int k = 0; k < 8; ++k) winv[k] = (lane + 64 * k) < c.frame_length ? window[lane + 64 * k] : 0.f;
     const int g1 = fb_bitrev(lane, 6), h1 = g1 >> 3, m1 = g1 & 7;      // pass 1: this lane's samples sit at positions (h1, m1, lo = brev3(k))
-    // the LDS words of the three access patterns are the same for every frame: 24 registers instead of ~240 integer operations per frame
-    int at1[8], at2[8], at3[8];
+    if (wave == 0) {
+        int at[24];
 #pragma unroll
-    for (int x = 0; x < 8; ++x) { at1[x] = fbf_addr(h1, m1, x); at2[x] = fbf_addr(h2, x, lo2); at3[x] = fbf_addr(x, m3, lo3); }
-    // this lane's mel work item: first bin (a multiple of 4), its 16 weights; as a FILTER lane: the range of items to add up
+        for (int x = 0; x < 8; ++x) { at[x] = fbf_addr(h1, m1, x); at[8 + x] = fbf_addr(h2, x, lo2); at[16 + x] = fbf_addr(x, m3, lo3); }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) tab_at[j * 64 + lane] = make_int4(at[4 * j], at[4 * j + 1], at[4 * j + 2], at[4 * j + 3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float w4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w4[e] = lane < n_items ? item_w[(size_t)lane * FBF_CHUNK + 4 * j + e] : 0.f;
+            tab_w[j * 64 + lane] = make_float4(w4[0], w4[1], w4[2], w4[3]);
+        }
+    }
+    __syncthreads();
+    // this lane's mel work item: first bin (a multiple of 4); as a FILTER lane: the range of items to add up
     const int ibin = lane < n_items ? item_bin[lane] : 0;
-    float mwv[FBF_CHUNK];
-#pragma unroll
-    for (int i = 0; i < FBF_CHUNK; ++i) mwv[i] = lane < n_items ? item_w[(size_t)lane * FBF_CHUNK + i] : 0.f;
     const int it0 = lane < c.num_mel ? item_first[lane] : 0, it1 = lane < c.num_mel ? item_first[lane + 1] : 0;
     const int width = c.num_mel + (c.use_energy ? 1 : 0);
-    // the samples of a pair are fetched one pair ahead (a wave works on its pairs one after the other: without it every pair
-    // starts with two dependent memory latencies — the utterance's sample offset, then the samples)
+    // the samples of a pair are fetched one pair ahead (a wave works on its pairs one after the other).  A frame's first sample is
+    // wave-uniform (scalar registers); the loads are unconditional on clamped offsets — lanes beyond the frame, or beyond the end of
+    // the PCM buffer, re-read its last sample and are zeroed by `keep` below — so they issue back to back instead of one exec-masked
+    // branch each
     short nxa[8], nxb[8];
+    const long long wav_last = woff[n_utts] - 1;
     auto fetch = [&](int f, short (&nx)[8]) {
-        const bool live = f < total_frames;
-        const int u = fb_find_utt(foff, n_utts, live ? f : 0);
-        const long long s0 = woff[u] + (long long)((live ? f : 0) - foff[u]) * c.frame_shift;
+        const int fc = min(f, total_frames - 1);
+        const int u = __builtin_amdgcn_readfirstlane(fb_find_utt(foff, n_utts, fc));
+        const long long s0v = woff[u] + (long long)(fc - foff[u]) * c.frame_shift;
+        const long long s0 = ((long long)__builtin_amdgcn_readfirstlane((int)(s0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)s0v);
+        const long long room = wav_last - s0;
+        const int lim = (int)(room < (long long)(c.frame_length - 1) ? room : (long long)(c.frame_length - 1));
+        const short* base = wav + s0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) nx[k] = (live && (lane + 64 * k) < c.frame_length) ? wav[s0 + lane + 64 * k] : (short)0;
+        for (int k = 0; k < 8; ++k) nx[k] = base[min(lane + 64 * k, lim)];
     };
-    // samples n = lane + 64 k of one frame -> DC removal, raw energy (after DC removal, before pre-emphasis / windowing), pre-emphasis
-    // (x[n-1] sits one lane down; lane 0: lane 63 of the previous k), window; the result lands at the lane's pass-1 positions brev3(k)
-    auto prepare = [&](const short (&nx)[8], float (&dst)[8]) -> float {
-        float xv[8];
-        float sum = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            xv[k] = (float)nx[k];
-            sum += xv[k];
-        }
-        const float mean = c.remove_dc ? wave_sum_dpp(sum) / (float)c.frame_length : 0.f;
-        float e = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            xv[k] = (lane + 64 * k) < c.frame_length ? xv[k] - mean : 0.f;
-            e += xv[k] * xv[k];
-        }
-        e = wave_sum_dpp(e);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane instead of two LDS-crossbar shuffles
-            const float dn = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k]), 0x138, 0xf, 0xf, false));
-            const float wrap = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0]), 63)) : xv[0];
-            const float prev = lane > 0 ? dn : wrap;
-            const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
-            dst[lo] = (xv[k] - c.preemph * prev) * winv[k];
-        }
-        return e;
-    };
+    // keep(k): is sample lane + 64 k inside the frame?  Uniform but for the one k the frame ends in
+    const int kfull = c.frame_length >> 6;
+    const float keep_edge = lane < (c.frame_length & 63) ? 1.f : 0.f;
+    auto keep = [&](int k) -> float { return k < kfull ? 1.f : (k == kfull ? keep_edge : 0.f); };
+    const float inv_len = 1.f / (float)c.frame_length;
     const int n_pairs = (total_frames + 1) / 2;
     const int p_first = blockIdx.x * FBF_WAVES + wave, p_step = gridDim.x * FBF_WAVES;
-    if (p_first < n_pairs) { fetch(2 * p_first, nxa); fetch(2 * p_first + 1, nxb); }
+    if (p_first < n_pairs && total_frames > 0) { fetch(2 * p_first, nxa); fetch(2 * p_first + 1, nxb); }
     for (int pr = p_first; pr < n_pairs; pr += p_step) {
         const int fa = 2 * pr, fb = fa + 1;
-        float ar[8], ai[8];
-        const float ea = prepare(nxa, ar);
-        const float eb = prepare(nxb, ai);
-        if (pr + p_step < n_pairs) { fetch(2 * (pr + p_step), nxa); fetch(2 * (pr + p_step) + 1, nxb); }
-        // ---- pass 1: stages 1-3 inside the lane's group of 8 positions (twiddles 1 | 1, -i | W8^j)
-        fbf_radix8_first(ar, ai);
+        // ---- samples n = lane + 64 k of both frames as (a, b) pairs: DC removal, raw energy (after DC removal, before pre-emphasis /
+        // windowing), pre-emphasis (x[n-1] sits one lane down; lane 0: lane 63 of the previous k), window
+        fb_c32 xv[8], z[8];
+        fb_c32 sum = {0.f, 0.f};
 #pragma unroll
-        for (int lo = 0; lo < 8; ++lo) { re[at1[lo]] = ar[lo]; im[at1[lo]] = ai[lo]; }
+        for (int k = 0; k < 8; ++k) {
+            xv[k] = (fb_c32){(float)nxa[k], (float)nxb[k]} * keep(k);
+            sum += xv[k];
+        }
+        if (pr + p_step < n_pairs) { fetch(2 * (pr + p_step), nxa); fetch(2 * (pr + p_step) + 1, nxb); }
+        fb_c32 mean = {0.f, 0.f};
+        if (c.remove_dc) mean = (fb_c32){wave_sum_dpp(sum.x), wave_sum_dpp(sum.y)} * inv_len;
+        fb_c32 e2 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            xv[k] = (xv[k] - mean) * keep(k);
+            e2 += xv[k] * xv[k];
+        }
+        const float ea = wave_sum_dpp(e2.x), eb = wave_sum_dpp(e2.y);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane per component instead of LDS-crossbar shuffles
+            fb_c32 dn, wrap;
+            dn.x = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k].x), 0x138, 0xf, 0xf, false));
+            dn.y = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k].y), 0x138, 0xf, 0xf, false));
+            wrap.x = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0].x), 63)) : xv[0].x;
+            wrap.y = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0].y), 63)) : xv[0].y;
+            const fb_c32 prev = lane > 0 ? dn : wrap;
+            const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
+            z[lo] = (xv[k] - c.preemph * prev) * winv[k];
+        }
+        // ---- pass 1: stages 1-3 inside the lane's group of 8 positions (twiddles 1 | 1, -i | W8^j)
+        fbf_radix8_first(z);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int4 a = tab_at[j * 64 + lane];
+            zb[a.x] = z[4 * j]; zb[a.y] = z[4 * j + 1]; zb[a.z] = z[4 * j + 2]; zb[a.w] = z[4 * j + 3];
+        }
         __builtin_amdgcn_wave_barrier();
         // ---- pass 2: stages 4-6 over m (positions 64 h + 8 m + lo of this lane's (lo, h))
-#pragma unroll
-        for (int m = 0; m < 8; ++m) { ar[m] = re[at2[m]]; ai[m] = im[at2[m]]; }
-        fbf_radix8(ar, ai, p2w1r, p2w1i, p2w2r, p2w2i, p2w4r, p2w4i);
+        const int4 a2lo = tab_at[2 * 64 + lane], a2hi = tab_at[3 * 64 + lane];
+        z[0] = zb[a2lo.x]; z[1] = zb[a2lo.y]; z[2] = zb[a2lo.z]; z[3] = zb[a2lo.w];
+        z[4] = zb[a2hi.x]; z[5] = zb[a2hi.y]; z[6] = zb[a2hi.z]; z[7] = zb[a2hi.w];
+        fbf_radix8(z, p2w1r, p2w1i, p2w2r, p2w2i, p2w4r, p2w4i);
         __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int m = 0; m < 8; ++m) { re[at2[m]] = ar[m]; im[at2[m]] = ai[m]; }
+        zb[a2lo.x] = z[0]; zb[a2lo.y] = z[1]; zb[a2lo.z] = z[2]; zb[a2lo.w] = z[3];
+        zb[a2hi.x] = z[4]; zb[a2hi.y] = z[5]; zb[a2hi.z] = z[6]; zb[a2hi.w] = z[7];
         __builtin_amdgcn_wave_barrier();
-        // ---- pass 3: stages 7-9 over h (positions 64 h + lane): bin lane + 64 h ends up in ar[h]
-#pragma unroll
-        for (int h = 0; h < 8; ++h) { ar[h] = re[at3[h]]; ai[h] = im[at3[h]]; }
-        fbf_radix8(ar, ai, p3w1r, p3w1i, p3w2r, p3w2i, p3w4r, p3w4i);
+        // ---- pass 3: stages 7-9 over h (positions 64 h + lane): bin lane + 64 h ends up in z[h]
+        {
+            const int4 a3lo = tab_at[4 * 64 + lane], a3hi = tab_at[5 * 64 + lane];
+            z[0] = zb[a3lo.x]; z[1] = zb[a3lo.y]; z[2] = zb[a3lo.z]; z[3] = zb[a3lo.w];
+            z[4] = zb[a3hi.x]; z[5] = zb[a3hi.y]; z[6] = zb[a3hi.z]; z[7] = zb[a3hi.w];
+        }
+        fbf_radix8(z, p3w1r, p3w1i, p3w2r, p3w2i, p3w4r, p3w4i);
         __builtin_amdgcn_wave_barrier();
         // ---- split the pair: Z in plain order through the slice, bin N - k read back
 #pragma unroll
-        for (int h = 0; h < 8; ++h) { re[lane + 64 * h] = ar[h]; im[lane + 64 * h] = ai[h]; }
+        for (int h = 0; h < 8; ++h) zb[lane + 64 * h] = z[h];
         __builtin_amdgcn_wave_barrier();
-        float pa[4], pb[4];
+        fb_c32 pw[4];
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            const int k2 = (FB_NFFT - (lane + 64 * h)) & (FB_NFFT - 1);
-            const float yr = re[k2], yi = im[k2];
-            const float sr = ar[h] + yr, di = ai[h] - yi, si = ai[h] + yi, dr = ar[h] - yr;
-            pa[h] = 0.25f * (sr * sr + di * di);          // |X_a[k]|^2
-            pb[h] = 0.25f * (si * si + dr * dr);          // |X_b[k]|^2
+            const fb_c32 y = zb[(FB_NFFT - (lane + 64 * h)) & (FB_NFFT - 1)];
+            const fb_c32 yc = {y.x, -y.y};
+            const fb_c32 s = z[h] + yc, d = z[h] - yc;            // 2 X_a[k] = (sr, si);  2 i X_b[k] = (dr, di)
+            const fb_c32 sq = s * s, dq = d * d;
+            pw[h] = (fb_c32){sq.x + sq.y, dq.x + dq.y} * 0.25f;       // (|X_a[k]|^2, |X_b[k]|^2)
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- power spectra of bins 0..255 (plain order: frame a in `re`, frame b in `im`), mel filters, log
+        // ---- power spectra of bins 0..255 in plain order, (frame a, frame b) side by side; mel filters, log
 #pragma unroll
-        for (int h = 0; h < 4; ++h) { re[lane + 64 * h] = pa[h]; im[lane + 64 * h] = pb[h]; }
+        for (int h = 0; h < 4; ++h) zb[lane + 64 * h] = pw[h];
         __builtin_amdgcn_wave_barrier();
         {
-            float acca = 0.f, accb = 0.f;
-            const float4* pwa = (const float4*)(re + ibin);
-            const float4* pwb = (const float4*)(im + ibin);
+            fb_c32 acc = {0.f, 0.f};
+            const float4* p4 = (const float4*)(zb + ibin);
 #pragma unroll
-            for (int i = 0; i < FBF_CHUNK / 4; ++i) {
-                const float4 va = pwa[i], vb = pwb[i];
-                acca += mwv[4 * i] * va.x + mwv[4 * i + 1] * va.y + mwv[4 * i + 2] * va.z + mwv[4 * i + 3] * va.w;
-                accb += mwv[4 * i] * vb.x + mwv[4 * i + 1] * vb.y + mwv[4 * i + 2] * vb.z + mwv[4 * i + 3] * vb.w;
+            for (int j = 0; j < 4; ++j) {
+                const float4 w4 = tab_w[j * 64 + lane];
+                const float4 v0 = p4[2 * j], v1 = p4[2 * j + 1];           // bins ibin + 4 j .. + 3 of both frames
+                acc += w4.x * (fb_c32){v0.x, v0.y};
+                acc += w4.y * (fb_c32){v0.z, v0.w};
+                acc += w4.z * (fb_c32){v1.x, v1.y};
+                acc += w4.w * (fb_c32){v1.z, v1.w};
             }
-            // (words 384..447 of the slices: beyond every chunk — bins < 256 + 16 — and free once the split has read Z)
-            re[384 + lane] = acca; im[384 + lane] = accb;
+            // (words 384..447 of the slice: beyond every chunk — bins < 256 + 16 — and free once the split has read Z)
+            zb[384 + lane] = acc;
             __builtin_amdgcn_wave_barrier();
-            acca = accb = 0.f;
-            for (int it = it0; it < it1; ++it) { acca += re[384 + it]; accb += im[384 + it]; }
+            acc = (fb_c32){0.f, 0.f};
+            for (int it = it0; it < it1; ++it) acc += zb[384 + it];
             float* oa = out + (size_t)fa * width;
-            if (lane < c.num_mel) oa[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acca, 1.1920929e-07f));
+            if (lane < c.num_mel) oa[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc.x, 1.1920929e-07f));
             if (c.use_energy && lane == 0) oa[0] = logf(fmaxf(ea, 1.1920929e-07f));
             if (fb < total_frames) {
                 float* ob = out + (size_t)fb * width;
-                if (lane < c.num_mel) ob[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(accb, 1.1920929e-07f));
+                if (lane < c.num_mel) ob[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc.y, 1.1920929e-07f));
                 if (c.use_energy && lane == 0) ob[0] = logf(fmaxf(eb, 1.1920929e-07f));
             }
         }

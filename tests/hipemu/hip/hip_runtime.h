@@ -366,6 +366,8 @@ inline long long max(long long a, long long b) { return a > b ? a : b; }
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct alignas(16) int4 { int x, y, z, w; };
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float __expf(float x) { return std::exp(x); }
 inline long long wall_clock64() { return 0; }

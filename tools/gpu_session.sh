@@ -12,6 +12,8 @@ for what in "$@"; do
     k:*) timeout 900 python -m pytest tests -m gpu -x -q -k "${what#k:}" > "$O/pytest_k_$(echo ${what#k:} | cut -c1-12 | tr " " _).log" 2>&1; echo "pytest -k rc=$?"; grep "^E " $O/pytest_k_*.log | cut -c1-300 | head -n 12; tail -n 3 $O/pytest_k_*.log;;
     testsk:*) k=${what#testsk:}; timeout 900 python -m pytest tests -m gpu -x -q --knob $k > $O/pytest_$k.log 2>&1; echo "pytest --knob $k rc=$?"; tail -n 3 $O/pytest_$k.log;;
     newtests) timeout 900 python -m pytest tests -m gpu -x -q -k "wsj_base_median or whole_list or persistent_decoder or wsj_deep or wsj_paper or stack2" > $O/pytest_new.log 2>&1; echo "pytest(new) rc=$?"; tail -n 6 $O/pytest_new.log;;
+    propparity) timeout 900 python tools/full_size_parity.py prop_median prop_mean > $O/prop_parity.md 2> $O/prop_parity.err; echo "propparity rc=$?"; cat $O/prop_parity.md | cut -c1-330; tail -n 3 $O/prop_parity.err;;
+    forcedist) timeout 300 python bench.py --steps 10 --warmup 3 --force-dist $B > $O/forcedist.json 2> $O/forcedist.err; echo "forcedist rc=$?"; python -c "import json;d=json.load(open('$O/forcedist.json'));print('force-dist', d['ms_per_step'], d['value'], d['self_check'], {k:d['config'].get(k) for k in ('collective_backend','collective_world_size','allreduce_ms','whole_step_graph_region')})"; tail -n 2 $O/forcedist.err;;
     parity) timeout 1500 python tools/full_size_parity.py > $O/full_size_parity.md 2> $O/full_size_parity.err; echo "parity rc=$?"; cat $O/full_size_parity.md | cut -c1-330; tail -n 3 $O/full_size_parity.err;;
     nk:*) timeout 1500 python -m pytest tests -m gpu -q -k "${what#nk:}" > "$O/pytest_nk.log" 2>&1; echo "pytest -k rc=$?"; grep "^E \|^FAILED\|^ERROR" $O/pytest_nk.log | cut -c1-400 | head -n 40; tail -n 3 $O/pytest_nk.log;;
     ragged) timeout 300 python bench.py --steps 10 --warmup 3 --ragged $B > $O/ragged.json 2> $O/ragged.err; python -c "import json;d=json.load(open('$O/ragged.json'));print('ragged', d['ms_per_step'], d['value'])"; tail -n 1 $O/ragged.err;;
