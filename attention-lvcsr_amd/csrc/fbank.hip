@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void deltas_cmvn_kernel(const float* feats, in
 //   leaves bin l + 64 m in lane l; the LDS address of a position is swizzled so that all three access patterns are 2-way conflicts
 //   at most (fbf_addr);
 // then the power spectrum and the mel filters from their non-zero spans, the weights of a lane's filter in REGISTERS.
-#define FBF_WAVES 4
-#define FBF_OFFS 2048          // frame offsets staged in LDS (a binary search through global memory costs ~10 dependent loads per frame)
+#define FBF_WAVES 8            // waves per work-group: they share the offset / address / twiddle / weight tables in LDS
+#define FBF_OFFS 1024          // frame / sample offsets staged in LDS (a binary search through global memory costs ~10 dependent loads per frame)
 
 __device__ __forceinline__ int fb_bitrev(int n, int bits) {
     int r = 0;
@@ -220,6 +220,8 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     // the swizzled LDS words of the three exchange patterns (6 x int4 per lane) and the lane's 16 mel weights (4 x float4)
     __shared__ int4 tab_at[6 * 64];
     __shared__ float4 tab_w[4 * 64];
+    __shared__ float4 tab_tw[8 * 64];      // twiddles of passes 2 and 3: (w1 | w2[0]), (w2[1] | w4[0]), (w4[1] | w4[2]), (w4[3] | -) as (re, im) pairs
+    __shared__ float win_lds[FB_NFFT];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool offs_lds = n_utts + 1 <= FBF_OFFS;
     if (offs_lds)
@@ -236,21 +238,24 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     };
     const int lo2 = lane & 7, h2 = lane >> 3;          // pass 2: this lane's (lo, h); its 8 values run over m
     const int lo3 = lane & 7, m3 = lane >> 3;          // pass 3: this lane's (m, lo) = bin l + 64 x; its 8 values run over h
-    float p2w1r, p2w1i, p2w2r[2], p2w2i[2], p2w4r[4], p2w4i[4];
-    float p3w1r, p3w1i, p3w2r[2], p3w2i[2], p3w4r[4], p3w4i[4];
-    tw(8, lo2, p2w1r, p2w1i);
+    if (wave == 0) {
+        float w[16][2];
+        tw(8, lo2, w[0][0], w[0][1]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) tw(16, lo2 + 8 * j, p2w2r[j], p2w2i[j]);
+        for (int j = 0; j < 2; ++j) tw(16, lo2 + 8 * j, w[1 + j][0], w[1 + j][1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tw(32, lo2 + 8 * j, p2w4r[j], p2w4i[j]);
-    tw(64, lane, p3w1r, p3w1i);
+        for (int j = 0; j < 4; ++j) tw(32, lo2 + 8 * j, w[3 + j][0], w[3 + j][1]);
+        w[7][0] = w[7][1] = 0.f;
+        tw(64, lane, w[8][0], w[8][1]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) tw(128, lane + 64 * j, p3w2r[j], p3w2i[j]);
+        for (int j = 0; j < 2; ++j) tw(128, lane + 64 * j, w[9 + j][0], w[9 + j][1]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tw(256, lane + 64 * j, p3w4r[j], p3w4i[j]);
-    float winv[8];
+        for (int j = 0; j < 4; ++j) tw(256, lane + 64 * j, w[11 + j][0], w[11 + j][1]);
+        w[15][0] = w[15][1] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) winv[k] = (lane + 64 * k) < c.frame_length ? window[lane + 64 * k] : 0.f;
+        for (int j = 0; j < 8; ++j) tab_tw[j * 64 + lane] = make_float4(w[2 * j][0], w[2 * j][1], w[2 * j + 1][0], w[2 * j + 1][1]);
+    }
+    for (int x = tid; x < FB_NFFT; x += 64 * FBF_WAVES) win_lds[x] = x < c.frame_length ? window[x] : 0.f;
     const int g1 = fb_bitrev(lane, 6), h1 = g1 >> 3, m1 = g1 & 7;      // pass 1: this lane's samples sit at positions (h1, m1, lo = brev3(k))
     if (wave == 0) {
         int at[24];
@@ -320,6 +325,7 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane per component instead of LDS-crossbar shuffles
+            // (fetching x[n-1] with a second set of loads instead was measured slower: 377 vs 354 us)
             fb_c32 dn, wrap;
             dn.x = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k].x), 0x138, 0xf, 0xf, false));
             dn.y = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k].y), 0x138, 0xf, 0xf, false));
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             wrap.y = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0].y), 63)) : xv[0].y;
             const fb_c32 prev = lane > 0 ? dn : wrap;
             const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
-            z[lo] = (xv[k] - c.preemph * prev) * winv[k];
+            z[lo] = (xv[k] - c.preemph * prev) * win_lds[lane + 64 * k];      // (the window is zero beyond the frame)
         }
         // ---- pass 1: stages 1-3 inside the lane's group of 8 positions (twiddles 1 | 1, -i | W8^j)
         fbf_radix8_first(z);
@@ -341,7 +347,11 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         const int4 a2lo = tab_at[2 * 64 + lane], a2hi = tab_at[3 * 64 + lane];
         z[0] = zb[a2lo.x]; z[1] = zb[a2lo.y]; z[2] = zb[a2lo.z]; z[3] = zb[a2lo.w];
         z[4] = zb[a2hi.x]; z[5] = zb[a2hi.y]; z[6] = zb[a2hi.z]; z[7] = zb[a2hi.w];
-        fbf_radix8(z, p2w1r, p2w1i, p2w2r, p2w2i, p2w4r, p2w4i);
+        {
+            const float4 t0 = tab_tw[0 * 64 + lane], t1 = tab_tw[1 * 64 + lane], t2 = tab_tw[2 * 64 + lane], t3 = tab_tw[3 * 64 + lane];
+            const float w2r[2] = {t0.z, t1.x}, w2i[2] = {t0.w, t1.y}, w4r[4] = {t1.z, t2.x, t2.z, t3.x}, w4i[4] = {t1.w, t2.y, t2.w, t3.y};
+            fbf_radix8(z, t0.x, t0.y, w2r, w2i, w4r, w4i);
+        }
         __builtin_amdgcn_wave_barrier();
         zb[a2lo.x] = z[0]; zb[a2lo.y] = z[1]; zb[a2lo.z] = z[2]; zb[a2lo.w] = z[3];
         zb[a2hi.x] = z[4]; zb[a2hi.y] = z[5]; zb[a2hi.z] = z[6]; zb[a2hi.w] = z[7];
@@ -352,7 +362,11 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             z[0] = zb[a3lo.x]; z[1] = zb[a3lo.y]; z[2] = zb[a3lo.z]; z[3] = zb[a3lo.w];
             z[4] = zb[a3hi.x]; z[5] = zb[a3hi.y]; z[6] = zb[a3hi.z]; z[7] = zb[a3hi.w];
         }
-        fbf_radix8(z, p3w1r, p3w1i, p3w2r, p3w2i, p3w4r, p3w4i);
+        {
+            const float4 t0 = tab_tw[4 * 64 + lane], t1 = tab_tw[5 * 64 + lane], t2 = tab_tw[6 * 64 + lane], t3 = tab_tw[7 * 64 + lane];
+            const float w2r[2] = {t0.z, t1.x}, w2i[2] = {t0.w, t1.y}, w4r[4] = {t1.z, t2.x, t2.z, t3.x}, w4i[4] = {t1.w, t2.y, t2.w, t3.y};
+            fbf_radix8(z, t0.x, t0.y, w2r, w2i, w4r, w4i);
+        }
         __builtin_amdgcn_wave_barrier();
         // ---- split the pair: Z in plain order through the slice, bin N - k read back
 #pragma unroll
@@ -388,7 +402,11 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             zb[384 + lane] = acc;
             __builtin_amdgcn_wave_barrier();
             acc = (fb_c32){0.f, 0.f};
-            for (int it = it0; it < it1; ++it) acc += zb[384 + it];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                   // a filter spans at most 64 bins: 4 chunks (the recipe: 2)
+                const fb_c32 part = zb[384 + min(it0 + j, 63)];
+                acc += it0 + j < it1 ? part : (fb_c32){0.f, 0.f};
+            }
             float* oa = out + (size_t)fa * width;
             if (lane < c.num_mel) oa[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc.x, 1.1920929e-07f));
             if (c.use_energy && lane == 0) oa[0] = logf(fmaxf(ea, 1.1920929e-07f));
@@ -476,7 +494,7 @@ int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, c
                  "lvsr_fbank_batch: unsupported framing (frame_length <= 512, num_mel <= 64: use lvsr_fbank otherwise)");
     if (total_frames <= 0) return LVSR_OK;
     int nb = ((total_frames + 1) / 2 + FBF_WAVES - 1) / FBF_WAVES;        // a wave takes a PAIR of frames per transform
-    if (nb > 2048) nb = 2048;          // grid-stride over the pairs: the tables are staged once per work-group
+    if (nb > 2048) nb = 2048;          // grid-stride over the pairs (capping the grid at the 512 resident work-groups was measured slower: 388 vs 377 us)
     hipLaunchKernelGGL(fbank_fft_kernel, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
                        window, item_bin, item_first, item_w, n_items, twiddle, out);
     return lvsr_check_launch("lvsr_fbank_batch");
