@@ -171,9 +171,7 @@ def test_full_size_batched_decode_equals_single_searches_at_other_beam_widths_gp
 
 # Round 5: beam 200 — the width the reference's README recommends for its best numbers (exp/wsj/README.md:58-60, exp/wsj/decode.sh:12):
 # 200 hypotheses x 33 characters = 6 600 candidates per position in lvsr_beam_select (capacity 8 192), row groups of 200 = 12.5 of the
-# 16-row MFMA tiles of the merge / energy kernels, finished lists of up to 200 x (max_length + 1) entries.  A Theano beam-200 search of
-# one full-size utterance is ~12x the hours the beam-16 fixture took: the yardstick here is the float32 oracle (which reproduces the
-# reference's whole beam-16 list on this very network and language model: test_oracles_reproduce_the_whole_list...).
+# 16-row MFMA tiles of the merge / energy kernels, finished lists of up to 200 x (max_length + 1) entries.
 def _full2_recognizer(device, lib=None):
     z, meta = load_golden("wsj_decode_full2")
     cfg = meta["cfg"]
@@ -186,30 +184,65 @@ def _full2_recognizer(device, lib=None):
     return z, meta, params, rec, s
 
 
+# The REFERENCE at beam 200 (tests/golden/wsj_decode_beam200.npz, gen_golden.py `wsj_decode_beam200`: lvsr's SpeechRecognizer.beam_search
+# on the first 400 frames of utterances 1 and 0 of the wsj_decode_full2 set, same network / language model / decode settings, beam_size
+# 200 — 52 and 61 s of Theano's Python linker): 299 and 61 ranked hypotheses.  The float32 oracle reproduces both lists in order (costs
+# within 5.6e-4: hypotheses of 100+ characters whose costs of ~40 are sums of as many float32 step costs).
+def _beam200_reference():
+    z, meta = load_golden("wsj_decode_beam200")
+    rows = {r["utt"]: r for r in meta["beam"]}
+    assert all(r["settings"]["beam_size"] == 200 for r in rows.values())
+    return z, meta, rows
+
+
 @pytest.mark.gpu
-def test_beam_200_single_search_equals_the_float32_oracle_gpu(gpu_device):
-    """One full-size utterance (400 of the fixture's 800 frames: T' = 100, up to 133 positions) at beam 200 against the float32
-    oracle's beam search with the same language model (the float32 and float64 oracles agree on all 299 hypotheses of this
-    utterance): the WHOLE ranked list token for token; costs to 1e-3 (measured: 3 of 299 beyond 1e-4, at most 4.6e-4 — hypotheses
-    of 100+ characters whose costs of ~40 are sums of as many float32 step costs)."""
+def test_beam_200_matches_the_reference_gpu(gpu_device):
+    """Beam 200 on the MI355X against the reference's own beam-200 search: the WHOLE ranked list of both utterances (299 and 61
+    hypotheses) token for token, costs to 1e-3 (and all but a few to 1e-4); eager / captured, then the replayed step graph."""
+    z, meta, rows = _beam200_reference()
+    _, _, params, rec, s = _full2_recognizer(gpu_device)
+    rec.init_beam_search(200)
+    for utt, r in rows.items():
+        for rep in range(2):
+            outs, costs = rec.beam_search({"recordings": z["x%d" % utt]}, **s)
+            assert len(outs) == len(r["outputs"]), (utt, len(outs), len(r["outputs"]))
+            assert outs == r["outputs"], "utterance %d" % utt
+            assert_allclose(costs, r["costs"], rtol=1e-3, atol=1e-4)
+            assert numpy.isclose(costs, r["costs"], rtol=1e-4, atol=1e-4).mean() > 0.95
+
+
+@pytest.mark.gpu
+def test_beam_200_batched_matches_the_reference_gpu(gpu_device):
+    """The two reference utterances and a third, longer one side by side at beam 200 (600 rows): the reference's lists as
+    `ranked_lists_agree` says (the batched search sums an utterance's weighted averages in another order)."""
+    z, meta, rows = _beam200_reference()
+    z2, _, params, rec, s = _full2_recognizer(gpu_device)
+    rec.init_beam_search(200)
+    order = sorted(rows)
+    xs = [z["x%d" % u] for u in order] + [z2["x3"][:480]]
+    for rep in range(2):
+        batched = rec.beam_search_batch(xs, **s)
+        for u, many in zip(order, batched):
+            assert not isinstance(many, Exception), (u, many)
+            ranked_lists_agree((rows[u]["outputs"], rows[u]["costs"]), many)
+
+
+@pytest.mark.slow
+def test_float32_oracle_reproduces_the_reference_at_beam_200():
+    """oracle/lvsr_oracle.py beam_search at beam 200 against the same fixture (~90 s per utterance): both lists in order."""
     import torch
     from oracle import lvsr_oracle as O, lm_oracle as LO
-    z, meta, params, rec, s = _full2_recognizer(gpu_device)
-    V = meta["cfg"]["num_phonemes"]
-    x = z["x1"][:400]
-    rec.init_beam_search(200)
-    outs, costs = rec.beam_search({"recordings": x}, **s)
-    outs2, costs2 = rec.beam_search({"recordings": x}, **s)                    # replayed step graph
-    assert outs2 == outs and costs2 == costs
-    torch.set_num_threads(8)
-    orc = O.OracleRecognizer(meta["cfg"], params, dtype=torch.float32)
+    z, meta, rows = _beam200_reference()
+    cfg = meta["cfg"]
+    V = cfg["num_phonemes"]
+    orc = O.OracleRecognizer(cfg, synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta["scales"]), dtype=torch.float32)
     arcs = [(int(a), int(b), int(il), float(w)) for a, b, il, w in z["arcs"]]
     lm = dict(dense=LO.DenseFST(arcs, arcs[0][0], V), remap={c: c + 1 for c in range(V)}, **meta["lm"])
-    ref_outs, ref_costs = orc.beam_search(x, 200, lm=lm, **s)
-    assert len(outs) >= 200 and len(outs) == len(ref_outs), (len(outs), len(ref_outs))
-    assert outs == ref_outs                                  # the whole ranked list
-    assert_allclose(costs, ref_costs, rtol=1e-3, atol=1e-4)
-    assert numpy.isclose(costs, ref_costs, rtol=1e-4, atol=1e-4).mean() > 0.95
+    for utt, r in rows.items():
+        s = dict(r["settings"])
+        outs, costs = orc.beam_search(z["x%d" % utt], s.pop("beam_size"), lm=lm, **s)
+        assert outs == r["outputs"]
+        assert_allclose(costs, r["costs"], rtol=1e-3, atol=1e-4)
 
 
 def ranked_lists_agree(one, many, head=200, common=0.8):
@@ -247,8 +280,9 @@ def test_beam_200_batched_equals_single_searches_gpu(gpu_device):
             assert [m[0] for m in batched] == [m[0] for m in first] and [m[1] for m in batched] == [m[1] for m in first]
 
 
+@pytest.mark.slow
 def test_beam_200_emulated_equals_the_float32_oracle():
-    """Beam 200 through the emulated kernels on a small network (20 characters: 4 000 candidates per position; 679 finished
+    """(~3 minutes of fiber emulation, hence `--runslow`.)  Beam 200 through the emulated kernels on a small network (20 characters: 4 000 candidates per position; 679 finished
     hypotheses): the whole ranked list of the float32 oracle, token for token."""
     import torch
     from emu import emu_lib
@@ -257,7 +291,7 @@ def test_beam_200_emulated_equals_the_float32_oracle():
     cfg = meta["cfg"]
     params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"])
     batch = synthetic.make_batch(cfg, meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
-    x = batch["recordings"][: int(batch["recordings_mask"][:, 1].sum()), 1][:28]
+    x = batch["recordings"][: int(batch["recordings_mask"][:, 1].sum()), 1][:16]
     kw = dict(char_discount=0.2, round_to_inf=1e9, stop_on="optimistic_future_cost")
     ref = O.OracleRecognizer(cfg, params, dtype=torch.float32).beam_search(x, 200, **kw)
     rec = SpeechRecognizer(device="cpu", params=params, lib=emu_lib(), net_config=cfg)
