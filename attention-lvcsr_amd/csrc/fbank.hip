@@ -421,38 +421,56 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 }
 
 // add-deltas + CMVN over a set of utterances: edge frames are replicated per UTTERANCE.  One thread per (frame, coefficient) in
-// flat order — consecutive lanes read consecutive floats of a row (the 9 neighbouring rows come from L2) and write three coalesced
-// runs (the first version gave a wave to a frame: 41 of 64 lanes live, 1.1 TB/s)
+// flat order — consecutive lanes read consecutive floats of a row and write three coalesced runs (the first version gave a wave to a
+// frame: 41 of 64 lanes live, 1.1 TB/s).  Round 5: a work-group takes a TILE of DC_TILE consecutive frames: the rows [tile - 4, tile + DC_TILE + 4) are ONE contiguous span of
+// `feats` — staged in LDS with coalesced loads, once (the first version read every row nine times out of L2: 1.65 TB/s) — the tile's
+// outputs one contiguous span of `out`.  Edge frames are replicated per utterance: neighbour t + k of frame t is row
+// clamp(t + k, first, last frame of t's utterance), which the clamp keeps inside the staged span.
+#define DC_TILE 56
+#define DC_MAXDIM 64
 __global__ __launch_bounds__(256) void deltas_cmvn_batch_kernel(const float* feats, const int* frame_off, int n_utts, int total_frames, int dim,
                                                                const float* mean, const float* istd, float* out) {
-    __shared__ int offs[FBF_OFFS];
-    const bool offs_lds = n_utts + 1 <= FBF_OFFS;
-    if (offs_lds)
-        for (int x = threadIdx.x; x <= n_utts; x += 256) offs[x] = frame_off[x];
-    __syncthreads();
-    const int* const foff = offs_lds ? offs : frame_off;
-    const long long total = (long long)total_frames * dim;
-    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
-        const int t = (int)(idx / dim), j = (int)(idx % dim);
-        const int u = fb_find_utt(foff, n_utts, t);
-        const int t0 = foff[u], t1 = foff[u + 1] - 1;
+    __shared__ float rows[(DC_TILE + 8) * DC_MAXDIM];
+    __shared__ int lo_of[DC_TILE], hi_of[DC_TILE];
+    const int ntiles = (total_frames + DC_TILE - 1) / DC_TILE;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ta = tile * DC_TILE, tb = min(total_frames, ta + DC_TILE);          // frames [ta, tb)
+        const int ra = max(0, ta - 4), rb = min(total_frames, tb + 4);                // staged rows [ra, rb)
+        __syncthreads();                                                              // (the previous tile's readers are done)
+        {
+            const float* src = feats + (size_t)ra * dim;
+            const int n = (rb - ra) * dim;
+            for (int x = threadIdx.x; x < n; x += 256) rows[x] = src[x];
+        }
+        if (threadIdx.x < tb - ta) {                 // the utterance bounds of the tile's frames (binary search through L2: 56 per tile)
+            const int t = ta + threadIdx.x;
+            const int u = fb_find_utt(frame_off, n_utts, t);
+            lo_of[threadIdx.x] = frame_off[u];
+            hi_of[threadIdx.x] = frame_off[u + 1] - 1;
+        }
+        __syncthreads();
         const float s1[5] = {-0.2f, -0.1f, 0.f, 0.1f, 0.2f};
         const float s2[9] = {0.04f, 0.04f, 0.01f, -0.04f, -0.1f, -0.04f, 0.01f, 0.04f, 0.04f};
-        float v9[9];
+        const int nel = (tb - ta) * dim;
+        for (int x = threadIdx.x; x < nel; x += 256) {
+            const int tl = x / dim, j = x - tl * dim, t = ta + tl;
+            const int t0 = lo_of[tl], t1 = hi_of[tl];
+            float v9[9];
 #pragma unroll
-        for (int k = -4; k <= 4; ++k) v9[k + 4] = feats[(size_t)min(t1, max(t0, t + k)) * dim + j];
-        float d1 = 0.f, d2 = 0.f;
+            for (int k = -4; k <= 4; ++k) v9[k + 4] = rows[(min(t1, max(t0, t + k)) - ra) * dim + j];
+            float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-        for (int k = -2; k <= 2; ++k) d1 += s1[k + 2] * v9[k + 4];
+            for (int k = -2; k <= 2; ++k) d1 += s1[k + 2] * v9[k + 4];
 #pragma unroll
-        for (int k = -4; k <= 4; ++k) d2 += s2[k + 4] * v9[k + 4];
-        float* o = out + (size_t)t * 3 * dim;
-        const float v[3] = {v9[4], d1, d2};
+            for (int k = -4; k <= 4; ++k) d2 += s2[k + 4] * v9[k + 4];
+            float* o = out + (size_t)t * 3 * dim;
+            const float v[3] = {v9[4], d1, d2};
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float r = v[q];
-            if (mean) r = (r - mean[q * dim + j]) * istd[q * dim + j];
-            o[q * dim + j] = r;
+            for (int q = 0; q < 3; ++q) {
+                float r = v[q];
+                if (mean) r = (r - mean[q * dim + j]) * istd[q * dim + j];
+                o[q * dim + j] = r;
+            }
         }
     }
 }
@@ -504,8 +522,9 @@ int lvsr_add_deltas_cmvn_batch(void* stream, const float* feats, const int* fram
                                const float* istd, float* out) {
     LVSR_REQUIRE(feats && frame_off && out && n > 0 && dim > 0, "lvsr_add_deltas_cmvn_batch: bad arguments");
     if (total_frames <= 0) return LVSR_OK;
-    long long nbl = ((long long)total_frames * dim + 255) / 256;
-    const int nb = (int)(nbl > 8192 ? 8192 : nbl);
+    LVSR_REQUIRE(dim <= DC_MAXDIM, "lvsr_add_deltas_cmvn_batch: at most %d coefficients per frame (use lvsr_add_deltas_cmvn otherwise)", DC_MAXDIM);
+    const int ntiles = (total_frames + DC_TILE - 1) / DC_TILE;
+    const int nb = ntiles > 8192 ? 8192 : ntiles;
     hipLaunchKernelGGL(deltas_cmvn_batch_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, feats, frame_off, n, total_frames, dim, mean, istd, out);
     return lvsr_check_launch("lvsr_add_deltas_cmvn_batch");
 }

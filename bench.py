@@ -213,14 +213,15 @@ def decode_leg(dev, utterances, batch=64, streams=2):
                 parity="tests/test_decode_golden.py::test_full_size_wsj_decode_batched_whole_list_matches_the_reference_gpu (reference-generated golden)")
 
 
-def beam200_leg(dev, utterances=8, batch=4):
+def beam200_leg(dev, utterances=32, batch=8, streams=2):
     """The beam width the reference's README recommends for its best numbers (exp/wsj/README.md:58-60, exp/wsj/decode.sh:12): 200
     hypotheses x 33 characters = 6 600 candidates per position in lvsr_beam_select, row groups of 200 across the 16-row tiles.
-    A bounded sample; parity: tests/test_decode_golden.py::test_beam_200_*."""
+    A bounded sample (32 of the synthetic 800-frame utterances, 8 per set of launches = 1 600 rows, two sets in flight)."""
     from tools.bench_decode import build, run_batched
-    recs = [build(dev, 200)[0]]
+    recs = [build(dev, 200)[0] for _ in range(streams)]
     sec, done, nframes, chars, steps = run_batched(recs, utterances, 800, batch=batch)
-    return dict(beam_size=200, utterances=done, utterances_per_launch_set=batch, ms_per_utterance=sec / done * 1e3,
+    return dict(beam_size=200, utterances=done, utterances_per_launch_set=batch, searches_in_flight=streams * batch, ms_per_utterance=sec / done * 1e3,
+                parity="tests/test_decode_golden.py::test_beam_200_matches_the_reference_gpu (reference-generated golden, whole ranked lists)",
                 positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1), mean_best_hypothesis_length=chars / max(done, 1))
 
 
