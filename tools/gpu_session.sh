@@ -30,7 +30,7 @@ for what in "$@"; do
     paper) timeout 300 python bench.py --workload wsj_paper --steps 10 --warmup 3 $B > $O/paper.json 2> $O/paper.err; python -c "import json;d=json.load(open('$O/paper.json'));print('wsj_paper', d['ms_per_step'], d['value'])"; tail -n 1 $O/paper.err;;
     batches) for b in 10 32 64 128; do timeout 300 python bench.py --steps 8 --warmup 2 --batch $b $B > $O/batch_$b.json 2> $O/batch_$b.err; python -c "import json;d=json.load(open('$O/batch_$b.json'));print('batch $b', d['ms_per_step'], d['value'])"; tail -n 1 $O/batch_$b.err; done;;
     gemm) timeout 400 python tools/probes/gemm_k_sweep.py sustained > $O/gemm_k_sweep.txt 2>&1; tail -n 22 $O/gemm_k_sweep.txt;;
-    prof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 $B > $R/$O/prof.log 2>&1; cd $R; ls $O/prof | head; python tools/rocpd_stats.py $O/prof/*/*.db > $O/kernel_stats.md 2>> $O/prof.log || python tools/rocpd_stats.py $O/prof/*.db > $O/kernel_stats.md 2>> $O/prof.log; head -n 30 $O/kernel_stats.md;;
+    prof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 $B > $R/$O/prof.log 2>&1; cd $R; ls $O/prof | head; python tools/rocpd_stats.py $O/prof/*/*.db > $O/kernel_stats.md 2>> $O/prof.log || python tools/rocpd_stats.py $O/prof/*.db > $O/kernel_stats.md 2>> $O/prof.log; python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>> $O/prof.log; head -n 30 $O/kernel_stats.md; tail -n 25 $O/timeline.txt; rm -rf $O/prof;;
     pmc) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY"; do
            n=$(echo $c | cut -d" " -f1)
@@ -59,6 +59,9 @@ for what in "$@"; do
     decodeb:*) bb=${what#decodeb:}; timeout 900 python bench.py --workload wsj_decode --decode-batch ${bb%x*} --streams ${bb#*x} > $O/decode_$bb.json 2> $O/decode_$bb.err; python -c "import json;d=json.load(open('$O/decode_$bb.json'));print('wsj_decode $bb', d['ms_per_step'], d['value'])"; tail -n 1 $O/decode_$bb.err;;
     decode) timeout 900 python bench.py --workload wsj_decode > $O/decode.json 2> $O/decode.err; echo "decode rc=$?"; cut -c1-600 $O/decode.json; tail -n 2 $O/decode.err;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log;;
+    prof200) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+         timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof200 -o dec -- python $R/tools/bench_decode.py --utts 16 --beam 200 --batch 8 --streams 1 > $R/$O/prof200.log 2>&1
+         cd $R; python tools/rocpd_stats.py $(find $O/prof200 -name "*.db" | head -n 1) > $O/decode200_kernel_stats.md 2>&1; tail -n 2 $O/prof200.log | cut -c1-400; head -n 30 $O/decode200_kernel_stats.md | cut -c1-160; rm -rf $O/prof200;;
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          for st in 1 8; do timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decprof$st -o dec -- python $R/tools/bench_decode.py --utts 8 --streams $st > $R/$O/decprof$st.log 2>&1; done
          cd $R; for st in 1 8; do python tools/rocpd_stats.py $(find $O/decprof$st -name "*.db" | head -n 1) > $O/decode_kernel_stats_$st.md 2>&1; tail -n 2 $O/decprof$st.log | cut -c1-400; head -n 34 $O/decode_kernel_stats_$st.md | cut -c1-150; done;;
