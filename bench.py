@@ -332,6 +332,8 @@ def main(backend=None):
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
                     help="tuning knob of the library (include/lvsr_hip.h LVSR_KNOB_*), for A/B measurements; recorded in config.knobs")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-drain", action="store_true",
+                    help="do not block the host until a step's graph has drained (Lib.sync_after_graph = False): the next step's launch is enqueued behind the running one")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group (RCCL) even with one rank")
     ap.add_argument("--ragged", action="store_true",
                     help="secondary run of SURVEY.md 8(d): utterance lengths ~U{T/2..T}, zero padded; counts real frames only")
@@ -393,6 +395,8 @@ def main(backend=None):
         B = global_batch // world
     params = synthetic.make_params(cfg, seed=10)
     rec = SpeechRecognizer(device=dev, params=params, lib=lib, net_config=cfg, use_graph=not args.no_graph)
+    if args.no_drain:
+        rec.lib.sync_after_graph = False
     knobs = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.knob}
     for k, v in knobs.items():
         rec.lib.set_knob(k, v)
@@ -639,7 +643,7 @@ def main(backend=None):
                        str(dims.subsample) + ", " + cfg["attention_type"] + " attention, %d-unit GRU decoder" % dims.D),
                        global_batch=global_batch, per_gpu_batch=B, frames_per_step=frames_per_step,
                        ragged=bool(args.ragged), parallelism="dp%d" % world, optimizer="clip100+adadelta+maxnorm1",
-                       hip_graph=not args.no_graph, priming_steps=PRIME,
+                       hip_graph=not args.no_graph, priming_steps=PRIME, host_blocks_per_step=bool(rec.lib.sync_after_graph),
                        encoder_kernels=encoder_kernels_of(rec, B, dims),
                        h2d="value: minibatches resident in HBM when the timed region starts (bench contract); with_h2d: the same steps fed from pinned host memory",
                        with_h2d=(dict(with_h2d, value=frames_per_step / (with_h2d["ms_per_step"] * 1e-3)) if with_h2d else None),

@@ -19,6 +19,8 @@ for what in "$@"; do
     ragged) timeout 300 python bench.py --steps 10 --warmup 3 --ragged $B > $O/ragged.json 2> $O/ragged.err; python -c "import json;d=json.load(open('$O/ragged.json'));print('ragged', d['ms_per_step'], d['value'])"; tail -n 1 $O/ragged.err;;
     bench) timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python -c "import json;d=json.load(open('$O/bench.json'));print({k:d.get(k) for k in ('value','ms_per_step','self_check','ragged')}, d.get('decode'), d.get('sustained'), d.get('strong'), {k:(v.get('achieved'),v.get('frac'),v.get('launch_us')) for k,v in d.get('fbank',{}).items() if isinstance(v,dict)}, d['roofline']['us_per_recurrent_step'], d['roofline']['dense_gemm']['layer_shapes'])" ; tail -n 3 $O/bench.err;;
     quick) timeout 300 python bench.py --steps 20 --warmup 5 $B > $O/quick.json 2> $O/quick.err; echo "quick rc=$?"; python -c "import json;d=json.load(open('$O/quick.json'));print('wsj_base', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 2 $O/quick.err;;
+    nodrain) timeout 300 python bench.py --steps 40 --warmup 5 --no-drain $B --no-ragged > $O/nodrain.json 2> $O/nodrain.err; python -c "import json;d=json.load(open('$O/nodrain.json'));print('no-drain', d['ms_per_step'], d['value'], d['self_check'])"; tail -n 2 $O/nodrain.err
+             timeout 300 python bench.py --steps 40 --warmup 5 $B --no-ragged > $O/drain.json 2> $O/drain.err; python -c "import json;d=json.load(open('$O/drain.json'));print('drain', d['ms_per_step'], d['value'])";;
     quick8) timeout 300 python bench.py --steps 20 --warmup 5 $B --knob dec_cluster=8 > $O/quick8.json 2> $O/quick8.err; python -c "import json;d=json.load(open('$O/quick8.json'));print('wsj_base clusters of 8', d['ms_per_step'], d['value'])"; tail -n 2 $O/quick8.err;;
     dec) for k in dec_cluster=0 dec_cluster=8; do timeout 300 python tools/probe_decoder_persist.py wsj_base $k > $O/dec_fwd_$k.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base $k > $O/dec_bwd_$k.txt 2>&1; echo "== $k"; grep -v "^    " $O/dec_fwd_$k.txt | tail -n 4; grep -v "^    " $O/dec_bwd_$k.txt | tail -n 4; done;;
     decmed) timeout 300 python tools/probe_decoder_persist.py wsj_base median > $O/dec_fwd_median.txt 2>&1; grep -v "^    " $O/dec_fwd_median.txt | tail -n 4;;
