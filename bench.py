@@ -198,6 +198,9 @@ def pmc_record(kernel):
     return (rec, None) if rec else (None, "kernel %s not in the PMC record" % kernel)
 
 
+PEAK_HBM = 8.0e12               # bytes/s (MI355X_MICROARCH.md)
+
+
 def decode_leg(dev, utterances, batch=64, streams=2):
     """configs[4] in the default line: a bounded sample of the decode workload (`--workload wsj_decode` runs all 1000 utterances) —
     beam 16 + char-trigram FST LM on the device, window_around_median(10, 100), exp/wsj/decode.sh settings, 800-frame synthetic
@@ -205,7 +208,19 @@ def decode_leg(dev, utterances, batch=64, streams=2):
     from tools.bench_decode import build, run_batched
     recs = [build(dev, 16)[0] for _ in range(streams)]
     sec, done, nframes, chars, steps = run_batched(recs, utterances, 800, batch=batch)
-    return dict(workload="wsj_decode sample: %d of the 1000 synthetic 800-frame utterances, WSJ-base weights, beam 16, device FST LM "
+    # what a position of one utterance has to move and compute at least: the attended rows and their preprocessed copies of the
+    # utterance once (T' x (E + M) floats: the 16 hypotheses share them), two transcendentals per (hypothesis, window position, match
+    # column) of the energies — priced against the HBM roofline and the quarter-rate transcendental pipe
+    Tp, E, M, K, window = 200, 512, 512, 16, 111
+    pos_s = sec / max(steps, 1)
+    hbm_bytes = Tp * (E + M) * 4
+    trans = 2.0 * K * window * M
+    trans_peak = 256 * 4 * 16 / 4 * 2.4e9          # CUs x SIMDs x lanes / 4 (quarter rate) x clock
+    roof = dict(bound="latency (13 small kernels per position)", us_per_position_per_utterance=pos_s * 1e6,
+                hbm=dict(algorithmic_bytes=hbm_bytes, achieved=hbm_bytes / pos_s / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=hbm_bytes / pos_s / PEAK_HBM),
+                transcendental=dict(ops=trans, achieved=trans / pos_s / 1e12, peak=trans_peak / 1e12, unit="Tops/s", frac=trans / pos_s / trans_peak),
+                note="neither roofline is near: the leg is bound by the ramp-up / tails of thirteen dependent kernels per position (DESIGN.md 7)")
+    return dict(roofline=roof, workload="wsj_decode sample: %d of the 1000 synthetic 800-frame utterances, WSJ-base weights, beam 16, device FST LM "
                          "(weight 0.5, no_transition_cost 20), char_discount 1.0, max length T/3" % done,
                 utterances=done, ms_per_utterance=sec / done * 1e3, utterances_per_s=done / sec, frames_per_s=nframes / sec,
                 utterances_per_launch_set=batch, searches_in_flight=streams * batch, positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1),
@@ -223,9 +238,6 @@ def beam200_leg(dev, utterances=32, batch=8, streams=2):
     return dict(beam_size=200, utterances=done, utterances_per_launch_set=batch, searches_in_flight=streams * batch, ms_per_utterance=sec / done * 1e3,
                 parity="tests/test_decode_golden.py::test_beam_200_matches_the_reference_gpu (reference-generated golden, whole ranked lists)",
                 positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1), mean_best_hypothesis_length=chars / max(done, 1))
-
-
-PEAK_HBM = 8.0e12               # bytes/s (MI355X_MICROARCH.md)
 
 
 def fbank_leg(dev, seconds=8.0, utterances=512):
