@@ -3,7 +3,8 @@
 // (exp/wsj/write_hdf_dataset.sh:94-104).  Kaldi is not part of the reference tree: the algorithm below restates
 // Kaldi's documented defaults (25 ms / 10 ms frames, snip-edges, DC removal, raw log-energy, pre-emphasis 0.97,
 // Povey window, 512-point power spectrum, triangular mel filters 20 Hz..Nyquist on the mel scale 1127 ln(1+f/700),
-// dither OFF for determinism).  PARITY UNPINNED — validated against oracle/fbank_oracle.py only.
+// dither OFF for determinism).  Validated against oracle/fbank_oracle.py and an independent Kaldi-compatible implementation
+// (tests/golden/fbank_hf_kaldi.npz); no Kaldi-produced vector exists in the build image.
 //
 // One work-group per frame: samples -> LDS, wave-shuffle reductions for mean/energy, power spectrum by direct DFT
 // over a 512-entry twiddle table (257 bins x 400 samples per frame: the kernel stays HBM/launch bound, an FFT would

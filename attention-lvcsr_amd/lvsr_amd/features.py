@@ -1,6 +1,6 @@
 """Feature front end on the device: log mel-filterbank (+energy), deltas, global CMVN — the offline Kaldi step of the
-reference's recipe (exp/wsj/write_hdf_dataset.sh:94-104) as HIP kernels (csrc/fbank.hip).  Parity with Kaldi is
-unpinned."""
+reference's recipe (exp/wsj/write_hdf_dataset.sh:94-104) as HIP kernels (csrc/fbank.hip).  The log-mel columns are pinned to an
+independent Kaldi-compatible implementation, not to Kaldi's own binary."""
 import ctypes
 
 import numpy

@@ -293,7 +293,8 @@ def fbank_leg(dev, seconds=8.0, utterances=512):
                                                 achieved=b_dl / t_dl / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=b_dl / t_dl / PEAK_HBM),
                 lvsr_fbank_per_utterance=dict(us_per_utterance=t_one * 1e6, achieved=(nsamp * 2 + T * 41 * 4) / t_one / 1e9, unit="GB/s",
                                               note="one launch of the direct-DFT kernel per 0.4-MB utterance: launch / latency bound"),
-                note="parity of this front end is unpinned (no Kaldi in the image, DESIGN.md section 4)")
+                note="parity: the 40 log-mel columns are pinned to an independent Kaldi-compatible implementation (HuggingFace transformers.audio_utils, "
+                     "tests/golden/fbank_hf_kaldi.npz); no Kaldi-produced vector exists in the image (DESIGN.md section 4)")
 
 
 def cpu_baseline(cfg, params, B, T, L, workload):

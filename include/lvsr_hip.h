@@ -517,7 +517,8 @@ int lvsr_fst_lm_step_groups(void* stream, const lvsr_fst* f, const long long* st
 /* ---- mel-filterbank front end ------------------------------------------------------------------------
  * The reference runs Kaldi offline (exp/wsj/write_hdf_dataset.sh:94-104: compute-fbank-feats --use-energy=true
  * --num-mel-bins=40 | add-deltas, then global CMVN); Kaldi's source is not part of the reference tree, so these
- * entry points follow Kaldi's documented defaults and their parity is UNPINNED (oracle/fbank_oracle.py). */
+ * entry points follow Kaldi's documented defaults; the log-mel columns are pinned to an independent Kaldi-compatible
+ * implementation (tests/golden/fbank_hf_kaldi.npz), not to Kaldi's own binary (oracle/fbank_oracle.py). */
 typedef struct lvsr_fbank_cfg {
     int frame_length, frame_shift;        /* samples (400, 160 at 16 kHz) */
     int num_mel, use_energy, remove_dc, pad0;

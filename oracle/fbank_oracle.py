@@ -1,6 +1,12 @@
 """CPU ORACLE of the filterbank front end.  TEST INFRASTRUCTURE — NOT PRODUCT CODE.
 
-PARITY UNPINNED: the reference computes features with Kaldi (`compute-fbank-feats --use-energy=true
+PARITY: PINNED TO AN INDEPENDENT KALDI-COMPATIBLE IMPLEMENTATION, NOT TO KALDI ITSELF (round 5).  The 40 log-mel columns agree to 9.4e-8
+with HuggingFace `transformers.audio_utils` — mel_filter_bank(mel_scale="kaldi", triangularize_in_mel_space=True), the Povey window and
+spectrogram(preemphasis, remove_dc_offset, snip-edges framing, FLT_EPSILON floor): the numpy path HF's feature extractors use without
+torchaudio and that HF holds to torchaudio.compliance.kaldi.fbank, the PyTorch port of Kaldi's feature-fbank.cc
+(tests/golden/fbank_hf_kaldi.npz, oracle/gen_fbank_hf_golden.py, tests/test_fbank.py; window 3e-16, mel weights 6e-15).  Kaldi's
+binary, torchaudio and librosa are not in the image, so no Kaldi-PRODUCED vector exists; the energy column and add-deltas have no
+counterpart in that library and rest on Kaldi's documented formulas.  The reference computes features with Kaldi (`compute-fbank-feats --use-energy=true
 --num-mel-bins=40 | add-deltas` + global CMVN, exp/wsj/write_hdf_dataset.sh:94-104, exp/timit/write_hdf_dataset.sh:45-55);
 Kaldi's source is not under /root/reference and no version is pinned, and no reference test touches features.  This is
 a float64 numpy restatement of Kaldi's published algorithm and defaults (feature-window / mel-computations / feature-fbank /

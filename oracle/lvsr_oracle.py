@@ -11,8 +11,8 @@ Parity status: PINNED.  tests/test_oracle_golden.py checks this restatement agai
   * the reference's own known-answer tests: tests/test_conv1d.py:6-13 (conv flip),
     libs/blocks/tests/test_search.py:65-69 (_smallest),
     libs/blocks/tests/bricks/test_recurrent.py:432-495 (GRU step, masked sequence), :498-535 (bidirectional).
-Exception: mel-filterbank extraction (Kaldi; not under /root/reference, no version pinned) — parity unpinned,
-see oracle/fbank_oracle.py.
+Exception: mel-filterbank extraction (Kaldi; not under /root/reference, no version pinned) — pinned to an independent
+Kaldi-compatible implementation only, see oracle/fbank_oracle.py.
 """
 import math
 from collections import OrderedDict

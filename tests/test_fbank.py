@@ -1,9 +1,13 @@
-"""Filterbank front end: HIP kernels (emulated on CPU, real on the GPU box) vs oracle/fbank_oracle.py.
-Parity with Kaldi itself is UNPINNED (no Kaldi in the reference tree) — see the oracle header."""
+"""Filterbank front end: HIP kernels (emulated on CPU, real on the GPU box) vs oracle/fbank_oracle.py and vs an independent
+Kaldi-compatible implementation (HuggingFace transformers.audio_utils, tests/golden/fbank_hf_kaldi.npz).  Kaldi's own binary is not
+in the image: parity with IT stays unproven — see the oracle header."""
 import numpy
 import pytest
 from numpy.testing import assert_allclose
 
+import torch
+
+from conftest import golden_path
 from oracle import fbank_oracle as FO
 from lvsr_amd.features import Fbank
 
@@ -112,6 +116,48 @@ def test_oracle_against_a_frozen_vector_a_naive_formulation_and_closed_forms():
     d = FO.add_deltas(ramp)
     assert_allclose(d[2:-2, 2:4], numpy.tile([[1.0, -2.5]], (8, 1)), atol=1e-12)
     assert_allclose(d[4:-4, 4:6], 0.0, atol=1e-12)
+
+
+# Round 5: an INDEPENDENT Kaldi-compatible implementation as the yardstick for the 40 log-mel columns — HuggingFace
+# transformers.audio_utils (mel_filter_bank(mel_scale="kaldi", triangularize_in_mel_space=True), the Povey window, spectrogram with
+# preemphasis / remove_dc_offset / snip-edges framing / FLT_EPSILON floor): the numpy path HF's feature extractors fall back to without
+# torchaudio and that HF holds to torchaudio.compliance.kaldi.fbank — the PyTorch port of Kaldi's feature-fbank.cc
+# (tests/golden/fbank_hf_kaldi.npz, oracle/gen_fbank_hf_golden.py; Kaldi, torchaudio and librosa are not in the image).
+def test_oracle_matches_the_independent_kaldi_compatible_implementation():
+    z = numpy.load(golden_path("fbank_hf_kaldi"))
+    f = FO.fbank(z["wav"])
+    assert f.shape == (z["fbank"].shape[0], 41)
+    assert_allclose(f[:, 1:], z["fbank"], rtol=0, atol=1e-6)                  # observed: 9.4e-8 in the log-mel domain
+    assert_allclose(FO.povey_window(400), z["window"], rtol=0, atol=1e-12)
+    assert_allclose(FO.mel_weights().T, z["mel_filters"][:256], rtol=0, atol=1e-12)
+    assert numpy.abs(z["mel_filters"][256]).max() == 0.0                    # the Nyquist bin Kaldi drops carries no weight anyway
+    # the energy column (--use-energy=true --raw-energy=true) has no counterpart there: log sum of squares of the DC-removed frame
+    frame = z["wav"][160 * 5: 160 * 5 + 400].astype(numpy.float64)
+    assert_allclose(f[5, 0], numpy.log(((frame - frame.mean()) ** 2).sum()), rtol=1e-12)
+
+
+def run_fbank_vs_hf(device, lib, nsamples=None):
+    """The HIP kernels (per-utterance direct DFT and batched FFT) against the independent implementation's features."""
+    z = numpy.load(golden_path("fbank_hf_kaldi"))
+    wav = z["wav"] if nsamples is None else z["wav"][:nsamples]
+    ref = z["fbank"][: 1 + (len(wav) - 400) // 160]
+    fb = Fbank(device=device, lib=lib)
+    one = fb(torch.from_numpy(wav).to(device)).cpu().numpy()
+    assert_allclose(one[:, 1:], ref, rtol=2e-4, atol=2e-4)
+    feats, off = fb.batch([wav, wav[: 400 + 160 * 3]])
+    feats = feats.cpu().numpy()
+    assert_allclose(feats[: len(ref), 1:], ref, rtol=2e-4, atol=2e-4)
+    assert_allclose(feats[len(ref): len(ref) + 4, 1:], ref[:4], rtol=2e-4, atol=2e-4)
+
+
+def test_fbank_vs_independent_implementation_emulated():
+    from emu import emu_lib
+    run_fbank_vs_hf("cpu", emu_lib(), nsamples=400 + 160 * 14)
+
+
+@pytest.mark.gpu
+def test_fbank_vs_independent_implementation_gpu(gpu_device):
+    run_fbank_vs_hf(gpu_device, None)
 
 
 def test_fbank_emulated():

@@ -4,7 +4,7 @@
 tag=$1; shift
 O=gpurun_out/$tag; mkdir -p $O
 export PYTHONUNBUFFERED=1
-B="--no-cpu-baseline --no-decode --no-fbank --no-strong --sustained-seconds 0"
+B="--no-cpu-baseline --no-decode --no-fbank --no-strong --no-ragged --sustained-seconds 0"
 for what in "$@"; do
   case $what in
     tests) timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep "^FAILED\|^ERROR" $O/pytest.log | cut -c1-200 | head -n 30; tail -n 4 $O/pytest.log;;
