@@ -398,6 +398,8 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
 // them (the fused glimpse kernel reads them once per row: 16 times here); thread = (column, row quad).
 #define GW_ROWS 16
 #define GW_FLOATS 12288
+#define GW_CHUNK 32            // rows of a group per work-group (grid.z walks the chunks): beam 200 = 7 work-groups per (group, 64 columns)
+                               // instead of ONE running 13 passes — 64 work-groups on 256 CUs, 49 us per call (round-5 profile)
 __global__ __launch_bounds__(256) void attdec_group_wa_kernel(AttDec a, int i) {
     __shared__ float gw_al[GW_FLOATS];             // [rows of a pass][span] alignments of the group over their common window
     const int g = blockIdx.y, rows = a.group_rows, B = a.B, Tp = a.Tp, E = a.E;
@@ -406,8 +408,9 @@ __global__ __launch_bounds__(256) void attdec_group_wa_kernel(AttDec a, int i) {
     const Win w = attdec_window_row(a, i, g * rows);
     const int span = w.end - w.begin;
     const int per = max(1, min(GW_ROWS, GW_FLOATS / max(span, 1)));       // rows per pass (16 up to T' = 768)
-    for (int r0 = 0; r0 < rows; r0 += per) {
-        const int nr = min(per, rows - r0);
+    const int r_end = min(rows, ((int)blockIdx.z + 1) * GW_CHUNK);
+    for (int r0 = blockIdx.z * GW_CHUNK; r0 < r_end; r0 += per) {
+        const int nr = min(per, r_end - r0);
         __syncthreads();
         for (int x = threadIdx.x; x < nr * span; x += 256) {
             const int r = x / span, t = w.begin + x % span;
@@ -553,7 +556,7 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
                 }
                 if (a.group_rows > 0) {
                     hipLaunchKernelGGL(attdec_glimpse_kernel<false>, dim3(1, a.B), dim3(256), 0, s, a, i);
-                    hipLaunchKernelGGL(attdec_group_wa_kernel, dim3((a.E + 63) / 64, a.B / a.group_rows), dim3(256), 0, s, a, i);
+                    hipLaunchKernelGGL(attdec_group_wa_kernel, dim3((a.E + 63) / 64, a.B / a.group_rows, (a.group_rows + GW_CHUNK - 1) / GW_CHUNK), dim3(256), 0, s, a, i);
                 } else {
                     hipLaunchKernelGGL(attdec_glimpse_kernel<true>, dim3((a.E + 31) / 32, a.B), dim3(256), 0, s, a, i);
                 }

@@ -90,8 +90,8 @@ def run_against_oracle_and_step_kernels(lib, Hs, sub, B, T, use_mask):
 def test_step_of_an_aborted_cluster_is_skipped_on_the_device_and_recovered():
     """A persistent cluster kernel that gives up waiting raises the (sticky) abort word of its workspace; lvsr_guard_collect carries
     it into the guard word in front of the gradient bucket and lvsr_opt_step skips the whole step on the device: parameters, rule
-    state and clipping statistics unchanged.  Trainer.recover() then puts the run on the step kernels; the batch run again gives
-    the update of an undisturbed step."""
+    state and clipping statistics unchanged.  Trainer.recover() (round-5 policy) first keeps the cluster kernels and leaves CUs
+    free; the batch run again gives the update of an undisturbed step.  A second abort right away puts the run on the step kernels."""
     from lvsr_amd.bricks.recognizer import SpeechRecognizer
     from lvsr_amd.training import Trainer
     lib = emu_lib()
@@ -123,12 +123,21 @@ def test_step_of_an_aborted_cluster_is_skipped_on_the_device_and_recovered():
         for k, v in tr.state_dict().items():
             if k != "layout":
                 assert (numpy.asarray(v) == state[k]).all(), "a skipped step changed the optimiser's %s" % k
-        tr.recover()
-        tr.train_step(batch)                     # the batch again, on the step kernels
-        assert not tr.step_was_skipped() and not rec.encoder.use_persistent
+        action = tr.recover()
+        assert action["action"] == "cluster_reserve" and lib.get_knob("cluster_reserve") == Trainer.RECOVER_RESERVE
+        tr.train_step(batch)                     # the batch again, still on the cluster kernels
+        assert not tr.step_was_skipped() and rec.encoder.use_persistent
         got, want = rec.store.get_values(), ref.store.get_values()
         for k in want:
             assert_allclose(got[k], want[k], rtol=2e-4, atol=2e-6, err_msg=k)
+        [t for k, t in rec.ws._bufs.items() if k[0] == "enc0.sync"][0][0] = 1          # again, right away
+        tr.train_step(batch)
+        assert tr.step_was_skipped()
+        action = tr.recover()
+        assert action["action"] == "step_kernels" and not rec.encoder.use_persistent
+        tr.train_step(batch)
+        assert not tr.step_was_skipped()
     finally:
         lib._dll.hipemu_set_concurrent(0)
         lib.set_knob("persist_rows", 0)
+        lib.set_knob("cluster_reserve", 0)
