@@ -545,7 +545,10 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
                 // the other batch, shorter work-groups only add PA traffic)
                 const int rows_g = a.group_rows > 0 ? a.group_rows : 1;
                 const int knob_rpw = lvsr_knob(LVSR_KNOB_ENERGY_ROWS);
-                const int rpw = knob_rpw > 0 ? min(knob_rpw, rows_g) : ((long long)eg.x * eg.y * eg.z <= 2048 ? min(8, rows_g) : rows_g);
+                // (wide beams — groups of 64 rows and more: 32 rows per work-group; beam 200, 2 x 8 utterances in flight: 18.5 / 16.8 /
+                // 15.9 / 16.6 / 17.5 ms per utterance at 8 / 16 / 32 / 64 / 200 rows, round 5)
+                const int rpw = knob_rpw > 0 ? min(knob_rpw, rows_g)
+                              : rows_g >= 64 ? 32 : ((long long)eg.x * eg.y * eg.z <= 2048 ? min(8, rows_g) : rows_g);
                 const dim3 egm(eg.x, eg.y * ((rows_g + rpw - 1) / rpw), eg.z);
                 switch (a.K > 0 ? (a.K + 3) / 4 * 4 : 0) {          // location-aware attention: the contraction on the matrix cores
                     case 0: hipLaunchKernelGGL(attdec_energy_kernel<0>, eg, dim3(256), 0, s, a, i); break;
