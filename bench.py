@@ -552,18 +552,25 @@ def main(backend=None):
             K = 8
             big = synthetic.make_batch(cfg, global_batch * K, T, L, seed=3456, ragged=True)
             tl, ll = big["recordings_mask"].sum(0).astype(int), big["labels_mask"].sum(0).astype(int)
-            exs = [(big["recordings"][: tl[i], i], big["labels"][: ll[i], i]) for i in range(global_batch * K)]
-            exs = list(Data._sort_k(iter(exs), global_batch * K))
-            sb, sframes, shapes = [], 0.0, []
-            for k in range(K):
-                pb = Data.pad_batch(exs[k * global_batch: (k + 1) * global_batch], pad_frames_to=32, pad_labels_to=4)
-                sframes += float(pb["recordings_mask"].sum())
-                shapes.append([int(pb["recordings"].shape[0]), int(pb["labels"].shape[0])])
-                sb.append({kk: torch.from_numpy(numpy.ascontiguousarray(v)).to(dev) for kk, v in pb.items()})
-            el, _ = timed(trainer, sb, 2 * K, global_batch, 3 * K)          # every shape: eager, captured, replayed once before the clock
-            ragged["sort_k_batches"] = dict(k=K, minibatch_shapes_TL=shapes, steps=2 * K, ms_per_step=el / (2 * K) * 1e3,
-                                            real_frames_per_step=sframes / K, value=2 * sframes / el, unit="real frames/s",
-                                            fraction_of_all_ones_value=(2 * sframes / el) / (frames_per_step * args.steps / elapsed))
+            def sorted_leg(label_len):
+                exs = [(big["recordings"][: tl[i], i], numpy.concatenate([big["labels"][: label_len(i) - 1, i] % max(1, dims.V - 1), [cfg["eos_label"]]]))
+                       for i in range(global_batch * K)]
+                exs = list(Data._sort_k(iter(exs), global_batch * K))
+                sb, sframes, shapes = [], 0.0, []
+                for k in range(K):
+                    pb = Data.pad_batch(exs[k * global_batch: (k + 1) * global_batch], pad_frames_to=32, pad_labels_to=4)
+                    sframes += float(pb["recordings_mask"].sum())
+                    shapes.append([int(pb["recordings"].shape[0]), int(pb["labels"].shape[0])])
+                    sb.append({kk: torch.from_numpy(numpy.ascontiguousarray(v)).to(dev) for kk, v in pb.items()})
+                el, _ = timed(trainer, sb, 2 * K, global_batch, 3 * K)      # every shape: eager, captured, replayed once before the clock
+                return dict(k=K, minibatch_shapes_TL=shapes, steps=2 * K, ms_per_step=el / (2 * K) * 1e3, real_frames_per_step=sframes / K,
+                            value=2 * sframes / el, unit="real frames/s",
+                            fraction_of_all_ones_value=(2 * sframes / el) / (frames_per_step * args.steps / elapsed))
+            ragged["sort_k_batches"] = sorted_leg(lambda i: int(ll[i]))
+            ragged["sort_k_batches"]["labels"] = "L_i ~ U{L/2..L}, independent of the utterance's length (synthetic.make_batch): the decoder's share of a step does not shrink with T"
+            # read speech has a roughly constant number of characters per second: label counts proportional to the durations
+            ragged["sort_k_batches_proportional_labels"] = sorted_leg(lambda i: max(2, int(round(L * tl[i] / float(T)))))
+            ragged["sort_k_batches_proportional_labels"]["labels"] = "L_i = round(L * T_i / T): characters proportional to duration, as in read speech"
 
     # ---- strong scaling (north_star: global batch 128 = BASELINE configs[2] sharded over the ranks, rank r takes r::N; target >= 6x
     # at 8 GPUs): the same job in the SAME launch as the weak line, and the one-GPU step at that global batch it is measured against
