@@ -553,7 +553,7 @@ def main(backend=None):
             big = synthetic.make_batch(cfg, global_batch * K, T, L, seed=3456, ragged=True)
             tl, ll = big["recordings_mask"].sum(0).astype(int), big["labels_mask"].sum(0).astype(int)
             def sorted_leg(label_len):
-                exs = [(big["recordings"][: tl[i], i], numpy.concatenate([big["labels"][: label_len(i) - 1, i] % max(1, dims.V - 1), [cfg["eos_label"]]]))
+                exs = [(big["recordings"][: tl[i], i], numpy.concatenate([big["labels"][: label_len(i) - 1, i] % max(1, dims.V - 1), [dims.cfg["eos_label"]]]))
                        for i in range(global_batch * K)]
                 exs = list(Data._sort_k(iter(exs), global_batch * K))
                 sb, sframes, shapes = [], 0.0, []
