@@ -307,37 +307,20 @@ __global__ __launch_bounds__(BEAM_THREADS) void beam_select_kernel(lvsr_beam_arg
         a.keep[i] = k;
         if (i < nl) { a.live_col[i] = k; a.running[i] = s_cost[k]; }
     }
-    if (a.WA_live) {
+    if (tid == 0 && a.WA_live) {
         // do the selected rows span the window centres of the live rows (all K rows of either pass: the tails replicate row 0 /
-        // candidate 0)?  Then the second attention pass would repeat the first one row by row: see lvsr_beam_args.WA_live.
-        // (Minimum / maximum over the K rows by the whole work-group: one thread walking 2 K dependent global loads was most of this
-        // kernel's 70 us at beam 200.)
+        // candidate 0)?  Then the second attention pass would repeat the first one row by row: see lvsr_beam_args.WA_live
         int same = 1;
         if (a.pos_live) {
             float mnA = 3.0e38f, mxA = -3.0e38f, mnB = 3.0e38f, mxB = -3.0e38f;
-            for (int k = tid; k < K; k += nt) {
+            for (int k = 0; k < K; ++k) {
                 const float pa = a.pos_live[k], pb = a.pos_live[s_par[k]];
                 mnA = fminf(mnA, pa); mxA = fmaxf(mxA, pa); mnB = fminf(mnB, pb); mxB = fmaxf(mxB, pb);
             }
-            float* red = (float*)keys;               // (the candidate keys are no longer needed) [4][nt]
-            __syncthreads();
-            red[tid] = mnA; red[nt + tid] = mxA; red[2 * nt + tid] = mnB; red[3 * nt + tid] = mxB;
-            __syncthreads();
-            for (int st = nt >> 1; st > 0; st >>= 1) {
-                if (tid < st) {
-                    red[tid] = fminf(red[tid], red[tid + st]);
-                    red[nt + tid] = fmaxf(red[nt + tid], red[nt + tid + st]);
-                    red[2 * nt + tid] = fminf(red[2 * nt + tid], red[2 * nt + tid + st]);
-                    red[3 * nt + tid] = fmaxf(red[3 * nt + tid], red[3 * nt + tid + st]);
-                }
-                __syncthreads();
-            }
-            same = (red[0] == red[2 * nt] && red[nt] == red[3 * nt]) ? 1 : 0;
+            same = (mnA == mnB && mxA == mxB) ? 1 : 0;
         }
-        if (tid == 0) {
-            ctl[9] = same;
-            ctl[10] += same;
-        }
+        ctl[9] = same;
+        ctl[10] += same;
     }
     if (tid == 0) {
         ctl[CTL_NLIVE] = nl;
