@@ -208,6 +208,10 @@ __device__ __forceinline__ void fbf_radix8_first(fb_c32 (&z)[8]) {
 // 16 packed multiply-adds per PAIR and lane (the recipe's 40 filters, spans 3..31 bins, are 53 items; a lane per FILTER had to carry the
 // longest span: 32 reads / multiply-adds and 32 weight registers per frame), the chunks of a filter summed by its lane through LDS.
 #define FBF_CHUNK 16
+// OFFS_LDS: the utterances' frame / sample offsets fit the LDS tables (n_utts < FBF_OFFS): searched there, else in global memory.
+// KFULL: frame_length / 64 when known at compile time (6 = the recipe's 400-sample frames), -1 = any: sample groups k < KFULL lie
+// wholly inside the frame (no masking), k > KFULL wholly outside (no loads, no arithmetic: they are zeros).
+template <bool OFFS_LDS, int KFULL>
 __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* wav, const long long* wav_off, const int* frame_off, int n_utts,
                                                                    int total_frames, lvsr_fbank_cfg c, const float* window, const int* item_bin,
                                                                    const int* item_first, const float* item_w, int n_items, const float* twid,
@@ -224,13 +228,18 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     __shared__ float4 tab_tw[8 * 64];      // twiddles of passes 2 and 3: (w1 | w2[0]), (w2[1] | w4[0]), (w4[1] | w4[2]), (w4[3] | -) as (re, im) pairs
     __shared__ float win_lds[FB_NFFT];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool offs_lds = n_utts + 1 <= FBF_OFFS;
-    if (offs_lds)
+    if (OFFS_LDS)
         for (int x = tid; x <= n_utts; x += 64 * FBF_WAVES) { offs[x] = frame_off[x]; woffs[x] = wav_off[x]; }
     __syncthreads();
-    const int* const foff = offs_lds ? offs : frame_off;
-    const long long* const woff = offs_lds ? woffs : wav_off;
+    // (two code paths with static address spaces: a pointer selected at run time between LDS and global memory compiles to FLAT
+    // loads in the binary search)
+    auto frame_start = [&](int f, int& u) -> long long {
+        if (OFFS_LDS) { u = fb_find_utt(offs, n_utts, f); return woffs[u] + (long long)(f - offs[u]) * c.frame_shift; }
+        u = fb_find_utt(frame_off, n_utts, f);
+        return wav_off[u] + (long long)(f - frame_off[u]) * c.frame_shift;
+    };
     fb_c32* const zb = z_all[wave];
+    auto zat = [&](int byte_off) -> fb_c32& { return *(fb_c32*)((char*)zb + byte_off); };
     // ---- per-lane constants, in registers for every frame of the wave
     // twiddle of stage s (butterflies `half` = 2^(s-1) apart) at offset j: exp(-2 pi i j / (2 half)) = (cos, -sin)(2 pi j (256 / half) / 512)
     auto tw = [&](int half, int j, float& wr, float& wi) {
@@ -261,7 +270,9 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     if (wave == 0) {
         int at[24];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { at[x] = fbf_addr(h1, m1, x); at[8 + x] = fbf_addr(h2, x, lo2); at[16 + x] = fbf_addr(x, m3, lo3); }
+        for (int x = 0; x < 8; ++x) {          // BYTE offsets into the wave's slice (8-byte complex words): no shift per access
+            at[x] = 8 * fbf_addr(h1, m1, x); at[8 + x] = 8 * fbf_addr(h2, x, lo2); at[16 + x] = 8 * fbf_addr(x, m3, lo3);
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) tab_at[j * 64 + lane] = make_int4(at[4 * j], at[4 * j + 1], at[4 * j + 2], at[4 * j + 3]);
 #pragma unroll
@@ -282,22 +293,27 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
     // the PCM buffer, re-read its last sample and are zeroed by `keep` below — so they issue back to back instead of one exec-masked
     // branch each
     short nxa[8], nxb[8];
-    const long long wav_last = woff[n_utts] - 1;
+    const long long wav_last = (OFFS_LDS ? woffs[n_utts] : wav_off[n_utts]) - 1;
     auto fetch = [&](int f, short (&nx)[8]) {
         const int fc = min(f, total_frames - 1);
-        const int u = __builtin_amdgcn_readfirstlane(fb_find_utt(foff, n_utts, fc));
-        const long long s0v = woff[u] + (long long)(fc - foff[u]) * c.frame_shift;
+        int u;
+        const long long s0v = frame_start(fc, u);
         const long long s0 = ((long long)__builtin_amdgcn_readfirstlane((int)(s0v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)s0v);
         const long long room = wav_last - s0;
-        const int lim = (int)(room < (long long)(c.frame_length - 1) ? room : (long long)(c.frame_length - 1));
-        const short* base = wav + s0;
+        const unsigned lim2 = 2u * (unsigned)(room < (long long)(c.frame_length - 1) ? room : (long long)(c.frame_length - 1));
+        const char* base = (const char*)(wav + s0);          // wave-uniform base + one 32-bit byte offset per load (one v_min each)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) nx[k] = base[min(lane + 64 * k, lim)];
+        for (int k = 0; k < 8; ++k) {
+            const unsigned want = 2u * (unsigned)(lane + 64 * k);
+            nx[k] = (KFULL >= 0 && k > KFULL) ? (short)0 : *(const short*)(base + (want < lim2 ? want : lim2));
+        }
     };
     // keep(k): is sample lane + 64 k inside the frame?  Uniform but for the one k the frame ends in
-    const int kfull = c.frame_length >> 6;
+    const int kfull = KFULL >= 0 ? KFULL : c.frame_length >> 6;
     const float keep_edge = lane < (c.frame_length & 63) ? 1.f : 0.f;
     auto keep = [&](int k) -> float { return k < kfull ? 1.f : (k == kfull ? keep_edge : 0.f); };
+    auto inside = [&](int k) -> bool { return KFULL >= 0 && k < KFULL; };       // compile-time: the whole group lies inside the frame
+    auto outside = [&](int k) -> bool { return KFULL >= 0 && k > KFULL; };      // ... or beyond it
     const float inv_len = 1.f / (float)c.frame_length;
     const int n_pairs = (total_frames + 1) / 2;
     const int p_first = blockIdx.x * FBF_WAVES + wave, p_step = gridDim.x * FBF_WAVES;
@@ -310,29 +326,37 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
         fb_c32 sum = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            xv[k] = (fb_c32){(float)nxa[k], (float)nxb[k]} * keep(k);
+            if (outside(k)) { xv[k] = (fb_c32){0.f, 0.f}; continue; }
+            xv[k] = (fb_c32){(float)nxa[k], (float)nxb[k]};
+            if (!inside(k)) xv[k] *= keep(k);
             sum += xv[k];
         }
-        if (pr + p_step < n_pairs) { fetch(2 * (pr + p_step), nxa); fetch(2 * (pr + p_step) + 1, nxb); }
+        // (unconditional: past the last pair the clamped frame index re-reads the last frame — a conditional prefetch costs the
+        // loop-carried sample registers a copy each way)
+        fetch(2 * (pr + p_step), nxa);
+        fetch(2 * (pr + p_step) + 1, nxb);
         fb_c32 mean = {0.f, 0.f};
         if (c.remove_dc) mean = (fb_c32){wave_sum_dpp(sum.x), wave_sum_dpp(sum.y)} * inv_len;
         fb_c32 e2 = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            xv[k] = (xv[k] - mean) * keep(k);
+            if (outside(k)) continue;
+            xv[k] = xv[k] - mean;
+            if (!inside(k)) xv[k] *= keep(k);
             e2 += xv[k] * xv[k];
         }
         const float ea = wave_sum_dpp(e2.x), eb = wave_sum_dpp(e2.y);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            // one DPP move (wave_shr:1: lane l reads lane l - 1) and one v_readlane per component instead of LDS-crossbar shuffles
+            if (outside(k)) { z[((k & 1) << 2) | (k & 2) | ((k >> 2) & 1)] = (fb_c32){0.f, 0.f}; continue; }
+            // x[n-1] in two DPP moves per component: wave_ror:1 of the previous k brings ITS lane 63 to lane 0 (the value lane 0
+            // needs), wave_shr:1 of this k then fills lanes 1..63 and leaves lane 0 alone (`old` operand) — no v_readlane, no select
             // (fetching x[n-1] with a second set of loads instead was measured slower: 377 vs 354 us)
-            fb_c32 dn, wrap;
-            dn.x = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k].x), 0x138, 0xf, 0xf, false));
-            dn.y = __uint_as_float((unsigned)__builtin_amdgcn_mov_dpp((int)__float_as_uint(xv[k].y), 0x138, 0xf, 0xf, false));
-            wrap.x = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0].x), 63)) : xv[0].x;
-            wrap.y = k > 0 ? __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(xv[k > 0 ? k - 1 : 0].y), 63)) : xv[0].y;
-            const fb_c32 prev = lane > 0 ? dn : wrap;
+            auto shifted = [&](float cur, float before) -> float {
+                const int wrapv = k > 0 ? __builtin_amdgcn_mov_dpp((int)__float_as_uint(before), 0x13C, 0xf, 0xf, false) : (int)__float_as_uint(cur);
+                return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(wrapv, (int)__float_as_uint(cur), 0x138, 0xf, 0xf, false));
+            };
+            const fb_c32 prev = {shifted(xv[k].x, xv[k > 0 ? k - 1 : 0].x), shifted(xv[k].y, xv[k > 0 ? k - 1 : 0].y)};
             const int lo = ((k & 1) << 2) | (k & 2) | ((k >> 2) & 1);        // brev3(k): position of sample k inside the lane's group
             z[lo] = (xv[k] - c.preemph * prev) * win_lds[lane + 64 * k];      // (the window is zero beyond the frame)
         }
@@ -341,27 +365,27 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int4 a = tab_at[j * 64 + lane];
-            zb[a.x] = z[4 * j]; zb[a.y] = z[4 * j + 1]; zb[a.z] = z[4 * j + 2]; zb[a.w] = z[4 * j + 3];
+            zat(a.x) = z[4 * j]; zat(a.y) = z[4 * j + 1]; zat(a.z) = z[4 * j + 2]; zat(a.w) = z[4 * j + 3];
         }
         __builtin_amdgcn_wave_barrier();
         // ---- pass 2: stages 4-6 over m (positions 64 h + 8 m + lo of this lane's (lo, h))
         const int4 a2lo = tab_at[2 * 64 + lane], a2hi = tab_at[3 * 64 + lane];
-        z[0] = zb[a2lo.x]; z[1] = zb[a2lo.y]; z[2] = zb[a2lo.z]; z[3] = zb[a2lo.w];
-        z[4] = zb[a2hi.x]; z[5] = zb[a2hi.y]; z[6] = zb[a2hi.z]; z[7] = zb[a2hi.w];
+        z[0] = zat(a2lo.x); z[1] = zat(a2lo.y); z[2] = zat(a2lo.z); z[3] = zat(a2lo.w);
+        z[4] = zat(a2hi.x); z[5] = zat(a2hi.y); z[6] = zat(a2hi.z); z[7] = zat(a2hi.w);
         {
             const float4 t0 = tab_tw[0 * 64 + lane], t1 = tab_tw[1 * 64 + lane], t2 = tab_tw[2 * 64 + lane], t3 = tab_tw[3 * 64 + lane];
             const float w2r[2] = {t0.z, t1.x}, w2i[2] = {t0.w, t1.y}, w4r[4] = {t1.z, t2.x, t2.z, t3.x}, w4i[4] = {t1.w, t2.y, t2.w, t3.y};
             fbf_radix8(z, t0.x, t0.y, w2r, w2i, w4r, w4i);
         }
         __builtin_amdgcn_wave_barrier();
-        zb[a2lo.x] = z[0]; zb[a2lo.y] = z[1]; zb[a2lo.z] = z[2]; zb[a2lo.w] = z[3];
-        zb[a2hi.x] = z[4]; zb[a2hi.y] = z[5]; zb[a2hi.z] = z[6]; zb[a2hi.w] = z[7];
+        zat(a2lo.x) = z[0]; zat(a2lo.y) = z[1]; zat(a2lo.z) = z[2]; zat(a2lo.w) = z[3];
+        zat(a2hi.x) = z[4]; zat(a2hi.y) = z[5]; zat(a2hi.z) = z[6]; zat(a2hi.w) = z[7];
         __builtin_amdgcn_wave_barrier();
         // ---- pass 3: stages 7-9 over h (positions 64 h + lane): bin lane + 64 h ends up in z[h]
         {
             const int4 a3lo = tab_at[4 * 64 + lane], a3hi = tab_at[5 * 64 + lane];
-            z[0] = zb[a3lo.x]; z[1] = zb[a3lo.y]; z[2] = zb[a3lo.z]; z[3] = zb[a3lo.w];
-            z[4] = zb[a3hi.x]; z[5] = zb[a3hi.y]; z[6] = zb[a3hi.z]; z[7] = zb[a3hi.w];
+            z[0] = zat(a3lo.x); z[1] = zat(a3lo.y); z[2] = zat(a3lo.z); z[3] = zat(a3lo.w);
+            z[4] = zat(a3hi.x); z[5] = zat(a3hi.y); z[6] = zat(a3hi.z); z[7] = zat(a3hi.w);
         }
         {
             const float4 t0 = tab_tw[4 * 64 + lane], t1 = tab_tw[5 * 64 + lane], t2 = tab_tw[6 * 64 + lane], t3 = tab_tw[7 * 64 + lane];
@@ -377,10 +401,10 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             const fb_c32 y = zb[(FB_NFFT - (lane + 64 * h)) & (FB_NFFT - 1)];
-            const fb_c32 yc = {y.x, -y.y};
-            const fb_c32 s = z[h] + yc, d = z[h] - yc;            // 2 X_a[k] = (sr, si);  2 i X_b[k] = (dr, di)
-            const fb_c32 sq = s * s, dq = d * d;
-            pw[h] = (fb_c32){sq.x + sq.y, dq.x + dq.y} * 0.25f;       // (|X_a[k]|^2, |X_b[k]|^2)
+            const fb_c32 sgn = {1.f, -1.f};                       // conj(y) = y * (1, -1): one packed multiply-add each for sum and difference
+            const fb_c32 s = y * sgn + z[h], d = z[h] - y * sgn;  // 2 X_a[k] = (sr, si);  2 i X_b[k] = (dr, di)
+            // (|X_a[k]|^2, |X_b[k]|^2): scalar multiply-adds — the packed form needs the two squares of a value in different pairs
+            pw[h] = (fb_c32){0.25f * (s.x * s.x + s.y * s.y), 0.25f * (d.x * d.x + d.y * d.y)};
         }
         __builtin_amdgcn_wave_barrier();
         // ---- power spectra of bins 0..255 in plain order, (frame a, frame b) side by side; mel filters, log
@@ -517,8 +541,14 @@ int lvsr_fbank_batch(void* stream, const short* wav, const long long* wav_off, c
     if (total_frames <= 0) return LVSR_OK;
     int nb = ((total_frames + 1) / 2 + FBF_WAVES - 1) / FBF_WAVES;        // a wave takes a PAIR of frames per transform
     if (nb > 2048) nb = 2048;          // grid-stride over the pairs (capping the grid at the 512 resident work-groups was measured slower: 388 vs 377 us)
-    hipLaunchKernelGGL(fbank_fft_kernel, dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, frame_off, n, total_frames, c,
-                       window, item_bin, item_first, item_w, n_items, twiddle, out);
+    const bool lds = n + 1 <= FBF_OFFS, k6 = (c.frame_length >> 6) == 6;
+#define FBF_LAUNCH(L, K) hipLaunchKernelGGL((fbank_fft_kernel<L, K>), dim3(nb), dim3(64 * FBF_WAVES), 0, (hipStream_t)stream, wav, wav_off, \
+                                            frame_off, n, total_frames, c, window, item_bin, item_first, item_w, n_items, twiddle, out)
+    if (lds && k6) FBF_LAUNCH(true, 6);
+    else if (lds) FBF_LAUNCH(true, -1);
+    else if (k6) FBF_LAUNCH(false, 6);
+    else FBF_LAUNCH(false, -1);
+#undef FBF_LAUNCH
     return lvsr_check_launch("lvsr_fbank_batch");
 }
 

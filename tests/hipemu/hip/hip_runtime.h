@@ -264,11 +264,22 @@ inline int hipemu_mov_dpp(int v, int ctrl, int, int, bool) {
     if (ctrl == 0x140) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | (15 - (l & 15)));      // row_mirror
     if (ctrl == 0x141) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~7) | (7 - (l & 7)));        // row_half_mirror
     if (ctrl == 0x138) return (int)hipemu::shfl_generic<long long, long long>(v, l > 0 ? l - 1 : l);                 // wave_shr:1 (lane 0 keeps its value)
+    if (ctrl == 0x13C) return (int)hipemu::shfl_generic<long long, long long>(v, (l + hipemu::wave_size_here() - 1) % hipemu::wave_size_here());   // wave_ror:1
     if (ctrl >= 0x121 && ctrl <= 0x12F) return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~15) | ((l - (ctrl - 0x120)) & 15));
     if (ctrl >= 0x100) { fprintf(stderr, "hipemu: DPP control 0x%x is not emulated\n", ctrl); abort(); }
     return (int)hipemu::shfl_generic<long long, long long>(v, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
 }
 #define __builtin_amdgcn_mov_dpp hipemu_mov_dpp
+// v_mov_b32 with a DPP control and an `old` operand for the lanes that have no source: wave_shr:1 (0x138: lane 0 keeps `old`),
+// wave_ror:1 (0x13C: lane l reads lane (l - 1) mod 64)
+inline int hipemu_update_dpp(int old, int v, int ctrl, int, int, bool) {
+    int l = hipemu::lane_id();
+    const int n = hipemu::wave_size_here();
+    if (ctrl == 0x138) { const int got = (int)hipemu::shfl_generic<long long, long long>(v, l > 0 ? l - 1 : l); return l > 0 ? got : old; }
+    if (ctrl == 0x13C) return (int)hipemu::shfl_generic<long long, long long>(v, (l + n - 1) % n);
+    fprintf(stderr, "hipemu: update_dpp control 0x%x is not emulated\n", ctrl); abort();
+}
+#define __builtin_amdgcn_update_dpp hipemu_update_dpp
 // v_permlane16_swap_b32 vdst, src0 (gfx950): the odd rows (16 lanes) of vdst are exchanged with the even rows of src0;
 // -> {new vdst, new src0}
 struct hipemu_u32x2 { unsigned v[2]; unsigned operator[](int i) const { return v[i]; } };

@@ -160,6 +160,32 @@ def test_fbank_vs_independent_implementation_gpu(gpu_device):
     run_fbank_vs_hf(gpu_device, None)
 
 
+def run_fbank_other_frame_lengths(device, lib):
+    """Frame lengths other than the recipe's 400 samples: the batched kernel's generic instantiation (`KFULL = -1`: the 64-sample group
+    the frame ends in is found at run time) — 20-ms frames (320 samples: the frame ends exactly on a group boundary), 30-ms frames
+    (480) and a full 512-sample frame, batched == per-utterance kernel == oracle."""
+    for ms in (20.0, 30.0, 32.0):
+        fb = Fbank(device=device, lib=lib, frame_length_ms=ms)
+        n = fb.frame_length
+        wavs = [_wav(n + 160 * 4 + 13, seed=3), _wav(n + 160 * 2, seed=4)]
+        feats, off = fb.batch(wavs)
+        feats, off = feats.cpu().numpy(), off.cpu().numpy()
+        for u, w in enumerate(wavs):
+            ref = FO.fbank(w, frame_length=n)
+            assert_allclose(feats[off[u]: off[u + 1]], ref, rtol=2e-4, atol=2e-4)
+            assert_allclose(fb(w).cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
+def test_fbank_other_frame_lengths_emulated():
+    from emu import emu_lib
+    run_fbank_other_frame_lengths("cpu", emu_lib())
+
+
+@pytest.mark.gpu
+def test_fbank_other_frame_lengths_gpu(gpu_device):
+    run_fbank_other_frame_lengths(gpu_device, None)
+
+
 def test_fbank_emulated():
     from emu import emu_lib
     run_fbank("cpu", emu_lib(), 400 + 160 * 5)
