@@ -457,8 +457,9 @@ __global__ __launch_bounds__(256) void deltas_cmvn_batch_kernel(const float* fea
                                                                const float* mean, const float* istd, float* out) {
     __shared__ float rows[(DC_TILE + 8) * DC_MAXDIM];
     __shared__ int lo_of[DC_TILE], hi_of[DC_TILE];
-    // (the utterance bounds come from a binary search through L2 per frame of the tile; staging the offsets in LDS per work-group
-    // first was measured slower: 155 vs 141 us)
+    __shared__ int u_first;
+    // (the utterance bounds come from global memory through L2; staging the offsets in LDS per work-group first was measured slower:
+    // 155 vs 141 us)
     const int* const foff = frame_off;
     const int ntiles = (total_frames + DC_TILE - 1) / DC_TILE;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -470,36 +471,55 @@ __global__ __launch_bounds__(256) void deltas_cmvn_batch_kernel(const float* fea
             const int n = (rb - ra) * dim;
             for (int x = threadIdx.x; x < n; x += 256) rows[x] = src[x];
         }
+        // the utterance of the tile's first frame: wave 0 probes 64 boundaries per round (two dependent loads for up to 4 096
+        // utterances instead of a ten-step binary search per frame), the frames of the tile then walk on from it
+        if (threadIdx.x < 64) {
+            int lo = 0, hi = n_utts;                 // the answer u — the last utterance with foff[u] <= ta — lies in [lo, hi)
+            while (hi - lo > 1) {
+                const int step = (hi - lo + 63) / 64, idx = lo + (int)threadIdx.x * step;
+                const bool le = idx < hi && foff[idx] <= ta;
+                const int c = __popcll(__ballot(le));             // monotone: the first c probes are <= ta (c >= 1: foff[lo] <= ta)
+                lo += (c - 1) * step;
+                hi = min(hi, lo + step);
+            }
+            if (threadIdx.x == 0) u_first = lo;
+        }
+        __syncthreads();
         if (threadIdx.x < tb - ta) {                 // the utterance bounds of the tile's frames
             const int t = ta + threadIdx.x;
-            const int u = fb_find_utt(foff, n_utts, t);
+            int u = u_first;
+            while (u + 1 < n_utts && foff[u + 1] <= t) ++u;
             lo_of[threadIdx.x] = foff[u];
             hi_of[threadIdx.x] = foff[u + 1] - 1;
         }
         __syncthreads();
         const float s1[5] = {-0.2f, -0.1f, 0.f, 0.1f, 0.2f};
         const float s2[9] = {0.04f, 0.04f, 0.01f, -0.04f, -0.1f, -0.04f, 0.01f, 0.04f, 0.04f};
-        const int nel = (tb - ta) * dim;
-        for (int x = threadIdx.x; x < nel; x += 256) {
-            const int tl = x / dim, j = x - tl * dim, t = ta + tl;
-            const int t0 = lo_of[tl], t1 = hi_of[tl];
-            float v9[9];
+        // thread = (frame slot, coefficient): the divisions by the run-time `dim` happen once per tile, not once per element (the
+        // kernel is bound by vector-ALU issue: 152 vector instructions per wave and element before, profiles/r05_pmc_fbank.md)
+        const int fpi = 256 / dim;                         // frames per iteration of the work-group (6 at dim = 41)
+        const int tl0 = threadIdx.x / dim, j = threadIdx.x - tl0 * dim;
+        float mj[3] = {0.f, 0.f, 0.f}, ij[3] = {1.f, 1.f, 1.f};
+        if (mean && tl0 < fpi)
 #pragma unroll
-            for (int k = -4; k <= 4; ++k) v9[k + 4] = rows[(min(t1, max(t0, t + k)) - ra) * dim + j];
-            float d1 = 0.f, d2 = 0.f;
+            for (int q = 0; q < 3; ++q) { mj[q] = mean[q * dim + j]; ij[q] = istd[q * dim + j]; }
+        if (tl0 < fpi)
+            for (int tl = tl0; tl < tb - ta; tl += fpi) {
+                const int t = ta + tl;
+                const int t0 = lo_of[tl], t1 = hi_of[tl];
+                float v9[9];
 #pragma unroll
-            for (int k = -2; k <= 2; ++k) d1 += s1[k + 2] * v9[k + 4];
+                for (int k = -4; k <= 4; ++k) v9[k + 4] = rows[(min(t1, max(t0, t + k)) - ra) * dim + j];
+                float d1 = 0.f, d2 = 0.f;
 #pragma unroll
-            for (int k = -4; k <= 4; ++k) d2 += s2[k + 4] * v9[k + 4];
-            float* o = out + (size_t)t * 3 * dim;
-            const float v[3] = {v9[4], d1, d2};
+                for (int k = -2; k <= 2; ++k) d1 += s1[k + 2] * v9[k + 4];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                float r = v[q];
-                if (mean) r = (r - mean[q * dim + j]) * istd[q * dim + j];
-                o[q * dim + j] = r;
+                for (int k = -4; k <= 4; ++k) d2 += s2[k + 4] * v9[k + 4];
+                float* o = out + (size_t)t * 3 * dim + j;
+                o[0] = (v9[4] - mj[0]) * ij[0];
+                o[dim] = (d1 - mj[1]) * ij[1];
+                o[2 * dim] = (d2 - mj[2]) * ij[2];
             }
-        }
     }
 }
 

@@ -299,6 +299,7 @@ inline int hipemu_readlane(int v, int src) { return (int)hipemu::shfl_generic<lo
 #define __builtin_amdgcn_readlane hipemu_readlane
 // v_readfirstlane_b32: only used on values that are already wave-uniform, so the lane's own value is the answer
 inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline unsigned long long __ballot(int pred) {
     unsigned long long m = 0;
     for (int src = 0; src < hipemu::wave_size_here(); ++src)
