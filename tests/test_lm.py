@@ -251,6 +251,31 @@ def test_batched_beam_search_with_device_fst_emulated():
     run_fused_beam_batched("cpu", emu_lib())
 
 
+def test_batched_search_falls_back_to_single_searches_for_a_host_language_model_emulated():
+    """`search_batch` with a language model walked on the HOST (or a validate callback) has nothing to share between utterances: it
+    decodes them one after the other instead of asserting (round-4 advisor finding) — same results as `beam_search` per utterance."""
+    from emu import emu_lib
+    from lvsr_amd import synthetic
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    lib = emu_lib()
+    params = synthetic.make_params(CFG, seed=41)
+    fst, cmap = LM.char_ngram_fst(6, seed=5)
+    rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=CFG)
+    rec.set_language_model(LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
+    xs = [numpy.random.RandomState(seed).normal(size=(T, 5)).astype(numpy.float32) for seed, T in ((1, 14), (2, 9))]
+    kw = dict(char_discount=0.2, stop_on="optimistic_future_cost")
+    rec.init_beam_search(4)
+    singles = [rec.beam_search({"recordings": x}, **kw) for x in xs]
+    assert rec.beam_search_batch(xs, **kw) == singles
+    seen = []
+    rec.set_language_model(None)
+    rec.init_beam_search(4)
+    ones = [rec.beam_search({"recordings": x}, **kw) for x in xs]
+    got = rec._beam_search.search_batch(xs, rec.eos_label, [int(len(x) / rec.max_decoded_length_scale) for x in xs],
+                                        validate_solution_function=lambda inp, toks: seen.append(len(toks)) or True, **kw)
+    assert [([[int(t) for t in o] for o in g[0]], [float(c) for c in g[1]]) for g in got] == ones and seen
+
+
 @pytest.mark.gpu
 def test_batched_beam_search_with_device_fst_gpu(gpu_device):
     run_fused_beam_batched(gpu_device, None)
