@@ -31,9 +31,10 @@ def _is_sync_word(key):
 
 class Trainer(object):
     # What recover() does about an aborted cluster launch (a work-group of a cluster was not resident: something else holds CUs).
-    # First abort: the cluster kernels stay, `cluster_reserve` CUs are left free from now on (the knob of csrc/runtime.hip; cluster
-    # shapes that no longer fit fall to the next smaller shape).  Another abort within REARM_STEPS steps: encoder and decoder move to
-    # the step kernels — for REARM_STEPS clean steps, after which the cluster kernels are armed again (with the reserve).
+    # First abort: the cluster kernels stay, `cluster_reserve` CUs are left free (the knob of csrc/runtime.hip; cluster shapes that no
+    # longer fit fall to the next smaller shape: +9 % per WSJ-base step) — for REARM_STEPS clean steps, then the reserve is given back.
+    # Another abort within REARM_STEPS steps: encoder and decoder move to the step kernels — for REARM_STEPS clean steps, after which
+    # the cluster kernels are armed again (with the reserve, which is given back REARM_STEPS clean steps later).
     RECOVER_RESERVE = 32
     REARM_STEPS = 200
     # CUs the cluster launches leave free when an RCCL kernel can be co-resident with them: only with overlap_allreduce (without it
@@ -108,6 +109,7 @@ class Trainer(object):
         self._skip_host = torch.zeros(1, dtype=torch.float32).pin_memory() if dev.type == "cuda" else None
         self.aborts = 0               # cluster launches that gave up so far (recover() calls)
         self._fallback = None         # while on the step kernels: dict(clean=steps since, saved=kernel choices to restore)
+        self._reserve_before = None   # while a recovery's reserve is in force: the value of the knob to give back
         self._last_abort_step = None
         self.steps_done = 0
 
@@ -190,6 +192,7 @@ class Trainer(object):
         self._last_abort_step = self.steps_done
         action = dict(aborts=self.aborts, step=self.steps_done)
         if not repeated and self._fallback is None and lib.get_knob("cluster_reserve") < self.RECOVER_RESERVE:
+            self._reserve_before = lib.get_knob("cluster_reserve")
             lib.set_knob("cluster_reserve", self.RECOVER_RESERVE)
             action.update(action="cluster_reserve", cluster_reserve=self.RECOVER_RESERVE)
             logger.warning("a persistent cluster kernel gave up waiting for its partners (step %d): the step was skipped on the device; "
@@ -230,6 +233,7 @@ class Trainer(object):
         if gen_stack is not None:
             rec.generator.use_persistent_stack = gen_stack
         self._fallback = None
+        self._last_abort_step = self.steps_done          # (an abort within REARM_STEPS of the re-arming counts as a repeated one)
         self._forget_graphs()
         logger.warning("step %d: %d clean steps on the step kernels; the persistent cluster kernels are armed again", self.steps_done,
                        self.REARM_STEPS)
@@ -242,6 +246,13 @@ class Trainer(object):
             self._fallback["clean"] += 1
             if self._fallback["clean"] > self.REARM_STEPS:
                 self._rearm()
+        elif self._reserve_before is not None and self.steps_done - self._last_abort_step > self.REARM_STEPS:
+            # REARM_STEPS clean steps on the cluster kernels behind the last recovery (or behind the re-arming): the CUs are given back
+            self.rec.lib.set_knob("cluster_reserve", self._reserve_before)
+            logger.warning("step %d: no cluster launch gave up for %d steps; cluster_reserve back to %d", self.steps_done,
+                           self.steps_done - self._last_abort_step, self._reserve_before)
+            self._reserve_before = None
+            self._forget_graphs()
         self.steps_done += 1
 
     def _all_reduce_gradients(self):

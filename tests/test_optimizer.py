@@ -228,5 +228,9 @@ def test_recover_state_machine_emulated():
             assert tr._fallback is not None
         tr.train_step(batch)                                                        # the third step arms the cluster kernels again
         assert tr._fallback is None and rec.encoder.persist_auto is True
+        assert lib.get_knob("cluster_reserve") == Trainer.RECOVER_RESERVE and tr._reserve_before == 0
+        for k in range(3):                                                          # 2 x REARM_STEPS clean steps behind the last abort:
+            tr.train_step(batch)                                                    # the reserved CUs are given back
+        assert lib.get_knob("cluster_reserve") == 0 and tr._reserve_before is None
     finally:
         lib.set_knob("cluster_reserve", old)
