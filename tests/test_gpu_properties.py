@@ -169,6 +169,40 @@ def test_persistent_decoder_in_passes_at_batch_64(gpu_device, setup):
     assert float((total - g_p).abs().max()) / float(g_p.abs().max()) < 2e-4
 
 
+def test_encoder_in_passes_above_64_utterances_per_gpu(gpu_device, setup):
+    """Per-GPU batches above 64: the encoder runs in passes over utterance columns on the cluster kernels (bricks.Encoder
+    _apply_in_passes, round 5) while the decoder sees the whole batch.  80 ragged utterances (two passes of 40): costs, alignments and
+    every gradient against the same batch with the encoder in ONE pass on the step kernels (round 4's form), and the gradient
+    against the sum over the two halves run on their own (the data-parallel invariant)."""
+    s = setup
+    batch = synthetic.make_batch(s["cfg"], 80, 240, 30, seed=83, ragged=True)
+    rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"])
+    cm = rec.cost_and_gradients(batch).cpu().numpy()
+    torch.cuda.synchronize()
+    rec.encoder.check_persistent()
+    assert rec.encoder._pass_cols == [(0, 40), (40, 80)], "the encoder did not run in passes"
+    assert any(k[0].startswith("enc.p0_") and k[0].endswith(".sync") for k in rec.ws._bufs), "the passes did not run on the cluster kernels"
+    w, g = rec.generator.last["weights"].cpu().numpy(), rec.store.grad.clone()
+    one = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"])
+    one.encoder.PASS_ROWS = 1 << 30
+    cm1 = one.cost_and_gradients(batch).cpu().numpy()
+    torch.cuda.synchronize()
+    assert one.encoder._pass_cols is None
+    assert abs(cm.sum() - cm1.sum()) / abs(cm1.sum()) < 1e-5
+    assert_allclose(cm, cm1, rtol=1e-3, atol=1e-3)
+    real = batch["labels_mask"] > 0
+    mism = (w.argmax(axis=2) != one.generator.last["weights"].cpu().numpy().argmax(axis=2))[real]
+    assert mism.mean() < 2e-3, "%d of %d alignment peaks differ" % (mism.sum(), mism.size)
+    g1 = one.store.grad
+    assert float((g - g1).abs().max()) / float(g1.abs().max()) < 2e-3
+    total, cost = None, 0.0
+    for r in range(2):
+        cost += float(rec.cost_and_gradients(synthetic.shard_batch(batch, r, 2)).sum())
+        total = rec.store.grad.clone() if total is None else total + rec.store.grad
+    assert abs(cost - cm.sum()) / abs(cm.sum()) < 1e-5
+    assert float((total - g).abs().max()) / float(g.abs().max()) < 2e-4
+
+
 def test_persistent_decoder_at_the_paper_width(gpu_device):
     """The README-recommended model (wsj_paper7: 250-unit BiGRUs, decoder and matcher, one location filter) has a decoder width that
     is not a multiple of 4: the persistent reverse walk reads its AW rows 16 bytes at a time and runs there with padded rows
