@@ -428,10 +428,12 @@ __global__ __launch_bounds__(64 * FBF_WAVES) void fbank_fft_kernel(const short* 
             __builtin_amdgcn_wave_barrier();
             acc = (fb_c32){0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {                                   // a filter spans at most 64 bins: 4 chunks (the recipe: 2)
+            for (int j = 0; j < 4; ++j) {                                   // the recipe's filters span 2 chunks; up to 4 without a branch
                 const fb_c32 part = zb[384 + min(it0 + j, 63)];
                 acc += it0 + j < it1 ? part : (fb_c32){0.f, 0.f};
             }
+            // filter banks of few, wide filters (num_mel 16 at 16 kHz: 5 chunks, 8: 8 chunks): the remaining chunks, in order
+            for (int it = it0 + 4; it < it1; ++it) acc += zb[384 + it];
             float* oa = out + (size_t)fa * width;
             if (lane < c.num_mel) oa[lane + (c.use_energy ? 1 : 0)] = logf(fmaxf(acc.x, 1.1920929e-07f));
             if (c.use_energy && lane == 0) oa[0] = logf(fmaxf(ea, 1.1920929e-07f));

@@ -259,8 +259,8 @@ class Encoder(object):
                 enc = ws.get("enc.passes.encoded", (Te, B, E))
                 msk = ws.get("enc.passes.mask", (Te, B))
             lib.copy_many([(ek.view(Te, (hi - lo) * E), self._cols2d(enc, lo, hi)), (emk, self._cols2d(msk, lo, hi))])
-        self._pass_cols = cols if save_for_backward else None
-        if save_for_backward:
+        if save_for_backward:            # (a forward that saves nothing leaves the branch backward() will take alone)
+            self._pass_cols = cols
             self._saved = None
         return enc, msk
 

@@ -74,7 +74,7 @@ class Fbank(object):
         int16 arrays / tensors -> (feats (total_frames, num_mel + use_energy) device tensor, frame_off (n + 1) int32 device tensor);
         utterance u = rows frame_off[u]:frame_off[u+1]."""
         if not self.batchable:
-            raise ValueError("the batched front end holds filters of up to 64 bins (num_mel <= 64): use __call__ per utterance")
+            raise ValueError("the batched front end holds the filters as at most 64 (filter, 16-bin chunk) items: use __call__ per utterance")
         host = [numpy.asarray(w.cpu() if torch.is_tensor(w) else w, dtype=numpy.int16).ravel() for w in wavs]
         lens = numpy.array([len(w) for w in host], dtype=numpy.int64)
         nfr = numpy.array([self.num_frames(int(n)) for n in lens], dtype=numpy.int64)

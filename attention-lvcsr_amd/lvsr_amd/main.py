@@ -125,6 +125,14 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                 action = trainer.recover()
                 log.append(dict(iterations_done=iterations, persistent_kernels_aborted=True, **action))
                 cm = trainer.train_step(batch, global_batch_size=gbs)
+            if trainer.step_was_skipped():
+                # the last attempt (already on the step kernels) was skipped as well: nothing was updated — the iteration is neither
+                # counted nor logged with the cost of a step that did not happen, and training does not go on over it
+                log.append(dict(iterations_done=iterations, persistent_kernels_aborted=True, action="gave_up",
+                                training_finish_requested="a step was skipped on the device %d times in a row" % 4))
+                trainer.close()
+                raise RuntimeError("training step %d was skipped on the device 4 times in a row (cluster kernels, a reserve of CUs and the "
+                                   "step kernels all gave up): the device is not usable for this run" % iterations)
             iterations += 1
             row = dict(iterations_done=iterations, epochs_done=epoch, train_cost=float(cm.sum()) / int(batch["labels"].shape[1]),
                        total_gradient_norm=trainer.gradient_norm(), gradient_norm_threshold=trainer.gradient_threshold())
@@ -175,6 +183,7 @@ def train(config, data, save_path, params=None, device="cuda:0", lib=None, log=N
                 done = True
         if not costs:
             done = True
+    trainer.close()
     return rec, log
 
 

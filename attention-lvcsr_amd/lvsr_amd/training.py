@@ -102,7 +102,10 @@ class Trainer(object):
         # all be resident (what concurrent GEMMs did to them is in bricks/__init__.py: slower, not faster).
         self.overlap_allreduce = bool(overlap_allreduce)
         self._comm = None
+        # (the knob is process-global state of the library: what this trainer changed is given back by close())
+        self._overlap_reserve_before = None
         if self.overlap_allreduce and self.world > 1 and recognizer.lib.get_knob("cluster_reserve") == 0:
+            self._overlap_reserve_before = 0
             recognizer.lib.set_knob("cluster_reserve", self.OVERLAP_RESERVE)
         # host mirror of scratch[3] ("the optimiser skipped the last step"), copied behind every optimiser step: train_step looks at
         # it (no synchronisation) before it enqueues the next step and refuses to go on over a skipped step nobody recovered from
@@ -191,12 +194,14 @@ class Trainer(object):
         repeated = self._last_abort_step is not None and self.steps_done - self._last_abort_step < self.REARM_STEPS
         self._last_abort_step = self.steps_done
         action = dict(aborts=self.aborts, step=self.steps_done)
-        if not repeated and self._fallback is None and lib.get_knob("cluster_reserve") < self.RECOVER_RESERVE:
+        if not repeated and self._fallback is None and self._reserve_before is None:
+            # RECOVER_RESERVE more CUs than were already left free (the overlapped all-reduce keeps OVERLAP_RESERVE of its own)
             self._reserve_before = lib.get_knob("cluster_reserve")
-            lib.set_knob("cluster_reserve", self.RECOVER_RESERVE)
-            action.update(action="cluster_reserve", cluster_reserve=self.RECOVER_RESERVE)
+            reserve = self._reserve_before + self.RECOVER_RESERVE
+            lib.set_knob("cluster_reserve", reserve)
+            action.update(action="cluster_reserve", cluster_reserve=reserve)
             logger.warning("a persistent cluster kernel gave up waiting for its partners (step %d): the step was skipped on the device; "
-                           "cluster launches now leave %d CUs free; run the batch again", self.steps_done, self.RECOVER_RESERVE)
+                           "cluster launches now leave %d CUs free; run the batch again", self.steps_done, reserve)
         else:
             if self._fallback is None:
                 self._fallback = dict(saved=(rec.encoder.use_persistent, rec.encoder.persist_auto, rec.generator.use_persistent,
@@ -215,6 +220,25 @@ class Trainer(object):
             torch.cuda.synchronize(rec.store.device)
             self._skip_host.zero_()
         return action
+
+    def close(self):
+        """Give back the process-global knobs this trainer changed (the overlap reserve, a recovery's reserve still in force): other
+        recognizers / trainers of the process see the library as this one found it."""
+        lib = self.rec.lib
+        if self._reserve_before is not None:
+            lib.set_knob("cluster_reserve", self._reserve_before)
+            self._reserve_before = None
+        if self._overlap_reserve_before is not None:
+            lib.set_knob("cluster_reserve", self._overlap_reserve_before)
+            self._overlap_reserve_before = None
+        self._forget_graphs()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _forget_graphs(self):
         """The captured whole-step graphs replay the launches of the old kernel choice: forget them and every region's counters (the

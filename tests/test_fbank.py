@@ -176,6 +176,37 @@ def run_fbank_other_frame_lengths(device, lib):
             assert_allclose(fb(w).cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
 
 
+def run_fbank_few_wide_filters(device, lib):
+    """Filter banks of few, wide filters: at 16 kHz a filter of an 8-, 12- or 16-filter bank spans 8 / 6 / 5 of the batched kernel's
+    16-bin chunks (the recipe's 40 filters: at most 2; 23: 3) — the chunk sums of a filter beyond the fourth (round-5 advisor
+    finding: they were dropped).  Batched == per-utterance kernel == oracle; 64 filters are more than 64 chunk items: refused."""
+    wavs = [_wav(400 + 160 * 4 + 13, seed=5), _wav(400 + 160 * 3, seed=6)]
+    for num_mel in (8, 12, 16, 23):
+        fb = Fbank(device=device, lib=lib, num_mel=num_mel)
+        assert fb.batchable
+        feats, off = fb.batch(wavs)
+        feats, off = feats.cpu().numpy(), off.cpu().numpy()
+        for u, w in enumerate(wavs):
+            ref = FO.fbank(w, num_mel=num_mel)
+            assert_allclose(feats[off[u]: off[u + 1]], ref, rtol=2e-4, atol=2e-4, err_msg="num_mel %d" % num_mel)
+            assert_allclose(fb(w).cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+    fb = Fbank(device=device, lib=lib, num_mel=64)
+    assert not fb.batchable
+    with pytest.raises(ValueError):
+        fb.batch(wavs)
+    assert_allclose(fb(wavs[0]).cpu().numpy(), FO.fbank(wavs[0], num_mel=64), rtol=2e-4, atol=2e-4)
+
+
+def test_fbank_few_wide_filters_emulated():
+    from emu import emu_lib
+    run_fbank_few_wide_filters("cpu", emu_lib())
+
+
+@pytest.mark.gpu
+def test_fbank_few_wide_filters_gpu(gpu_device):
+    run_fbank_few_wide_filters(gpu_device, None)
+
+
 def test_fbank_other_frame_lengths_emulated():
     from emu import emu_lib
     run_fbank_other_frame_lengths("cpu", emu_lib())

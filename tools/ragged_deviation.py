@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Where does the gradient deviation on the ragged full-size fixture come from?  (round-5 verdict, weak 2)
+
+For `wsj_base_ragged` (or another full-size fixture) the gradient wrt the decoder GRU's pre-activations, d x_in (L,B,D) and
+d g_in (L,B,2D) — the rows whose sums over (label, utterance) are the `generator/fork/*` and `distribute/*` weight gradients —
+is taken from
+  * the float64 oracle (autograd hooks on the pre-activations of oracle/lvsr_oracle.py decoder_gru),
+  * the float32 oracle (same code, float32),
+  * on a GPU: the cluster kernels and the step kernels (workspace `gen.DXG`, written by the reverse walk),
+and compared per (label, utterance): error of a row relative to the LARGEST row norm, split by
+  real label / last real label of its utterance / masked label, and by label index (does the error grow smoothly towards label 0 —
+  BPTT amplification of rounding — or sit on particular rows?).
+
+    python tools/ragged_deviation.py [case] [--cpu-only] [--out profiles/r06_ragged_deviation.md]
+"""
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "attention-lvcsr_amd"), os.path.join(REPO, "tests")):
+    sys.path.insert(0, p)
+import numpy
+import torch
+
+from lvsr_amd import synthetic
+
+
+def oracle_rows(cfg, params, batch, dtype):
+    """-> (DXG (L,B,3D) float64 [d x_in | d g_in], grads, cost matrix, weights argmax)."""
+    from oracle import lvsr_oracle as O
+    orc = O.OracleRecognizer(cfg, params, dtype=dtype)
+    rows = []
+    inner = O.gru_step
+    active = [False]
+
+    def spy(h, x_in, g_in, *a, **kw):
+        if active[0]:
+            slot = [None, None]
+            rows.append(slot)
+            x_in.register_hook(lambda g, s=slot: s.__setitem__(0, g.detach().double().numpy().copy()))
+            g_in.register_hook(lambda g, s=slot: s.__setitem__(1, g.detach().double().numpy().copy()))
+        return inner(h, x_in, g_in, *a, **kw)
+
+    dec = orc.decoder_gru
+
+    def decoder_gru(*a, **kw):
+        active[0] = True
+        try:
+            return dec(*a, **kw)
+        finally:
+            active[0] = False
+    O.gru_step = spy
+    orc.decoder_gru = decoder_gru
+    try:
+        out, grads = orc.cost_and_grads(batch)
+    finally:
+        O.gru_step = inner
+    B, D = batch["labels"].shape[1], orc.d.D
+    # (the state after the last label feeds nothing: its hooks never fire — those rows are zero)
+    dxg = numpy.stack([numpy.concatenate([numpy.zeros((B, D)) if r[0] is None else r[0],
+                                          numpy.zeros((B, 2 * D)) if r[1] is None else r[1]], axis=1) for r in rows], 0)
+    return dxg, grads, out["cost_matrix"].detach().double().numpy(), out["weights"].detach().numpy().argmax(axis=2)
+
+
+def gpu_rows(cfg, params, batch, persistent):
+    from lvsr_amd.bricks.recognizer import SpeechRecognizer
+    rec = SpeechRecognizer(device=torch.device("cuda:0"), params=params, net_config=cfg, use_persistent_decoder=persistent)
+    cm = rec.cost_and_gradients(batch)
+    torch.cuda.synchronize()
+    rec.generator.check_persistent()
+    L, B = batch["labels"].shape
+    D = rec.generator.d.D
+    dxg = rec.ws.get("gen.DXG", (L * B, 3 * D)).view(L, B, 3 * D).double().cpu().numpy()
+    return dxg, rec.store.get_grads(), cm.double().cpu().numpy(), rec.generator.last["weights"].cpu().numpy().argmax(axis=2)
+
+
+def describe(name, dxg, ref, ym, out):
+    """Row errors of `dxg` against `ref` (both (L,B,3D) float64)."""
+    L, B, _ = ref.shape
+    err = numpy.sqrt(((dxg - ref) ** 2).sum(-1))                  # (L,B)
+    nrm = numpy.sqrt((ref ** 2).sum(-1))
+    top = nrm.max()
+    last = numpy.zeros((L, B), bool)
+    for b in range(B):
+        last[int(ym[:, b].sum()) - 1, b] = True
+    real = ym > 0
+    out.append("### %s\n" % name)
+    out.append("largest row norm of the float64 rows %.4e; rows past an utterance's last label: largest norm %.3e (float64), %.3e (this path)\n"
+               % (top, nrm[~real].max() if (~real).any() else 0.0, numpy.sqrt((dxg ** 2).sum(-1))[~real].max() if (~real).any() else 0.0))
+    out.append("| rows | count | max row error / largest row norm | mean | max row error / own row norm |")
+    out.append("|---|---|---|---|---|")
+    for label, sel in (("real labels, not the last", real & ~last), ("last real label (<eol>)", last), ("masked labels", ~real)):
+        if sel.any():
+            own = err[sel] / numpy.maximum(nrm[sel], 1e-30)
+            out.append("| %s | %d | %.2e | %.2e | %s |" % (label, sel.sum(), err[sel].max() / top, err[sel].mean() / top,
+                                                       ("%.2e" % own.max()) if nrm[sel].max() > 0 else "(rows are zero)"))
+    out.append("")
+    out.append("By label index (max over utterances of row error / largest row norm; row norm of the float64 rows for scale):\n")
+    out.append("| labels | " + " | ".join("%d-%d" % (a, min(L, a + 10) - 1) for a in range(0, L, 10)) + " |")
+    out.append("|---|" + "---|" * len(range(0, L, 10)))
+    out.append("| error | " + " | ".join("%.1e" % (err[a:a + 10].max() / top) for a in range(0, L, 10)) + " |")
+    out.append("| float64 row norm / largest | " + " | ".join("%.2f" % (nrm[a:a + 10].max() / top) for a in range(0, L, 10)) + " |")
+    out.append("")
+    worst = numpy.dstack(numpy.unravel_index(numpy.argsort(-err.ravel())[:6], err.shape))[0]
+    out.append("worst rows (label, utterance, labels of that utterance, error / largest norm): " +
+               ", ".join("(%d, %d, %d, %.1e)" % (l, b, int(ym[:, b].sum()), err[l, b] / top) for l, b in worst) + "\n")
+    # how much of each utterance's error is common-mode along the label axis: error summed over labels (what a column sum sees)
+    col = numpy.abs((dxg - ref).sum(axis=(0, 1))).max() / numpy.abs(ref.sum(axis=(0, 1))).max()
+    out.append("column sums over all (label, utterance) rows (= the bias gradients): max |difference| / max |float64 sum| = %.2e\n" % col)
+    return err / top
+
+
+def tensor_table(name, grads, ref, out, only=("generator",)):
+    rowsx = []
+    for k, r in ref.items():
+        a, b = numpy.asarray(grads[k], numpy.float64).ravel(), numpy.asarray(r, numpy.float64).ravel()
+        rowsx.append((float(numpy.abs(a - b).max() / max(numpy.abs(b).max(), 1e-30)), k))
+    rowsx.sort(reverse=True)
+    out.append("%s — worst gradient tensors vs the float64 oracle (max |difference| / tensor max): " % name +
+               ", ".join("%s %.2e" % (k.replace("/recognizer/", ""), v) for v, k in rowsx[:5]) + "\n")
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    case = args[0] if args else "wsj_base_ragged"
+    cpu_only = "--cpu-only" in sys.argv
+    z = numpy.load(os.path.join(REPO, "tests", "golden", case + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    cfg = meta["cfg"]
+    params = synthetic.make_params(cfg, seed=meta["param_seed"], scale=meta["scale"], scales=meta.get("scales"))
+    batch = synthetic.make_batch(cfg, meta["B"], meta["T"], meta["L"], seed=meta["batch_seed"], ragged=meta["ragged"])
+    ym = batch["labels_mask"]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    out = ["# Decoder pre-activation gradients per (label, utterance) on `%s`\n" % case,
+           "`tools/ragged_deviation.py %s`: rows of d x_in | d g_in of the decoder GRU (L x B rows of 3D), every path against the float64 "
+           "oracle.  The weight gradients the verdict names (`generator/fork/*`, `distribute/fork_inputs.W`) are sums of these rows "
+           "against the feedback / the glimpses.\n" % case]
+    t0 = time.time()
+    ref, g64, cm64, arg64 = oracle_rows(cfg, params, batch, torch.float64)
+    sys.stderr.write("float64 oracle %.0f s\n" % (time.time() - t0))
+    t0 = time.time()
+    r32, g32, cm32, arg32 = oracle_rows(cfg, params, batch, torch.float32)
+    sys.stderr.write("float32 oracle %.0f s\n" % (time.time() - t0))
+    describe("float32 oracle (torch CPU, the same statements in float32)", r32, ref, ym, out)
+    tensor_table("float32 oracle", g32, g64, out)
+    if "gsub:" + str(z["grad_names"][0]) in z.files:
+        rows = []
+        for k in g64:
+            idx = synthetic.grad_sample_index(k, g64[k].shape)
+            scale = float(z["gmax:" + k])
+            rows.append((float(numpy.abs(numpy.asarray(g64[k], numpy.float64).ravel()[idx] - z["gsub:" + k]).max() / scale), k))
+        rows.sort(reverse=True)
+        out.append("reference (Theano float32, sampled elements) vs the float64 oracle: " +
+                   ", ".join("%s %.2e" % (k.replace("/recognizer/", ""), v) for v, k in rows[:5]) + "\n")
+    if not cpu_only:
+        for persistent, name in ((True, "cluster kernels (persistent decoder)"), (False, "step kernels")):
+            dxg, g, cm, arg = gpu_rows(cfg, params, batch, persistent)
+            describe(name, dxg, ref, ym, out)
+            tensor_table(name, g, g64, out)
+            out.append("cost sum rel. diff %.1e; alignment argmax of every real label equal: %s\n"
+                       % (abs(cm.sum() - cm64.sum()) / abs(cm64.sum()), bool((arg == arg64)[ym > 0].all())))
+    text = "\n".join(out)
+    dest = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--out=")]
+    if dest:
+        open(dest[0], "w").write(text + "\n")
+    print(text)
+
+
+if __name__ == "__main__":
+    main()
