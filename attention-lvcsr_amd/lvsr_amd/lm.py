@@ -393,7 +393,9 @@ def _eps_depends(eps):
 # float32 final weight, int64 narcs, narcs x {int32 ilabel, int32 olabel, float32 weight, int32 nextstate}.
 # Strings are int32 length + bytes.  Symbol table: int32 magic 2125658996, string name, int64 available_key, int64 size,
 # size x {string symbol, int64 key}.  Stated from the OpenFST sources' documented format; no OpenFST binary exists in the
-# reference tree or this image, so only the writer<->reader round trip is tested (parity UNPINNED).
+# reference tree or this image: the reader is tested on its own writer's output and on a file assembled byte by byte in
+# tests/test_lm.py from that layout (both symbol tables, an epsilon arc, 64-bit properties, kNoStateId headers) — not on a file
+# OpenFST itself wrote.
 _FST_MAGIC = 2125659606
 _SYMTAB_MAGIC = 2125658996
 
@@ -423,8 +425,16 @@ def _rd_symtab(buf, pos):
 
 
 def read_openfst_binary(path_or_bytes):
-    """-> ArcFST from an OpenFST binary `vector` FST with `standard` (tropical, float32) arcs."""
+    """-> ArcFST from an OpenFST binary `vector` FST with `standard` (tropical, float32) arcs (what `fst.read` of lvsr/ops.py:44
+    is given: the outputs of bin/lm2fst.sh).  Output labels are read over (the reference looks at `arc.ilabel` only, ops.py:57-59)."""
     buf = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    try:
+        return _parse_openfst(buf)
+    except struct.error:
+        raise ValueError("truncated OpenFST binary (%d bytes)" % len(buf))
+
+
+def _parse_openfst(buf):
     (magic,), pos = _rd("<i", buf, 0)
     if magic != _FST_MAGIC:
         raise ValueError("not an OpenFST binary (magic %d)" % magic)
@@ -436,19 +446,22 @@ def read_openfst_binary(path_or_bytes):
     (version, flags), pos = _rd("<ii", buf, pos)
     (_props, start, num_states, _num_arcs), pos = _rd("<Qqqq", buf, pos)
     if flags & 4:
-        raise ValueError("aligned OpenFST files are not supported")
+        raise ValueError("aligned OpenFST files are not supported (write without --fst_align)")
     f = ArcFST(start=start)
     if flags & 1:
         f.isyms, pos = _rd_symtab(buf, pos)
     if flags & 2:
         _, pos = _rd_symtab(buf, pos)
-    for q in range(num_states):
+    q = 0
+    # num_states = -1 (kNoStateId): the header went out before the states were counted — they run to the end of the file
+    while (q < num_states) if num_states >= 0 else (pos < len(buf)):
         (final, narcs), pos = _rd("<fq", buf, pos)
         if final != float("inf"):
             f.final[q] = final
         for _ in range(narcs):
             (il, _ol, w, nxt), pos = _rd("<iifi", buf, pos)
             f.add_arc(q, nxt, il, w)
+        q += 1
     return f
 
 

@@ -306,6 +306,129 @@ def test_openfst_binary_round_trip(tmp_path):
         LM.read_openfst_binary(b"\x00" * 64)
 
 
+# ---- an OpenFST binary assembled byte by byte HERE (not by lm.write_openfst_binary) --------------------------------------------
+# Layout as OpenFST documents / writes it (fst/fst.cc FstHeader::Write, fst/fst.h FstImpl::WriteFstHeader, fst/vector-fst.h
+# VectorFst::WriteFst, fst/symbol-table.cc SymbolTableImpl::Write; little endian, strings = int32 length + bytes):
+#   int32 magic 2125659606 | string fst type | string arc type | int32 version | int32 flags (1 isymbols, 2 osymbols, 4 aligned)
+#   | uint64 properties | int64 start | int64 num_states | int64 num_arcs
+#   [input symbols] [output symbols]:  int32 magic 2125658996 | string name | int64 available_key | int64 size | size x (string, int64 key)
+#   per state: float32 final weight (tropical: +inf = not final) | int64 number of arcs | arcs x (int32 ilabel, int32 olabel, float32 weight, int32 nextstate)
+# The reference reads such files with PyFST's `fst.read` (lvsr/ops.py:37-49); bin/lm2fst.sh:38-126 builds them with fstcompile ...
+# fstrmepsilon / fstpush, all of which write `vector` FSTs of `standard` arcs.
+def _hand_assembled_openfst(num_states_in_header=None, fst_type=b"vector", arc_type=b"standard", flags=3, with_osyms=True):
+    import struct
+    i32, i64, u64, f32 = (lambda v: struct.pack("<i", v)), (lambda v: struct.pack("<q", v)), (lambda v: struct.pack("<Q", v)), \
+        (lambda v: struct.pack("<f", v))
+    string = lambda b: i32(len(b)) + b
+    NOT_FINAL = bytes([0x00, 0x00, 0x80, 0x7f])                   # float32 +infinity, spelled as its bytes
+    syms = [(b"<eps>", 0), (b"a", 1), (b"b", 2), (b"<eol>", 3), (b"c", 7)]      # a key gap: available_key 8, 5 symbols
+    words = [(b"<eps>", 0), (b"ab", 1), (b"ba", 2)]
+    # (src, ilabel, olabel, weight, dst) — an epsilon arc 0 -> 1, two arcs with the same label from one state (non-deterministic),
+    # output labels that differ from the input labels (LG.fst is a transducer: the reference looks at arc.ilabel only, ops.py:57-59),
+    # a state without arcs, a final state with a weight
+    arcs = {0: [(0, 0, 0.5, 1), (1, 1, 0.25, 2), (1, 0, 1.5, 3)],
+            1: [(1, 0, 0.75, 2), (2, 2, 0.125, 3)],
+            2: [(2, 1, 1.0, 0), (0, 0, 2.0, 3), (7, 0, 0.375, 2)],
+            3: [(0, 0, 0.3125, 5), (3, 0, 0.0625, 4), (1, 0, 3.0, 0)],
+            4: [(1, 1, 0.875, 0)],
+            5: []}
+    final = {5: 0.5, 2: 1.25}
+    n_arcs = sum(len(v) for v in arcs.values())
+    props = 0x0000956a5a950003                                     # kExpanded | kMutable + a spread of high bits: needs all 64
+    out = [i32(2125659606), string(fst_type), string(arc_type), i32(2), i32(flags), u64(props), i64(0),
+           i64(len(arcs) if num_states_in_header is None else num_states_in_header), i64(n_arcs)]
+    if flags & 1:
+        out += [i32(2125658996), string(b"chars_disambig.txt"), i64(8), i64(len(syms))] + [string(sy) + i64(k) for sy, k in syms]
+    if flags & 2 and with_osyms:
+        out += [i32(2125658996), string(b"words.txt"), i64(3), i64(len(words))] + [string(sy) + i64(k) for sy, k in words]
+    for q in range(len(arcs)):
+        out.append((f32(final[q]) if q in final else NOT_FINAL) + i64(len(arcs[q])))
+        out += [i32(il) + i32(ol) + f32(w) + i32(d) for (il, ol, w, d) in arcs[q]]
+    flat = [(q, d, il, w) for q, lst in arcs.items() for (il, ol, w, d) in lst]
+    return b"".join(out), flat, final, {sy.decode(): k for sy, k in syms}
+
+
+def test_openfst_binary_assembled_by_hand_reads_and_walks(tmp_path):
+    """N4 (round-5 verdict, ask 7): the `vector`/`standard` container read from bytes this test assembles from the documented layout
+    — header strings, version, flags, 64-bit properties, both symbol tables, an epsilon arc, final weights — then the host walk and
+    the device walk (emulated here) over what was read against the dense oracle built from the same arc list."""
+    from emu import emu_lib
+    data, flat, final, isyms = _hand_assembled_openfst()
+    assert len(data) == 4 + (4 + 6) + (4 + 8) + 4 + 4 + 8 + 8 + 8 + 8 \
+        + (4 + 4 + 18 + 8 + 8 + sum(4 + len(k) + 8 for k in ("<eps>", "a", "b", "<eol>", "c"))) \
+        + (4 + 4 + 9 + 8 + 8 + sum(4 + len(k) + 8 for k in ("<eps>", "ab", "ba"))) + 6 * 12 + len(flat) * 16
+    path = str(tmp_path / "LG_pushed.fst")
+    open(path, "wb").write(data)
+    for src in (path, data):
+        f = LM.read_openfst_binary(src)
+        assert f.start == 0 and f.isyms == isyms
+        assert f.final == final
+        got = sorted((q, d, il, numpy.float32(w)) for q, lst in f.arcs.items() for (il, d, w) in lst)
+        assert got == sorted((q, d, il, numpy.float32(w)) for q, d, il, w in flat)
+        assert [il for (il, d, w) in f.arcs[0]] == [0, 1, 1]        # arc order of a state preserved (ilabel-sorted files stay sorted)
+    # a header written to a pipe before the states were counted (num_states = -1, OpenFST's kNoStateId): states run to the end of file
+    f2 = LM.read_openfst_binary(_hand_assembled_openfst(num_states_in_header=-1)[0])
+    assert f2.final == final and sum(len(v) for v in f2.arcs.values()) == len(flat)
+    # what the reader must refuse, by name
+    for kw, word in ((dict(fst_type=b"const"), "const"), (dict(arc_type=b"log"), "log"), (dict(flags=7), "aligned")):
+        with pytest.raises(ValueError) as e:
+            LM.read_openfst_binary(_hand_assembled_openfst(**kw)[0])
+        assert word in str(e.value)
+    with pytest.raises(ValueError):
+        LM.read_openfst_binary(data[: len(data) - 7])               # truncated inside the last arc
+    # ---- the walks over the automaton that was READ: host (CsrWalk), device kernel (emulated), dense oracle
+    cmap = {"a": 0, "b": 1, "<eol>": 2, "c": 3}
+    dense = LO.DenseFST(flat, 0, 7)
+    host = LM.FSTLanguageModel(f, nn_char_map=cmap, no_transition_cost=23.0)
+    dev = LM.DeviceFSTLanguageModel(f, "cpu", lib=emu_lib(), nn_char_map=cmap, no_transition_cost=23.0)
+    assert host.remap_table == {0: 1, 1: 2, 2: 3, 3: 7}
+    rng = numpy.random.RandomState(4)
+    n = 4
+    hs, ds, vecs = host.initial_states(n), dev.initial_states(n), [dense.initial() for _ in range(n)]
+    assert set(_as_sets(hs)[0]) == {0, 1}                          # the epsilon closure of the start state
+    visited = set()
+    for step in range(12):
+        for b in range(n):
+            want = {i: v for i, v in enumerate(vecs[b]) if numpy.isfinite(v)}
+            for st in (hs, ds):
+                got = _as_sets(st)[b]
+                assert set(got) == set(want)
+                assert all(abs(got[q] - want[q]) < 1e-9 for q in got)
+            ref = dense.costs(vecs[b], host.remap_table, 23.0)
+            assert_allclose(hs["add"][b], ref, rtol=1e-5, atol=1e-5)
+            assert_allclose(ds["add"][b].cpu().numpy(), ref, rtol=2e-6, atol=2e-6)
+            visited |= set(want)
+        outs = []
+        for b in range(n):
+            ok = [c for c in range(4) if hs["add"][b, c] < 23.0]
+            outs.append(ok[rng.randint(len(ok))])
+        outs = numpy.array(outs)
+        hs, ds = host.transition(hs, outs), dev.transition(ds, outs)
+        vecs = [dense.step(v, host.remap_table[int(o)]) for v, o in zip(vecs, outs)]
+    assert visited == {0, 1, 2, 3, 4, 5}
+
+
+@pytest.mark.gpu
+def test_openfst_binary_assembled_by_hand_walks_on_the_gpu(gpu_device):
+    data, flat, final, isyms = _hand_assembled_openfst()
+    f = LM.read_openfst_binary(data)
+    cmap = {"a": 0, "b": 1, "<eol>": 2, "c": 3}
+    dense = LO.DenseFST(flat, 0, 7)
+    dev = LM.DeviceFSTLanguageModel(f, gpu_device, nn_char_map=cmap, no_transition_cost=23.0)
+    rng = numpy.random.RandomState(4)
+    ds, vecs = dev.initial_states(4), [dense.initial() for _ in range(4)]
+    for step in range(12):
+        add = ds["add"].cpu().numpy()
+        for b in range(4):
+            want = {i: v for i, v in enumerate(vecs[b]) if numpy.isfinite(v)}
+            got = _as_sets(ds)[b]
+            assert set(got) == set(want) and all(abs(got[q] - want[q]) < 1e-9 for q in got)
+            assert_allclose(add[b], dense.costs(vecs[b], dev.remap_table, 23.0), rtol=2e-6, atol=2e-6)
+        outs = numpy.array([[c for c in range(4) if add[b, c] < 23.0][rng.randint(sum(add[b] < 23.0))] for b in range(4)])
+        ds = dev.transition(ds, outs)
+        vecs = [dense.step(v, dev.remap_table[int(o)]) for v, o in zip(vecs, outs)]
+
+
 def test_lm_block_of_the_net_section_builds_the_fusion_model(tmp_path):
     """`net: {lm: {path: ..., weight: ...}, character_map: ...}` as in the reference's decode configs
     (lvsr/bricks/recognizer.py:322-337), from an OpenFST binary and from AT&T text + symbols."""
