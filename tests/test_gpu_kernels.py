@@ -140,6 +140,18 @@ FP_RTOL = {"wsj_base_ragged": 5e-3, "wsj_base_mean": 5e-3}
 # wsj_base 4.7e-6 / 4.9e-6, median 4.9e-4 / 2.7e-4, mean 1.7e-4 / 1.1e-3, ragged 3.0e-3 / 5.6e-3 (cosine >= 0.999996 everywhere); the
 # REFERENCE's float32 run itself is 3.5e-3 (mean) / 8.5e-4 (ragged) from the float64 oracle, the float32 oracle 3.3e-3 (ragged).
 SAMPLE_RTOL = {"wsj_base": 1e-4, "wsj_base_median": 3e-3, "wsj_base_mean": 6e-3, "wsj_base_ragged": 8e-3}
+# Round 6 (profiles/r06_ragged_deviation.md): on the ragged fixture the deviation sits on a few (label, utterance) rows of ONE
+# ill-conditioned region (utterance 2, labels 7-12) in every float32 computation — the float64 oracle on inputs moved by one float32
+# rounding moves the same tensors by 1.0-1.5e-3, the torch float32 oracle is 3.7e-3 on one host and 9.2e-3 on another; masked and last
+# labels contribute exactly zero in all paths.  The default path (cluster kernels, 2.95e-3 from the oracle, 3.8e-3 from the
+# reference's elements) gets the tighter bar.
+SAMPLE_RTOL_CLUSTER = {"wsj_base_ragged": 5e-3}
+
+
+def sample_rtol(case, persistent_decoder, default=5e-3):
+    if persistent_decoder and case in SAMPLE_RTOL_CLUSTER:
+        return SAMPLE_RTOL_CLUSTER[case]
+    return SAMPLE_RTOL.get(case, default)
 FULL_SIZE = [("timit_tiny", None), ("wsj_base", None), ("wsj_deep", None), ("wsj_stack2", None), ("wsj_paper", None),
              ("wsj_base_median", True), ("wsj_base_median", False), ("wsj_base_ragged", True), ("wsj_base_ragged", False),
              ("wsj_base_mean", True), ("wsj_base_mean", False)]
@@ -198,7 +210,7 @@ def test_full_size_configs_vs_reference_golden(gpu_device, case, persistent_deco
             name = str(name)
             idx = synthetic.grad_sample_index(name, got[name].shape)
             rel, cos = gradient_errors(got[name].ravel()[idx], z["gsub:" + name], z["gmax:" + name])
-            assert rel <= SAMPLE_RTOL.get(case, 5e-3) and cos >= 0.99999, (name, rel, cos)
+            assert rel <= sample_rtol(case, persistent_decoder) and cos >= 0.99999, (name, rel, cos)
 
 
 # the float64 oracle's FULL gradient tensors as the yardstick at full size (round-4 verdict, weak 1): the restatement is pinned to the
@@ -243,7 +255,7 @@ def test_full_size_full_gradient_tensors_vs_float64_oracle(gpu_device, float64_o
     got = rec.store.get_grads()
     for name, ref in ref_grads.items():
         rel, cos = gradient_errors(got[name], ref)
-        assert rel <= SAMPLE_RTOL[case] and cos >= 0.99999, (name, rel, cos)
+        assert rel <= sample_rtol(case, persistent_decoder) and cos >= 0.99999, (name, rel, cos)
 
 
 # ---- beam search on the GPU vs the hypotheses the reference produced --------------------------------

@@ -154,6 +154,19 @@ def main():
         rows.sort(reverse=True)
         out.append("reference (Theano float32, sampled elements) vs the float64 oracle: " +
                    ", ".join("%s %.2e" % (k.replace("/recognizer/", ""), v) for v, k in rows[:5]) + "\n")
+    if "--perturb" in sys.argv:
+        # the conditioning of the fixture itself, no float32 arithmetic involved: the float64 oracle on parameters and features moved by
+        # ONE float32 rounding (relative 2^-24, random signs) — what any float32 implementation does to its inputs before it starts
+        for seed in (1, 2):
+            rng = numpy.random.RandomState(seed)
+            eps = 2.0 ** -24
+            pp = {k: (numpy.asarray(v, numpy.float64) * (1.0 + eps * rng.choice([-1.0, 1.0], size=v.shape))) for k, v in params.items()}
+            bb = dict(batch, recordings=numpy.asarray(batch["recordings"], numpy.float64) * (1.0 + eps * rng.choice([-1.0, 1.0], size=batch["recordings"].shape)))
+            t0 = time.time()
+            rp, gp, cmp_, argp = oracle_rows(cfg, pp, bb, torch.float64)
+            sys.stderr.write("perturbed float64 oracle %.0f s\n" % (time.time() - t0))
+            describe("float64 oracle, every parameter and feature moved by one float32 rounding (2^-24 relative, random signs, seed %d)" % seed, rp, ref, ym, out)
+            tensor_table("perturbed float64 oracle", gp, g64, out)
     if not cpu_only:
         for persistent, name in ((True, "cluster kernels (persistent decoder)"), (False, "step kernels")):
             dxg, g, cm, arg = gpu_rows(cfg, params, batch, persistent)
