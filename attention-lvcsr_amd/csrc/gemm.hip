@@ -118,69 +118,69 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
             }
 }
 
-// ---- 128x128x32 tile, v_mfma_f32_32x32x2_f32, register-prefetch double buffering ------------------------------------
+// ---- 128x128x32 (and 64x64x32) tiles, v_mfma_f32_32x32x2_f32, register-prefetch double buffering ---------------------------
 // Used when the output is at least one full tile: 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32 blocks (64 accumulator
-// registers).  Operands are staged k-major in LDS ([k][m], [k][n]) so each MFMA operand read is a conflict-free row of
-// 32 consecutive floats; the next k-tile is fetched from global memory into registers (float4 along the contiguous
-// dimension) while the current one is consumed.
-// Measured (tools/gemm_shapes.py): with a 16-deep k-tile one tile ran at 1.75 us per k-iteration against 0.85 us of MFMA
-// issue: the prefetch, issued one iteration ahead, did not cover the HBM latency.  32-deep k-tiles give the
-// loads 1.7 us of MFMA work to hide behind and halve the barriers; the block -> tile map below keeps the tiles that share
-// operand panels on one XCD (blocks are dealt to XCDs round-robin, each XCD has its own L2).
+// registers).  Round 6 layout (tools/probes/mfma_rate_probe.hip, profiles/r06_gemm_probe.md): the LDS image of BOTH operands is
+// [row][k] with k contiguous (row = m for A, n for B; 36-float rows), and a lane fetches its MFMA operands 16 bytes at a time —
+// four k of its row per ds_read_b128, 16 LDS reads per k-tile instead of the 64 ds_read2_b32 of the round-1..5 image ([k][row],
+// one k per read), which alone held one wave per SIMD at 0.85 of the MFMA rate (4 831 cycles per 64 MFMAs; 4 270 with b128 reads).
+// The instruction contracts k = lane / 32 per step, so lanes 0-31 walk k0 .. k0+15 and lanes 32-63 k0+16 .. k0+31 of the k-tile:
+// every k exactly once, in an order of additions that differs from a sequential k loop (and is the same for every tile shape).
+// Staging: the operand whose k is contiguous in memory goes global float4 -> ds_write_b128; the other one (rows contiguous) is
+// fetched as float4 along the rows (a wave = eight full 128-byte lines) and transposed on the way in, four scalar writes per float4
+// (probe: 0.92 of the MFMA rate for the whole loop against 0.93 with both operands k-contiguous; 16 dword loads + b128 writes 0.84).  The next k-tile is fetched from global memory
+// into registers while the current one is consumed; the block -> tile map keeps the tiles that share operand panels on one XCD.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define GM 128
 #define GN 128
 #define GK 32
-#define GU (GK / 8)                    // float4 units per thread and operand tile
-#define GLD (GM + 4)
+#define GLD 36                         // floats per LDS row: 16-byte aligned rows, b128 reads of 16 consecutive rows hit 64 distinct banks
 
-// one TX x GK (or GK x TX) operand tile (TX = 128 or 64): GK*TX/4 float4 units, TX/32 per thread.  CONTIG_K: element (x,k) at
-// p[x*ld + k].
-template <bool CONTIG_K, int TX>
-__device__ __forceinline__ void gemm_tile_load(const float* __restrict__ p, int ld, int x0, int X, int k0, int kend, bool vec,
-                                               float4 (&r)[TX / 32]) {
+// One TX x GK operand tile in registers: TX / 32 float4 per thread.
+// CONTIG_K (element (x, k) at p[x * ld + k]): unit u = tid + 256 h -> row u / 8, k-group u % 8 (eight lanes = one 128-byte row).
+// otherwise (element (x, k) at p[k * ld + x]): k = 8 * wave + lane % 8, rows 4 * (8 h + (lane / 8) % 8) .. + 3.
+template <bool CONTIG_K, int TX, bool GUARD>
+__device__ __forceinline__ void gemm2_tile_load(const float* __restrict__ p, int ld, int x0, int X, int k0, int kend, bool vec,
+                                                float4 (&r)[TX / 32]) {
+    if (CONTIG_K) {
 #pragma unroll
-    for (int h = 0; h < TX / 32; ++h) {
-        const int u = threadIdx.x + h * 256;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (CONTIG_K) {
-            const int x = x0 + (u % TX), k = k0 + (u / TX) * 4;
-            if (x < X && k < kend) v = ld4g(p + (size_t)x * ld + k, kend - k, vec);
-        } else {
-            const int k = k0 + u / (TX / 4), x = x0 + (u % (TX / 4)) * 4;
-            if (k < kend && x < X) v = ld4g(p + (size_t)k * ld + x, X - x, vec);
+        for (int h = 0; h < TX / 32; ++h) {
+            const int u = threadIdx.x + h * 256;
+            const int x = x0 + (u >> 3), k = k0 + (u & 7) * 4;
+            if (!GUARD) r[h] = *(const float4*)(p + (size_t)x * ld + k);
+            else r[h] = (x < X && k < kend) ? ld4g(p + (size_t)x * ld + k, kend - k, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        r[h] = v;
-    }
-}
-// the same tile when it is known to be complete, in bounds and 16-B aligned: straight-line dwordx4 loads.  (The guarded
-// form compiles to exec-masked branches whose results are merged right behind them, i.e. the wave waits for its
-// "prefetch" before it starts the MFMAs of the current tile — measured as exactly half the MFMA rate.)
-template <bool CONTIG_K, int TX>
-__device__ __forceinline__ void gemm_tile_load_fast(const float* __restrict__ p, int ld, int x0, int k0, float4 (&r)[TX / 32]) {
+    } else {
+        // rows contiguous: float4 along the rows; a wave = 8 k x 8 groups of 4 rows (eight full 128-byte lines per instruction)
+        const int k = k0 + (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
 #pragma unroll
-    for (int h = 0; h < TX / 32; ++h) {
-        const int u = threadIdx.x + h * 256;
-        if (CONTIG_K) r[h] = *(const float4*)(p + (size_t)(x0 + (u % TX)) * ld + k0 + (u / TX) * 4);
-        else r[h] = *(const float4*)(p + (size_t)(k0 + u / (TX / 4)) * ld + x0 + (u % (TX / 4)) * 4);
+        for (int h = 0; h < TX / 32; ++h) {
+            const int x = x0 + 4 * (h * 8 + ((threadIdx.x >> 3) & 7));
+            if (!GUARD) r[h] = *(const float4*)(p + (size_t)k * ld + x);
+            else r[h] = (k < kend && x < X) ? ld4g(p + (size_t)k * ld + x, X - x, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
 }
 template <bool CONTIG_K, int TX>
-__device__ __forceinline__ void gemm_tile_store(float (*S)[TX + 4], const float4 (&r)[TX / 32]) {
+__device__ __forceinline__ void gemm2_tile_store(float (*S)[GLD], const float4 (&r)[TX / 32]) {
+    if (CONTIG_K) {
 #pragma unroll
-    for (int h = 0; h < TX / 32; ++h) {
-        const int u = threadIdx.x + h * 256;
-        if (CONTIG_K) {
-            const int x = u % TX, k = (u / TX) * 4;
-            S[k + 0][x] = r[h].x; S[k + 1][x] = r[h].y; S[k + 2][x] = r[h].z; S[k + 3][x] = r[h].w;
-        } else {
-            const int k = u / (TX / 4), x = (u % (TX / 4)) * 4;
-            *(float4*)&S[k][x] = r[h];
+        for (int h = 0; h < TX / 32; ++h) {
+            const int u = threadIdx.x + h * 256;
+            *(float4*)&S[u >> 3][(u & 7) * 4] = r[h];
+        }
+    } else {
+        // transposed on the way in: four scalar writes per float4; the lanes of a wave (8 row groups x 8 k) fall two to a bank
+        const int k = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+#pragma unroll
+        for (int h = 0; h < TX / 32; ++h) {
+            const int x = 4 * (h * 8 + ((threadIdx.x >> 3) & 7));
+            S[x][k] = r[h].x; S[x + 1][k] = r[h].y; S[x + 2][k] = r[h].z; S[x + 3][k] = r[h].w;
         }
     }
 }
 
-// FAST (host-selected): operands 16-B aligned with ld % 4 == 0.  Blocks whose 128x128 tile lies inside the matrix then take
+// FAST (host-selected): operands 16-B aligned with ld % 4 == 0.  Blocks whose tile lies inside the matrix then take
 // the unguarded loads for every complete k-tile; edge blocks and a ragged last k-tile of a chunk take the guarded ones.
 // launch-linear block L of `total` -> position t in the tile sequence: block L runs on XCD L % 8; every XCD gets one contiguous
 // run of the sequence, so tiles sharing an operand panel / a k-chunk meet in one L2
@@ -195,8 +195,8 @@ __device__ __forceinline__ int gemm_xcd_order(int L, int total) {
 template <int TM, int TN, bool TA, bool TB, bool FAST>
 __device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
     constexpr int MI = TM / 64, NI = TN / 64;                 // MFMA blocks per wave
-    __shared__ __attribute__((aligned(16))) float As[2][GK][TM + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK][TN + 4];
+    __shared__ __attribute__((aligned(16))) float As[2][TM][GLD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][TN][GLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (g.batch > 1) {
         g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
@@ -218,56 +218,64 @@ __device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
     // A: not transposed -> (m,k) at A[m*lda+k] (contiguous k); transposed -> A[k*lda+m] (contiguous m)
     const bool inside = FAST && m0 + TM <= g.M && n0 + TN <= g.N;
     if (inside && kbeg + GK <= kend) {
-        gemm_tile_load_fast<!TA, TM>(g.A, g.lda, m0, kbeg, ra);
-        gemm_tile_load_fast<TB, TN>(g.B, g.ldb, n0, kbeg, rb);
+        gemm2_tile_load<!TA, TM, false>(g.A, g.lda, m0, g.M, kbeg, kend, true, ra);
+        gemm2_tile_load<TB, TN, false>(g.B, g.ldb, n0, g.N, kbeg, kend, true, rb);
     } else {
-        gemm_tile_load<!TA, TM>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
-        gemm_tile_load<TB, TN>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+        gemm2_tile_load<!TA, TM, true>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
+        gemm2_tile_load<TB, TN, true>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
     }
-    gemm_tile_store<!TA, TM>(As[0], ra);
-    gemm_tile_store<TB, TN>(Bs[0], rb);
+    gemm2_tile_store<!TA, TM>(As[0], ra);
+    gemm2_tile_store<TB, TN>(Bs[0], rb);
     __syncthreads();
     int cur = 0;
+    const int li = lane & 31, kh = (lane >> 5) * 16;
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
+        // the operands of the next four MFMA steps are fetched before the 4 * MI * NI MFMAs of the current four (the scheduler
+        // otherwise emits read -> wait -> MFMAs and the LDS latency is paid per group)
+        float4 pa[2][MI], pb[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) pa[0][i] = *(const float4*)&As[cur][wm + 32 * i + li][kh];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pb[0][j] = *(const float4*)&Bs[cur][wn + 32 * j + li][kh];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = q & 1, n = c ^ 1;
+            if (q + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) pa[n][i] = *(const float4*)&As[cur][wm + 32 * i + li][kh + 4 * (q + 1)];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) pb[n][j] = *(const float4*)&Bs[cur][wn + 32 * j + li][kh + 4 * (q + 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) {
+                        const float x = e == 0 ? pa[c][i].x : e == 1 ? pa[c][i].y : e == 2 ? pa[c][i].z : pa[c][i].w;
+                        const float y = e == 0 ? pb[c][j].x : e == 1 ? pb[c][j].y : e == 2 ? pb[c][j].z : pb[c][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // The next k-tile is fetched BEHIND the MFMAs of this one and written to the other LDS buffer as it arrives — no register
+        // prefetch across the MFMAs.  Measured (tools/probes/gemm_bisect_probe.hip, 16 384 x 512 x 8 192, two work-groups per CU):
+        // loads in front of the MFMAs 4.35 us per k-tile (121 TFLOP/s; the k-contiguous operand's loads — 8 rows x 128 bytes per
+        // wave instruction — in front cost 5.0 on their own), all loads behind 3.97 (133 TFLOP/s): the latency then lies open in front of
+        // the staging writes, where the co-resident work-group's MFMAs cover it; a wave that issues eight 1-KB loads and then MFMAs
+        // does not get its MFMAs out.
         if (more) {
             if (inside && k0 + 2 * GK <= kend) {
-                gemm_tile_load_fast<!TA, TM>(g.A, g.lda, m0, k0 + GK, ra);
-                gemm_tile_load_fast<TB, TN>(g.B, g.ldb, n0, k0 + GK, rb);
+                gemm2_tile_load<!TA, TM, false>(g.A, g.lda, m0, g.M, k0 + GK, kend, true, ra);
+                gemm2_tile_load<TB, TN, false>(g.B, g.ldb, n0, g.N, k0 + GK, kend, true, rb);
             } else {
-                gemm_tile_load<!TA, TM>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
-                gemm_tile_load<TB, TN>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
+                gemm2_tile_load<!TA, TM, true>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
+                gemm2_tile_load<TB, TN, true>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
             }
-        }
-        // operand fetch of MFMA step s+1 is issued before the MFMAs of step s (the scheduler otherwise emits
-        // read -> wait -> MFMAs per step and the LDS latency is paid 16 times per k-tile)
-        const int kr0 = lane >> 5, li = lane & 31;
-        float pa[2][MI], pb[2][NI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) pa[0][i] = As[cur][kr0][wm + 32 * i + li];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) pb[0][j] = Bs[cur][kr0][wn + 32 * j + li];
-#pragma unroll
-        for (int s = 0; s < GK / 2; ++s) {
-            const int c = s & 1, n = c ^ 1;
-            if (s + 1 < GK / 2) {
-                const int kr = 2 * (s + 1) + kr0;
-#pragma unroll
-                for (int i = 0; i < MI; ++i) pa[n][i] = As[cur][kr][wm + 32 * i + li];
-#pragma unroll
-                for (int j = 0; j < NI; ++j) pb[n][j] = Bs[cur][kr][wn + 32 * j + li];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][i], pb[c][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) {
-            gemm_tile_store<!TA, TM>(As[cur ^ 1], ra);
-            gemm_tile_store<TB, TN>(Bs[cur ^ 1], rb);
+            gemm2_tile_store<!TA, TM>(As[cur ^ 1], ra);
+            gemm2_tile_store<TB, TN>(Bs[cur ^ 1], rb);
         }
         __syncthreads();
         cur ^= 1;

@@ -575,16 +575,18 @@ def main(backend=None):
     # ---- strong scaling (north_star: global batch 128 = BASELINE configs[2] sharded over the ranks, rank r takes r::N; target >= 6x
     # at 8 GPUs): the same job in the SAME launch as the weak line, and the one-GPU step at that global batch it is measured against
     strong = None
-    if backend.measured and not args.no_strong and args.scaling == "weak" and args.workload in STRONG_GLOBAL_BATCH and not args.ragged \
-            and not args.frames and not args.batch:
-        GB = STRONG_GLOBAL_BATCH[args.workload]
+    strong_batches = dict(STRONG_GLOBAL_BATCH, **getattr(backend, "strong_global_batch", {}))
+    if (backend.measured or getattr(backend, "strong_leg", False)) and not args.no_strong and args.scaling == "weak" \
+            and args.workload in strong_batches and not args.ragged and not args.frames and not args.batch:
+        GB = strong_batches[args.workload]
         if GB % world == 0:
             sb = []
             for k in range(2):
                 gbatch = synthetic.make_batch(cfg, GB, T, L, seed=4321 + k)
                 sb.append({kk: torch.from_numpy(v).to(dev) for kk, v in synthetic.shard_batch(gbatch, rank, world).items()})
-            n_st = max(5, min(args.steps, 10))
-            el, _ = timed(trainer, sb, n_st, GB, 3)
+            # (a stand-in backend — the CPU emulator of the launch tests — runs ONE step of each form: the plumbing, not the numbers)
+            n_st, n_warm = (max(5, min(args.steps, 10)), 3) if backend.measured else (1, 0)
+            el, _ = timed(trainer, sb, n_st, GB, n_warm)
             strong = dict(global_batch=GB, per_gpu_batch=GB // world, steps=n_st, ms_per_step=el / n_st * 1e3,
                           value=GB * T * n_st / el, unit="frames/s", scaling="strong",
                           encoder_kernels=encoder_kernels_of(rec, GB // world, dims))
@@ -597,7 +599,7 @@ def main(backend=None):
                 try:
                     solo = Trainer(rec, distributed=False, **TRAIN_CONF)
                     full = [{kk: torch.from_numpy(v).to(dev) for kk, v in synthetic.make_batch(cfg, GB, T, L, seed=4321 + k).items()} for k in range(2)]
-                    for k in range(3):
+                    for k in range(n_warm):
                         solo.train_step(full[k % 2], global_batch_size=GB)
                     sync()
                     t_a = time.perf_counter()
@@ -620,6 +622,15 @@ def main(backend=None):
                               one_gpu_how="rank 0 alone on the whole global batch (no collective) in this same launch; the speed-up is "
                                           "quoted against the FASTER of the two one-GPU forms (encoder in passes of 64 utterances on the "
                                           "cluster kernels / one pass on the step kernels)")
+                if args.workload == "wsj_base":
+                    # what a reader of an 8-GPU line should expect (no 8-GPU node was available to the build in any round): the
+                    # north_star asks for >= 6x; the step of 16 utterances per GPU is a chain of dependent recurrent steps that does
+                    # not shorten with the batch, so the projection from the one-GPU measurements is below it
+                    strong.update(north_star_target_at_8_gpus=6.0, projected_speedup_at_8_gpus=4.2,
+                                  projection_how="one-GPU step at global batch 128 (encoder in passes, 57.3 ms) / (one-GPU step at 16 "
+                                                 "utterances, 13.5 ms + one 20.9 MB all-reduce, 0.3 ms): DESIGN.md section 5; the chain "
+                                                 "floor of 16 utterances per GPU (2 x 2 800 recurrent steps x 1.1 us + decoder + "
+                                                 "products = 10.8 ms) bounds this mechanism at 5.3x")
     last_cost = float(cm.sum())
     assert numpy.isfinite(last_cost), "training diverged in the benchmark"
     # ---- self-check inputs (all ranks): was any step skipped, did the step replay as a captured graph region
@@ -632,7 +643,20 @@ def main(backend=None):
         skipped_total, graph_region_ok = float(t[0]), float(t[1]) == 0.0
     else:
         skipped_total, graph_region_ok = skipped_local, graph_local == 1.0
-    check_ok = skipped_total == 0 and graph_region_ok and ((not dist) or torch.distributed.get_world_size() == args.gpus)
+    # rank r works on utterances r::world of every global minibatch: every rank fingerprints the shard it was
+    # actually fed, rank 0 compares with the fingerprints of columns r::world of the global minibatch it generates itself
+    import zlib
+    def shard_crc(b):
+        return zlib.crc32(b"".join(numpy.ascontiguousarray(b[k]).tobytes() for k in ("recordings", "recordings_mask", "labels", "labels_mask")))
+    mine = shard_crc({k: v.cpu().numpy() for k, v in staged[0].items()})
+    shards_ok = True
+    if dist:
+        got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        torch.distributed.all_gather(got, torch.tensor([mine], dtype=torch.int64, device=dev))
+        if rank == 0:
+            gb0 = synthetic.make_batch(cfg, global_batch, T, L, seed=1234, ragged=args.ragged)
+            shards_ok = all(int(got[r][0]) == shard_crc(synthetic.shard_batch(gb0, r, world)) for r in range(world))
+    check_ok = skipped_total == 0 and graph_region_ok and shards_ok and ((not dist) or torch.distributed.get_world_size() == args.gpus)
     rec.generator.check_persistent()
     rec.encoder.check_persistent()          # raises if a persistent cluster kernel gave up waiting (results would be invalid)
     ms = elapsed / args.steps * 1e3
@@ -684,6 +708,7 @@ def main(backend=None):
         # whole-step graph region, no step of any rank was skipped by the guard and no cluster launch gave up
         out["self_check"] = dict(ok=bool(check_ok), collective_world_size_is_n_gpus=(not dist) or torch.distributed.get_world_size() == args.gpus,
                                  whole_step_graph_region=bool(graph_region_ok), steps_skipped=int(skipped_total), cluster_aborts=int(trainer.aborts),
+                                 rank_r_holds_utterances_r_mod_world=bool(shards_ok),
                                  cluster_reserve=int(rec.lib.get_knob("cluster_reserve")))
         if backend.measured:
             pr = dominant_kernel_probe(rec, dims, T, B)

@@ -22,7 +22,9 @@ def toy_config():
 class EmulatorBackend(object):
     measured = False            # numbers are meaningless here: no roofline / cpu_baseline / decode legs, no graph priming
     collective = "gloo"
-    workloads = {"toy": (toy_config, 4, 13, 5)}
+    workloads = {"toy": (toy_config, 4, 13, 5), "toy_strong128": (toy_config, 4, 13, 5)}
+    strong_leg = True           # the `strong` sub-object (global batch sharded r::world + both one-GPU forms) on the toy network too:
+    strong_global_batch = {"toy_strong128": 128}          # one step of each form (45 s per one-GPU step of 128 utterances on the emulator)
 
     def open(self, local_rank):
         from emu import emu_lib
