@@ -101,9 +101,13 @@ __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
         const int k = x / g.nq, t = (x % g.nq) * 4;
         const float* f = fl + k * FW4;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+        // taps whose source positions t + c - e - 3 .. t + c - e + 4 reach into the window; the others multiply zeros of the cut
+        // alignment (adding +-0 to a sum that started at +0 leaves it as it is: the same bits as the full loop).  Under the
+        // window_around_* priors the window is ~110 of the 201 taps' reach: half the loop.
+        const int e_lo = max(0, (t + c - 3 - (w.end - 1) + 3 - 7) & ~3), e_hi = min(FW4, t + c + 4 - w.begin + 1);
         if (t + 3 >= w.begin && t < w.end)
 #pragma unroll 4
-            for (int e = 0; e < FW4; e += 4) {
+            for (int e = e_lo; e < e_hi; e += 4) {
                 const float4 fe = *(const float4*)(f + e);
                 const float* src = al + (OFF + t + c - e - 3);          // v[n] = al_cut[t + c - e - 3 + n]
                 const float4 lo = *(const float4*)src, hi = *(const float4*)(src + 4);
@@ -237,56 +241,62 @@ __global__ __launch_bounds__(256) void attdec_energy_mfma_kernel(AttDec a, int i
         wet[tile] = -2.f * wv;
         wsum += wv;
     }
-    // A operands of the first row; the next row's are fetched while this one is worked on
-    float av[KCP / 4], an[KCP / 4];
-    auto fetch = [&](int b, float (&dst)[KCP / 4]) {
+    // Rows in chunks of EN_RC: the operands of a whole chunk (convolution features and state projections: the only loads of the row
+    // loop) are fetched before its first row is worked on — one exposed round trip per chunk instead of one per row (round 5 fetched
+    // one row ahead: the loop of 8-16 rows was a chain of ~1 us load latencies with a hundred instructions of work between them).
+    // The arithmetic of a row is unchanged (bit-identical energies).
+    constexpr int EN_RC = 8;
+    for (int r0 = rbeg; r0 < rend; r0 += EN_RC) {
+        float av[EN_RC][KCP / 4], sw[EN_RC][2];
 #pragma unroll
-        for (int sq = 0; sq < KCP / 4; ++sq) {
-            const int k = 4 * sq + g4;
-            dst[sq] = k < K ? a.CV[(((size_t)i * B + b) * K + k) * Tp + tA] : 0.f;
+        for (int rr = 0; rr < EN_RC; ++rr) {
+            const int b = bfirst + min(r0 + rr, rend - 1);
+#pragma unroll
+            for (int sq = 0; sq < KCP / 4; ++sq) {
+                const int k = 4 * sq + g4;
+                av[rr][sq] = k < K ? a.CV[(((size_t)i * B + b) * K + k) * Tp + tA] : 0.f;
+            }
+#pragma unroll
+            for (int tile = 0; tile < 2; ++tile) sw[rr][tile] = C2 * a.sW[((size_t)i * B + b) * M + mcol[tile]];
         }
-    };
-    fetch(bfirst + rbeg, av);
-    for (int row = rbeg; row < rend; ++row) {
-        const int b = bfirst + row;
-        if (row + 1 < rend) fetch(b + 1, an);
-        f32x4 acc[2];
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
-            const float sw = C2 * a.sW[((size_t)i * B + b) * M + mcol[tile]];
-            acc[tile] = (f32x4){pa[tile][0] + sw, pa[tile][1] + sw, pa[tile][2] + sw, pa[tile][3] + sw};
-        }
-#pragma unroll
-        for (int sq = 0; sq < KCP / 4; ++sq)
+        for (int rr = 0; rr < EN_RC; ++rr) {
+            if (r0 + rr >= rend) break;
+            const int b = bfirst + r0 + rr;
+            f32x4 acc[2];
 #pragma unroll
             for (int tile = 0; tile < 2; ++tile)
-                acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[sq], Hb[tile][sq], acc[tile], 0, 0, 0);
-        float ra[4] = {wsum, wsum, wsum, wsum};
+                acc[tile] = (f32x4){pa[tile][0] + sw[rr][tile], pa[tile][1] + sw[rr][tile], pa[tile][2] + sw[rr][tile], pa[tile][3] + sw[rr][tile]};
 #pragma unroll
-        for (int tile = 0; tile < 2; ++tile) {
-            float ex[4];
+            for (int sq = 0; sq < KCP / 4; ++sq)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(acc[tile][r]);
+                for (int tile = 0; tile < 2; ++tile)
+                    acc[tile] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rr][sq], Hb[tile][sq], acc[tile], 0, 0, 0);
+            float ra[4] = {wsum, wsum, wsum, wsum};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_rcpf(1.0f + ex[r]);
+            for (int tile = 0; tile < 2; ++tile) {
+                float ex[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ra[r] += wet[tile] * ex[r];
+                for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_exp2f(acc[tile][r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ex[r] = __builtin_amdgcn_rcpf(1.0f + ex[r]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ra[r] += wet[tile] * ex[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                      // fold the 16 column lanes of the row group
+                ra[r] += lvsr_dpp_quad_xor1(ra[r]);
+                ra[r] += lvsr_dpp_quad_xor2(ra[r]);
+                ra[r] += lvsr_dpp_half_mirror(ra[r]);
+                ra[r] += lvsr_dpp_mirror(ra[r]);
+            }
+            if (c16 == 0) {
+                float* ep = a.ep + ((size_t)b * nslice + slice) * Tp;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (tC + r >= w.begin && tC + r < w.end) ep[tC + r] = ra[r];
+            }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {                      // fold the 16 column lanes of the row group
-            ra[r] += lvsr_dpp_quad_xor1(ra[r]);
-            ra[r] += lvsr_dpp_quad_xor2(ra[r]);
-            ra[r] += lvsr_dpp_half_mirror(ra[r]);
-            ra[r] += lvsr_dpp_mirror(ra[r]);
-        }
-        if (c16 == 0) {
-            float* ep = a.ep + ((size_t)b * nslice + slice) * Tp;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (tC + r >= w.begin && tC + r < w.end) ep[tC + r] = ra[r];
-        }
-#pragma unroll
-        for (int sq = 0; sq < KCP / 4; ++sq) av[sq] = an[sq];
     }
 }
 

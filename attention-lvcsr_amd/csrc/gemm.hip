@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
 // [row][k] with k contiguous (row = m for A, n for B; 36-float rows), and a lane fetches its MFMA operands 16 bytes at a time —
 // four k of its row per ds_read_b128, 16 LDS reads per k-tile instead of the 64 ds_read2_b32 of the round-1..5 image ([k][row],
 // one k per read), which alone held one wave per SIMD at 0.85 of the MFMA rate (4 831 cycles per 64 MFMAs; 4 270 with b128 reads).
-// The instruction contracts k = lane / 32 per step, so lanes 0-31 walk k0 .. k0+15 and lanes 32-63 k0+16 .. k0+31 of the k-tile:
-// every k exactly once, in an order of additions that differs from a sequential k loop (and is the same for every tile shape).
+// The instruction contracts k = lane / 32 per step: the columns of a row are permuted (gemm2_col) so that a lane's four values are
+// its k of four consecutive steps and the k loop stays ASCENDING — bit for bit the sums of the [k][row] image.
 // Staging: the operand whose k is contiguous in memory goes global float4 -> ds_write_b128; the other one (rows contiguous) is
 // fetched as float4 along the rows (a wave = eight full 128-byte lines) and transposed on the way in, four scalar writes per float4
 // (probe: 0.92 of the MFMA rate for the whole loop against 0.93 with both operands k-contiguous; 16 dword loads + b128 writes 0.84).  The next k-tile is fetched from global memory
@@ -161,17 +161,27 @@ __device__ __forceinline__ void gemm2_tile_load(const float* __restrict__ p, int
         }
     }
 }
+// column of k in a row of the LDS image: within every group of 8 k the four even ones, then the four odd ones — lanes 0-31 of an
+// MFMA step take an even k and lanes 32-63 the odd one behind it, so the 16-byte read of a lane holds ITS k of four consecutive steps
+// and the contraction runs over k in ascending order, two per instruction: the order (and the bits) of the [k][row] image of rounds
+// 1-5 and of the small-tile kernel's sequential k loop — what an utterance's encoder output rounds to must not depend on the tile shape
+// its batch size selects (batched == single searches, tests/test_decode_golden.py)
+__device__ __forceinline__ int gemm2_col(int k) { return (k & ~7) + ((k & 1) << 2) + ((k & 7) >> 1); }
+
 template <bool CONTIG_K, int TX>
 __device__ __forceinline__ void gemm2_tile_store(float (*S)[GLD], const float4 (&r)[TX / 32]) {
     if (CONTIG_K) {
+        // k = 4 (u % 8) .. + 3 -> columns gemm2_col(k): the even k of the float4 side by side, then the odd ones (two 8-byte writes)
 #pragma unroll
         for (int h = 0; h < TX / 32; ++h) {
             const int u = threadIdx.x + h * 256;
-            *(float4*)&S[u >> 3][(u & 7) * 4] = r[h];
+            const int c0 = ((u & 7) >> 1) * 8 + (u & 1) * 2;
+            *(float2*)&S[u >> 3][c0] = make_float2(r[h].x, r[h].z);
+            *(float2*)&S[u >> 3][c0 + 4] = make_float2(r[h].y, r[h].w);
         }
     } else {
         // transposed on the way in: four scalar writes per float4; the lanes of a wave (8 row groups x 8 k) fall two to a bank
-        const int k = (threadIdx.x >> 6) * 8 + (threadIdx.x & 7);
+        const int k = gemm2_col((threadIdx.x >> 6) * 8 + (threadIdx.x & 7));
 #pragma unroll
         for (int h = 0; h < TX / 32; ++h) {
             const int x = 4 * (h * 8 + ((threadIdx.x >> 3) & 7));
@@ -228,7 +238,7 @@ __device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
     gemm2_tile_store<TB, TN>(Bs[0], rb);
     __syncthreads();
     int cur = 0;
-    const int li = lane & 31, kh = (lane >> 5) * 16;
+    const int li = lane & 31, kh = (lane >> 5) * 4;           // (gemm2_col: even k of a group of 8 in columns 0-3, odd k in 4-7)
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         const bool more = k0 + GK < kend;
         // the operands of the next four MFMA steps are fetched before the 4 * MI * NI MFMAs of the current four (the scheduler
@@ -243,9 +253,9 @@ __device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
             const int c = q & 1, n = c ^ 1;
             if (q + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) pa[n][i] = *(const float4*)&As[cur][wm + 32 * i + li][kh + 4 * (q + 1)];
+                for (int i = 0; i < MI; ++i) pa[n][i] = *(const float4*)&As[cur][wm + 32 * i + li][kh + 8 * (q + 1)];
 #pragma unroll
-                for (int j = 0; j < NI; ++j) pb[n][j] = *(const float4*)&Bs[cur][wn + 32 * j + li][kh + 4 * (q + 1)];
+                for (int j = 0; j < NI; ++j) pb[n][j] = *(const float4*)&Bs[cur][wn + 32 * j + li][kh + 8 * (q + 1)];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

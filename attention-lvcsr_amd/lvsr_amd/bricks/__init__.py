@@ -97,6 +97,8 @@ class Encoder(object):
         # concurrent GEMM work-groups delay the latency-bound step kernels more than the overlap saves), so off by default
         # (round 3, persistent cluster kernels, groups flushed per layer on the second stream inside the step graph: 16.36 vs
         # 15.64 ms — the GEMM work-groups sharing the CUs slow the polling clusters by more than the 1.4 ms they hide)
+        # (round 6, tools/probes/cu_partition_probe.py: the side stream created with hipExtStreamCreateWithCUMask on its own CUs and the
+        # clusters on the others — eager launches only, a hipGraph kernel node has no CU-mask attribute: profiles/r06_cu_partition.md)
         self.overlap = False        # measured and rejected (comment above); the attribute keeps the second-stream code reachable for probes
         self._side = None
         self._side_pending = False
@@ -426,6 +428,11 @@ class Encoder(object):
                     o = di * 3 * H
                     self._scatter += [(gW[:, o: o + H], g[n["Wi"]]), (gW[:, o + H: o + 3 * H], g[n["Wg"]]),
                                       (gb[o: o + H], g[n["bi"]]), (gb[o + H: o + 3 * H], g[n["bg"]])]
+                if self.overlap and getattr(lib, "_group", None) is not None:
+                    # second-stream probes: the grouped products collected so far (this layer's, and — for the top layer — the
+                    # decoder's) run NOW on the side stream, beside the next layer's recurrence, not in one launch at the end
+                    lib.flush_group(ws.get("gemm_ws.grouped.side", (1 << 26,)))
+                    lib.begin_group()
             dy = dx
         self.join_side_stream()
         if getattr(lib, "_group", None) is None:      # no grouped launch pending: the fork gradients are there

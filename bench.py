@@ -201,8 +201,9 @@ def pmc_record(kernel):
 PEAK_HBM = 8.0e12               # bytes/s (MI355X_MICROARCH.md)
 
 
-def decode_leg(dev, utterances, batch=64, streams=2):
-    """configs[4] in the default line: a bounded sample of the decode workload (`--workload wsj_decode` runs all 1000 utterances) —
+def decode_leg(dev, utterances, batch=64, streams=4):
+    """configs[4] in the default line: ALL 1000 synthetic utterances by default (round 5 decoded a 128-utterance sample here; the whole
+    set is about a second of GPU time; `--workload wsj_decode` runs the same set as a line of its own) —
     beam 16 + char-trigram FST LM on the device, window_around_median(10, 100), exp/wsj/decode.sh settings, 800-frame synthetic
     utterances, `batch` utterances per set of launches and `streams` such batches in flight on one GPU (tools/bench_decode.py)."""
     from tools.bench_decode import build, run_batched
@@ -220,7 +221,7 @@ def decode_leg(dev, utterances, batch=64, streams=2):
                 hbm=dict(algorithmic_bytes=hbm_bytes, achieved=hbm_bytes / pos_s / 1e9, peak=PEAK_HBM / 1e9, unit="GB/s", frac=hbm_bytes / pos_s / PEAK_HBM),
                 transcendental=dict(ops=trans, achieved=trans / pos_s / 1e12, peak=trans_peak / 1e12, unit="Tops/s", frac=trans / pos_s / trans_peak),
                 note="neither roofline is near: the leg is bound by the ramp-up / tails of thirteen dependent kernels per position (DESIGN.md 7)")
-    return dict(roofline=roof, workload="wsj_decode sample: %d of the 1000 synthetic 800-frame utterances, WSJ-base weights, beam 16, device FST LM "
+    return dict(roofline=roof, workload="wsj_decode: %d synthetic 800-frame utterances (BASELINE configs[4]: 1000), WSJ-base weights, beam 16, device FST LM "
                          "(weight 0.5, no_transition_cost 20), char_discount 1.0, max length T/3" % done,
                 utterances=done, ms_per_utterance=sec / done * 1e3, utterances_per_s=done / sec, frames_per_s=nframes / sec,
                 utterances_per_launch_set=batch, searches_in_flight=streams * batch, positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1),
@@ -339,8 +340,8 @@ def main(backend=None):
     ap.add_argument("--frames", type=int, default=None, help="frames per utterance override (labels scale along unless --labels)")
     ap.add_argument("--labels", type=int, default=None, help="labels per utterance override")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (configs[4] sample) of the default line")
-    ap.add_argument("--decode-utterances", type=int, default=128)
+    ap.add_argument("--no-decode", action="store_true", help="skip the decode leg (configs[4]: all 1000 utterances) of the default line")
+    ap.add_argument("--decode-utterances", type=int, default=1000, help="utterances of the decode leg (configs[4] names 1000)")
     ap.add_argument("--decode-batch", type=int, default=64, help="decode: utterances per set of launches (1: one search per recognizer, --streams in flight)")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=INT",
                     help="tuning knob of the library (include/lvsr_hip.h LVSR_KNOB_*), for A/B measurements; recorded in config.knobs")
