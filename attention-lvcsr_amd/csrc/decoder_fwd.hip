@@ -96,9 +96,20 @@ __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
         fl[x] = e < FW ? a.filters[(size_t)(k0 + k) * FW + e] : 0.f;
     }
     __syncthreads();
-    // true convolution of the CUT alignment: out[t] = sum_e f[e] * al[t + c - e] (e = c + d), the alignment zero outside the window
-    for (int x = threadIdx.x; x < nk * g.nq; x += 256) {
-        const int k = x / g.nq, t = (x % g.nq) * 4;
+    // true convolution of the CUT alignment: out[t] = sum_e f[e] * al[t + c - e] (e = c + d), the alignment zero outside the window.
+    // Work items = (filter, quad of positions) over the quads that meet the WINDOW (round 6: 28 of the 50 quads of a 200-position
+    // row under window_around_median(10, 100) — the threads whose quads lay outside idled while the others took two items each);
+    // the positions outside the window are zeroed by a loop of their own.
+    {
+        float* rowout = a.CV + (((size_t)i * B + b) * a.K + k0) * Tp;
+        for (int x = threadIdx.x; x < nk * Tp; x += 256) {
+            const int t = x % Tp;
+            if (t < w.begin || t >= w.end) rowout[x] = 0.f;
+        }
+    }
+    const int q0 = max(w.begin, 0) >> 2, nqw = w.end > w.begin ? ((w.end + 3) >> 2) - q0 : 0;
+    for (int x = threadIdx.x; x < nk * nqw; x += 256) {
+        const int k = x / nqw, t = (q0 + x % nqw) * 4;
         const float* f = fl + k * FW4;
         float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
         // taps whose source positions t + c - e - 3 .. t + c - e + 4 reach into the window; the others multiply zeros of the cut
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void attdec_conv_kernel(AttDec a, int i) {
         const float o[4] = {o0, o1, o2, o3};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            if (t + j < Tp) out[t + j] = (t + j >= w.begin && t + j < w.end) ? o[j] : 0.f;
+            if (t + j >= w.begin && t + j < w.end) out[t + j] = o[j];
     }
 }
 
@@ -211,10 +222,15 @@ __global__ __launch_bounds__(256) void attdec_energy_mfma_kernel(AttDec a, int i
     const int slice = blockIdx.x, nslice = gridDim.x, B = a.B, Tp = a.Tp, M = a.M, K = a.K;
     const int rows = a.group_rows > 0 ? a.group_rows : 1, nsub = (rows + rpw - 1) / rpw;
     const int bfirst = (blockIdx.y / nsub) * rows, rbeg = (blockIdx.y % nsub) * rpw, rend = min(rows, rbeg + rpw);
-    const int t0 = blockIdx.z * ATT_TT;
     if (attdec_skip(a, bfirst)) return;
     const Win w = attdec_window_row(a, i, bfirst);
-    if (t0 >= w.end || t0 + ATT_TT <= w.begin) return;             // tile outside the window: nothing to add
+    // position tiles count from the window's first position (round 6): a 111-position window is TWO tiles of 64, not the 2.7 it
+    // touches on average of tiles laid from position 0 — the kernel is bound by its transcendentals (16 quarter-rate instructions per
+    // row and wave: 1 024 rows x 16 slices x 4 waves x ~650 cycles over 1 024 SIMDs = the 35 us it took), a third of which were
+    // spent on positions outside the window.  A position's partial energy does not depend on the tile that computes it (same
+    // operands, same order over the match columns): identical bits.  38.7 -> 22.8 us per pass at 64 utterances x 16 hypotheses.
+    const int t0 = w.begin + blockIdx.z * ATT_TT;
+    if (t0 >= w.end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
     const float C2 = 2.885390081777927f;                            // 2 log2(e)
     const int tA = min(t0 + 16 * wave + c16, Tp - 1);               // position whose features this lane feeds (A operand)
@@ -544,6 +560,11 @@ extern "C" int lvsr_attdec_fwd(void* stream, const lvsr_attdec_args* args, int u
         if ((a.phases & 1) && !(a.phases & 4) && a.K > 0 && a.prior_type != 0 && a.label0 == 0)
             hipLaunchKernelGGL(attdec_pos_kernel, dim3(a.B), dim3(64), 0, s, a, 0);
         for (int i = a.label0; i < a.L; ++i) {
+            // Round 6, measured at 64 utterances x 16 hypotheses and rejected (profiles/r06_decode.md): convolution and state products
+            // in ONE launch (21.0 us against 12.7 + 10.7 apart; the merged kernel takes the products' registers and the convolution's
+            // LDS); four column tiles per work-group in the 16 x 16 tile products (fragments of the row tile fetched once: gru1
+            // 20.7 -> 25.5 us, pre 10.7 -> 11.5, gru2 6.4 -> 7.7, readout merge 11.4 -> 15.0 — these kernels live off the NUMBER of
+            // short work-groups in flight, not off their operand traffic)
             if (g.nconv > 0 && g.small) hipLaunchKernelGGL((attdec_conv_kernel<PRE_AL_S, PRE_FL_S>), dim3(g.nconv), dim3(256), 0, s, a, i);
             else if (g.nconv > 0) hipLaunchKernelGGL((attdec_conv_kernel<PRE_AL, PRE_FL>), dim3(g.nconv), dim3(256), 0, s, a, i);
             if (g.nmm > 0) hipLaunchKernelGGL(attdec_pre_kernel, dim3(g.nmm), dim3(256), 0, s, a, i);

@@ -948,6 +948,10 @@ def _beam_methods():
         transition, then the surviving rows become the new beam."""
         d, lib, st = self.d, self.lib, self._beam
         K, B_ = st["rows"], st["B"]
+        # (The language-model walk needs the chosen characters and the gathered state sets, nothing of pass B — and pass B nothing of it.
+        # Run on a second stream beside pass B — fork / join through events, two branches of the step's graph — it was measured in round 6:
+        # 0.94 -> 1.12 ms per utterance at 64 x 4, 0.92 -> 1.18 at 64 x 8.  A fork and a join per position cost more than the 18 us of
+        # pointer chasing they take off the chain; serial.)
         if "stepB" in st:
             self._beam_step_run(st)
         else:
@@ -955,16 +959,20 @@ def _beam_methods():
                 self._feedback_fork(st["chars"], K, B_["xg"], st["fb"])
             lib.call("lvsr_attdec_fwd", lib.stream_for(B_["S"]), ctypes.byref(st["argsB"]), 0)
         if st["on_dev_lm"]:
-            L, lm = st["lm"], self.language_model
-            if st["groups"] > 1:       # the rows of finished searches are skipped (their characters are stale)
-                lib.call("lvsr_fst_lm_step_groups", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
-                         lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
-                         lib_ptr(L["add_new"]), lib_ptr(lm._err), lib_ptr(st["ctl"]), st["K"])
-            else:
-                lib.call("lvsr_fst_lm_step", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
-                         lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
-                         lib_ptr(L["add_new"]), lib_ptr(lm._err))
+            self._beam_lm_step(st, K)
         lib.call("lvsr_beam_compact", lib.stream_for(st["ctl"]), ctypes.byref(st["args"]))
+
+    def _beam_lm_step(self, st, K):
+        """Language-model transition on the chosen characters + look-ahead costs of the new state sets (lvsr_fst_lm_step*)."""
+        lib, L, lm = self.lib, st["lm"], self.language_model
+        if st["groups"] > 1:       # the rows of finished searches are skipped (their characters are stale)
+            lib.call("lvsr_fst_lm_step_groups", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
+                     lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
+                     lib_ptr(L["add_new"]), lib_ptr(lm._err), lib_ptr(st["ctl"]), st["K"])
+        else:
+            lib.call("lvsr_fst_lm_step", lib.stream_for(L["states_sel"]), ctypes.byref(lm._fst), lib_ptr(L["states_sel"]),
+                     lib_ptr(L["weights_sel"]), lib_ptr(st["chars"]), K, lib_ptr(L["states_new"]), lib_ptr(L["weights_new"]),
+                     lib_ptr(L["add_new"]), lib_ptr(lm._err))
 
     def beam_step(self):
         """All launches of one position as one replayed hipGraph (captured on the second step of a search shape)."""
@@ -991,7 +999,7 @@ def _beam_methods():
         self.lib.region(self, (st["key"], "x%d" % n), st["ctl"], enabled=self.use_graph, volatile=st["volatile"], drain=False).run(enqueue)
 
     return dict(beam_begin=beam_begin, _beam_begin=_beam_begin, beam_costs=beam_costs, beam_select=beam_select, beam_advance=beam_advance,
-                beam_step=beam_step, beam_steps=beam_steps, _readout_step_args=_readout_step_args)
+                _beam_lm_step=_beam_lm_step, beam_step=beam_step, beam_steps=beam_steps, _readout_step_args=_readout_step_args)
 
 
 for _k, _v in _beam_methods().items():

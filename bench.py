@@ -201,7 +201,7 @@ def pmc_record(kernel):
 PEAK_HBM = 8.0e12               # bytes/s (MI355X_MICROARCH.md)
 
 
-def decode_leg(dev, utterances, batch=64, streams=4):
+def decode_leg(dev, utterances, batch=64, streams=8):
     """configs[4] in the default line: ALL 1000 synthetic utterances by default (round 5 decoded a 128-utterance sample here; the whole
     set is about a second of GPU time; `--workload wsj_decode` runs the same set as a line of its own) —
     beam 16 + char-trigram FST LM on the device, window_around_median(10, 100), exp/wsj/decode.sh settings, 800-frame synthetic

@@ -180,7 +180,7 @@ def decode_bench(args, rank, world, local_rank, json_out=None):
     batch = int(getattr(args, "decode_batch", None) or 64)
     # batches in flight: 1 000 utterances measured 1.17 / 1.11 / 1.08 ms per utterance at 2 / 3 / 4 (batches of 64), 1.14 / 1.12 at
     # 2 / 3 x 128, 1.31 at 6 x 32
-    streams = max(1, int(getattr(args, "streams", None) or (4 if batch > 1 else 8)))
+    streams = max(1, int(getattr(args, "streams", None) or 8))          # batches (or single searches) in flight: 8 measured best in round 6 (64 x 8: 0.916 ms per utterance, 64 x 4: 0.941)
     recs = [build(dev, beam)[0] for _ in range(streams)]
     rec = recs[0]
     if dist:
