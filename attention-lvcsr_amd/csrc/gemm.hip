@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void lvsr_sgemm_kernel(GemmArgs g) {
             }
 }
 
-// ---- 128x128x32 (and 64x64x32) tiles, v_mfma_f32_32x32x2_f32, register-prefetch double buffering ---------------------------
+// ---- 128x128x32 tiles, v_mfma_f32_32x32x2_f32 (the 64x64x32 tiles: sgemm_tile_kmajor below) ---------------------------------------
 // Used when the output is at least one full tile: 4 waves, each a 64x64 sub-tile = 2x2 MFMA 32x32 blocks (64 accumulator
 // registers).  Round 6 layout (tools/probes/mfma_rate_probe.hip, profiles/r06_gemm_probe.md): the LDS image of BOTH operands is
 // [row][k] with k contiguous (row = m for A, n for B; 36-float rows), and a lane fetches its MFMA operands 16 bytes at a time —
@@ -311,6 +311,160 @@ __device__ __forceinline__ void sgemm_tile(GemmArgs g, int bx, int by, int bz) {
                 }
             }
 }
+// ---- the [k][row] LDS image of rounds 1-5, kept for the 64 x 64 tiles --------------------------------------------------------------
+// Operands staged k-major ([k][m], [k][n]: an MFMA operand read is a conflict-free row of 32 consecutive floats, one k per read), the next
+// k-tile prefetched into registers across the MFMAs.  For a wave of ONE 32 x 32 block at four work-groups per CU this is the faster form
+// (in-step products, rocprofv3 totals of 26 steps: transposed-A 77.3 ms against 86.0 with the [row][k] image, plain 81.7 against 87.6 —
+// a row-contiguous operand needs no transposition on the way in, and the k-tile's 16 MFMAs are too few to amortise one); the 128 x 128
+// tiles (64 MFMAs per wave and k-tile) run the [row][k] image above.  Both walk k in ascending order: the same bits.
+#define GU (GK / 8)                    // float4 units per thread and operand tile
+// one TX x GK (or GK x TX) operand tile (TX = 128 or 64): GK*TX/4 float4 units, TX/32 per thread.  CONTIG_K: element (x,k) at
+// p[x*ld + k].
+template <bool CONTIG_K, int TX>
+__device__ __forceinline__ void gemm1_tile_load(const float* __restrict__ p, int ld, int x0, int X, int k0, int kend, bool vec,
+                                               float4 (&r)[TX / 32]) {
+#pragma unroll
+    for (int h = 0; h < TX / 32; ++h) {
+        const int u = threadIdx.x + h * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (CONTIG_K) {
+            const int x = x0 + (u % TX), k = k0 + (u / TX) * 4;
+            if (x < X && k < kend) v = ld4g(p + (size_t)x * ld + k, kend - k, vec);
+        } else {
+            const int k = k0 + u / (TX / 4), x = x0 + (u % (TX / 4)) * 4;
+            if (k < kend && x < X) v = ld4g(p + (size_t)k * ld + x, X - x, vec);
+        }
+        r[h] = v;
+    }
+}
+// the same tile when it is known to be complete, in bounds and 16-B aligned: straight-line dwordx4 loads.  (The guarded
+// form compiles to exec-masked branches whose results are merged right behind them, i.e. the wave waits for its
+// "prefetch" before it starts the MFMAs of the current tile — measured as exactly half the MFMA rate.)
+template <bool CONTIG_K, int TX>
+__device__ __forceinline__ void gemm1_tile_load_fast(const float* __restrict__ p, int ld, int x0, int k0, float4 (&r)[TX / 32]) {
+#pragma unroll
+    for (int h = 0; h < TX / 32; ++h) {
+        const int u = threadIdx.x + h * 256;
+        if (CONTIG_K) r[h] = *(const float4*)(p + (size_t)(x0 + (u % TX)) * ld + k0 + (u / TX) * 4);
+        else r[h] = *(const float4*)(p + (size_t)(k0 + u / (TX / 4)) * ld + x0 + (u % (TX / 4)) * 4);
+    }
+}
+template <bool CONTIG_K, int TX>
+__device__ __forceinline__ void gemm1_tile_store(float (*S)[TX + 4], const float4 (&r)[TX / 32]) {
+#pragma unroll
+    for (int h = 0; h < TX / 32; ++h) {
+        const int u = threadIdx.x + h * 256;
+        if (CONTIG_K) {
+            const int x = u % TX, k = (u / TX) * 4;
+            S[k + 0][x] = r[h].x; S[k + 1][x] = r[h].y; S[k + 2][x] = r[h].z; S[k + 3][x] = r[h].w;
+        } else {
+            const int k = u / (TX / 4), x = (u % (TX / 4)) * 4;
+            *(float4*)&S[k][x] = r[h];
+        }
+    }
+}
+
+template <int TM, int TN, bool TA, bool TB, bool FAST>
+__device__ __forceinline__ void sgemm_tile_kmajor(GemmArgs g, int bx, int by, int bz) {
+    constexpr int MI = TM / 64, NI = TN / 64;                 // MFMA blocks per wave
+    __shared__ __attribute__((aligned(16))) float As[2][GK][TM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][TN + 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (g.batch > 1) {
+        g.A += bz * g.sA; g.B += bz * g.sB; g.C += bz * g.sC;
+        bz = 0;
+    }
+    const int m0 = by * TM, n0 = bx * TN;
+    const int kbeg = bz * g.kchunk, kend = min(g.K, kbeg + g.kchunk);
+    const int wm = (wave >> 1) * (TM / 2), wn = (wave & 1) * (TN / 2);
+    const bool vecA = ((g.lda & 3) == 0) && ((((size_t)g.A) & 15) == 0);
+    const bool vecB = ((g.ldb & 3) == 0) && ((((size_t)g.B) & 15) == 0);
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[TM / 32], rb[TN / 32];
+    // A: not transposed -> (m,k) at A[m*lda+k] (contiguous k); transposed -> A[k*lda+m] (contiguous m)
+    const bool inside = FAST && m0 + TM <= g.M && n0 + TN <= g.N;
+    if (inside && kbeg + GK <= kend) {
+        gemm1_tile_load_fast<!TA, TM>(g.A, g.lda, m0, kbeg, ra);
+        gemm1_tile_load_fast<TB, TN>(g.B, g.ldb, n0, kbeg, rb);
+    } else {
+        gemm1_tile_load<!TA, TM>(g.A, g.lda, m0, g.M, kbeg, kend, vecA, ra);
+        gemm1_tile_load<TB, TN>(g.B, g.ldb, n0, g.N, kbeg, kend, vecB, rb);
+    }
+    gemm1_tile_store<!TA, TM>(As[0], ra);
+    gemm1_tile_store<TB, TN>(Bs[0], rb);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += GK) {
+        const bool more = k0 + GK < kend;
+        if (more) {
+            if (inside && k0 + 2 * GK <= kend) {
+                gemm1_tile_load_fast<!TA, TM>(g.A, g.lda, m0, k0 + GK, ra);
+                gemm1_tile_load_fast<TB, TN>(g.B, g.ldb, n0, k0 + GK, rb);
+            } else {
+                gemm1_tile_load<!TA, TM>(g.A, g.lda, m0, g.M, k0 + GK, kend, vecA, ra);
+                gemm1_tile_load<TB, TN>(g.B, g.ldb, n0, g.N, k0 + GK, kend, vecB, rb);
+            }
+        }
+        // operand fetch of MFMA step s+1 is issued before the MFMAs of step s (the scheduler otherwise emits
+        // read -> wait -> MFMAs per step and the LDS latency is paid 16 times per k-tile)
+        const int kr0 = lane >> 5, li = lane & 31;
+        float pa[2][MI], pb[2][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) pa[0][i] = As[cur][kr0][wm + 32 * i + li];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) pb[0][j] = Bs[cur][kr0][wn + 32 * j + li];
+#pragma unroll
+        for (int s = 0; s < GK / 2; ++s) {
+            const int c = s & 1, n = c ^ 1;
+            if (s + 1 < GK / 2) {
+                const int kr = 2 * (s + 1) + kr0;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) pa[n][i] = As[cur][kr][wm + 32 * i + li];
+#pragma unroll
+                for (int j = 0; j < NI; ++j) pb[n][j] = Bs[cur][kr][wn + 32 * j + li];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c][i], pb[c][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) {
+            gemm1_tile_store<!TA, TM>(As[cur ^ 1], ra);
+            gemm1_tile_store<TB, TN>(Bs[cur ^ 1], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    // C/D layout of 32x32: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn + j * 32 + (lane & 31);
+                if (m < g.M && n < g.N) {
+                    if (g.ksplit > 1) {
+                        g.part[((size_t)bz * g.M + m) * g.N + n] = acc[i][j][r];
+                    } else {
+                        float v = g.alpha * acc[i][j][r];
+                        if (g.beta != 0.f) v += g.beta * g.C[(size_t)m * g.ldc + n];
+                        if (g.bias) v += g.bias[n];
+                        g.C[(size_t)m * g.ldc + n] = v;
+                    }
+                }
+            }
+}
 template <bool TA, bool TB, bool FAST>
 __device__ __forceinline__ void sgemm128_tile(GemmArgs g, int bx, int by, int bz) { sgemm_tile<128, 128, TA, TB, FAST>(g, bx, by, bz); }
 
@@ -318,7 +472,7 @@ template <bool TA, bool TB, bool FAST>
 __global__ __launch_bounds__(256) void lvsr_sgemm64_kernel(GemmArgs g) {
     const int total = gridDim.x * gridDim.y * gridDim.z;
     const int t = gemm_xcd_order(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), total);
-    sgemm_tile<64, 64, TA, TB, FAST>(g, t % gridDim.x, (t / gridDim.x) % gridDim.y, t / (gridDim.x * gridDim.y));
+    sgemm_tile_kmajor<64, 64, TA, TB, FAST>(g, t % gridDim.x, (t / gridDim.x) % gridDim.y, t / (gridDim.x * gridDim.y));
 }
 
 template <bool TA, bool TB, bool FAST>
