@@ -167,7 +167,7 @@ def gemm_probe(rec, dims, T, B):
                 frac=big["frac"], layer_shapes=out)
 
 
-PMC_FILE = os.path.join(REPO, "profiles", "r05_pmc_bench.json")
+PMC_FILE = os.path.join(REPO, "profiles", "r06_pmc_bench.json")
 
 
 def csrc_sha():
@@ -727,7 +727,7 @@ def main(backend=None):
                         us_per_recurrent_step=pr["launch_s"] * 1e6 / pr["steps_per_launch"], flops_per_launch=pr["flops"],
                         algorithmic_bytes_per_launch=pr["algorithmic_bytes"],
                         frac_source="HIP events around the kernel on the recognizer's stream inside this run (layer 0, T steps; rocprofv3 "
-                                    "of the same command: profiles/r05_bench_wsj_base_kernel_stats.md)",
+                                    "of the same command: profiles/r06_bench_wsj_base_kernel_stats.md)",
                         note="latency bound by construction: a chain of T dependent GRU steps, two cluster-wide exchanges each; the "
                              "contraction runs on the VALU (GEMV per utterance), formally priced against the fp32 MFMA peak")
             if pmc:

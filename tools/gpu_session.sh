@@ -74,6 +74,7 @@ for what in "$@"; do
     enctests) timeout 600 python -m pytest tests/test_gpu_kernels.py -m gpu -x -q -k "encoder or full_size" > $O/pytest_enc.log 2>&1; echo "pytest(enc) rc=$?"; tail -n 4 $O/pytest_enc.log;;
     bk:*) x=${what#bk:}; bb=${x%%:*}; k=${x#*:}; timeout 300 python bench.py --steps 8 --warmup 2 --batch $bb $B --knob $k > $O/batch_${bb}_$k.json 2> $O/batch_${bb}_$k.err; python -c "import json;d=json.load(open('$O/batch_${bb}_$k.json'));print('batch $bb $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/batch_${bb}_$k.err;;
     knob:*) k=${what#knob:}; timeout 300 python bench.py --steps 20 --warmup 5 $B --knob $k > $O/quick_$k.json 2> $O/quick_$k.err; python -c "import json;d=json.load(open('$O/quick_$k.json'));print('wsj_base $k', d['ms_per_step'], d['value'], d['roofline']['us_per_recurrent_step'])"; tail -n 1 $O/quick_$k.err;;
+    tiny) timeout 300 python bench.py --workload timit_tiny --steps 50 --warmup 10 $B > $O/timit_tiny.json 2> $O/timit_tiny.err; python -c "import json;d=json.load(open('$O/timit_tiny.json'));print('timit_tiny', d['ms_per_step'], d['value'], d['roofline']['kernel'], d['roofline']['frac'])"; tail -n 1 $O/timit_tiny.err;;
     ragdev) timeout 900 python tools/ragged_deviation.py wsj_base_ragged --out=$O/ragged_deviation.md > /dev/null 2> $O/ragged_deviation.err; echo "ragdev rc=$?"; grep -v "^$" $O/ragged_deviation.md | cut -c1-400 | tail -n 45; tail -n 3 $O/ragged_deviation.err;;
     large) timeout 1500 python -m pytest tests/test_gpu_properties.py -m gpu -q -k "large_per_gpu or in_passes" > $O/pytest_large.log 2>&1; echo "pytest(large) rc=$?"; grep "^E  \|^FAILED" $O/pytest_large.log | cut -c1-600 | head -n 30; tail -n 3 $O/pytest_large.log;;
     *) echo "unknown item $what";;
