@@ -234,9 +234,12 @@ def beam200_leg(dev, utterances=32, batch=8, streams=2):
     hypotheses x 33 characters = 6 600 candidates per position in lvsr_beam_select, row groups of 200 across the 16-row tiles.
     A bounded sample (32 of the synthetic 800-frame utterances, 8 per set of launches = 1 600 rows, two sets in flight)."""
     from tools.bench_decode import build, run_batched
-    recs = [build(dev, 200)[0] for _ in range(streams)]
+    # on the CONDITIONED network of the reference-generated decode fixtures (round-5 verdict, weak 4: on the random-weight set of the beam-16 leg
+    # a beam-200 search ends on a bare <eol> — all 222 positions run, but nothing is explored)
+    recs = [build(dev, 200, conditioned=True)[0] for _ in range(streams)]
     sec, done, nframes, chars, steps = run_batched(recs, utterances, 800, batch=batch)
     return dict(beam_size=200, utterances=done, utterances_per_launch_set=batch, searches_in_flight=streams * batch, ms_per_utterance=sec / done * 1e3,
+                network="WSJ-base at the parameter scales of tests/golden/wsj_decode_full2 / wsj_decode_beam200 (WSJ_COND_DECODE on scale 2, LM seed 9)",
                 parity="tests/test_decode_golden.py::test_beam_200_matches_the_reference_gpu (reference-generated golden, whole ranked lists)",
                 positions_per_utterance=steps / max(done, 1), us_per_position=sec * 1e6 / max(steps, 1), mean_best_hypothesis_length=chars / max(done, 1))
 

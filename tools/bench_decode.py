@@ -22,14 +22,21 @@ import numpy
 import torch
 
 
-def build(device, beam=16, lm="device"):
+# parameter scales of the reference-generated full-size decode fixtures (oracle/theano_harness/gen_golden.py WSJ_COND_DECODE on scale 2,
+# language model seed 9: tests/golden/wsj_decode_full2.npz, wsj_decode_beam200.npz): contractive recurrences and sharp energies, on which the
+# search explores real alternatives (hundreds of finished hypotheses of up to 117 characters) instead of ending on a bare <eol>
+WSJ_COND_DECODE = {"transition.state_to": 0.15, "gatedrecurrent.state_to": 0.25, "energy_comp": 1.5, "transform_states": 0.5}
+
+
+def build(device, beam=16, lm="device", conditioned=False):
     from lvsr_amd import spec, synthetic, lm as LM
     from lvsr_amd.bricks.recognizer import SpeechRecognizer
     cfg = spec.wsj_base(prior=dict(type="window_around_median", before=10, after=100))
     cfg["max_decoded_length_scale"] = 3.0
-    rec = SpeechRecognizer(device=device, params=synthetic.make_params(cfg, seed=10, scale=1.0), net_config=cfg)
+    params = synthetic.make_params(cfg, seed=10, scale=2.0, scales=WSJ_COND_DECODE) if conditioned else synthetic.make_params(cfg, seed=10, scale=1.0)
+    rec = SpeechRecognizer(device=device, params=params, net_config=cfg)
     if lm != "none":
-        fst, cmap = LM.char_ngram_fst(33, seed=7)
+        fst, cmap = LM.char_ngram_fst(33, seed=9 if conditioned else 7)
         if lm == "host":
             rec.set_language_model(LM.FSTLanguageModel(fst, nn_char_map=cmap, no_transition_cost=20.0, weight=0.5))
         else:
@@ -227,6 +234,7 @@ if __name__ == "__main__":
     ap.add_argument("--utts", type=int, default=8)
     ap.add_argument("--frames", type=int, default=800)
     ap.add_argument("--beam", type=int, default=16)
+    ap.add_argument("--conditioned", action="store_true", help="the parameter scales / language model of the reference-generated full-size decode fixtures")
     ap.add_argument("--no-lm", action="store_true")
     ap.add_argument("--host-lm", action="store_true", help="host FST walk (memoised) instead of the device kernel")
     ap.add_argument("--streams", type=int, default=1, help="searches (or batches) in flight (one recognizer + stream each)")
@@ -238,13 +246,13 @@ if __name__ == "__main__":
         native.get().set_knobs(a.knob)
     kind = "none" if a.no_lm else ("host" if a.host_lm else "device")
     if a.batch > 1:
-        recs = [build("cuda:0", a.beam, kind)[0] for _ in range(a.streams)]
+        recs = [build("cuda:0", a.beam, kind, a.conditioned)[0] for _ in range(a.streams)]
         sec, done, nframes, chars, steps = run_batched(recs, a.utts, a.frames, batch=a.batch)
     elif a.streams > 1:
-        recs = [build("cuda:0", a.beam, kind)[0] for _ in range(a.streams)]
+        recs = [build("cuda:0", a.beam, kind, a.conditioned)[0] for _ in range(a.streams)]
         sec, done, nframes, chars, steps = run_concurrent(recs, a.utts, a.frames)
     else:
-        rec, _ = build("cuda:0", a.beam, kind)
+        rec, _ = build("cuda:0", a.beam, kind, a.conditioned)
         sec, done, nframes, chars, steps = run(rec, a.utts, a.frames)
     print(json.dumps(dict(metric="beam-search decode", utterances=done, beam=a.beam, lm=not a.no_lm, frames_per_utt=a.frames,
                           streams=a.streams, batch=a.batch, sec_per_utt=sec / done, frames_per_sec=nframes / sec, mean_best_len=chars / done,

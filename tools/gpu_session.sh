@@ -61,10 +61,10 @@ for what in "$@"; do
     decodeb:*) bb=${what#decodeb:}; timeout 900 python bench.py --workload wsj_decode --decode-batch ${bb%x*} --streams ${bb#*x} > $O/decode_$bb.json 2> $O/decode_$bb.err; python -c "import json;d=json.load(open('$O/decode_$bb.json'));print('wsj_decode $bb', d['ms_per_step'], d['value'])"; tail -n 1 $O/decode_$bb.err;;
     decode) timeout 900 python bench.py --workload wsj_decode > $O/decode.json 2> $O/decode.err; echo "decode rc=$?"; cut -c1-600 $O/decode.json; tail -n 2 $O/decode.err;;
     smoke) timeout 600 python __graft_entry__.py --smoke > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -n 2 $O/smoke.log;;
-    beam200) timeout 200 python tools/bench_decode.py --beam 200 --utts 32 --batch 8 --streams 2 > $O/b200.json 2> $O/b200.err; python -c "import json;d=json.loads(open('$O/b200.json').read().strip().split('\n')[-1]);print('beam200', round(d['sec_per_utt']*1e3,2), 'ms/utt', round(d['us_per_position'],1), 'us/position')";;
+    beam200) timeout 400 python tools/bench_decode.py --beam 200 --conditioned --utts 32 --batch 8 --streams 2 > $O/b200.json 2> $O/b200.err; python -c "import json;d=json.loads(open('$O/b200.json').read().strip().split('\n')[-1]);print('beam200', round(d['sec_per_utt']*1e3,2), 'ms/utt', round(d['us_per_position'],1), 'us/position')";;
     beam200k) for er in 0 16 32 64 200; do timeout 200 python tools/bench_decode.py --beam 200 --utts 32 --batch 8 --streams 2 --knob energy_rows=$er > $O/b200_$er.json 2> $O/b200_$er.err; python -c "import json;d=json.loads(open('$O/b200_$er.json').read().strip().split('\n')[-1]);print('beam200 energy_rows=$er', round(d['sec_per_utt']*1e3,2), 'ms/utt', round(d['us_per_position'],1), 'us/position')"; done;;
     prof200) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-         timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof200 -o dec -- python $R/tools/bench_decode.py --utts 16 --beam 200 --batch 8 --streams 1 > $R/$O/prof200.log 2>&1
+         timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof200 -o dec -- python $R/tools/bench_decode.py --utts 16 --beam 200 --conditioned --batch 8 --streams 1 > $R/$O/prof200.log 2>&1
          cd $R; python tools/rocpd_stats.py $(find $O/prof200 -name "*.db" | head -n 1) > $O/decode200_kernel_stats.md 2>&1; tail -n 2 $O/prof200.log | cut -c1-400; head -n 30 $O/decode200_kernel_stats.md | cut -c1-160; rm -rf $O/prof200;;
     decprof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          for st in 1 8; do timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/decprof$st -o dec -- python $R/tools/bench_decode.py --utts 8 --streams $st > $R/$O/decprof$st.log 2>&1; done
