@@ -615,7 +615,9 @@ def main(backend=None):
                     rec.encoder.PASS_ROWS = keep
             one = one_steps = None
             if rank == 0 and (world > 1 or GB // world > rec.encoder.PASS_ROWS):
-                one, one_steps = one_gpu_step_ms(True), one_gpu_step_ms(False)
+                one = one_gpu_step_ms(True)
+                # (a stand-in backend runs no cluster kernels: its two one-GPU forms are the same code — measured once)
+                one_steps = one_gpu_step_ms(False) if backend.measured else one
             barrier()
             if rank == 0:
                 if one is None:

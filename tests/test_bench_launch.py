@@ -36,6 +36,7 @@ def test_bench_launches_two_ranks_by_itself(scaling):
         assert c["global_batch"] == 8 and c["per_gpu_batch"] == 4
     assert c["frames_per_step"] == c["global_batch"] * 13            # T = 13 real frames per utterance, all ranks counted
     assert out["steps"] == 2 and out["warmup"] == 1 and out["higher_is_better"] is True
+    assert out["self_check"]["cluster_reserve"] == 0 and out["self_check"]["rank_r_holds_utterances_r_mod_world"] is True      # (no overlapped exchange: nothing reserved)
 
 
 def test_single_rank_line_has_no_collective_fields():
@@ -69,5 +70,3 @@ def test_overlapped_allreduce_reserves_cus_for_the_collective():
     out = _run("--gpus", "2", "--overlap-allreduce")
     assert out["config"]["overlap_allreduce"] is True and out["self_check"]["cluster_reserve"] == 32
     assert out["self_check"]["ok"] is True and out["self_check"]["rank_r_holds_utterances_r_mod_world"] is True
-    plain = _run("--gpus", "2")
-    assert plain["self_check"]["cluster_reserve"] == 0
