@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void attdec_energy_mfma_kernel(AttDec a, int i
     const int t0 = w.begin + blockIdx.z * ATT_TT;
     if (t0 >= w.end) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g4 = lane >> 4;
+    if (t0 + 16 * wave >= w.end) return;          // this wave's 16 positions lie behind the window (no LDS, no barrier: a wave may leave alone)
     const float C2 = 2.885390081777927f;                            // 2 log2(e)
     const int tA = min(t0 + 16 * wave + c16, Tp - 1);               // position whose features this lane feeds (A operand)
     const int tC = t0 + 16 * wave + 4 * g4;                         // first of the four positions this lane accumulates
