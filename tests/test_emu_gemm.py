@@ -126,3 +126,29 @@ def test_copy_many():
     for s_, d_ in pairs:
         assert (s_ == d_).all()
     assert float(dst[39].abs().sum()) == 0.0 and float(vec_d[:7].abs().sum()) == 0.0
+
+
+def run_tile_shape_independence(device, lib):
+    """What a row of a product rounds to must not depend on the tile shape its size selects (round 6: the 128 x 128 tiles read their
+    operands from a [row][k] LDS image with permuted columns, the 64 x 64 tiles from the [k][row] image of rounds 1-5 — both walk k in
+    ascending order, two per MFMA): the same product through 64 x 64 tiles (default for few tiles) and through 128 x 128 tiles
+    (knob gemm_mid_tiles = 1: never the small tiles) is BIT-IDENTICAL, in all three layouts the step uses, with and without split-K."""
+    rng = numpy.random.RandomState(7)
+    for transA, transB, (M, N, K) in ((False, False, (384, 256, 96)), (False, True, (256, 384, 160)), (True, False, (256, 256, 1312))):
+        A = torch.tensor(rng.normal(size=(K, M) if transA else (M, K)), dtype=torch.float32, device=device)
+        B = torch.tensor(rng.normal(size=(N, K) if transB else (K, N)), dtype=torch.float32, device=device)
+        ws = torch.empty(1 << 22, device=device) if transA else None
+        out = {}
+        for mid in (0, 1):
+            lib.set_knob("gemm_mid_tiles", mid)
+            C = torch.zeros(M, N, device=device)
+            lib.sgemm(A, B, C, transA=transA, transB=transB, ws=ws)
+            out[mid] = C.cpu().numpy().copy()
+        lib.set_knob("gemm_mid_tiles", 0)
+        ref = ((A.T if transA else A).double() @ (B.T if transB else B).double()).cpu().numpy()
+        assert_allclose(out[0], ref, rtol=2e-5, atol=2e-4)
+        assert (out[0] == out[1]).all(), (transA, transB, float(numpy.abs(out[0] - out[1]).max()))
+
+
+def test_tile_shape_independence_emulated():
+    run_tile_shape_independence("cpu", emu_lib())

@@ -258,6 +258,12 @@ def test_full_size_full_gradient_tensors_vs_float64_oracle(gpu_device, float64_o
         assert rel <= sample_rtol(case, persistent_decoder) and cos >= 0.99999, (name, rel, cos)
 
 
+def test_gemm_tile_shape_independence_gpu(gpu_device):
+    from test_emu_gemm import run_tile_shape_independence
+    from lvsr_amd import native
+    run_tile_shape_independence(gpu_device, native.get())
+
+
 # ---- beam search on the GPU vs the hypotheses the reference produced --------------------------------
 @pytest.mark.parametrize("case", ["tiny_conv_nowindow", "tiny_conv_median", "tiny_conv_logistic", "tiny_conv_relu",
                                   "tiny_conv_bottom", "tiny_conv_postmerge2", "tiny_content_embed", "tiny_content_relu", "small_conv_median",
