@@ -572,6 +572,55 @@ __global__ __launch_bounds__(256) void lvsr_colsum_kernel(const float* X, int M,
     }
 }
 
+// ---- many column sums in one launch: block -> (member, column block x, row split s); the member's arithmetic is lvsr_colsum_kernel's
+#define COLSUM_MANY_MAX 32
+struct ColsumMember { const float* X; float* out; float* part; int M, N, ldx, S, rows_per, nx, block0, fin0; float beta; };
+struct ColsumPack { ColsumMember m[COLSUM_MANY_MAX]; int n; };
+__global__ __launch_bounds__(256) void lvsr_colsum_many_kernel(ColsumPack pk) {
+    __shared__ float red[4][64];
+    int p = 0;
+    for (int i = 1; i < pk.n; ++i)
+        if ((int)blockIdx.x >= pk.m[i].block0) p = i;
+    const ColsumMember& c = pk.m[p];
+    const int local = blockIdx.x - c.block0, bx = local % c.nx, by = local / c.nx;
+    const int n = bx * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int m0 = by * c.rows_per, m1 = min(c.M, m0 + c.rows_per);
+    const float* X = c.X;
+    const int ldx = c.ldx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < c.N) {
+        int m = m0 + g;
+        for (; m + 12 < m1; m += 16) {          // 4 independent loads in flight per thread
+            s0 += X[(size_t)m * ldx + n];
+            s1 += X[(size_t)(m + 4) * ldx + n];
+            s2 += X[(size_t)(m + 8) * ldx + n];
+            s3 += X[(size_t)(m + 12) * ldx + n];
+        }
+        for (; m < m1; m += 4) s0 += X[(size_t)m * ldx + n];
+    }
+    red[g][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && n < c.N) {
+        const int col = threadIdx.x & 63;
+        const float v = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+        if (c.S > 1) c.part[(size_t)by * c.N + n] = v;
+        else c.out[n] = (c.beta != 0.f ? c.beta * c.out[n] : 0.f) + v;
+    }
+}
+__global__ __launch_bounds__(256) void lvsr_colsum_many_finish(ColsumPack pk) {
+    int p = 0;
+    for (int i = 1; i < pk.n; ++i)
+        if ((int)blockIdx.x >= pk.m[i].fin0) p = i;
+    const ColsumMember& c = pk.m[p];
+    if (c.S <= 1) return;
+    const int n = ((int)blockIdx.x - c.fin0) * 256 + threadIdx.x;
+    if (n >= c.N) return;
+    float v = 0.f;
+    for (int s = 0; s < c.S; ++s) v += c.part[(size_t)s * c.N + n];
+    c.out[n] = (c.beta != 0.f ? c.beta * c.out[n] : 0.f) + v;
+}
+
 __global__ __launch_bounds__(256) void lvsr_colsum_finish(const float* part, int S, int N, float* out, float beta) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
@@ -812,6 +861,44 @@ int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out,
     if (S > 1)
         hipLaunchKernelGGL(lvsr_colsum_finish, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, S, N, out, beta);
     return lvsr_check_launch("lvsr_colsum");
+}
+
+int lvsr_colsum_many(void* stream, const lvsr_colsum_desc* descs, int n, float* ws, long long ws_bytes, long long split_ws_bytes) {
+    LVSR_REQUIRE(n >= 0 && (n == 0 || descs), "lvsr_colsum_many: bad arguments");
+    for (int i = 0; i < n; ++i)
+        LVSR_REQUIRE(descs[i].X && descs[i].out && descs[i].M >= 0 && descs[i].N > 0, "lvsr_colsum_many: bad descriptor %d", i);
+    for (int i0 = 0; i0 < n; i0 += COLSUM_MANY_MAX) {
+        ColsumPack pk;
+        pk.n = n - i0 < COLSUM_MANY_MAX ? n - i0 : COLSUM_MANY_MAX;
+        int blocks = 0, fin = 0;
+        long long off = 0;
+        bool any_split = false;
+        for (int i = 0; i < pk.n; ++i) {
+            const lvsr_colsum_desc& d = descs[i0 + i];
+            ColsumMember& c = pk.m[i];
+            c.X = d.X; c.out = d.out; c.M = d.M; c.N = d.N; c.ldx = d.ldx; c.beta = d.beta;
+            c.nx = (d.N + 63) / 64;
+            int S = 1;                                      // the split lvsr_colsum makes, from the workspace IT would have been given
+            if (ws && d.M >= 512) {
+                S = (d.M + 255) / 256;
+                const int want = (1024 + c.nx - 1) / c.nx;
+                if (S > want) S = want;
+                while (S > 1 && (long long)S * d.N * 4 > split_ws_bytes) --S;
+            }
+            c.S = S;
+            c.rows_per = (d.M + S - 1) / S;
+            c.part = ws ? ws + off : nullptr;
+            if (S > 1) { off += (long long)S * d.N; any_split = true; }
+            c.block0 = blocks; blocks += c.nx * S;
+            c.fin0 = fin; fin += (d.N + 255) / 256;
+        }
+        LVSR_REQUIRE(off * 4 <= ws_bytes, "lvsr_colsum_many: workspace too small for the partial sums (%lld bytes needed)", off * 4);
+        if (blocks > 0) hipLaunchKernelGGL(lvsr_colsum_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pk);
+        if (any_split) hipLaunchKernelGGL(lvsr_colsum_many_finish, dim3(fin), dim3(256), 0, (hipStream_t)stream, pk);
+        // (a second chunk of members would reuse the partials' region: one chunk per call is what the step needs; guard it)
+        LVSR_REQUIRE(i0 + COLSUM_MANY_MAX >= n || !any_split, "lvsr_colsum_many: more than %d members with row splits", COLSUM_MANY_MAX);
+    }
+    return lvsr_check_launch("lvsr_colsum_many");
 }
 
 int lvsr_copy2d_many(void* stream, const lvsr_copy_desc* descs, int n) {

@@ -216,6 +216,7 @@ class Lib(object):
     def begin_group(self):
         """Until flush_group(): sgemm(..., transA=True, group=True) calls are collected instead of launched."""
         self._group, self._group_after = [], []
+        self._group_colsums = []
 
     def flush_group(self, ws):
         """One lvsr_sgemm_tn_grouped launch for everything collected since begin_group() (then the deferred follow-ups, in
@@ -230,8 +231,29 @@ class Lib(object):
                 d.M, d.N, d.K = A.shape[1], B.shape[1], A.shape[0]
                 d.lda, d.ldb, d.ldc, d.beta = A.stride(0), B.stride(0), C.stride(0), beta
             self.call("lvsr_sgemm_tn_grouped", self.stream_for(jobs[0][2]), arr, len(jobs), ptr(ws), ws.numel() * 4)
-        for kw in after or ():
-            self.sgemm(**kw)
+        after = list(after or ())
+        # the follow-ups (rank-B updates with beta = 1 onto outputs of the grouped launch: K = batch rows, eight of them per step at 9.6 us
+        # a launch) go out as ONE more grouped launch when they are plain transposed-A products onto distinct outputs (round 6)
+        plain = [kw for kw in after if kw["transA"] and not kw["transB"] and kw["alpha"] == 1.0 and kw["bias"] is None
+                 and kw["B"].stride(1) == 1 and kw["C"].stride(1) == 1]
+        if len(plain) == len(after) and len(after) > 1 and len({kw["C"].data_ptr() for kw in after}) == len(after):
+            cls = self.structs["lvsr_gemm_desc"]
+            arr = (cls * len(after))()
+            for d, kw in zip(arr, after):
+                A, B, C = kw["A"], kw["B"], kw["C"]
+                d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+                d.M = kw["M"] if kw["M"] is not None else A.shape[1]
+                d.K = kw["K"] if kw["K"] is not None else A.shape[0]
+                d.N = kw["N"] if kw["N"] is not None else B.shape[1]
+                d.lda = kw["lda"] if kw["lda"] is not None else A.stride(0)
+                d.ldb = kw["ldb"] if kw["ldb"] is not None else B.stride(0)
+                d.ldc = kw["ldc"] if kw["ldc"] is not None else C.stride(0)
+                d.beta = float(kw["beta"])
+            self.call("lvsr_sgemm_tn_grouped", self.stream_for(after[0]["C"]), arr, len(after), None, 0)
+        else:
+            for kw in after:
+                self.sgemm(**kw)
+        self._flush_colsums(ws)
 
     def sgemm(self, A, B, C, transA=False, transB=False, alpha=1.0, beta=0.0, bias=None, ws=None,
               M=None, N=None, K=None, lda=None, ldb=None, ldc=None, group=False):
@@ -258,10 +280,35 @@ class Lib(object):
                   beta, ptr(C), ldc, ptr(bias), ptr(ws), (ws.numel() * 4 if ws is not None else 0))
 
     def colsum(self, X, out, beta=0.0, M=None, N=None, ldx=None, ws=None):
+        """out[n] = beta * out[n] + sum_m X[m, n].  While a grouped launch is open (begin_group) the sum is collected and runs with the
+        others in ONE lvsr_colsum_many launch at flush_group() — X must still hold its values then, `out` must not be read before
+        (the bias gradients of a backward pass: 21 launches of 5-13 us per training step before round 6)."""
         M = X.shape[0] if M is None else M
         N = X.shape[1] if N is None else N
-        self.call("lvsr_colsum", self.stream_for(out), ptr(X), M, N, X.stride(0) if ldx is None else ldx, ptr(out), beta,
+        ldx = X.stride(0) if ldx is None else ldx
+        pending = getattr(self, "_group_colsums", None)
+        if pending is not None and getattr(self, "_group", None) is not None:
+            pending.append((X, out, float(beta), int(M), int(N), int(ldx), (ws.numel() * 4 if ws is not None else 0)))
+            return
+        self.call("lvsr_colsum", self.stream_for(out), ptr(X), M, N, ldx, ptr(out), beta,
                   ptr(ws), (ws.numel() * 4 if ws is not None else 0))
+
+    def _flush_colsums(self, ws):
+        pending, self._group_colsums = getattr(self, "_group_colsums", None), None
+        if not pending:
+            return
+        outs = {p[1].data_ptr() for p in pending}
+        split_ws = {p[6] for p in pending}
+        if len(outs) != len(pending) or len(split_ws) != 1 or len(pending) > 32:
+            for X, out, beta, M, N, ldx, wsb in pending:       # (a shared output or mixed workspaces: as separate launches, in order)
+                self.call("lvsr_colsum", self.stream_for(out), ptr(X), M, N, ldx, ptr(out), beta, ptr(ws) if wsb else None, min(wsb, ws.numel() * 4))
+            return
+        cls = self.structs["lvsr_colsum_desc"]
+        arr = (cls * len(pending))()
+        for d, (X, out, beta, M, N, ldx, wsb) in zip(arr, pending):
+            d.X, d.out, d.M, d.N, d.ldx, d.beta = X.data_ptr(), out.data_ptr(), M, N, ldx, beta
+        wsb = split_ws.pop()
+        self.call("lvsr_colsum_many", self.stream_for(pending[0][1]), arr, len(pending), ptr(ws) if wsb else None, ws.numel() * 4 if wsb else 0, wsb)
 
     def copy_many(self, pairs):
         """pairs: [(src, dst)] or [(src, dst, beta)] of equally shaped 1-D / 2-D fp32 tensors with unit inner stride -> one

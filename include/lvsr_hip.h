@@ -88,6 +88,15 @@ int lvsr_copy2d_many(void* stream, const lvsr_copy_desc* descs, int n);
 /* out[n] = beta*out[n] + sum_m X[m*ldx+n]  (bias gradients); ws: optional workspace for the row-split partials */
 int lvsr_colsum(void* stream, const float* X, int M, int N, int ldx, float* out, float beta, float* ws,
                 long long ws_bytes);
+/* n column sums in ONE launch (+ one for the row-split partials) per 32 descriptors: the ~12 bias gradients of a training step were 21
+ * launches of 5-13 us.  Every member is split over rows exactly as lvsr_colsum would split it given `split_ws_bytes` of workspace (same
+ * partial sums, same order: the same bits); ws holds the partials of all members (sum_i S_i * N_i floats). */
+typedef struct lvsr_colsum_desc {
+    const float* X; float* out;
+    int M, N, ldx;
+    float beta;
+} lvsr_colsum_desc;
+int lvsr_colsum_many(void* stream, const lvsr_colsum_desc* descs, int n, float* ws, long long ws_bytes, long long split_ws_bytes);
 int lvsr_transpose(void* stream, const float* in, int rows, int cols, float* out);
 
 /* Pack a (K x N) weight (row-major, leading dim ldw; trans=1: the logical weight is W^T of an (N x K)

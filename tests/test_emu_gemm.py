@@ -152,3 +152,47 @@ def run_tile_shape_independence(device, lib):
 
 def test_tile_shape_independence_emulated():
     run_tile_shape_independence("cpu", emu_lib())
+
+
+def run_colsum_many(device, lib):
+    """lvsr_colsum_many (the column sums of a backward pass in one launch at flush_group) == lvsr_colsum member by member, BIT for bit:
+    row splits, a strided input, beta = 1 onto an existing output, a one-row input, 33 members (more than one launch of 32 without splits)."""
+    rng = numpy.random.RandomState(11)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=device)
+    shapes = [(1600, 768), (700, 33), (1, 5), (513, 64), (12, 512), (1600, 256)]
+    xs = [t(rng.normal(size=s)) for s in shapes]
+    xs[3] = t(rng.normal(size=(513, 100)))[:, 7:71]                    # strided rows
+    ws = torch.empty(1 << 20, device=device)
+    want = []
+    for i, x in enumerate(xs):
+        o = t(rng.normal(size=(x.shape[1],)))
+        ref = o.clone()
+        lib.colsum(x, ref, beta=1.0 if i == 1 else 0.0, ws=ws)
+        want.append((o, ref))
+    big = torch.empty(1 << 22, device=device)
+    lib.begin_group()
+    outs = []
+    for i, x in enumerate(xs):
+        o = want[i][0].clone()
+        lib.colsum(x, o, beta=1.0 if i == 1 else 0.0, ws=ws)
+        outs.append(o)
+    assert all((o == w[0]).all() for o, w in zip(outs, want)), "a collected column sum must not run before the flush"
+    lib.flush_group(big)
+    for o, (_, ref) in zip(outs, want):
+        assert (o.cpu().numpy() == ref.cpu().numpy()).all()
+    assert_allclose(outs[0].cpu().numpy(), xs[0].double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    # more members than one launch holds (no row splits: small inputs)
+    small = [t(rng.normal(size=(40, 17))) for _ in range(33)]
+    lib.begin_group()
+    so = [torch.zeros(17, device=device) for _ in small]
+    for x, o in zip(small, so):
+        lib.colsum(x, o)
+    lib.flush_group(big)
+    for x, o in zip(small, so):
+        ref = torch.zeros(17, device=device)
+        lib.colsum(x, ref)
+        assert (o.cpu().numpy() == ref.cpu().numpy()).all()
+
+
+def test_colsum_many_emulated():
+    run_colsum_many("cpu", emu_lib())

@@ -258,6 +258,12 @@ def test_full_size_full_gradient_tensors_vs_float64_oracle(gpu_device, float64_o
         assert rel <= sample_rtol(case, persistent_decoder) and cos >= 0.99999, (name, rel, cos)
 
 
+def test_colsum_many_gpu(gpu_device):
+    from test_emu_gemm import run_colsum_many
+    from lvsr_amd import native
+    run_colsum_many(gpu_device, native.get())
+
+
 def test_gemm_tile_shape_independence_gpu(gpu_device):
     from test_emu_gemm import run_tile_shape_independence
     from lvsr_amd import native

@@ -32,7 +32,7 @@ for what in "$@"; do
     paper) timeout 300 python bench.py --workload wsj_paper --steps 10 --warmup 3 $B > $O/paper.json 2> $O/paper.err; python -c "import json;d=json.load(open('$O/paper.json'));print('wsj_paper', d['ms_per_step'], d['value'])"; tail -n 1 $O/paper.err;;
     batches) for b in 10 32 64 128; do timeout 300 python bench.py --steps 8 --warmup 2 --batch $b $B > $O/batch_$b.json 2> $O/batch_$b.err; python -c "import json;d=json.load(open('$O/batch_$b.json'));print('batch $b', d['ms_per_step'], d['value'])"; tail -n 1 $O/batch_$b.err; done;;
     gemm) timeout 400 python tools/probes/gemm_k_sweep.py sustained > $O/gemm_k_sweep.txt 2>&1; tail -n 22 $O/gemm_k_sweep.txt;;
-    prof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 $B > $R/$O/prof.log 2>&1; cd $R; ls $O/prof | head; python tools/rocpd_stats.py $O/prof/*/*.db > $O/kernel_stats.md 2>> $O/prof.log || python tools/rocpd_stats.py $O/prof/*.db > $O/kernel_stats.md 2>> $O/prof.log; python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) > $O/timeline.txt 2>> $O/prof.log; head -n 30 $O/kernel_stats.md; tail -n 25 $O/timeline.txt; rm -rf $O/prof;;
+    prof) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; timeout 600 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o bench -- python $R/bench.py --steps 10 --warmup 3 $B > $R/$O/prof.log 2>&1; cd $R; ls $O/prof | head; python tools/rocpd_stats.py $O/prof/*/*.db > $O/kernel_stats.md 2>> $O/prof.log || python tools/rocpd_stats.py $O/prof/*.db > $O/kernel_stats.md 2>> $O/prof.log; python tools/rocpd_timeline.py $(find $O/prof -name "*.db" | head -n 1) --list > $O/timeline.txt 2>> $O/prof.log; head -n 30 $O/kernel_stats.md; head -n 25 $O/timeline.txt; rm -rf $O/prof;;
     pmc) cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
          for c in FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY"; do
            n=$(echo $c | cut -d" " -f1)

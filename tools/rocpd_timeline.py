@@ -1,5 +1,5 @@
 """Per-step timeline from a rocprofv3 rocpd database: wall span of the last training step, busy time, and the largest idle
-gaps with their neighbouring kernels.  Usage: python tools/rocpd_timeline.py results.db"""
+gaps with their neighbouring kernels.  Usage: python tools/rocpd_timeline.py results.db [--list]   (--list: every kernel of the step in order)"""
 import sqlite3, sys, collections
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name,start,end from kernels order by start"))
@@ -31,3 +31,9 @@ tot = sum(g for g, _, _ in gaps if g > 0)
 print("idle between kernels: %.2f ms; top gaps:" % (tot / 1e6))
 for g, n0, n1 in sorted(gaps, reverse=True)[:15]:
     print("  %8.1f us  %s -> %s" % (g / 1e3, n0[:40], n1[:40]))
+
+if "--list" in sys.argv:
+    print("every kernel of the last step (start offset us, duration us, name):")
+    t0 = step[0][1]
+    for n, s_, e in step:
+        print("  %9.1f %8.1f  %s" % ((s_ - t0) / 1e3, (e - s_) / 1e3, (n[5:] if n.startswith("void ") else n).split("(")[0][:70]))
