@@ -420,58 +420,80 @@ __global__ __launch_bounds__(256) void attdec_glimpse_kernel(AttDec a, int i) {
 }
 
 // Weighted averages of a row group (batched beam search): WA[r, :] = sum_t alpha[r, t] * attended_g[t, :] for the rows r of group g,
-// which share the group's attended sequence.  Grid (ceil(E/64), groups): a work-group keeps the group's alignments in LDS
-// (rows x T' <= 16 x 4096 floats at most; rows <= GW_ROWS per pass) and streams 64 columns of the attended rows once for all of
-// them (the fused glimpse kernel reads them once per row: 16 times here); thread = (column, row quad).
+// which share the group's attended sequence.  Grid (ceil(E/64), groups, row chunks): a work-group keeps the group's alignments in LDS
+// (rows <= GW_ROWS per pass) and streams 64 columns of the attended rows once for all of them (the fused glimpse kernel reads them
+// once per row: 16 times here); thread = (column, row quad).
+// The ORDER of the sum is the fused kernel's (attdec_glimpse_kernel<true>): 32 partial sums over the positions begin + p + 32 j of the
+// window, j ascending, then the partials p = 0..31 added in turn — so that a hypothesis's glimpse, and with it every hypothesis of a
+// search, comes out bit for bit the same whether its utterance is searched alone or beside others.
 #define GW_ROWS 16
 #define GW_FLOATS 12288
 #define GW_CHUNK 32            // rows of a group per work-group (grid.z walks the chunks): beam 200 = 7 work-groups per (group, 64 columns)
                                // instead of ONE running 13 passes — 64 work-groups on 256 CUs, 49 us per call (round-5 profile)
 __global__ __launch_bounds__(256) void attdec_group_wa_kernel(AttDec a, int i) {
-    __shared__ float gw_al[GW_FLOATS];             // [rows of a pass][span] alignments of the group over their common window
+    // [rows of a pass][partial p][j]: the alignment of window position p + 32 j, zero beyond the window; a partial's terms are consecutive
+    __shared__ __attribute__((aligned(16))) float gw_al[GW_FLOATS];
     const int g = blockIdx.y, rows = a.group_rows, B = a.B, Tp = a.Tp, E = a.E;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63), rq = threadIdx.x >> 6;
     if (attdec_skip(a, g * rows)) return;
     const Win w = attdec_window_row(a, i, g * rows);
     const int span = w.end - w.begin;
-    const int per = max(1, min(GW_ROWS, GW_FLOATS / max(span, 1)));       // rows per pass (16 up to T' = 768)
+    const int J = max(4, (((span + 31) >> 5) + 3) & ~3);                   // terms of a partial, padded to whole 16-byte reads
+    const int stride = 32 * J;
+    const int per = max(1, min(GW_ROWS, GW_FLOATS / stride));              // rows per pass (16 up to T' = 768)
     const int r_end = min(rows, ((int)blockIdx.z + 1) * GW_CHUNK);
+    constexpr int RQ = GW_ROWS / 4;
+    const float* Ab = a.A + (size_t)g * a.A_bs + min(col, E - 1) + (size_t)w.begin * a.A_ts;
     for (int r0 = blockIdx.z * GW_CHUNK; r0 < r_end; r0 += per) {
         const int nr = min(per, r_end - r0);
         __syncthreads();
-        for (int x = threadIdx.x; x < nr * span; x += 256) {
-            const int r = x / span, t = w.begin + x % span;
-            gw_al[r * span + (t - w.begin)] = a.W[((size_t)(i + 1) * B + g * rows + r0 + r) * Tp + t];
+        for (int x = threadIdx.x; x < nr * stride; x += 256) {
+            const int r = x / stride, y = x % stride, t = (y / J) + 32 * (y % J);
+            gw_al[x] = t < span ? a.W[((size_t)(i + 1) * B + g * rows + r0 + r) * Tp + w.begin + t] : 0.f;
         }
         __syncthreads();
-        const float* Ab = a.A + (size_t)g * a.A_bs + min(col, E - 1);
-        float acc[GW_ROWS / 4] = {};
-        int t = 0;
-        for (; t + 8 <= span; t += 8) {              // eight attended rows in flight
-            float v[8];
+        // rows of this thread that exist in the pass read their own alignments, the others row 0's (and store nothing)
+        const float* alr[RQ];
+        float sum[RQ];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = Ab[(size_t)(w.begin + t + u) * a.A_ts];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-#pragma unroll
-                for (int q = 0; q < GW_ROWS / 4; ++q) {
-                    const int r = rq * (GW_ROWS / 4) + q;
-                    acc[q] += (r < nr ? gw_al[r * span + t + u] : 0.f) * v[u];
-                }
+        for (int q = 0; q < RQ; ++q) {
+            alr[q] = gw_al + (rq * RQ + q < nr ? rq * RQ + q : 0) * stride;
+            sum[q] = 0.f;
         }
-        for (; t < span; ++t) {
-            const float v = Ab[(size_t)(w.begin + t) * a.A_ts];
+        for (int p0 = 0; p0 < 32; p0 += 4) {                               // four partials at a time: 16 independent chains
+            float acc[RQ][4];
 #pragma unroll
-            for (int q = 0; q < GW_ROWS / 4; ++q) {
-                const int r = rq * (GW_ROWS / 4) + q;
-                acc[q] += (r < nr ? gw_al[r * span + t] : 0.f) * v;
+            for (int q = 0; q < RQ; ++q)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) acc[q][pp] = 0.f;
+            for (int j0 = 0; j0 < J; j0 += 4) {
+                float v[4][4];
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)                         // (beyond the window: any row of it, times a zero alignment)
+                        v[pp][jj] = Ab[(size_t)max(min(p0 + pp + 32 * (j0 + jj), span - 1), 0) * a.A_ts];
+#pragma unroll
+                for (int q = 0; q < RQ; ++q)
+#pragma unroll
+                    for (int pp = 0; pp < 4; ++pp) {
+                        const float4 al = *(const float4*)(alr[q] + (p0 + pp) * J + j0);
+                        acc[q][pp] += al.x * v[pp][0];
+                        acc[q][pp] += al.y * v[pp][1];
+                        acc[q][pp] += al.z * v[pp][2];
+                        acc[q][pp] += al.w * v[pp][3];
+                    }
             }
+#pragma unroll
+            for (int q = 0; q < RQ; ++q)
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) sum[q] += acc[q][pp];
         }
         if (col < E)
 #pragma unroll
-            for (int q = 0; q < GW_ROWS / 4; ++q) {
-                const int r = rq * (GW_ROWS / 4) + q;
-                if (r < nr) a.WA[((size_t)i * B + g * rows + r0 + r) * E + col] = acc[q];
+            for (int q = 0; q < RQ; ++q) {
+                const int r = rq * RQ + q;
+                if (r < nr) a.WA[((size_t)i * B + g * rows + r0 + r) * E + col] = sum[q];
             }
     }
 }
