@@ -287,6 +287,14 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
     };
     float pf[NLD];
     if (STAGED) stage_issue(1, pf);                               // (no loads unless `loader`)
+    // subsampled output: phase t % sub and row t / sub of the step's time index, carried along instead of divided per step.  Same-box
+    // A/B (round 6, two boxes each): 13.34 -> 13.12 ms per WSJ-base step on the pool's usual boxes — every layer's forward kernel 2 %
+    // faster, the two with a subsampled output 6 % — but 14.02 -> 14.19 on the one box whose hand-offs are slower (all four layers 5 %
+    // slower there): at 1.27 us per step the kernel's time follows how the polls of a step happen to line up with their partners' stores
+    // (tools/probes/poll_probe.hip), which a few instructions more or less between publish and first poll shift either way.  The same
+    // change in the BPTT kernel's prefetch (pb_dy_at) measured slower on both kinds of box and is not made.
+    int sub_ph = 0, sub_row = 0;
+    if (a.ysub) { const int t0 = dir == 0 ? 0 : T - 1; sub_ph = t0 % a.sub; sub_row = t0 / a.sub; }
     for (int n = 0; n < T; ++n) {
         const int t = dir == 0 ? n : T - 1 - n;
         float xin[NR], gu[NR], gr[NR], m[NR];
@@ -362,10 +370,15 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
                     const size_t o = ((size_t)t * B + b0 + r) * 2 * H + dir * H + j;
                     if (save) a.c[o] = cand;
                     a.y[o] = hn;
-                    if (a.ysub && (t % a.sub) == 0) a.ysub[((size_t)(t / a.sub) * B + b0 + r) * 2 * H + dir * H + j] = hn;
+                    if (a.ysub && sub_ph == 0) a.ysub[((size_t)sub_row * B + b0 + r) * 2 * H + dir * H + j] = hn;
                 }
                 hown[i] = hn;
             }
+        }
+        if (a.ysub) {
+            if (dir == 0) { if (++sub_ph == a.sub) { sub_ph = 0; ++sub_row; } }
+            else if (sub_ph == 0) { sub_ph = a.sub - 1; --sub_row; }
+            else --sub_ph;
         }
         // ---- operands of the next step (independent of the recurrence)
         if (n + 1 < T && !(flags & PF_NOPREFETCH)) {
