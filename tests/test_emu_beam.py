@@ -209,8 +209,9 @@ def run_batched_case(case, device, lib, cost_tol=2e-5):
                 assert_allclose(many[1], one[1], rtol=cost_tol, atol=cost_tol)
                 # ... and bit for bit what the same kernels find for the utterance alone (a batch of one: the tiled readout merge like
                 # every batched search; weighted averages added in the same order by the fused and the per-group kernel)
-                alone = rec.beam_search_batch([xs[u]], **s)[0]
-                assert alone[0] == many[0] and alone[1] == many[1], (case, u)
+                if u < 2 or device != "cpu":          # (the emulator takes seconds per search: two utterances per setting there)
+                    alone = rec.beam_search_batch([xs[u]], **s)[0]
+                    assert alone[0] == many[0] and alone[1] == many[1], (case, u)
         if b.get("error"):
             assert isinstance(batched[utt], CandidateNotFoundError)
         else:
