@@ -235,7 +235,7 @@ class Lib(object):
         # the follow-ups (rank-B updates with beta = 1 onto outputs of the grouped launch: K = batch rows, eight of them per step at 9.6 us
         # a launch) go out as ONE more grouped launch when they are plain transposed-A products onto distinct outputs (round 6)
         plain = [kw for kw in after if kw["transA"] and not kw["transB"] and kw["alpha"] == 1.0 and kw["bias"] is None
-                 and kw["A"].stride(1) == 1 and kw["B"].stride(1) == 1 and kw["C"].stride(1) == 1]
+                 and kw["A"].stride(-1) == 1 and kw["B"].stride(-1) == 1 and kw["C"].stride(-1) == 1]
         if len(plain) == len(after) and len(after) > 1 and len({kw["C"].data_ptr() for kw in after}) == len(after):
             cls = self.structs["lvsr_gemm_desc"]
             arr = (cls * len(after))()
