@@ -418,12 +418,19 @@ __device__ __forceinline__ float pb_dy_at(const EncBwd0& a, int t, int b, int di
 
 // (clusters of 8 — KS = 16 — are sized by what the device holds at once, wide_cluster_capacity(): two of their work-groups must fit
 // a CU, i.e. 4 waves per SIMD = at most 128 registers)
-template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
-__global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbwd_kernel(EncBwd0 a, u64* planes, u64* hello, int* abort_word, float* dh_out, int Bp, int flags) {
+// LD9 (one utterance per cluster of 8, one work-group per CU): the work-group is launched with a NINTH wave that does nothing but fetch
+// the next steps' saved operands (u, c, r, h_prev, mask, dy of every unit of the work-group: 6 x 32 values) two steps ahead and hand them
+// over through LDS in front of a step's FIRST fence; the owners pick them up behind it, in the shadow of the second hand-off.  All eight
+// computing waves sweep the two-plane first gather of a step, and a global load issued by a sweeping wave sits in front of its sweep in
+// the wave's in-order memory queue (0.33 us per step: tools/probe_persist.py, persist_flags 128).
+template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256, bool LD9 = false>
+__global__ __launch_bounds__(NTH + (LD9 ? 64 : 0), (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbwd_kernel(EncBwd0 a, u64* planes, u64* hello, int* abort_word, float* dh_out, int Bp, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;
     constexpr int NBUF = PRIV ? 4 : 1;
+    static_assert(!LD9 || (RB == 1 && P > 1 && !PRIV && UNITS == 32), "the loader wave serves one utterance per cluster, 32 units per work-group");
+    __shared__ float opnd9[LD9 ? 6 * UNITS : 1];
     __shared__ __attribute__((aligned(16))) float vbuf_all[3][NBUF][RB * KSPLIT * LDH];     // dpre_c | dpre_u | dpre_r
     float* const vbuf[3] = {vbuf_all[0][PRIV ? (threadIdx.x >> 6) : 0], vbuf_all[1][PRIV ? (threadIdx.x >> 6) : 0],
                             vbuf_all[2][PRIV ? (threadIdx.x >> 6) : 0]};
@@ -434,6 +441,39 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
     const bool save = !(flags & PF_NOSAVE);
     const bool plain = P > 1 && cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
     const int dir = cl / rt, b0 = (cl % rt) * RB;
+    if (LD9 && (int)threadIdx.x >= NTH) {
+        // ---- the loader wave.  Lane = (half, unit): per step three loads — [u | c] of step t, [r | h_prev], [mask | dy] — from pointers
+        //      that move by one (T) row per step; two work-group barriers per step, in step with the computing waves' gather fences
+        const int lane = (int)threadIdx.x - NTH, hi = lane >> 5, jj = p * UNITS + (lane & 31);
+        const bool live = jj < H && b0 < B;
+        const size_t jo = (size_t)b0 * 2 * H + dir * H + min(jj, H - 1);
+        const long long row = (long long)B * 2 * H, sgn = dir == 0 ? -1 : 1;
+        const float* p0 = (hi ? a.c : a.u) + jo;                       // + t * row
+        const float* p1 = (hi ? a.y : a.r) + jo;                       // r at t, h_prev = y at tp
+        const float h0v = a.h0[dir][min(jj, H - 1)];
+        auto issue = [&](int ns, float (&dst)[3]) {
+            const int t = dir == 0 ? T - 1 - ns : ns, tp = t + (int)sgn;
+            dst[0] = dst[1] = 0.f;
+            dst[2] = hi ? 0.f : 1.f;
+            if (ns < T && live) {
+                dst[0] = p0[(long long)t * row];
+                const bool edge = tp < 0 || tp >= T;
+                dst[1] = hi ? (edge ? h0v : p1[(long long)tp * row]) : p1[(long long)t * row];
+                if (hi) dst[2] = pb_dy_at(a, tp, b0, dir, jj);
+                else if (a.mask) dst[2] = a.mask[(size_t)t * B + b0];
+            }
+        };
+        float pf[3], pf_new[3];
+        issue(1, pf);
+        for (int n = 0; n < T; ++n) {
+            issue(n + 2, pf_new);
+            if (n + 1 < T) { opnd9[lane] = pf[0]; opnd9[64 + lane] = pf[1]; opnd9[128 + lane] = pf[2]; }      // step n + 1's, fetched a step ago
+            __syncthreads();
+            __syncthreads();
+            pf[0] = pf_new[0]; pf[1] = pf_new[1]; pf[2] = pf_new[2];
+        }
+        return;
+    }
     const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
     const bool junit = j < H;
     f32x2 wa[KS / 2], wbu[KS / 2], wbr[KS / 2];
@@ -505,14 +545,19 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pbw
                 }
             }
         }
-        // operands of the next step: in flight during the hand-offs
-        if (n + 1 < T && !(flags & PF_NOPREFETCH)) {
+        // operands of the next step: in flight during the hand-offs (LD9: the loader wave's business)
+        if (!LD9 && n + 1 < T && !(flags & PF_NOPREFETCH)) {
 #pragma unroll
             for (int i = 0; i < NR; ++i)
                 if (rvalid[i]) prefetch(dir == 0 ? t - 1 : t + 1, i);
         }
         if (P > 1 && !gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 2, NBUF * RB * KSPLIT * LDH, NTH>(gc, (unsigned)(n + 1), vbuf[0], abort_word)) return;
         gather_fence<PRIV>();
+        if (LD9 && n + 1 < T && rvalid[0]) {          // handed over by the loader wave in front of this fence: [u | c], [r | h_prev], [mask | dy]
+            const int ju = tid / KSPLIT;
+            n_u[0] = opnd9[ju]; n_c[0] = opnd9[32 + ju]; n_r[0] = opnd9[64 + ju]; n_hp[0] = opnd9[96 + ju];
+            n_m[0] = opnd9[128 + ju]; n_dy[0] = opnd9[160 + ju];
+        }
         float s[RB], vu[RB];
         slice_dot<KS, RB, LDH, KSPLIT>(wa, vbuf[0], q, s);                     // d(r*h)
 #pragma unroll
@@ -754,7 +799,9 @@ static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64
 template <int KS, int KSPLIT>
 static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u64* planes, u64* hello, int* ab, float* dh, int Bp, int flags) {
     if (g.NTH == 512) {
-        if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        if (g.P == 8 && g.KS == 16 && g.RB == 1 && !(flags & PF_NOLD9) && g.grid <= lvsr_max_cluster_wgs())      // one work-group per CU: nine waves fit
+            hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 1, false, 512, true>), dim3(g.grid), dim3(576), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        else if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         else if (g.P == 8 && g.KS == 16) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         else if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         else hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);

@@ -29,6 +29,7 @@ variants = [("steps+graph", False, None, None), ("persist", True, "0", "0"), ("p
             ("persist rows=2, write-through", True, "2", "4"), ("persist rows=4", True, "4", "0"), ("persist nosave", True, "0", "1"),
             ("persist spread over XCDs", True, "0", "2"), ("persist 256 threads", True, "0", "0", "256"),
             ("persist 256 threads, write-through", True, "0", "4", "256"), ("persist, owners fetch (no loader waves)", True, "0", "256"), ("persist, one unit per lane group (H > 256)", True, "0", "2048"), ("persist, no prefetch", True, "0", "128"), ("persist, no prefetch, no saves", True, "0", "129"),
+            ("persist, no operand fetches", True, "0", "128"), ("persist, no operand fetches, no saves", True, "0", "129"),
             ("persist, no prefetch, no saves, no dots", True, "0", "145"), ("persist, clusters of 4", True, "0", "64"),
             ("persist, clusters of 4, no dots", True, "0", "80"), ("persist, clusters of 4, write-through", True, "0", "68")]
 for (H, B, T) in shapes:
