@@ -195,8 +195,9 @@ static bool persist_geom(int B, int H, PersistGeom& g) {
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256>
-__global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfwd_kernel(EncFwd a, u64* planes, u64* hello, int* abort_word, int flags) {
+// LD9 (see enc_pbwd_kernel): a ninth wave does the staging (gate inputs and mask of step n + 2) instead of waves 4..7, which compute too.
+template <int KS, int KSPLIT, int RB, bool PRIVOK, int NTH = 256, bool LD9 = false>
+__global__ __launch_bounds__(NTH + (LD9 ? 64 : 0), (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfwd_kernel(EncFwd a, u64* planes, u64* hello, int* abort_word, int flags) {
     constexpr int HP = KS * KSPLIT, UNITS = NTH / KSPLIT, P = HP / UNITS, LDH = KS + 4, NG = RB * HP;
     constexpr int NR = (RB + KSPLIT - 1) / KSPLIT;          // rows a lane owns in the epilogue
     constexpr bool PRIV = PRIVOK && NG <= 512 && P > 1 && NTH == 256;     // wave-private operand buffers, see gather_plane
@@ -219,10 +220,49 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
     const bool save = !(flags & PF_NOSAVE);
     const bool plain = P > 1 && cluster_shares_xcd(hello + (size_t)cl * P, P, p, abort_word) && !(flags & PF_SC1);
     const int dir = cl / rt, b0 = (cl % rt) * RB;
+    static_assert(!LD9 || (STAGED && RB == 1), "the loader wave serves one utterance per cluster");
+    if (LD9 && (int)threadIdx.x >= NTH) {
+        // ---- the loader wave: item idx = gate * UNITS + unit, idx = 3 UNITS: the row's mask; two barriers per step = the computing waves' fences
+        const int lane = (int)threadIdx.x - NTH;
+        // (straight-line loads from clamped addresses, fixed up by selects: loads under branches make the compiler wait for ALL outstanding
+        // loads — the ones just issued too — where the older set is handed over)
+        auto issue = [&](int ns, float (&dst)[2]) {
+            const int nsc = min(ns, T - 1), tn = dir == 0 ? nsc : T - 1 - nsc;
+            const float* xrow = a.xg + ((size_t)tn * B + b0) * 6 * H + dir * 3 * H;
+#pragma unroll
+            for (int l = 0; l < 2; ++l) {
+                const int idx = lane + 64 * l, jj = min(p * UNITS + idx % UNITS, H - 1), gsel = min(idx / UNITS, 2);
+                const bool is_mask = idx == 3 * UNITS;
+                const float* src = (is_mask && a.mask) ? a.mask + (size_t)tn * B + b0 : xrow + gsel * H + jj;
+                const float v = *src;
+                dst[l] = is_mask ? (a.mask ? v : 1.f) : ((idx < 3 * UNITS && p * UNITS + idx % UNITS < H) ? v : 0.f);
+            }
+        };
+        // two register sets in turn (a copy at the end of a step would wait for the loads that step has just issued)
+        float pa[2], pb[2];
+        auto hand = [&](int n, const float (&v)[2]) {             // step n: the operands of step n + 1 between the step's two fences
+            __syncthreads();
+            if (n + 1 < T) {
+                opnd[lane] = v[0];
+                if (lane + 64 < ITEMS) opnd[lane + 64] = v[1];
+            }
+            __syncthreads();
+        };
+        issue(1, pa);
+        for (int n = 0; n < T; n += 2) {
+            issue(n + 2, pb);
+            hand(n, pa);
+            if (n + 1 < T) {
+                issue(n + 3, pa);
+                hand(n + 1, pb);
+            }
+        }
+        return;
+    }
     const int tid = threadIdx.x, q = tid % KSPLIT, j = p * UNITS + tid / KSPLIT, k0 = q * KS;
     const bool junit = j < H;
-    const bool staged = STAGED && !(flags & PF_NOSTAGE);          // (PF_NOSTAGE: the owners fetch their operands themselves, for A/B runs)
-    const bool loader = staged && tid >= 256;
+    const bool staged = STAGED && (LD9 || !(flags & PF_NOSTAGE)); // (PF_NOSTAGE: the owners fetch their operands themselves, for A/B runs)
+    const bool loader = !LD9 && staged && tid >= 256;
     // ---- this thread's weight slice, in registers for the whole sequence
     f32x2 wr[KS / 2], wu[KS / 2], wc[KS / 2];
     {
@@ -286,7 +326,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
         }
     };
     float pf[NLD];
-    if (STAGED) stage_issue(1, pf);                               // (no loads unless `loader`)
+    if (STAGED && !LD9) stage_issue(1, pf);                       // (no loads unless `loader`)
     // subsampled output: phase t % sub and row t / sub of the step's time index, carried along instead of divided per step.  Same-box
     // A/B (round 6, two boxes each): 13.34 -> 13.12 ms per WSJ-base step on the pool's usual boxes — every layer's forward kernel 2 %
     // faster, the two with a subsampled output 6 % — but 14.02 -> 14.19 on the one box whose hand-offs are slower (all four layers 5 %
@@ -303,7 +343,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
         // waves 4..7: the operands of step n + 2 are issued here; those of step n + 1 (issued a step ago: long landed) are handed
         // over in front of the second barrier of this step
         float pf_new[NLD];
-        if (STAGED) stage_issue(n + 2, pf_new);
+        if (STAGED && !LD9) stage_issue(n + 2, pf_new);
         if (P > 1 && n > 0) {
             const bool ok = (NG <= 256 || staged) ? gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, SWEEP>(gh, (unsigned)n, hbuf[0], abort_word, flags)
                                                   : gather_plane<NG, HP, KS, LDH, KSPLIT, PRIV, 1, 0, NTH>(gh, (unsigned)n, hbuf[0], abort_word, flags);
@@ -337,7 +377,7 @@ __global__ __launch_bounds__(NTH, (KS == 16 && NTH == 512) ? 4 : 1) void enc_pfw
                 if (rvalid[i] && save) a.u[((size_t)t * B + b0 + r) * 2 * H + dir * H + j] = uu[i];
             }
         }
-        if (STAGED) {
+        if (STAGED && !LD9) {
             if (loader && n + 1 < T) {
 #pragma unroll
                 for (int l = 0; l < NLD; ++l) {
@@ -451,26 +491,35 @@ __global__ __launch_bounds__(NTH + (LD9 ? 64 : 0), (KS == 16 && NTH == 512) ? 4 
         const float* p0 = (hi ? a.c : a.u) + jo;                       // + t * row
         const float* p1 = (hi ? a.y : a.r) + jo;                       // r at t, h_prev = y at tp
         const float h0v = a.h0[dir][min(jj, H - 1)];
+        // (straight-line loads from clamped addresses, fixed up by selects: loads under branches make the compiler wait for ALL outstanding
+        // loads — the ones just issued too — where the older set is handed over)
+        const float* p2 = hi ? a.dy + (size_t)b0 * 2 * H + dir * H + min(jj, H - 1) : (a.mask ? a.mask + b0 : a.h0[dir]);
+        const long long row2 = hi ? row : (a.mask ? (long long)B : 0);
         auto issue = [&](int ns, float (&dst)[3]) {
-            const int t = dir == 0 ? T - 1 - ns : ns, tp = t + (int)sgn;
-            dst[0] = dst[1] = 0.f;
-            dst[2] = hi ? 0.f : 1.f;
-            if (ns < T && live) {
-                dst[0] = p0[(long long)t * row];
-                const bool edge = tp < 0 || tp >= T;
-                dst[1] = hi ? (edge ? h0v : p1[(long long)tp * row]) : p1[(long long)t * row];
-                if (hi) dst[2] = pb_dy_at(a, tp, b0, dir, jj);
-                else if (a.mask) dst[2] = a.mask[(size_t)t * B + b0];
-            }
+            const int nsc = min(ns, T - 1), t = dir == 0 ? T - 1 - nsc : nsc, tp = t + (int)sgn, tpc = min(max(tp, 0), T - 1);
+            const bool edge = tp != tpc, dy_here = !edge && (tp % a.sub) == 0;
+            const float v0 = p0[(long long)t * row];
+            const float v1 = p1[(long long)(hi ? tpc : t) * row];
+            const float v2 = p2[(long long)(hi ? tpc / a.sub : t) * row2];
+            dst[0] = live ? v0 : 0.f;
+            dst[1] = live ? ((hi && edge) ? h0v : v1) : 0.f;
+            dst[2] = hi ? ((live && dy_here) ? v2 : 0.f) : ((live && a.mask) ? v2 : 1.f);
         };
-        float pf[3], pf_new[3];
-        issue(1, pf);
-        for (int n = 0; n < T; ++n) {
-            issue(n + 2, pf_new);
-            if (n + 1 < T) { opnd9[lane] = pf[0]; opnd9[64 + lane] = pf[1]; opnd9[128 + lane] = pf[2]; }      // step n + 1's, fetched a step ago
+        // two register sets in turn (a copy at the end of a step would wait for the loads that step has just issued)
+        float pa[3], pb[3];
+        auto hand = [&](int n, const float (&v)[3]) {             // step n: the operands of step n + 1 (fetched a step ago) in front of its first fence
+            if (n + 1 < T) { opnd9[lane] = v[0]; opnd9[64 + lane] = v[1]; opnd9[128 + lane] = v[2]; }
             __syncthreads();
             __syncthreads();
-            pf[0] = pf_new[0]; pf[1] = pf_new[1]; pf[2] = pf_new[2];
+        };
+        issue(1, pa);
+        for (int n = 0; n < T; n += 2) {
+            issue(n + 2, pb);
+            hand(n, pa);
+            if (n + 1 < T) {
+                issue(n + 3, pa);
+                hand(n + 1, pb);
+            }
         }
         return;
     }
@@ -780,7 +829,9 @@ static void launch_fwd(hipStream_t s, const EncFwd& a, const PersistGeom& g, u64
         return;
     }
     if (g.NTH == 512) {                        // two waves per SIMD: half the k-slice per thread (one or two utterances per cluster)
-        if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
+        if (g.P == 8 && g.KS == 16 && g.RB == 1 && !(flags & (PF_NOLD9F | PF_NOSTAGE)) && g.grid <= lvsr_max_cluster_wgs())      // one work-group per CU: nine waves fit
+            hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 1, false, 512, true>), dim3(g.grid), dim3(576), 0, s, a, planes, hello, ab, flags);
+        else if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         else if (g.P == 8 && g.KS == 16) hipLaunchKernelGGL((enc_pfwd_kernel<16, 16, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         else if (g.RB == 1) hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
         else hipLaunchKernelGGL((enc_pfwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, flags);
