@@ -854,7 +854,15 @@ static void launch_bwd(hipStream_t s, const EncBwd0& a, const PersistGeom& g, u6
             hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 1, false, 512, true>), dim3(g.grid), dim3(576), 0, s, a, planes, hello, ab, dh, Bp, flags);
         else if (g.P == 8 && g.KS == 16 && g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         else if (g.P == 8 && g.KS == 16) hipLaunchKernelGGL((enc_pbwd_kernel<16, 16, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
-        else if (g.RB == 1) hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        else if (g.RB == 1) {
+            if constexpr (KSPLIT == 8) {       // H = 512 (WSJ-deep): 16 work-groups of 32 units per utterance — the loader wave as above
+                if (!(flags & PF_NOLD9) && g.grid <= lvsr_max_cluster_wgs()) {
+                    hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512, true>), dim3(g.grid), dim3(576), 0, s, a, planes, hello, ab, dh, Bp, flags);
+                    return;
+                }
+            }
+            hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 1, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
+        }
         else hipLaunchKernelGGL((enc_pbwd_kernel<KS / 2, KSPLIT * 2, 2, false, 512>), dim3(g.grid), dim3(512), 0, s, a, planes, hello, ab, dh, Bp, flags);
         return;
     }
