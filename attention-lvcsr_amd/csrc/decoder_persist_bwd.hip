@@ -38,7 +38,7 @@ typedef lvsr_attdec_bwd_args AttBwd;
 #define PB_PERWG_STACK (4 * 512)
 
 struct PbGeom {
-    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL;
+    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL, DPAL, DPS, o_dpa;
     int o_ft, o_nx, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
     int nb, b0;          // utterances of this launch: [b0, b0 + nb) (pd_pick_passes)
 };
@@ -107,6 +107,15 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack 
     g.AWS = (3 * a.D + 3) / 4 * 4 + 4;
     g.AWL = o + g.nown * g.AWS <= PD_LDS_FLOATS;
     g.o_aw = g.AWL ? take(g.nown * g.AWS) : 0;
+    // the gradient wrt the preprocessed contexts of the own positions, summed over the labels: every element belongs to ONE lane for the whole
+    // walk — accumulated in LDS (ds_add_f32) and added to the caller's buffer once behind the loop when it fits, else by no-return L2 atomics
+    // label by label (rounds 3-6: 16 per lane and label; PF_NODPAL).  Row stride M + 4: the four position groups of a wave fall on different
+    // banks.  Same sums in the same order either way.  Measured (round 6, same box, two boxes): 12.43 / 12.41 against 12.44 / 12.48 ms per
+    // WSJ-base step, 12.58 / 12.58 against 12.61 / 12.63; the energy phase itself does not change (4.4-4.5 us per label: it is bound by its 11
+    // K = 4 matrix-core products and 8 transcendentals per 16 x 16 tile, not by the adds)
+    g.DPS = (a.M + 3) / 4 * 4 + 4;
+    g.DPAL = !(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NODPAL) && o + g.nown * g.DPS <= PD_LDS_FLOATS;
+    g.o_dpa = g.DPAL ? take(g.nown * g.DPS) : 0;
     g.total = o;
     g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);
     if (o > PD_LDS_FLOATS && k.shape == 1 && allow16 && !stack) return pb_geom(a, g, false);      // clusters of 8 instead, if they fit
@@ -377,6 +386,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const red = lds + g.o_red;
     float* const fT = lds + g.o_ft;       // FTL: [FW][KCP] conv1d.filters, transposed
     float* const nx = lds + g.o_nx;       // [5][64] saved gate values of the own units, fetched one label ahead
+    float* const dpas = lds + g.o_dpa;    // DPAL: [nown][DPS] gradient wrt the preprocessed contexts of the own positions, summed over the labels
     const int P = g.P, nown = g.nown;
     int b, p;
     if (!cluster_of_block(STACK ? 2 * P : P, g.nb, 0, b, p)) return;  // (work-groups of the grid's padding)
@@ -759,8 +769,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 for (int r = 0; r < 4; ++r) {
                     // dPA += dm as a no-return L2 atomic: every element belongs to this lane alone (its adds happen in program
                     // order, label by label: deterministic), and no load has to come back before the store can leave
-                    if (rowok[r] && m < M)
-                        unsafeAtomicAdd((float*)((char*)(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile) + dpaoff), dv[r]);
+                    if (rowok[r] && m < M) {
+                        if (g.DPAL) unsafeAtomicAdd(dpas + (tl0 + 4 * g4 + r) * g.DPS + m, dv[r]);
+                        else unsafeAtomicAdd((float*)((char*)(gb.dPA + (size_t)b * M + (size_t)r * P * B * M + 16 * tile) + dpaoff), dv[r]);
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (KC > 0) {
@@ -972,6 +984,12 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         }
     }
     if (a.e_bias && tid == 0) gb.accEb[prow] = ebacc;
+    if (g.DPAL) {          // (the last label's adds of the other waves: the barriers of its exchanges lie in between)
+        for (int x = tid; x < nown * M; x += PD_THREADS) {
+            const int tl = x / M, m = x % M, t = tl * P + p;
+            if (t < Tp) gb.dPA[((size_t)t * B + b) * M + m] += dpas[tl * g.DPS + m];
+        }
+    }
 }
 
 extern "C" long long lvsr_attdec_bwd_persist_ws_bytes(const lvsr_attdec_args* args) {

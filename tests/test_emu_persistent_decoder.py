@@ -117,6 +117,33 @@ def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K,
     check_against(rec, cm, None, out, grads)
 
 
+def test_context_gradient_in_lds_equals_the_atomic_form():
+    """Round 6: the reverse walk sums the gradient wrt the preprocessed contexts of a work-group's own positions in LDS and adds it to the
+    caller's buffer once behind the label loop (decoder_persist_bwd.hip PbGeom.DPAL); persist_flags 16384 (PF_NODPAL) keeps the L2 atomics
+    of rounds 3-6.  Every element is one lane's own either way, added label by label in the same order: every gradient bit for bit."""
+    lib = emu_lib()
+    lib._dll.hipemu_set_concurrent(1)
+    try:
+        _, meta = load_golden("tiny_conv_median")
+        cfg = dict(meta["cfg"])
+        cfg.update(conv_num_filters=5, dim_matcher=12, dim_dec=8)
+        params = synthetic.make_params(cfg, seed=11, scale=meta["scale"])
+        batch = synthetic.make_batch(cfg, 3, 13, 5, seed=12, ragged=True)
+        got = {}
+        for flags in (0, 16384):
+            lib.set_knob("persist_flags", flags)
+            rec = SpeechRecognizer(device="cpu", params=params, lib=lib, net_config=cfg, use_persistent_decoder=True)
+            rec.cost_and_gradients(batch)
+            assert any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs), "persistent decoder backward did not engage"
+            rec.generator.check_persistent()
+            got[flags] = rec.store.get_grads()
+        for k in got[0]:
+            assert numpy.array_equal(got[0][k], got[16384][k]), k
+    finally:
+        lib.set_knob("persist_flags", 0)
+        lib._dll.hipemu_set_concurrent(0)
+
+
 # dec_stack = 2: the label loop of the two-layer stack and its reverse walk as one persistent launch each
 # (lvsr_attdec_fwd_persistent_stack2 / lvsr_attdec_bwd_persistent_stack2: a cluster for the attention + layer 0 and one for layer 1
 # per utterance).  Costs, alignments and every gradient against the reference's goldens / the float64 oracle.

@@ -130,6 +130,27 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
         assert numpy.abs(g_p[k] - g_s[k]).max() / scale < gtol, k
 
 
+def test_context_gradient_in_lds_equals_the_atomic_form_at_full_size(gpu_device, setup):
+    """The reverse walk's LDS-resident sum of the gradient wrt the preprocessed contexts (round 6, PbGeom.DPAL) against the L2 atomics of
+    rounds 3-6 (persist_flags 16384) on the ragged full-size batch: the same adds in the same order — every gradient bit for bit."""
+    from lvsr_amd import native
+    s = setup
+    lib = native.get()
+    lib.set_knob("persist_flags", 16384)
+    try:
+        rec = SpeechRecognizer(device=gpu_device, params=s["params"], net_config=s["cfg"])
+        cm = rec.cost_and_gradients(s["batch"]).cpu().numpy()
+        torch.cuda.synchronize()
+        rec.generator.check_persistent()
+        assert any(k[0] == "gen.sync_bwd" for k in rec.generator.ws._bufs), "persistent decoder backward did not engage"
+        g = rec.store.get_grads()
+    finally:
+        lib.set_knob("persist_flags", 0)
+    assert (cm == s["cm"]).all()
+    for k in g:
+        assert (g[k] == s["grads"][k]).all(), k
+
+
 def test_persistent_decoder_in_passes_at_batch_64(gpu_device, setup):
     """Per-GPU batch 64: 64 clusters of 8 work-groups do not fit the 256 CUs at once; under the expanding prior the utterances are
     independent and the persistent kernels run two passes of 32 utterances (decoder_persist.h pd_pick_passes).  Costs and alignments
