@@ -480,7 +480,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     const bool plain = cluster_shares_xcd(gA + 4 * PD_MAXV, STACK ? 2 * P : P, p, abort_word);
     __syncthreads();
     PdClock clk;
-    clk.start(g.prof != 0 && blockIdx.x == 0 && tid == 0, lds + g.o_clk);
+    clk.start(g.prof != 0 && b == g.b0 && p == min(g.prof, P) - 1 && tid == 0, lds + g.o_clk);        // (knob phase_clock = 1 + the work-group of the first cluster that keeps the clock)
 
     for (int n = 0; n < L; ++n) {
         const int i = L - 1 - n;

@@ -24,6 +24,7 @@ for what in "$@"; do
     quick8) timeout 300 python bench.py --steps 20 --warmup 5 $B --knob dec_cluster=8 > $O/quick8.json 2> $O/quick8.err; python -c "import json;d=json.load(open('$O/quick8.json'));print('wsj_base clusters of 8', d['ms_per_step'], d['value'])"; tail -n 2 $O/quick8.err;;
     dec) for k in dec_cluster=0 dec_cluster=8; do timeout 300 python tools/probe_decoder_persist.py wsj_base $k > $O/dec_fwd_$k.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base $k > $O/dec_bwd_$k.txt 2>&1; echo "== $k"; grep -v "^    " $O/dec_fwd_$k.txt | tail -n 4; grep -v "^    " $O/dec_bwd_$k.txt | tail -n 4; done;;
     decab:*) k=${what#decab:}; for kk in persist_flags=0 $k persist_flags=0 $k; do timeout 300 python tools/probe_decoder_persist_bwd.py wsj_base $kk > $O/decab_$kk.txt 2>&1; echo "== $kk"; grep "persistent:\|energies\|D gather\|A gather\|publish dpc\|sum" $O/decab_$kk.txt; done;;
+    skew) timeout 600 python tools/probe_decoder_bwd_skew.py wsj_base > $O/dec_bwd_skew.txt 2>&1; grep -v amdgpu.ids $O/dec_bwd_skew.txt | tail -n 20;;
     decmed) timeout 300 python tools/probe_decoder_persist.py wsj_base median > $O/dec_fwd_median.txt 2>&1; grep -v "^    " $O/dec_fwd_median.txt | tail -n 4;;
     deep) timeout 600 python bench.py --workload wsj_deep --steps 5 --warmup 2 $B > $O/deep.json 2> $O/deep.err; echo "deep rc=$?"; python -c "import json;d=json.load(open('$O/deep.json'));print('wsj_deep', d['ms_per_step'], d['value'])"; tail -n 2 $O/deep.err
           timeout 300 python tools/probe_decoder_persist.py wsj_deep > $O/deep_dec_fwd.txt 2>&1; timeout 300 python tools/probe_decoder_persist_bwd.py wsj_deep > $O/deep_dec_bwd.txt 2>&1; grep -v "^    " $O/deep_dec_fwd.txt | tail -n 4; grep -v "^    " $O/deep_dec_bwd.txt | tail -n 4;;
