@@ -38,7 +38,7 @@ typedef lvsr_attdec_bwd_args AttBwd;
 #define PB_PERWG_STACK (4 * 512)
 
 struct PbGeom {
-    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL, DPAL, DPS, o_dpa;
+    int P, nown, nownp, KC, KCP, FW, RL, AWL, AWS, FTL, shape, NTL, DPAL, DPS, o_dpa, YMD;
     int o_ft, o_nx, o_pa, o_cv, o_dcv, o_al, o_q, o_des, o_dalp, o_dgl, o_dpc, o_dpu, o_dpr, o_dms, o_r8, o_r8b, o_dsw, o_ws, o_aw, o_red, o_clk, prof, total;
     int nb, b0;          // utterances of this launch: [b0, b0 + nb) (pd_pick_passes)
 };
@@ -97,7 +97,7 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack 
     g.o_ws = take(DP * (MS + 4));                         // Ws[unit][own column slice] (+4 pad per row)
     g.o_red = take(2 * PD_NW);
     g.o_clk = take(2 * (PD_NPROF + 1));
-    g.o_nx = take(5 * 64);                    // u | r | c | s | dS_readout of the own units for the next label walked
+    g.o_nx = take(6 * 64);                    // u | r | c | s | dS_readout of the own units | label mask of the utterance for the next label walked
     // the location filters, transposed [tap][filter] (row = one 16-byte-aligned vector of KCP floats, zero beyond K): resident
     // for the whole walk when they fit; else the alignment correlation reads them row-major (staged per label or from L2)
     g.FTL = g.KCP > 0 && o + g.FW * g.KCP <= PD_LDS_FLOATS;
@@ -116,6 +116,7 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack 
     g.DPS = (a.M + 3) / 4 * 4 + 4;
     g.DPAL = !(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NODPAL) && o + g.nown * g.DPS <= PD_LDS_FLOATS;
     g.o_dpa = g.DPAL ? take(g.nown * g.DPS) : 0;
+    g.YMD = (lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NOYMPRE) != 0;
     g.total = o;
     g.prof = lvsr_knob(LVSR_KNOB_PHASE_CLOCK);
     if (o > PD_LDS_FLOATS && k.shape == 1 && allow16 && !stack) return pb_geom(a, g, false);      // clusters of 8 instead, if they fit
@@ -372,7 +373,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const al = lds + g.o_al;       // [T'] alignment produced by this label
     float* const qv = lds + g.o_q;        // [T'] q of all positions
     float* const des = lds + g.o_des;     // [nownp] energy gradients of the own positions
-    float* const dalp = lds + g.o_dalp;   // [nownp] gradient wrt the alignment this label produced (from the next label's convolution)
     float* const dgl = lds + g.o_dgl;     // [3 D] dpc | dpu | dpr, as the columns of AW
     float* const dpcs = lds + g.o_dpc;    // sliced copies for the register contractions
     float* const dpus = lds + g.o_dpu;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
     float* const AWl = lds + g.o_aw;      // AWL: [nown][AWS] rows of AW of the own positions
     float* const red = lds + g.o_red;
     float* const fT = lds + g.o_ft;       // FTL: [FW][KCP] conv1d.filters, transposed
-    float* const nx = lds + g.o_nx;       // [5][64] saved gate values of the own units, fetched one label ahead
+    float* const nx = lds + g.o_nx;       // [6][64] saved gate values of the own units + the label mask, fetched one label ahead
     float* const dpas = lds + g.o_dpa;    // DPAL: [nown][DPS] gradient wrt the preprocessed contexts of the own positions, summed over the labels
     const int P = g.P, nown = g.nown;
     int b, p;
@@ -535,7 +535,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 }
             }
         }
-        const float ym = a.ymask ? a.ymask[row] : 1.f;
+        // (the label mask opens the chain — dsn, dpc, the first publish: fetched here it cost every wave a memory round trip per label, and
+        // waves 4-7 the latency of the alignment row / feature loads above, which sit in front of it in their in-order queues; it comes
+        // with the saved gate values now, one label ahead)
+        const float ym = a.ymask ? ((n == 0 || g.YMD) ? a.ymask[row] : nx[320]) : 1.f;
         // ---- 1. GRU
         const float dsn = ym * dsj;
         const float dpc = junit ? dsn * uu * (1.f - cc * cc) : 0.f;
@@ -566,11 +569,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
             if (tid < D) { dpcs[pd_slot(tid, PD_KD)] = v[0]; dgl[tid] = v[0]; }
         }
         __syncthreads();
-        if (n > 0 && KC > 0 && tid < g.NTL) {
-            float s = 0.f;
-            for (int src = 0; src < P; ++src) s += r8b[src * g.NTL + tid];
-            dalp[tid] = s;
-        }
         clk.mark(1);
         const float drh = pd_dot<PD_KD, PD_KSPLIT>(whh, dpcs, q);
         const float dpr = junit ? drh * sp * rr * (1.f - rr) : 0.f;
@@ -649,8 +647,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
                 s1 += aw.z * dg.z + aw.w * dg.w;
             }
             clk.mark(12);
-            float qs = group_sum<QL>(s0 + s1);
-            if (qok) qs += gb.QR[row * Tp + qt] + (KC > 0 ? dalp[qtl] : 0.f);
+            // + the gradient wrt the alignment this label produced: the partials gathered at the top of the label, row src = l16 of the
+            // position's column — the lane group's fold IS the sum over the cluster's work-groups (P <= QL; rows of absent work-groups
+            // hold zeros; positions this work-group does not own read a neighbour's column and are dropped below).  As a loop of 16
+            // lanes over the cluster's runtime size in front of exchange B's publish — 16 dependent LDS reads — it held back wave 0's
+            // units of the exchange by 0.5 us on every label
+            const float fpart = r8b[l16 * g.NTL + qtl];
+            float qs = group_sum<QL>(s0 + s1 + ((n > 0 && KC > 0) ? fpart : 0.f));
+            if (qok) qs += gb.QR[row * Tp + qt];
             else qs = 0.f;
             if (l16 == 0 && qtl < nown && qt < Tp) granule_store(gC + qt, epoch, qs, plain);
         }
@@ -705,9 +709,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_pbwd_kernel(AttBwd gb, lvsr
         // on every label.  They are fetched HERE instead — straight into LDS (global_load_lds: no register lives through the energy
         // phase, the register-pressure peak of the kernel), one array per wave, and no wave polls before the phase is over (a poll
         // issued behind them would wait for them: vector-memory results return in order)
-        if (i > 0 && wave < 5 && lane < PD_UNITS) {
-            const float* arr = wave == 0 ? a.U : wave == 1 ? a.R : wave == 2 ? a.C : wave == 3 ? a.S : gb.dS_r;
-            if (arr) __builtin_amdgcn_global_load_lds(arr + (row - (size_t)B) * (wave >= 3 ? SLD : D) + min(p * PD_UNITS + lane, D - 1), nx + wave * 64, 4, 0, 0);
+        if (i > 0 && wave < 6 && lane < PD_UNITS) {
+            const float* arr = wave == 0 ? a.U : wave == 1 ? a.R : wave == 2 ? a.C : wave == 3 ? a.S : wave == 4 ? gb.dS_r : a.ymask;
+            const size_t at = wave == 5 ? row - (size_t)B : (row - (size_t)B) * (wave >= 3 ? SLD : D) + min(p * PD_UNITS + lane, D - 1);
+            if (arr) __builtin_amdgcn_global_load_lds(arr + at, nx + wave * 64, 4, 0, 0);
         }
         // ---- 3. energies backward on the matrix cores
         float swc[4], dsw[4] = {0.f, 0.f, 0.f, 0.f};

@@ -23,6 +23,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PF_NOSTAGE 256      // forward kernel: no loader waves (every owner lane fetches its next operands itself, the round-2 form)
 #define PF_NOLD9F 8192      // forward kernel, one utterance per cluster of 8: waves 4..7 stage the operands (round 3-5) instead of a ninth wave
 #define PF_NOLD9 4096       // BPTT kernel, one utterance per cluster of 8: no ninth (loader) wave — the owners fetch their operands themselves
+#define PF_NOYMPRE 32768    // decoder reverse walk: the label mask fetched at the top of its label (rounds 3-6) instead of one label ahead
 #define PF_NODPAL 16384     // decoder reverse walk: dPA accumulated by L2 atomics (rounds 3-6) instead of in LDS (decoder_persist_bwd.hip)
 #define PF_NOUB 2048        // forward kernel at 256 < H <= 512: one unit per lane group instead of four (see enc_pfwd_ub_kernel)
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
