@@ -114,7 +114,9 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack 
     // WSJ-base step, 12.58 / 12.58 against 12.61 / 12.63; the energy phase itself does not change (4.4-4.5 us per label: it is bound by its 11
     // K = 4 matrix-core products and 8 transcendentals per 16 x 16 tile, not by the adds)
     g.DPS = (a.M + 3) / 4 * 4 + 4;
-    g.DPAL = !(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NODPAL) && o + g.nown * g.DPS <= PD_LDS_FLOATS;
+    // Only in the clusters of 16 at D <= 256 (WSJ-base), where it was measured to pay: in WSJ-deep's clusters of 32 (PdShape32) the same adds
+    // made the energy phase 10.2 instead of 4.3 us per label (reverse walk 5.03 against 3.87 ms, profiles/r06_decoder_bwd_ab.md section 8)
+    g.DPAL = !(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NODPAL) && k.shape == 1 && !stack && o + g.nown * g.DPS <= PD_LDS_FLOATS;
     g.o_dpa = g.DPAL ? take(g.nown * g.DPS) : 0;
     g.YMD = (lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NOYMPRE) != 0;
     g.total = o;
