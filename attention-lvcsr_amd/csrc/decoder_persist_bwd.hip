@@ -108,15 +108,14 @@ static bool pb_geom(const AttDec& a, PbGeom& g, bool allow16 = true, bool stack 
     g.AWL = o + g.nown * g.AWS <= PD_LDS_FLOATS;
     g.o_aw = g.AWL ? take(g.nown * g.AWS) : 0;
     // the gradient wrt the preprocessed contexts of the own positions, summed over the labels: every element belongs to ONE lane for the whole
-    // walk — accumulated in LDS (ds_add_f32) and added to the caller's buffer once behind the loop when it fits, else by no-return L2 atomics
-    // label by label (rounds 3-6: 16 per lane and label; PF_NODPAL).  Row stride M + 4: the four position groups of a wave fall on different
-    // banks.  Same sums in the same order either way.  Measured (round 6, same box, two boxes): 12.43 / 12.41 against 12.44 / 12.48 ms per
-    // WSJ-base step, 12.58 / 12.58 against 12.61 / 12.63; the energy phase itself does not change (4.4-4.5 us per label: it is bound by its 11
-    // K = 4 matrix-core products and 8 transcendentals per 16 x 16 tile, not by the adds)
+    // walk — by no-return L2 atomics label by label (16 per lane and label), or, OPT-IN (persist_flags PF_DPAL), in LDS (ds_add_f32) and added
+    // to the caller's buffer once behind the loop.  Same sums in the same order either way.  Measured (round 6, profiles/r06_decoder_bwd_ab.md):
+    // in LDS the WSJ-base step is 0.3 % faster (12.42 against 12.46 ms over four same-box pairs), but the energy phase of WSJ-deep's clusters
+    // of 32 takes 10.2 instead of 4.3 us per label, TIMIT-tiny's step 1.88 instead of 1.76 ms, the paper model's 12.43 instead of 12.07:
+    // the LDS float atomics are the slower ones wherever a tile's lanes are not all live.  Row stride M + 4: the four position groups of a wave
+    // fall on different banks
     g.DPS = (a.M + 3) / 4 * 4 + 4;
-    // Only in the clusters of 16 at D <= 256 (WSJ-base), where it was measured to pay: in WSJ-deep's clusters of 32 (PdShape32) the same adds
-    // made the energy phase 10.2 instead of 4.3 us per label (reverse walk 5.03 against 3.87 ms, profiles/r06_decoder_bwd_ab.md section 8)
-    g.DPAL = !(lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NODPAL) && k.shape == 1 && !stack && o + g.nown * g.DPS <= PD_LDS_FLOATS;
+    g.DPAL = (lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_DPAL) && o + g.nown * g.DPS <= PD_LDS_FLOATS;
     g.o_dpa = g.DPAL ? take(g.nown * g.DPS) : 0;
     g.YMD = (lvsr_knob(LVSR_KNOB_PERSIST_FLAGS) & PF_NOYMPRE) != 0;
     g.total = o;

@@ -24,7 +24,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define PF_NOLD9F 8192      // forward kernel, one utterance per cluster of 8: waves 4..7 stage the operands (round 3-5) instead of a ninth wave
 #define PF_NOLD9 4096       // BPTT kernel, one utterance per cluster of 8: no ninth (loader) wave — the owners fetch their operands themselves
 #define PF_NOYMPRE 32768    // decoder reverse walk: the label mask fetched at the top of its label (rounds 3-6) instead of one label ahead
-#define PF_NODPAL 16384     // decoder reverse walk: dPA accumulated by L2 atomics (rounds 3-6) instead of in LDS (decoder_persist_bwd.hip)
+#define PF_DPAL 16384       // decoder reverse walk: dPA summed in LDS and written once behind the loop instead of by L2 atomics label by label (opt-in:
+                            // -0.3 % per WSJ-base step, +3 to +30 % on the reverse walk of every other shape measured; decoder_persist_bwd.hip)
 #define PF_NOUB 2048        // forward kernel at 256 < H <= 512: one unit per lane group instead of four (see enc_pfwd_ub_kernel)
 #define PF_PRIVATE 32    // every wave sweeps the whole vector into a buffer of its own, no work-group barrier (RB = 1 only):
                          // measured slower, 2.69 vs 2.45 us per step — four times the sc1 loads in the CU's memory queue

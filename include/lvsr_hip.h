@@ -43,7 +43,7 @@ int lvsr_region_end(void* stream, int keep);
  * key of every cached graph, so a graph captured under one setting is not replayed under another. */
 #define LVSR_KNOB_PERSIST_ROWS 0      /* utterances per encoder cluster: 0 = the smallest number whose grid fits the chip; 1, 2, 4, 8 = at least that */
 #define LVSR_KNOB_PERSIST_FLAGS 1     /* kernel-variant bits of csrc/persist.h (PF_*; same results): 2 clusters spread over XCDs, 4 write-through publish, 64 clusters of 4,
-                                         4096 / 8192 no loader wave in the BPTT / forward encoder kernel, 16384 decoder reverse walk sums dPA by L2 atomics instead of in LDS, ...
+                                         4096 / 8192 no loader wave in the BPTT / forward encoder kernel, 16384 decoder reverse walk sums dPA in LDS instead of by L2 atomics (opt-in), ...
                                          The timing ablations that change results (1, 8, 16, 128) are refused: they exist only in the probe build (csrc/build.py --probes) */
 #define LVSR_KNOB_PERSIST_THREADS 2   /* 0 = 512-thread work-groups when a cluster serves <= 2 utterances; 256 = always 256 */
 #define LVSR_KNOB_PHASE_CLOCK 3       /* 1 = work-group 0 of the persistent decoder kernels leaves per-phase times in the workspace header */

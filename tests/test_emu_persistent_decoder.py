@@ -118,9 +118,9 @@ def test_persistent_backward_filter_counts_and_matcher_widths(concurrent_lib, K,
 
 
 def test_context_gradient_in_lds_equals_the_atomic_form():
-    """Round 6: the reverse walk sums the gradient wrt the preprocessed contexts of a work-group's own positions in LDS and adds it to the
-    caller's buffer once behind the label loop (decoder_persist_bwd.hip PbGeom.DPAL); persist_flags 16384 (PF_NODPAL) keeps the L2 atomics
-    of rounds 3-6.  Every element is one lane's own either way, added label by label in the same order: every gradient bit for bit."""
+    """Round 6: the reverse walk can sum the gradient wrt the preprocessed contexts of a work-group's own positions in LDS and adds it to the
+    caller's buffer once behind the label loop (decoder_persist_bwd.hip PbGeom.DPAL); persist_flags 16384 (PF_DPAL) opts in; the default keeps the L2
+    atomics of rounds 3-6.  Every element is one lane's own either way, added label by label in the same order: every gradient bit for bit."""
     lib = emu_lib()
     lib._dll.hipemu_set_concurrent(1)
     try:

@@ -131,8 +131,8 @@ def test_persistent_decoder_agrees_with_step_kernels(gpu_device, setup, prior):
 
 
 def test_context_gradient_in_lds_equals_the_atomic_form_at_full_size(gpu_device, setup):
-    """The reverse walk's LDS-resident sum of the gradient wrt the preprocessed contexts (round 6, PbGeom.DPAL) against the L2 atomics of
-    rounds 3-6 (persist_flags 16384) on the ragged full-size batch: the same adds in the same order — every gradient bit for bit."""
+    """The reverse walk's opt-in LDS-resident sum of the gradient wrt the preprocessed contexts (round 6, PbGeom.DPAL, persist_flags 16384)
+    against the default L2 atomics on the ragged full-size batch: the same adds in the same order — every gradient bit for bit."""
     from lvsr_amd import native
     s = setup
     lib = native.get()
